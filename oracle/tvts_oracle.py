@@ -1,0 +1,589 @@
+"""CPU oracle for the TVTSv2 pretrain step -- TEST INFRASTRUCTURE ONLY.
+
+This file is a plain fp32 torch-CPU restatement of the reference algorithm for
+the hot path named in BASELINE.json.  It is *not* part of
+the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it, and there only as the
+checker.  ``tvts_amd`` never imports it and fails loudly when the HIP library is
+missing.
+
+Parity status: PINNED against outputs of the reference itself, imported in the
+build container by ``tests/golden/make_golden.py`` (the reference has no golden
+vectors of its own).  The fixtures live in
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks this file against
+every one of them.  Exception: the optimizer.  ``transformers.AdamW`` (pinned
+``transformers==4.10.2`` in ``v2/requirement.txt``) is a third-party dependency
+that is absent from the reference tree and from this image, so
+``hf_adamw_step`` restates the published algorithm and is "parity unpinned".
+
+Every function cites the reference file:line it follows (paths relative to the
+reference checkout).  The formulation is index-based (explicit token index
+tables) rather than the reference's einops regrouping, so the two share no code.
+
+Parameters are passed as a flat ``dict[str, Tensor]`` that uses the reference
+state-dict key names.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+# --------------------------------------------------------------------------------------
+# architecture table (v2/model/model_dist_TVTSv2_ViT_{B_32,B_16,H_14}.py ctor arguments)
+# --------------------------------------------------------------------------------------
+
+ARCHS = {
+    # v2/model/model_dist_TVTSv2_ViT_B_32.py:29-31, CLIP ViT-B/32 text tower 512/8/12
+    "B_32": dict(name="B_32", image=224, patch=32, width=768, heads=12, layers=12, embed=512,
+                 text_width=512, text_heads=8, text_layers=12, text_tune_from=9, vocab=49408, context=77,
+                 act="quick_gelu", tail="all_tokens", num_frames=12, mask_ratio=0.0,
+                 sort_heads=8, sort_depth=2, n_trans=4),
+    # v2/model/model_dist_TVTSv2_ViT_B_16.py:29-31
+    "B_16": dict(name="B_16", image=224, patch=16, width=768, heads=12, layers=12, embed=512,
+                 text_width=512, text_heads=8, text_layers=12, text_tune_from=9, vocab=49408, context=77,
+                 act="quick_gelu", tail="all_tokens", num_frames=12, mask_ratio=0.5,
+                 sort_heads=8, sort_depth=2, n_trans=4),
+    # v2/model/model_dist_TVTSv2_ViT_H_14.py:44-83, OpenCLIP/model_configs/ViT-H-14.json
+    "H_14": dict(name="H_14", image=224, patch=14, width=1280, heads=16, layers=32, embed=1024,
+                 text_width=1024, text_heads=16, text_layers=24, text_tune_from=18, vocab=49408, context=77,
+                 act="gelu", tail="pooled_and_patches", num_frames=12, mask_ratio=0.7,
+                 sort_heads=16, sort_depth=2, n_trans=4),
+}
+
+
+def tiny_arch(**over) -> dict:
+    """A miniature architecture with the same structure, for fast unit parity."""
+    a = dict(name="tiny", image=32, patch=8, width=64, heads=2, layers=2, embed=32,
+             text_width=32, text_heads=2, text_layers=3, text_tune_from=1, vocab=97, context=12,
+             act="quick_gelu", tail="all_tokens", num_frames=12, mask_ratio=0.5,
+             sort_heads=2, sort_depth=2, n_trans=4)
+    a.update(over)
+    return a
+
+
+def patches_per_frame(arch) -> int:
+    return (arch["image"] // arch["patch"]) ** 2
+
+
+def n_keep(arch) -> int:
+    # v2/model/video_encoder_ViT_B_16.py:220 -- same float expression as the reference
+    return int(patches_per_frame(arch) * (1 - arch["mask_ratio"]))
+
+
+# --------------------------------------------------------------------------------------
+# parameter inventory + deterministic synthetic parameters / batches
+# --------------------------------------------------------------------------------------
+
+def param_shapes(arch) -> "Dict[str, Tuple[int, ...]]":
+    """State-dict key -> shape, in the reference's registration order."""
+    W, E, Wt = arch["width"], arch["embed"], arch["text_width"]
+    p = arch["patch"]
+    out: Dict[str, Tuple[int, ...]] = {}
+    out["text_positional_embedding"] = (arch["context"], Wt)
+    out["text_projection"] = (Wt, E)
+    for i in range(arch["text_layers"]):
+        pre = f"text_model.resblocks.{i}."
+        out[pre + "attn.in_proj_weight"] = (3 * Wt, Wt)
+        out[pre + "attn.in_proj_bias"] = (3 * Wt,)
+        out[pre + "attn.out_proj.weight"] = (Wt, Wt)
+        out[pre + "attn.out_proj.bias"] = (Wt,)
+        out[pre + "ln_1.weight"] = (Wt,)
+        out[pre + "ln_1.bias"] = (Wt,)
+        out[pre + "mlp.c_fc.weight"] = (4 * Wt, Wt)
+        out[pre + "mlp.c_fc.bias"] = (4 * Wt,)
+        out[pre + "mlp.c_proj.weight"] = (Wt, 4 * Wt)
+        out[pre + "mlp.c_proj.bias"] = (Wt,)
+        out[pre + "ln_2.weight"] = (Wt,)
+        out[pre + "ln_2.bias"] = (Wt,)
+    out["text_token_embedding.weight"] = (arch["vocab"], Wt)
+    out["text_ln_final.weight"] = (Wt,)
+    out["text_ln_final.bias"] = (Wt,)
+    out["video_model.class_embedding"] = (W,)
+    out["video_model.positional_embedding"] = (patches_per_frame(arch) + 1, W)
+    out["video_model.proj"] = (W, E)
+    out["video_model.temporal_embedding"] = (arch["num_frames"], W)
+    out["video_model.conv1.weight"] = (W, 3, p, p)
+    out["video_model.ln_pre.weight"] = (W,)
+    out["video_model.ln_pre.bias"] = (W,)
+    for i in range(arch["layers"]):
+        pre = f"video_model.transformer.resblocks.{i}."
+        for a in ("attn", "timeattn"):
+            out[pre + a + ".qkv.weight"] = (3 * W, W)
+            out[pre + a + ".qkv.bias"] = (3 * W,)
+            out[pre + a + ".proj.weight"] = (W, W)
+            out[pre + a + ".proj.bias"] = (W,)
+        out[pre + "ln_3.weight"] = (W,)
+        out[pre + "ln_3.bias"] = (W,)
+        out[pre + "ln_1.weight"] = (W,)
+        out[pre + "ln_1.bias"] = (W,)
+        out[pre + "mlp.c_fc.weight"] = (4 * W, W)
+        out[pre + "mlp.c_fc.bias"] = (4 * W,)
+        out[pre + "mlp.c_proj.weight"] = (W, 4 * W)
+        out[pre + "mlp.c_proj.bias"] = (W,)
+        out[pre + "ln_2.weight"] = (W,)
+        out[pre + "ln_2.bias"] = (W,)
+    out["video_model.ln_post.weight"] = (W,)
+    out["video_model.ln_post.bias"] = (W,)
+    out["pred_model.type_embed"] = (1, 2, E)
+    for i in range(arch["sort_depth"]):
+        pre = f"pred_model.blocks.{i}."
+        out[pre + "norm1.weight"] = (E,)
+        out[pre + "norm1.bias"] = (E,)
+        out[pre + "attn.qkv.weight"] = (3 * E, E)
+        out[pre + "attn.qkv.bias"] = (3 * E,)
+        out[pre + "attn.proj.weight"] = (E, E)
+        out[pre + "attn.proj.bias"] = (E,)
+        out[pre + "norm2.weight"] = (E,)
+        out[pre + "norm2.bias"] = (E,)
+        out[pre + "mlp.fc1.weight"] = (4 * E, E)
+        out[pre + "mlp.fc1.bias"] = (4 * E,)
+        out[pre + "mlp.fc2.weight"] = (E, 4 * E)
+        out[pre + "mlp.fc2.bias"] = (E,)
+    out["pred_model.norm.weight"] = (E,)
+    out["pred_model.norm.bias"] = (E,)
+    out["pred_model.head.weight"] = (arch["n_trans"], E)
+    out["pred_model.head.bias"] = (arch["n_trans"],)
+    return out
+
+
+def _key_seed(seed: int, name: str) -> int:
+    h = 1469598103934665603
+    for ch in name.encode():
+        h = ((h ^ ch) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return (h ^ (seed * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
+
+
+def synth_params(arch, seed: int = 0) -> Params:
+    """Deterministic per-key synthetic parameters (independent of module construction order).
+
+    Scales mimic a trained CLIP checkpoint's order of magnitude; ``timeattn`` is drawn
+    N(0, 0.02^2) because at reference init it is numerically dead.
+    LayerNorm gains are 1 + small noise, biases small noise, so every term is exercised.
+    """
+    out: Params = {}
+    for name, shape in param_shapes(arch).items():
+        g = torch.Generator().manual_seed(_key_seed(seed, name))
+        t = torch.randn(shape, generator=g, dtype=torch.float32)
+        leaf = name.rsplit(".", 1)[-1]
+        is_norm = any(s in name for s in ("ln_", "norm"))
+        if is_norm and leaf == "weight":
+            t = 1.0 + 0.05 * t
+        elif leaf in ("bias", "in_proj_bias"):
+            t = 0.02 * t
+        elif name == "text_token_embedding.weight":
+            t = 0.02 * t
+        elif name == "text_positional_embedding":
+            t = 0.01 * t
+        elif name in ("video_model.class_embedding", "video_model.positional_embedding",
+                      "video_model.temporal_embedding", "video_model.proj"):
+            t = t * arch["width"] ** -0.5
+        elif name == "text_projection":
+            t = t * arch["text_width"] ** -0.5
+        elif name == "pred_model.type_embed":
+            t = 0.02 * t
+        elif name == "video_model.conv1.weight":
+            t = t * (3 * arch["patch"] ** 2) ** -0.5
+        elif "timeattn" in name:
+            t = 0.02 * t
+        else:  # dense weights [out, in]
+            t = t * (shape[-1] ** -0.5) * 0.7
+        out[name] = t
+    return out
+
+
+def synth_batch(arch, B: int, T: int, seed: int = 0, n_trans: Optional[int] = None,
+                caption_len: int = 32) -> Dict[str, Tensor]:
+    """Synthetic clip-caption batch in the reference's batch-dict contract."""
+    NT = arch["n_trans"] if n_trans is None else n_trans
+    g = torch.Generator().manual_seed(seed)
+    video = torch.randn(B, T, 3, arch["image"], arch["image"], generator=g, dtype=torch.float32)
+    L = arch["context"]
+    cl = min(caption_len, L)
+    text = torch.zeros(NT * B, L, dtype=torch.int32)
+    sot, eot = arch["vocab"] - 2, arch["vocab"] - 1
+    text[:, 0] = sot
+    text[:, 1:cl - 1] = torch.randint(1, arch["vocab"] - 408 if arch["vocab"] > 1000 else arch["vocab"] - 2,
+                                      (NT * B, cl - 2), generator=g, dtype=torch.int32)
+    text[:, cl - 1] = eot
+    ppf, n = patches_per_frame(arch), n_keep(arch)
+    keep = torch.stack([torch.randperm(ppf, generator=g)[:n] for _ in range(B)]).to(torch.int64)
+    batch = {"video": video, "text": text, "keep_ind": keep}
+    if NT == arch["n_trans"]:
+        batch["label"] = torch.arange(arch["n_trans"]).repeat(B, 1)
+    return batch
+
+
+# --------------------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------------------
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
+    # v2/model/video_encoder_ViT_B_16.py:79-85 (fp32 LayerNorm), sort_transformer.py:99 (eps 1e-6)
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def quick_gelu(x: Tensor) -> Tensor:
+    # v2/model/video_encoder_ViT_B_16.py:88-90
+    return x * torch.sigmoid(1.702 * x)
+
+
+def gelu_erf(x: Tensor) -> Tensor:
+    # nn.GELU default (sort_transformer.py:17; H/14 act_layer)
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def _act(arch):
+    return quick_gelu if arch["act"] == "quick_gelu" else gelu_erf
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def _softmax_attend(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+    """softmax(q k^T) v over the last two dims (v2/model/video_encoder_ViT_B_16.py:11-15)."""
+    s = q @ k.transpose(-1, -2)
+    if mask is not None:
+        s = s + mask
+    return torch.softmax(s, dim=-1) @ v
+
+
+# --------------------------------------------------------------------------------------
+# divided space-time attention (v2/model/video_encoder_ViT_B_16.py:38-76)
+# --------------------------------------------------------------------------------------
+
+def divided_attention(x: Tensor, wqkv: Tensor, bqkv: Tensor, wo: Tensor, bo: Tensor,
+                      heads: int, mode: str, T: int, n: int) -> Tensor:
+    """VarAttention.forward restated with explicit token tables.
+
+    x: [B, 1+T*n, W].  mode 'time': token (f, i) attends {CLS} + {(f', i)}; mode 'space':
+    token (f, i) attends {CLS} + {(f, i')}.  The CLS query attends all tokens.  q is scaled by
+    dh^-0.5 before the CLS split (:45-51); CLS k/v are key 0 of every group (:56-60).
+    """
+    B, S, W = x.shape
+    dh = W // heads
+    qkv = linear(x, wqkv, bqkv).reshape(B, S, 3, heads, dh)
+    q = qkv[:, :, 0].permute(0, 2, 1, 3) * dh ** -0.5  # [B,h,S,dh]
+    k = qkv[:, :, 1].permute(0, 2, 1, 3)
+    v = qkv[:, :, 2].permute(0, 2, 1, 3)
+    cls_out = _softmax_attend(q[:, :, 0:1], k, v)  # [B,h,1,dh]
+
+    def grid(t):  # patch tokens -> [B,h,T,n,dh]
+        return t[:, :, 1:].reshape(B, heads, T, n, dh)
+
+    qg, kg, vg = grid(q), grid(k), grid(v)
+    if mode == "time":  # groups over i, sequence over f
+        qg, kg, vg = (t.transpose(2, 3) for t in (qg, kg, vg))  # [B,h,n,T,dh]
+    G = qg.shape[2]
+    kc = k[:, :, 0:1].unsqueeze(2).expand(B, heads, G, 1, dh)
+    vc = v[:, :, 0:1].unsqueeze(2).expand(B, heads, G, 1, dh)
+    out = _softmax_attend(qg, torch.cat([kc, kg], 3), torch.cat([vc, vg], 3))
+    if mode == "time":
+        out = out.transpose(2, 3)
+    out = torch.cat([cls_out, out.reshape(B, heads, T * n, dh)], 2)  # [B,h,S,dh]
+    out = out.permute(0, 2, 1, 3).reshape(B, S, W)
+    return linear(out, wo, bo)
+
+
+def st_block(x: Tensor, P: Params, pre: str, arch, T: int, n: int) -> Tensor:
+    """ResidualSpaceTimeAttentionBlock.forward (v2/model/video_encoder_ViT_B_16.py:113-124).
+
+    NB the space residual starts from the block input x, not from the time residual (:121).
+    """
+    h = arch["heads"]
+    t_out = divided_attention(layer_norm(x, P[pre + "ln_3.weight"], P[pre + "ln_3.bias"], 1e-5),
+                              P[pre + "timeattn.qkv.weight"], P[pre + "timeattn.qkv.bias"],
+                              P[pre + "timeattn.proj.weight"], P[pre + "timeattn.proj.bias"], h, "time", T, n)
+    t_res = x + t_out
+    s_out = divided_attention(layer_norm(t_res, P[pre + "ln_1.weight"], P[pre + "ln_1.bias"], 1e-5),
+                              P[pre + "attn.qkv.weight"], P[pre + "attn.qkv.bias"],
+                              P[pre + "attn.proj.weight"], P[pre + "attn.proj.bias"], h, "space", T, n)
+    s_res = x + s_out
+    hid = _act(arch)(linear(layer_norm(s_res, P[pre + "ln_2.weight"], P[pre + "ln_2.bias"], 1e-5),
+                            P[pre + "mlp.c_fc.weight"], P[pre + "mlp.c_fc.bias"]))
+    return s_res + linear(hid, P[pre + "mlp.c_proj.weight"], P[pre + "mlp.c_proj.bias"])
+
+
+def video_embed_tokens(P: Params, video: Tensor, keep_ind: Tensor, arch) -> Tensor:
+    """Patch embed + CLS + space/time position + tube-mask gather + ln_pre
+    (v2/model/video_encoder_ViT_B_16.py:176-218).  Gather-then-embed, which is
+    output-equivalent to the reference's embed-then-gather."""
+    B, T = video.shape[:2]
+    p, W = arch["patch"], arch["width"]
+    g = arch["image"] // p
+    n = keep_ind.shape[1]
+    # patch pixel vectors in conv-weight order (c, py, px): [B,T,ppf,3*p*p]
+    pix = video.reshape(B, T, 3, g, p, g, p).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, T, g * g, 3 * p * p)
+    idx = keep_ind.to(torch.int64)[:, None, :, None].expand(B, T, n, 3 * p * p)
+    kept = torch.gather(pix, 2, idx)  # [B,T,n,3pp]
+    tok = kept @ P["video_model.conv1.weight"].reshape(W, -1).t()  # [B,T,n,W]
+    pos = P["video_model.positional_embedding"]
+    tok = tok + pos[1:][keep_ind.to(torch.int64)][:, None] + P["video_model.temporal_embedding"][:T][None, :, None]
+    cls = (P["video_model.class_embedding"] + pos[0]).expand(B, 1, W)
+    x = torch.cat([cls, tok.reshape(B, T * n, W)], 1)
+    return layer_norm(x, P["video_model.ln_pre.weight"], P["video_model.ln_pre.bias"], 1e-5)
+
+
+def video_tower(P: Params, video: Tensor, keep_ind: Tensor, arch,
+                taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
+    """VisionTransformer.forward -> (video_embedding [B,E], sort-head tokens [B,S',E]).
+
+    tail 'all_tokens' (B models, video_encoder_ViT_B_16.py:229-235 + model_dist..B_16.py:113-116):
+    ln_post on all S tokens, @proj, CLS row is the embedding, all S rows go to the sort head.
+    tail 'pooled_and_patches' (H/14, video_encoder_ViT_H_14.py:472-484): ln_post on CLS only,
+    patch tokens projected without LN and without CLS.
+    """
+    if video.dim() == 4:
+        video = video.unsqueeze(1)
+    T = video.shape[1]
+    n = keep_ind.shape[1]
+    x = video_embed_tokens(P, video, keep_ind, arch)
+    if taps is not None:
+        taps["vit_in"] = x
+    for i in range(arch["layers"]):
+        x = st_block(x, P, f"video_model.transformer.resblocks.{i}.", arch, T, n)
+        if taps is not None:
+            taps[f"vit_block{i}"] = x
+    lw, lb, proj = P["video_model.ln_post.weight"], P["video_model.ln_post.bias"], P["video_model.proj"]
+    if arch["tail"] == "all_tokens":
+        out = layer_norm(x, lw, lb, 1e-5) @ proj
+        return out[:, 0], out
+    pooled = layer_norm(x[:, 0], lw, lb, 1e-5) @ proj
+    return pooled, x[:, 1:] @ proj
+
+
+# --------------------------------------------------------------------------------------
+# CLIP text tower (v2/CLIP/clip/model.py:171-203,330-358; model_dist..B_16.py:97-111)
+# --------------------------------------------------------------------------------------
+
+def text_block(x: Tensor, P: Params, pre: str, heads: int, act) -> Tensor:
+    """ResidualAttentionBlock with causal nn.MultiheadAttention, x: [N, L, Wt]."""
+    N, L, Wt = x.shape
+    dh = Wt // heads
+    y = layer_norm(x, P[pre + "ln_1.weight"], P[pre + "ln_1.bias"], 1e-5)
+    qkv = linear(y, P[pre + "attn.in_proj_weight"], P[pre + "attn.in_proj_bias"]).reshape(N, L, 3, heads, dh)
+    q = qkv[:, :, 0].permute(0, 2, 1, 3) * dh ** -0.5
+    k = qkv[:, :, 1].permute(0, 2, 1, 3)
+    v = qkv[:, :, 2].permute(0, 2, 1, 3)
+    mask = torch.full((L, L), float("-inf")).triu(1)  # model.py:330-336
+    o = _softmax_attend(q, k, v, mask).permute(0, 2, 1, 3).reshape(N, L, Wt)
+    x = x + linear(o, P[pre + "attn.out_proj.weight"], P[pre + "attn.out_proj.bias"])
+    y = layer_norm(x, P[pre + "ln_2.weight"], P[pre + "ln_2.bias"], 1e-5)
+    y = act(linear(y, P[pre + "mlp.c_fc.weight"], P[pre + "mlp.c_fc.bias"]))
+    return x + linear(y, P[pre + "mlp.c_proj.weight"], P[pre + "mlp.c_proj.bias"])
+
+
+def text_tower(P: Params, ids: Tensor, arch, truncate: bool = True, taps: Optional[dict] = None) -> Tensor:
+    """compute_text: ids int [N, context] -> [N, E] (row at argmax(ids) = EOT, @ text_projection).
+
+    With truncate=True the context is cut to max(EOT)+1, exact under the causal mask
+    (SURVEY.md App. B #14).
+    """
+    ids = ids.to(torch.int64)
+    eot = ids.argmax(dim=-1)
+    L = int(eot.max()) + 1 if truncate else ids.shape[1]
+    x = P["text_token_embedding.weight"][ids[:, :L]] + P["text_positional_embedding"][:L]
+    act = _act(arch)
+    for i in range(arch["text_layers"]):
+        x = text_block(x, P, f"text_model.resblocks.{i}.", arch["text_heads"], act)
+        if taps is not None:
+            taps[f"text_block{i}"] = x
+    rows = x[torch.arange(x.shape[0]), eot]
+    rows = layer_norm(rows, P["text_ln_final.weight"], P["text_ln_final.bias"], 1e-5)
+    return rows @ P["text_projection"]
+
+
+# --------------------------------------------------------------------------------------
+# transcript sorting head (v2/model/sort_transformer.py:35-142)
+# --------------------------------------------------------------------------------------
+
+def sort_head(P: Params, text: Tensor, tokens: Tensor, arch) -> Tensor:
+    """SortTransformer.forward(text [B,NT,E] (detached), tokens [B,S',E]) -> [B,NT,n_trans]."""
+    E, h = arch["embed"], arch["sort_heads"]
+    dh = E // h
+    te = P["pred_model.type_embed"]
+    x = torch.cat([tokens + te[:, 0], text + te[:, 1]], 1)
+    B, So, _ = x.shape
+    for i in range(arch["sort_depth"]):
+        pre = f"pred_model.blocks.{i}."
+        y = layer_norm(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], 1e-6)
+        qkv = linear(y, P[pre + "attn.qkv.weight"], P[pre + "attn.qkv.bias"]).reshape(B, So, 3, h, dh)
+        q = qkv[:, :, 0].permute(0, 2, 1, 3) * dh ** -0.5
+        o = _softmax_attend(q, qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3))
+        x = x + linear(o.permute(0, 2, 1, 3).reshape(B, So, E), P[pre + "attn.proj.weight"], P[pre + "attn.proj.bias"])
+        y = layer_norm(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-6)
+        y = gelu_erf(linear(y, P[pre + "mlp.fc1.weight"], P[pre + "mlp.fc1.bias"]))
+        x = x + linear(y, P[pre + "mlp.fc2.weight"], P[pre + "mlp.fc2.bias"])
+    y = layer_norm(x[:, tokens.shape[1]:], P["pred_model.norm.weight"], P["pred_model.norm.bias"], 1e-6)
+    return linear(y, P["pred_model.head.weight"], P["pred_model.head.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# model forward + losses (model_dist..B_16.py:61-127, loss.py:13-25, trainer.py:479-496)
+# --------------------------------------------------------------------------------------
+
+def model_forward(P: Params, batch: dict, arch, truncate_text: bool = True,
+                  taps: Optional[dict] = None) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+    """TVTSv2_*.forward(data) -> (text_emb [B,E], video_emb [B,E], pred_order [B,NT,4] | None).
+
+    Captions are clip-major rows i*B+b (trainer.py:465-472); the sort head sees the *detached*
+    per-caption embeddings (:69) and the contrastive text embedding is their mean (:74-76).
+    """
+    video = batch["video"]
+    B = video.shape[0]
+    t = text_tower(P, batch["text"], arch, truncate_text, taps)
+    NT = t.shape[0] // B
+    t = t.reshape(NT, B, -1)
+    text_before = t.detach().permute(1, 0, 2)
+    text_emb = t.mean(0)
+    video_emb, tokens = video_tower(P, video, batch["keep_ind"], arch, taps)
+    pred = sort_head(P, text_before, tokens, arch) if NT != 1 else None
+    return text_emb, video_emb, pred
+
+
+def sim_matrix(a: Tensor, b: Tensor, eps: float = 1e-8) -> Tensor:
+    # model_dist..B_16.py:119-127
+    an = a / a.norm(dim=1, keepdim=True).clamp_min(eps)
+    bn = b / b.norm(dim=1, keepdim=True).clamp_min(eps)
+    return an @ bn.t()
+
+
+def norm_softmax_loss(sim: Tensor, temperature: float = 0.05) -> Tensor:
+    # loss.py:13-25 : both directions, no 1/2 factor
+    x = sim / temperature
+    li = torch.diagonal(x - torch.logsumexp(x, dim=1, keepdim=True)).mean()
+    lj = torch.diagonal(x.t() - torch.logsumexp(x.t(), dim=1, keepdim=True)).mean()
+    return -li - lj
+
+
+def sorting_ce(pred: Tensor, label: Tensor) -> Tensor:
+    # trainer.py:487-492 : 2 * CrossEntropy(mean)
+    lg = pred.reshape(-1, pred.shape[-1])
+    lb = label.reshape(-1).to(torch.int64)
+    lse = torch.logsumexp(lg, dim=1)
+    return 2.0 * (lse - lg[torch.arange(lg.shape[0]), lb]).mean()
+
+
+def step_losses(P: Params, batch: dict, arch, truncate_text: bool = True):
+    """One rank, world 1: (loss1, loss2, text_emb, video_emb, pred)."""
+    te, ve, pred = model_forward(P, batch, arch, truncate_text)
+    loss1 = norm_softmax_loss(sim_matrix(ve, te))
+    loss2 = sorting_ce(pred, batch["label"]) if pred is not None else torch.zeros(())
+    return loss1, loss2, te, ve, pred
+
+
+def multi_rank_step(P: Params, batches: List[dict], arch, truncate_text: bool = True):
+    """Single-process emulation of the W-rank step.
+
+    Every rank computes the same global InfoNCE over the gathered embeddings;
+    AllGather_multi.backward keeps the local rows only (trainer.py:52-57) and DDP averages,
+    so the update gradient is grad( L1_global / W + mean_r L2_r ).  Returns
+    (total_for_backward, loss1_global, [loss2_r]).
+    """
+    Wn = len(batches)
+    tes, ves, l2 = [], [], []
+    for b in batches:
+        te, ve, pred = model_forward(P, b, arch, truncate_text)
+        tes.append(te)
+        ves.append(ve)
+        l2.append(sorting_ce(pred, b["label"]) if pred is not None else torch.zeros(()))
+    loss1 = norm_softmax_loss(sim_matrix(torch.cat(ves), torch.cat(tes)))
+    total = loss1 / Wn + sum(l2) / Wn
+    return total, loss1, l2
+
+
+# --------------------------------------------------------------------------------------
+# optimizer: parameter grouping + HF AdamW  (train_dist_TVTSv2_ViT_B_16.py:66-125)
+# --------------------------------------------------------------------------------------
+
+GROUP_HPARAMS = (  # (lr, weight_decay) for new-decay, new-nodecay, clip-decay, clip-nodecay (:118-123)
+    (1e-4, 0.05), (1e-4, 0.0), (1e-7, 0.05), (1e-7, 0.0))
+
+
+def param_groups(names: List[str], arch) -> Tuple[List[List[str]], List[str]]:
+    """Name-substring grouping of train_dist_TVTSv2_ViT_B_16.py:66-107.
+
+    Returns ([new_decay, new_nodecay, clip_decay, clip_nodecay], frozen)."""
+    no_decay = ["bias", "LayerNorm", "ln_", "norm"]
+    if arch["name"] == "H_14":  # train_dist_TVTSv2_ViT_H_14.py:68
+        no_decay = no_decay + ["ls_", "LayerScale"]
+    tune = ["resblocks.%d." % i for i in range(arch["text_tune_from"], arch["text_layers"])]
+    groups: List[List[str]] = [[], [], [], []]
+    frozen: List[str] = []
+    for name in names:
+        nd = any(s in name for s in no_decay)
+        if "video_model" in name:
+            new = "timeattn" in name or "ln_3" in name
+            groups[(0 if new else 2) + (1 if nd else 0)].append(name)
+        elif "text" in name:
+            if "resblocks" in name and not any(t in name for t in tune):
+                frozen.append(name)
+            else:
+                groups[2 + (1 if nd else 0)].append(name)
+        else:
+            groups[1 if nd else 0].append(name)
+    return groups, frozen
+
+
+def hf_adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, wd: float,
+                  beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-6) -> None:
+    """transformers.AdamW.step for one tensor, in place (transformers==4.10.2, optimization.py,
+    class AdamW; absent from the reference tree -> restated from the published algorithm,
+    PARITY UNPINNED).  eps is added outside the bias correction; the decoupled decay
+    ``p -= lr*wd*p`` is applied after the Adam update."""
+    m.mul_(beta1).add_(g, alpha=1.0 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+    denom = v.sqrt().add_(eps)
+    step_size = lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+    p.addcdiv_(m, denom, value=-step_size)
+    if wd > 0.0:
+        p.add_(p, alpha=-lr * wd)
+
+
+def train_step(P: Params, batch: dict, arch, opt_state: dict, truncate_text: bool = True):
+    """Full single-rank step on leaf copies of P: losses, grads, HF-AdamW update (in place on P).
+
+    opt_state: {'step': int, 'm': {name: Tensor}, 'v': {name: Tensor}}."""
+    groups, frozen = param_groups(list(P.keys()), arch)
+    leaves = {k: t.detach().clone().requires_grad_(k not in frozen) for k, t in P.items()}
+    loss1, loss2, *_ = step_losses(leaves, batch, arch, truncate_text)
+    (loss1 + loss2).backward()
+    opt_state["step"] = opt_state.get("step", 0) + 1
+    grads = {}
+    for gi, names in enumerate(groups):
+        lr, wd = GROUP_HPARAMS[gi]
+        for k in names:
+            g = leaves[k].grad
+            if g is None:
+                continue
+            grads[k] = g
+            m = opt_state.setdefault("m", {}).setdefault(k, torch.zeros_like(P[k]))
+            v = opt_state.setdefault("v", {}).setdefault(k, torch.zeros_like(P[k]))
+            hf_adamw_step(P[k], g, m, v, opt_state["step"], lr, wd)
+    return float(loss1), float(loss2), grads
+
+
+def step_flops_per_pair(arch, T: int, caption_len: int = 32, NT: int = 4) -> Tuple[float, float]:
+    """Algorithmic matmul FLOPs per video-text pair (fwd, bwd) -- SURVEY.md 8d formula."""
+    p, W, E, Wt = arch["patch"], arch["width"], arch["embed"], arch["text_width"]
+    n = n_keep(arch)
+    S = 1 + T * n
+    layers, Lt, L = arch["layers"], arch["text_layers"], caption_len
+    So = (S if arch["tail"] == "all_tokens" else S - 1) + NT
+    patch = 2 * T * n * 3 * p * p * W
+    text_gemm = NT * Lt * L * 24 * Wt * Wt
+    fwd = (patch + layers * S * 32 * W * W + layers * (4 * n * T * (T + 1) * W + 4 * T * n * (n + 1) * W + 8 * S * W)
+           + 2 * S * W * E + text_gemm + NT * Lt * 4 * L * L * Wt + NT * 2 * Wt * E
+           + 2 * So * 24 * E * E + 8 * So * So * E + 32 * E)
+    frozen = arch["text_tune_from"]
+    bwd = 2 * fwd - patch - (frozen / Lt) * text_gemm
+    return float(fwd), float(bwd)

@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""Generate the parity fixtures in tests/golden/ by RUNNING THE REFERENCE (container only).
+
+The reference (/root/reference, TencentARC/TVTS v2) is imported read-only with import shims for
+third-party modules that are absent from this image (timm, torchvision, humanize, ftfy ...).
+No reference file is edited or copied: this script only calls into it and stores *data*
+(inputs, expected outputs, expected gradients) as small .npz files.  The reference never
+travels to the GPU box; the fixtures do.
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py block vit  # a subset
+
+Synthetic parameters and batches come from oracle/tvts_oracle.py (synth_params / synth_batch),
+so the test side can regenerate identical inputs without storing 186 M parameters.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("TVTS_REFERENCE", "/root/reference/v2")
+sys.path.insert(0, ROOT)
+
+from oracle import tvts_oracle as O  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- import shims
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []  # behave as a package
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    """Returns a namespace of the reference classes on the hot path."""
+    if "ref_ns" in globals():
+        return globals()["ref_ns"]
+    ident = lambda *a, **k: None  # noqa: E731
+    _stub("timm"); _stub("timm.models")
+    _stub("timm.models.layers", StdConv2dSame=object, DropPath=torch.nn.Identity, to_2tuple=ident,
+          trunc_normal_=ident)
+    _stub("torchvision"); _stub("torchvision.utils", make_grid=ident)
+    _stub("torchvision.ops"); _stub("torchvision.ops.misc", FrozenBatchNorm2d=torch.nn.Identity)
+    _stub("humanize")
+    # `base`: only BaseModel is needed for the model classes
+    base = _stub("base")
+    bm = _load("base.base_model", os.path.join(REF, "base/base_model.py"))
+    base.BaseModel = bm.BaseModel
+    # `utils.util`
+    utils = _stub("utils")
+    uu = _load("utils.util", os.path.join(REF, "utils/util.py"))
+    utils.util = uu
+    utils.inf_loop = uu.inf_loop
+    # `CLIP.clip` : real model.py, stubbed loader (no pretrained weights in the tree)
+    clip_pkg = _stub("CLIP")
+    clip_model = _load("CLIP.clip.model", os.path.join(REF, "CLIP/clip/model.py"))
+    clip_mod = _stub("CLIP.clip", model=clip_model)
+    clip_pkg.clip = clip_mod
+
+    def fake_load(path, device="cpu", **kw):
+        patch = 32 if "32" in path else 16
+        torch.manual_seed(1234)
+        return clip_model.CLIP(512, 224, 12, 768, patch, 77, 49408, 512, 8, 12), None
+    clip_mod.load = fake_load
+    model_pkg = _stub("model")
+    st = _load("model.sort_transformer", os.path.join(REF, "model/sort_transformer.py"))
+    ve16 = _load("model.video_encoder_ViT_B_16", os.path.join(REF, "model/video_encoder_ViT_B_16.py"))
+    ve32 = _load("model.video_encoder_ViT_B_32", os.path.join(REF, "model/video_encoder_ViT_B_32.py"))
+    loss = _load("model.loss", os.path.join(REF, "model/loss.py"))
+    m32 = _load("model.model_dist_TVTSv2_ViT_B_32", os.path.join(REF, "model/model_dist_TVTSv2_ViT_B_32.py"))
+    m16 = _load("model.model_dist_TVTSv2_ViT_B_16", os.path.join(REF, "model/model_dist_TVTSv2_ViT_B_16.py"))
+    model_pkg.sort_transformer = st
+    ns = types.SimpleNamespace(clip_model=clip_model, sort=st, ve16=ve16, ve32=ve32, loss=loss, m32=m32, m16=m16)
+    globals()["ref_ns"] = ns
+    return ns
+
+
+def import_reference_allgather():
+    """trainer.trainer.AllGather_multi (needs `logger` + base_trainer shims)."""
+    ns = import_reference()
+    _stub("logger", TensorboardWriter=object)
+    bt = _load("base.base_trainer", os.path.join(REF, "base/base_trainer.py"))
+    sys.modules["base"].Multi_BaseTrainer_dist = bt.Multi_BaseTrainer_dist
+    sys.modules["base"].BaseTrainer = bt.BaseTrainer
+    tr = _load("trainer.trainer", os.path.join(REF, "trainer/trainer.py"))
+    ns.trainer = tr
+    return tr
+
+
+# ----------------------------------------------------------------------------- helpers
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def sub(P, prefix):
+    return {k[len(prefix):]: v for k, v in P.items() if k.startswith(prefix)}
+
+
+class TinyRefModel(torch.nn.Module):
+    """Reference sub-modules at the tiny architecture, wired by the reference's own
+    TVTSv2_B_32.forward / compute_text / compute_video (called as unbound functions)."""
+
+    def __init__(self, ns, arch, P):
+        super().__init__()
+        a = arch
+        clip = ns.clip_model.CLIP(a["embed"], a["image"], 1, a["width"], a["patch"], a["context"], a["vocab"],
+                                  a["text_width"], a["text_heads"], a["text_layers"])
+        self.text_model = clip.transformer
+        self.text_token_embedding = clip.token_embedding
+        self.text_positional_embedding = clip.positional_embedding
+        self.text_ln_final = clip.ln_final
+        self.text_projection = clip.text_projection
+        self.video_model = ns.ve16.VisionTransformer(input_resolution=a["image"], patch_size=a["patch"],
+                                                     width=a["width"], layers=a["layers"], heads=a["heads"],
+                                                     output_dim=a["embed"], num_frames=a["num_frames"],
+                                                     mask_ratio=a["mask_ratio"])
+        self.pred_model = ns.sort.SortTransformer(num_classes=a["n_trans"], embed_dim=a["embed"],
+                                                  num_heads=a["sort_heads"])
+        missing = self.load_state_dict(P, strict=True)
+        self._ref = ns.m32.TVTSv2_B_32
+
+    def compute_text(self, t):
+        return self._ref.compute_text(self, t)
+
+    def compute_video(self, v, k):
+        return self._ref.compute_video(self, v, k)
+
+    def forward(self, data, return_embeds=True):
+        return self._ref.forward(self, data, return_embeds)
+
+
+def ref_losses(ns, te, ve, pred, label):
+    loss1 = ns.loss.NormSoftmaxLoss()(ns.m32.sim_matrix(ve, te))
+    loss2 = torch.nn.CrossEntropyLoss()(pred.reshape(-1, pred.shape[-1]), label.reshape(-1)) * 2
+    return loss1, loss2
+
+
+# ----------------------------------------------------------------------------- fixtures
+def gen_block():
+    """One ResidualSpaceTimeAttentionBlock (video_encoder_ViT_B_16.py:94-124), fwd + grads."""
+    ns = import_reference()
+    arch = O.tiny_arch()
+    P = O.synth_params(arch, seed=11)
+    pre = "video_model.transformer.resblocks.1."
+    blk = ns.ve16.ResidualSpaceTimeAttentionBlock(arch["width"], arch["heads"])
+    blk.load_state_dict(sub(P, pre), strict=True)
+    B, T, n = 2, 3, 5
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 1 + T * n, arch["width"], generator=g, requires_grad=True)
+    r = torch.randn(B, 1 + T * n, arch["width"], generator=g)
+    y = blk(x, "b (f n) d", "(b f) n d", "b (f n) d", "(b n) f d", n, T)
+    (y * r).sum().backward()
+    grads = {"g_" + k: v.grad for k, v in blk.named_parameters()}
+    save("block_tiny", x=x, r=r, y=y, gx=x.grad, T=T, n=n, seed=11, **grads)
+
+
+def gen_vit():
+    """VisionTransformer.forward with tube masking (video_encoder_ViT_B_16.py:176-235)."""
+    ns = import_reference()
+    arch = O.tiny_arch()
+    P = O.synth_params(arch, seed=12)
+    vit = ns.ve16.VisionTransformer(arch["image"], arch["patch"], arch["width"], arch["layers"], arch["heads"],
+                                    arch["embed"], num_frames=arch["num_frames"], mask_ratio=arch["mask_ratio"])
+    vit.load_state_dict(sub(P, "video_model."), strict=True)
+    batch = O.synth_batch(arch, B=2, T=3, seed=3)
+    out = vit(batch["video"], batch["keep_ind"])
+    g = torch.Generator().manual_seed(6)
+    r = torch.randn(out.shape, generator=g)
+    (out * r).sum().backward()
+    sel = ["conv1.weight", "positional_embedding", "temporal_embedding", "class_embedding", "proj",
+           "ln_pre.weight", "transformer.resblocks.0.timeattn.qkv.weight", "transformer.resblocks.1.mlp.c_fc.bias"]
+    grads = {"g_" + k: dict(vit.named_parameters())[k].grad for k in sel}
+    save("vit_tiny", out=out, r=r, seed=12, batch_seed=3, B=2, T=3, **grads)
+
+
+def gen_text():
+    """compute_text (model_dist_TVTSv2_ViT_B_32.py:97-111) on the CLIP text tower."""
+    ns = import_reference()
+    arch = O.tiny_arch()
+    P = O.synth_params(arch, seed=13)
+    m = TinyRefModel(ns, arch, P)
+    batch = O.synth_batch(arch, B=3, T=1, seed=4, caption_len=9)
+    ids = batch["text"].clone()
+    ids[1, 5] = arch["vocab"] - 1; ids[1, 6:] = 0  # a ragged row: EOT earlier than the others
+    before, emb = m.compute_text(ids)
+    g = torch.Generator().manual_seed(7)
+    r = torch.randn(emb.shape, generator=g)
+    (emb * r).sum().backward()
+    save("text_tiny", ids=ids, emb=emb, r=r, seed=13,
+         g_tok=m.text_token_embedding.weight.grad, g_pos=m.text_positional_embedding.grad,
+         g_proj=m.text_projection.grad, g_qkv0=m.text_model.resblocks[0].attn.in_proj_weight.grad,
+         g_lnf=m.text_ln_final.weight.grad)
+
+
+def gen_sort():
+    """SortTransformer.forward (sort_transformer.py:124-142)."""
+    ns = import_reference()
+    arch = O.tiny_arch()
+    P = O.synth_params(arch, seed=14)
+    sh = ns.sort.SortTransformer(num_classes=4, embed_dim=arch["embed"], num_heads=arch["sort_heads"])
+    sh.load_state_dict(sub(P, "pred_model."), strict=True)
+    g = torch.Generator().manual_seed(8)
+    text = torch.randn(2, 4, arch["embed"], generator=g)
+    tok = torch.randn(2, 11, arch["embed"], generator=g, requires_grad=True)
+    out = sh(text, tok)
+    r = torch.randn(out.shape, generator=g)
+    (out * r).sum().backward()
+    save("sort_tiny", text=text, tok=tok, out=out, r=r, g_tok=tok.grad, seed=14,
+         g_type=sh.type_embed.grad, g_head=sh.head.weight.grad, g_qkv1=sh.blocks[1].attn.qkv.weight.grad,
+         g_fc1b=sh.blocks[0].mlp.fc1.bias.grad)
+
+
+def gen_model_tiny():
+    """Whole TVTSv2 forward (reference's own forward wiring) + both losses + all grads, tiny arch."""
+    ns = import_reference()
+    arch = O.tiny_arch()
+    P = O.synth_params(arch, seed=15)
+    m = TinyRefModel(ns, arch, P)
+    batch = O.synth_batch(arch, B=3, T=3, seed=9, caption_len=10)
+    te, ve, pred = m(batch)
+    loss1, loss2 = ref_losses(ns, te, ve, pred, batch["label"])
+    (loss1 + loss2).backward()
+    gn = {k: v.grad.norm() for k, v in m.named_parameters() if v.grad is not None}
+    total = torch.sqrt(sum(v ** 2 for v in gn.values()))
+    sel = ["video_model.proj", "video_model.transformer.resblocks.0.timeattn.proj.weight",
+           "text_projection", "text_model.resblocks.2.mlp.c_proj.weight", "pred_model.head.weight",
+           "video_model.conv1.weight", "text_positional_embedding"]
+    grads = {"g_" + k: dict(m.named_parameters())[k].grad for k in sel}
+    save("model_tiny", te=te, ve=ve, pred=pred, loss1=loss1, loss2=loss2, grad_norm=total, seed=15, batch_seed=9,
+         B=3, T=3, caption_len=10, gn_names=np.array(list(gn.keys())), gn_vals=torch.stack(list(gn.values())),
+         **grads)
+    # WebVid-style batch: NT = 1, no sort head (model_dist..:87-90, trainer.py:494)
+    m.zero_grad()
+    b1 = O.synth_batch(arch, B=3, T=3, seed=10, n_trans=1, caption_len=10)
+    te, ve, pred = m(b1)
+    assert pred is None
+    l1 = ns.loss.NormSoftmaxLoss()(ns.m32.sim_matrix(ve, te))
+    l1.backward()
+    save("model_tiny_nt1", te=te, ve=ve, loss1=l1, seed=15, batch_seed=10,
+         g_proj=m.video_model.proj.grad, g_tproj=m.text_projection.grad)
+
+
+def gen_model_b32():
+    """The real TVTSv2_B_32 class at BASELINE config 1 (B=2, T=4, 49 patches, context 77)."""
+    ns = import_reference()
+    arch = O.ARCHS["B_32"]
+    P = O.synth_params(arch, seed=0)
+    args = types.SimpleNamespace(local_rank=0, rank=0, world_size=1)
+    m = ns.m32.TVTSv2_B_32(args, load_checkpoint="")
+    m.load_state_dict(P, strict=True)
+    assert list(m.state_dict().keys()) == list(P.keys()), "state-dict key order differs from param_shapes()"
+    batch = O.synth_batch(arch, B=2, T=4, seed=0)
+    te, ve, pred = m(batch)
+    loss1, loss2 = ref_losses(ns, te, ve, pred, batch["label"])
+    (loss1 + loss2).backward()
+    names, vals = [], []
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            names.append(k); vals.append(v.grad.norm())
+    total = torch.sqrt(sum(v ** 2 for v in vals))
+    pd = dict(m.named_parameters())
+    sel = {"g_video_proj": pd["video_model.proj"].grad[:8, :16],
+           "g_text_proj": pd["text_projection"].grad[:8, :16],
+           "g_head": pd["pred_model.head.weight"].grad,
+           "g_cfc11": pd["video_model.transformer.resblocks.11.mlp.c_fc.weight"].grad[:8, :16],
+           "g_tqkv0": pd["video_model.transformer.resblocks.0.timeattn.qkv.weight"].grad[:8, :16],
+           "g_temporal": pd["video_model.temporal_embedding"].grad[:, :16],
+           "g_textqkv10": pd["text_model.resblocks.10.attn.in_proj_weight"].grad[:8, :16]}
+    save("model_b32_cfg1", te=te, ve=ve, pred=pred, loss1=loss1, loss2=loss2, grad_norm=total, seed=0,
+         batch_seed=0, B=2, T=4, gn_names=np.array(names), gn_vals=torch.stack(vals), **sel)
+
+
+def gen_groups():
+    """Name -> optimizer group, by executing the reference entrypoint's own grouping statements
+    (train_dist_TVTSv2_ViT_B_16.py:66-107) on a module exposing the A13 parameter names."""
+    src = open(os.path.join(REF, "train_dist_TVTSv2_ViT_B_16.py")).read().splitlines()
+    start = next(i for i, l in enumerate(src) if "no_decay_names = [" in l)
+    stop = next(i for i, l in enumerate(src) if "optimizer_grouped_parameters = [" in l)
+    body = "\n".join(l[4:] if l.startswith("    ") else l for l in src[start:stop])
+    arch = O.ARCHS["B_16"]
+
+    class Fake:
+        def named_parameters(self_inner):
+            return [(k, torch.nn.Parameter(torch.zeros(1))) for k in O.param_shapes(arch)]
+    env = {"model": Fake()}
+    exec(compile(body, "<reference grouping>", "exec"), env)
+    names, gid = [], []
+    for gi, key in enumerate(["decay_new_params", "no_decay_new_params", "decay_clip_params", "no_decay_clip_params"]):
+        for n, _ in env[key]:
+            names.append(n); gid.append(gi)
+    frozen = [k for k, p in env["model"].named_parameters()]
+    grouped = set(names)
+    frozen = [k for k in O.param_shapes(arch) if k not in grouped]
+    save("param_groups_b16", names=np.array(names), group=np.array(gid), frozen=np.array(frozen))
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ns = import_reference()
+    tr = import_reference_allgather()
+    arch = O.tiny_arch()
+    P = O.synth_params(arch, seed=16)
+    m = TinyRefModel(ns, arch, P)
+    ddp = torch.nn.parallel.DistributedDataParallel(m, find_unused_parameters=True)
+    args = types.SimpleNamespace(local_rank=rank, rank=rank, world_size=world)
+    batch = O.synth_batch(arch, B=2, T=2, seed=100 + rank, caption_len=8)
+    te, ve, pred = ddp(batch)
+    ve_all = tr.AllGather_multi.apply(ve, world, args)     # trainer.py:481-482
+    te_all = tr.AllGather_multi.apply(te, world, args)
+    loss1 = ns.loss.NormSoftmaxLoss()(ns.m32.sim_matrix(ve_all, te_all))
+    loss2 = torch.nn.CrossEntropyLoss()(pred.reshape(-1, 4), batch["label"].reshape(-1)) * 2
+    (loss1 + loss2).backward()
+    pd = dict(m.named_parameters())
+    sel = ["video_model.proj", "text_projection", "pred_model.head.weight",
+           "video_model.transformer.resblocks.1.mlp.c_fc.weight", "text_token_embedding.weight"]
+    gn = torch.sqrt(sum(p.grad.norm() ** 2 for p in m.parameters() if p.grad is not None))
+    q.put((rank, float(loss1), float(loss2), float(gn), {k: pd[k].grad.clone().numpy() for k in sel}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gen_ddp2():
+    """The reference under gloo DDP, world 2: AllGather_multi + DDP averaging semantics."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    [p.join() for p in procs]
+    g0, g1 = res[0][4], res[1][4]
+    for k in g0:  # DDP leaves identical averaged grads on both ranks
+        assert np.allclose(g0[k], g1[k], atol=1e-6), k
+    save("ddp2_tiny", loss1=np.array([res[0][1], res[1][1]]), loss2=np.array([res[0][2], res[1][2]]),
+         grad_norm=res[0][3], seed=16, batch_seed0=100, batch_seed1=101, B=2, T=2, caption_len=8,
+         **{"g_" + k: v for k, v in g0.items()})
+
+
+GENS = {"block": gen_block, "vit": gen_vit, "text": gen_text, "sort": gen_sort, "model_tiny": gen_model_tiny,
+        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2}
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or list(GENS)
+    for w in which:
+        with torch.enable_grad():
+            GENS[w]()

@@ -1,0 +1,191 @@
+"""Pins the CPU oracle (oracle/tvts_oracle.py) against the fixtures produced by running the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tvts_oracle as O
+
+RTOL = 1e-5   # fp32 restatement vs reference: <= 1e-5 rel on activations / losses
+GTOL = 1e-4   # <= 1e-4 rel on gradients / grad-norm
+
+
+def relerr(a, b):
+    a = torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b), dtype=torch.float64) if not isinstance(b, torch.Tensor) else b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def leaves(P):
+    return {k: v.clone().requires_grad_(True) for k, v in P.items()}
+
+
+def test_block(golden):
+    f = golden("block_tiny")
+    arch = O.tiny_arch()
+    P = leaves(O.synth_params(arch, seed=int(f["seed"])))
+    x = torch.tensor(f["x"], requires_grad=True)
+    pre = "video_model.transformer.resblocks.1."
+    y = O.st_block(x, P, pre, arch, int(f["T"]), int(f["n"]))
+    assert relerr(f["y"], y.detach()) < RTOL
+    (y * torch.tensor(f["r"])).sum().backward()
+    assert relerr(f["gx"], x.grad) < GTOL
+    for k in f.files:
+        if k.startswith("g_") and k != "gx":
+            assert relerr(f[k], P[pre + k[2:]].grad) < GTOL, k
+
+
+def test_vit(golden):
+    f = golden("vit_tiny")
+    arch = O.tiny_arch()
+    P = leaves(O.synth_params(arch, seed=int(f["seed"])))
+    b = O.synth_batch(arch, B=int(f["B"]), T=int(f["T"]), seed=int(f["batch_seed"]))
+    _, out = O.video_tower(P, b["video"], b["keep_ind"], arch)
+    assert relerr(f["out"], out.detach()) < RTOL
+    (out * torch.tensor(f["r"])).sum().backward()
+    for k in f.files:
+        if k.startswith("g_"):
+            assert relerr(f[k], P["video_model." + k[2:]].grad) < GTOL, k
+
+
+@pytest.mark.parametrize("truncate", [True, False])
+def test_text(golden, truncate):
+    f = golden("text_tiny")
+    arch = O.tiny_arch()
+    P = leaves(O.synth_params(arch, seed=int(f["seed"])))
+    emb = O.text_tower(P, torch.tensor(f["ids"]), arch, truncate=truncate)
+    assert relerr(f["emb"], emb.detach()) < RTOL
+    (emb * torch.tensor(f["r"])).sum().backward()
+    assert relerr(f["g_tok"], P["text_token_embedding.weight"].grad) < GTOL
+    assert relerr(f["g_pos"], P["text_positional_embedding"].grad) < GTOL
+    assert relerr(f["g_proj"], P["text_projection"].grad) < GTOL
+    assert relerr(f["g_qkv0"], P["text_model.resblocks.0.attn.in_proj_weight"].grad) < GTOL
+    assert relerr(f["g_lnf"], P["text_ln_final.weight"].grad) < GTOL
+
+
+def test_sort(golden):
+    f = golden("sort_tiny")
+    arch = O.tiny_arch()
+    P = leaves(O.synth_params(arch, seed=int(f["seed"])))
+    tok = torch.tensor(f["tok"], requires_grad=True)
+    out = O.sort_head(P, torch.tensor(f["text"]), tok, arch)
+    assert relerr(f["out"], out.detach()) < RTOL
+    (out * torch.tensor(f["r"])).sum().backward()
+    assert relerr(f["g_tok"], tok.grad) < GTOL
+    assert relerr(f["g_type"], P["pred_model.type_embed"].grad) < GTOL
+    assert relerr(f["g_head"], P["pred_model.head.weight"].grad) < GTOL
+    assert relerr(f["g_qkv1"], P["pred_model.blocks.1.attn.qkv.weight"].grad) < GTOL
+    assert relerr(f["g_fc1b"], P["pred_model.blocks.0.mlp.fc1.bias"].grad) < GTOL
+
+
+def _check_model(f, arch, P, batch):
+    l1, l2, te, ve, pred = O.step_losses(P, batch, arch)
+    assert relerr(f["te"], te.detach()) < RTOL
+    assert relerr(f["ve"], ve.detach()) < RTOL
+    assert relerr(f["pred"], pred.detach()) < 10 * RTOL
+    assert abs(float(l1) - float(f["loss1"])) < 1e-5 * max(1.0, abs(float(f["loss1"])))
+    assert abs(float(l2) - float(f["loss2"])) < 1e-5 * max(1.0, abs(float(f["loss2"])))
+    (l1 + l2).backward()
+    gn = {k: float(v.grad.norm()) for k, v in P.items() if v.grad is not None}
+    total = sum(v * v for v in gn.values()) ** 0.5
+    assert abs(total - float(f["grad_norm"])) < GTOL * float(f["grad_norm"])
+    ref = dict(zip([str(s) for s in f["gn_names"]], f["gn_vals"]))
+    for k, v in ref.items():
+        assert abs(gn[k] - float(v)) <= 5e-4 * float(v) + 1e-7 * float(f["grad_norm"]), (k, gn[k], float(v))
+    return gn
+
+
+def test_model_tiny(golden):
+    f = golden("model_tiny")
+    arch = O.tiny_arch()
+    P = leaves(O.synth_params(arch, seed=int(f["seed"])))
+    b = O.synth_batch(arch, B=int(f["B"]), T=int(f["T"]), seed=int(f["batch_seed"]), caption_len=int(f["caption_len"]))
+    _check_model(f, arch, P, b)
+    for k in f.files:
+        if k.startswith("g_") and k not in ("gn_names", "gn_vals", "grad_norm"):
+            assert relerr(f[k], P[k[2:]].grad) < GTOL, k
+
+
+def test_model_tiny_nt1(golden):
+    f = golden("model_tiny_nt1")
+    arch = O.tiny_arch()
+    P = leaves(O.synth_params(arch, seed=int(f["seed"])))
+    b = O.synth_batch(arch, B=3, T=3, seed=int(f["batch_seed"]), n_trans=1, caption_len=10)
+    l1, l2, te, ve, pred = O.step_losses(P, b, arch)
+    assert pred is None and float(l2) == 0.0
+    assert relerr(f["te"], te.detach()) < RTOL and relerr(f["ve"], ve.detach()) < RTOL
+    assert abs(float(l1) - float(f["loss1"])) < 1e-5
+    l1.backward()
+    assert relerr(f["g_proj"], P["video_model.proj"].grad) < GTOL
+    assert relerr(f["g_tproj"], P["text_projection"].grad) < GTOL
+    assert P["pred_model.head.weight"].grad is None
+
+
+def test_model_b32_config1(golden):
+    """BASELINE config 1: the real TVTSv2_B_32 class, B=2, T=4 (reference ran at context 77)."""
+    f = golden("model_b32_cfg1")
+    arch = O.ARCHS["B_32"]
+    P = leaves(O.synth_params(arch, seed=0))
+    b = O.synth_batch(arch, B=2, T=4, seed=0)
+    _check_model(f, arch, P, b)
+    sl = {"g_video_proj": ("video_model.proj", (slice(0, 8), slice(0, 16))),
+          "g_text_proj": ("text_projection", (slice(0, 8), slice(0, 16))),
+          "g_head": ("pred_model.head.weight", (slice(None), slice(None))),
+          "g_cfc11": ("video_model.transformer.resblocks.11.mlp.c_fc.weight", (slice(0, 8), slice(0, 16))),
+          "g_tqkv0": ("video_model.transformer.resblocks.0.timeattn.qkv.weight", (slice(0, 8), slice(0, 16))),
+          "g_temporal": ("video_model.temporal_embedding", (slice(None), slice(0, 16))),
+          "g_textqkv10": ("text_model.resblocks.10.attn.in_proj_weight", (slice(0, 8), slice(0, 16)))}
+    for k, (name, idx) in sl.items():
+        assert relerr(f[k], P[name].grad[idx]) < 2e-4, k
+
+
+def test_param_groups(golden):
+    f = golden("param_groups_b16")
+    arch = O.ARCHS["B_16"]
+    groups, frozen = O.param_groups(list(O.param_shapes(arch)), arch)
+    ref = dict(zip([str(s) for s in f["names"]], [int(g) for g in f["group"]]))
+    mine = {n: gi for gi, names in enumerate(groups) for n in names}
+    assert mine == ref
+    assert sorted(frozen) == sorted(str(s) for s in f["frozen"])
+    # App. B #11 spot checks
+    assert mine["pred_model.blocks.0.norm1.weight"] == 1 and mine["text_ln_final.weight"] == 3
+    assert mine["video_model.positional_embedding"] == 2 and mine["video_model.temporal_embedding"] == 2
+
+
+def test_ddp2_emulation(golden):
+    """World-2 reference run (gloo DDP + AllGather_multi) vs the single-process emulation."""
+    f = golden("ddp2_tiny")
+    arch = O.tiny_arch()
+    P = leaves(O.synth_params(arch, seed=int(f["seed"])))
+    bs = [O.synth_batch(arch, B=int(f["B"]), T=int(f["T"]), seed=int(f[f"batch_seed{r}"]),
+                        caption_len=int(f["caption_len"])) for r in range(2)]
+    total, loss1, l2 = O.multi_rank_step(P, bs, arch)
+    assert abs(float(loss1) - float(f["loss1"][0])) < 1e-5 and abs(float(loss1) - float(f["loss1"][1])) < 1e-5
+    for r in range(2):
+        assert abs(float(l2[r]) - float(f["loss2"][r])) < 1e-5
+    total.backward()
+    gn = sum(float(v.grad.norm()) ** 2 for v in P.values() if v.grad is not None) ** 0.5
+    assert abs(gn - float(f["grad_norm"])) < GTOL * float(f["grad_norm"])
+    for k in f.files:
+        if k.startswith("g_"):
+            assert relerr(f[k], P[k[2:]].grad) < GTOL, k
+
+
+def test_hf_adamw_restated():
+    """Optimizer parity is UNPINNED (transformers.AdamW absent); this checks the restatement's
+    algebra against a closed form for two steps."""
+    p = torch.tensor([1.0, -2.0]); g = torch.tensor([0.5, 0.25])
+    m = torch.zeros(2); v = torch.zeros(2)
+    p0 = p.clone()
+    O.hf_adamw_step(p, g, m, v, 1, lr=1e-2, wd=0.1)
+    m1 = 0.1 * g; v1 = 0.001 * g * g
+    upd = 1e-2 * (1 - 0.999) ** 0.5 / (1 - 0.9) * m1 / (v1.sqrt() + 1e-6)
+    exp = (p0 - upd) * (1 - 1e-2 * 0.1)
+    assert torch.allclose(p, exp, rtol=1e-6, atol=1e-8)
+
+
+def test_flops_formula():
+    # BASELINE.md section 3 table
+    for name, T, step in (("B_32", 4, 167.5), ("B_32", 8, 313.3), ("B_16", 8, 606.1)):
+        f, b = O.step_flops_per_pair(O.ARCHS[name], T)
+        assert abs((f + b) / 1e9 - step) / step < 0.01, (name, (f + b) / 1e9)
