@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""TVTSv2 pretrain-step benchmark (BASELINE.json metric): video-text pairs/sec, ViT-B/16, 8 frames, mask 0.5,
+32-token captions, NT=4 captions per video, bf16 MFMA compute, synthetic data, random-init weights.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad, forward (text tower, space-time ViT, sort head), all-gather of embeddings, InfoNCE + 2*CE,
+backward, gradient all-reduce, fused HF-AdamW -- on a batch that is already resident in HBM.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (measured 2495)
+
+
+def step_flops_per_pair(a, T, caption_len=32, NT=4):
+    """SURVEY.md 8d algorithmic matmul FLOPs per pair (fwd, bwd)."""
+    p, W, E, Wt = a["patch"], a["width"], a["embed"], a["text_width"]
+    n = int((a["image"] // p) ** 2 * (1 - a["mask_ratio"]))
+    S, layers, Lt, L = 1 + T * n, a["layers"], a["text_layers"], caption_len
+    So = S + NT
+    patch = 2 * T * n * 3 * p * p * W
+    text_gemm = NT * Lt * L * 24 * Wt * Wt
+    fwd = (patch + layers * S * 32 * W * W + layers * (4 * n * T * (T + 1) * W + 4 * T * n * (n + 1) * W + 8 * S * W)
+           + 2 * S * W * E + text_gemm + NT * Lt * 4 * L * L * Wt + NT * 2 * Wt * E + 2 * So * 24 * E * E + 8 * So * So * E + 32 * E)
+    bwd = 2 * fwd - patch - (a["text_tune_from"] / Lt) * text_gemm
+    return fwd, bwd
+
+
+def cpu_baseline(arch_name, T, caption_len, pairs, max_seconds):
+    """The CPU oracle (oracle/tvts_oracle.py, a port) timed on this host: full step incl. HF-AdamW."""
+    from oracle import tvts_oracle as O
+    oarch = O.ARCHS[arch_name]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = O.synth_params(oarch, seed=0)
+    batch = O.synth_batch(oarch, B=pairs, T=T, seed=0, caption_len=caption_len)
+    state = {}
+    O.train_step(P, batch, oarch, state)  # warm-up
+    t0, n = time.time(), 0
+    while n < 1 or (time.time() - t0 < max_seconds and n < 4):
+        O.train_step(P, batch, oarch, state)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full steps (fwd+bwd+HF-AdamW) of the fp32 torch-CPU oracle, {arch_name}, T={T}, "
+                      f"{pairs} pairs/step, {caption_len}-token captions"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--arch", default="B_16")
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU (the reference config uses 12 on V100)")
+    ap.add_argument("--caption-len", type=int, default=32)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+
+    from tvts_amd import arch as A
+    from tvts_amd import hip as K
+    from tvts_amd.data_loader import synth_batch
+    from tvts_amd.model._common import TVTSv2Base
+    from tvts_amd.optim import FusedHFAdamW
+    from tvts_amd.step import StepRunner
+
+    a = A.ARCHS[args.arch]
+    margs = types.SimpleNamespace(local_rank=local_rank, rank=rank, world_size=world)
+    model = TVTSv2Base(margs, arch=a, init_seed=0)
+    groups = [[], [], [], []]
+    for name, p in model.named_parameters():
+        gi = A.param_group_of(name, a)
+        if gi < 0:
+            p.requires_grad = False
+        else:
+            groups[gi].append(p)
+    opt = FusedHFAdamW([dict(params=groups[i], lr=A.GROUP_HPARAMS[i][0], weight_decay=A.GROUP_HPARAMS[i][1])
+                        for i in range(4)], model.store, model=model)
+    runner = StepRunner(model, opt)
+    B, T = args.batch, args.frames
+    dev = model.store.device
+
+    # resident synthetic batches (rank-dependent seeds); inputs are copied into static buffers each step
+    pool = [synth_batch(a, B, T, seed=1000 * rank + i, caption_len=args.caption_len) for i in range(2)]
+    model._fresh_shadows(); model._sync_requires_grad()
+    pbs = [model.engine.prepare_batch(b) for b in pool]
+    labels = pool[0]["label"].reshape(-1).to(torch.int32).to(dev)
+    static = pbs[0]
+    srcs = [dict(video=pb["video"].clone(), ids=pb["ids"].clone(), keep=pb["keep"].clone()) for pb in pbs]
+
+    def load(i):
+        s = srcs[i % len(srcs)]
+        static["video"].copy_(s["video"]); static["ids"].copy_(s["ids"]); static["keep"].copy_(s["keep"])
+
+    def one_step(i, device_step):
+        load(i)
+        return runner.run(static, labels, device_step=device_step)
+
+    use_graph = (world == 1) and not args.no_graph
+    for i in range(max(args.warmup, 1)):
+        out = one_step(i, device_step=use_graph)
+    torch.cuda.synchronize()
+    graphs = None
+    if use_graph:
+        try:
+            graphs = []
+            for gi in range(len(srcs)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = one_step(gi, device_step=True)
+                graphs.append(g)
+            torch.cuda.synchronize()
+        except Exception as e:  # stay correct: fall back to eager launches
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graphs, use_graph = None, False
+            torch.cuda.synchronize()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if graphs is not None:
+            graphs[i % len(graphs)].replay()
+        else:
+            out = one_step(i, device_step=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    loss = float(out["loss1"]) + float(out["loss2"])
+
+    fwd, bwd = step_flops_per_pair(a, T, args.caption_len)
+    pairs_per_s = world * B * args.steps / dt
+    line = {
+        "metric": "video-text pairs/sec/node, TVTSv2 pretrain step", "value": pairs_per_s, "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"TVTSv2 ViT-{args.arch.replace('_', '/')} {T}-frame 224^2, mask {a['mask_ratio']}, "
+                               f"{args.caption_len}-token captions x4, full pretrain step (fwd+losses+bwd+HF-AdamW)",
+                   "pairs_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
+                   "hip_graph": bool(graphs is not None), "step_gflop_per_pair": (fwd + bwd) / 1e9,
+                   "final_loss": loss},
+        "step_mfma_frac": pairs_per_s * (fwd + bwd) / (world * PEAK_BF16_TFLOPS * 1e12),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel family = the bf16 MFMA GEMMs (gemm_nt_kernel / gemm_tn_kernel): one instrumented eager
+        # step with a HIP event pair around every GEMM launch on the launch stream.
+        K.GEMM_PROFILE = []
+        one_step(0, device_step=False)
+        torch.cuda.synchronize()
+        recs, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+        tot_ms = sum(s.elapsed_ms(e) for _, _, s, e in recs)
+        tot_fl = sum(f for _, f, _, _ in recs)
+        by = {}
+        for kind, f, s, e in recs:
+            d = by.setdefault(kind, [0, 0.0, 0.0]); d[0] += 1; d[1] += f; d[2] += s.elapsed_ms(e)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                            "kernel": "gemm_nt_kernel + gemm_tn_kernel (all MFMA GEMM launches of one step)",
+                            "launches": len(recs), "gemm_ms_per_step": tot_ms,
+                            "by_kernel": {k: {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]}
+                                          for k, v in by.items()}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.arch, T, args.caption_len, pairs=2, max_seconds=args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

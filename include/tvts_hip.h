@@ -1,0 +1,102 @@
+/* C ABI of libtvts_hip.so -- the MI355X (gfx950) kernels under the TVTSv2 pretrain step.
+ *
+ * The reference (TencentARC/TVTS v2) has no FFI: its hot path is stock PyTorch ops.
+ * Each entry point below replaces the ATen op(s) at the cited reference site; INTEGRATION.md shows the
+ * ctypes binding a maintainer adds.  Conventions: raw device pointers, explicit sizes / leading
+ * dimensions in ELEMENTS, asynchronous on `stream`, no allocation inside, re-entrant, return 0 or a
+ * hipError_t (> 0) / -22 for an invalid argument.  bf16 = 16-bit brain float, row-major everywhere.
+ */
+#ifndef TVTS_HIP_H
+#define TVTS_HIP_H
+#include <hip/hip_runtime_api.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TVTS_ACT_NONE = 0, TVTS_ACT_QUICK_GELU = 1, TVTS_ACT_GELU_ERF = 2 };
+enum { TVTS_ATTN_FULL = 0, TVTS_ATTN_SPACE = 1, TVTS_ATTN_TIME = 2, TVTS_ATTN_CLS = 3 };
+
+/* ---- GEMM (gemm.hip).  nn.Linear forward / dgrad: v2/model/video_encoder_ViT_B_16.py:26-27,41,74,105-109;
+ *      v2/CLIP/clip/model.py:175-181; v2/model/sort_transformer.py:21-23,41-42.  K % 64 == 0, N % 4 == 0.
+ *      out = [gate'(gate_h) *] act(A.B^T + bias) [+ residual]; preact (bf16) receives A.B^T + bias when act != 0. */
+int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                      const float* residual, int ldr, int act, void* preact, int ldp, const void* gate_h, int ldh,
+                      int gate_act, void* out, int ldc, int out_f32, hipStream_t stream);
+/* weight gradient: out[Na,Nb] (+)= P[M,Na]^T . Q[M,Nb], bf16 in, fp32 out (autograd of the Linear sites above) */
+int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb, float* out, int ldo,
+                      int accumulate, hipStream_t stream);
+/* strided fp32 matmul for the tiny products (text_projection model_dist..B_16.py:108, head sort_transformer.py:113,
+ * sim_matrix model_dist..B_16.py:126): C[i,j] (+)= alpha * sum_k A[i*sai+k*sak] * B[k*sbk+j*sbj] + bias[j] */
+int tvts_gemm_small_f32(const float* A, long sai, long sak, const float* B, long sbk, long sbj, int M, int N, int K,
+                        float alpha, const float* bias, float* C, long ldc, int accumulate, hipStream_t stream);
+/* bias gradient: out[n] += sum_m X[m,n] */
+int tvts_colsum_bf16(const void* X, int ld, int M, int N, float* out, hipStream_t stream);
+
+/* ---- LayerNorm (norm.hip): video_encoder_ViT_B_16.py:79-85 (eps 1e-5), sort_transformer.py:99 (eps 1e-6) */
+int tvts_layernorm_fwd(const float* x, int ldx, const int* rows, const float* gamma, const float* beta, float eps, int M,
+                       int W, void* y, int ldy, int y_f32, float* mean, float* rstd, hipStream_t stream);
+int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const float* x, int ldx, const int* rows, const float* mean,
+                       const float* rstd, const float* gamma, const float* res1, const float* res2, int ldr, int M, int W,
+                       float* dx, int lddx, void* dx_bf16, int lddxb, float* dgamma, float* dbeta, hipStream_t stream);
+
+/* ---- attention (attention.hip), head dim 64, packed qkv [rows, 3*heads*64]:
+ *      divided space-time attention video_encoder_ViT_B_16.py:11-15,38-76; causal text attention
+ *      CLIP/clip/model.py:185-187,330-336; sort-head attention sort_transformer.py:45-53 */
+int tvts_attn_fwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, void* out, int ldo,
+                  float* lse2, hipStream_t stream);
+int tvts_attn_delta(const void* dO, int lddo, const void* O, int ldo, int rows, int heads, float* delta,
+                    hipStream_t stream);
+int tvts_attn_bwd_dq(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
+                     int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, hipStream_t stream);
+int tvts_attn_bwd_dkv(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
+                      int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, float* cls_acc,
+                      hipStream_t stream);
+int tvts_attn_cls_finalize(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq, hipStream_t stream);
+void tvts_attn_set_transpose_read(int on);
+
+/* ---- token assembly (embed.hip): video_encoder_ViT_B_16.py:176-216; model_dist..B_16.py:69-76,98-100;
+ *      sort_transformer.py:124-128 */
+int tvts_patch_gather(const float* video, const int* keep, int B, int T, int n, int img, int patch, void* out, int ldo,
+                      hipStream_t stream);
+int tvts_vit_assemble(const float* patch, int ldp, const float* cls, const float* pos, const float* temporal,
+                      const int* keep, int B, int T, int n, int W, float* tok, int ldt, hipStream_t stream);
+int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int B, int T, int n, int W, void* dpatch, int ldp,
+                          float* dcls, float* dpos, float* dtemporal, hipStream_t stream);
+int tvts_text_embed(const int* ids, int ld_ids, int N, int L, const float* emb, const float* pos, int Wt, float* x, int ldx,
+                    hipStream_t stream);
+int tvts_text_embed_bwd(const float* dx, int ldx, const int* ids, int ld_ids, int N, int L, int Wt, float* demb, float* dpos,
+                        hipStream_t stream);
+int tvts_text_mean(const float* t, int NT, int B, int E, float* mean, float* before, hipStream_t stream);
+int tvts_text_mean_bwd(const float* dmean, int NT, int B, int E, float* dt, hipStream_t stream);
+int tvts_sort_assemble(const float* tok, int ldt, int B, int S, int off, int Sv, const float* text, int NT,
+                       const float* type, int E, float* xs, int ldx, hipStream_t stream);
+int tvts_sort_assemble_bwd(const float* dxs, int ldx, int B, int S, int off, int Sv, int NT, const float* dvid, int E,
+                           void* dout, int ldo, float* dtype, hipStream_t stream);
+int tvts_rows_gather(const float* src, int ld_src, const int* rows, int R, int W, float* dst, int ld_dst, int scatter_add,
+                     hipStream_t stream);
+
+/* ---- losses (loss.hip): model_dist..B_16.py:119-127, loss.py:13-25, trainer.py:487-492 */
+int tvts_l2norm_rows(const float* x, int R, int E, float eps, float* xn, float* inv, hipStream_t stream);
+int tvts_l2norm_rows_bwd(const float* dxn, const float* xn, const float* inv, int R, int E, float* dx, hipStream_t stream);
+int tvts_infonce(const float* x, int G, float* lse, float* dx, float* loss, hipStream_t stream);
+int tvts_cross_entropy(const float* logits, const int* labels, int R, int C, float scale, float* dlogits, float* loss,
+                       hipStream_t stream);
+
+/* ---- optimizer (optim.hip): transformers.AdamW as built at train_dist_TVTSv2_ViT_B_16.py:118-125 */
+int tvts_adamw_hf(float* p, const float* g, float* m, float* v, void* shadow_bf16, const unsigned char* chunk_group,
+                  int nchunks, const float* lr4, const float* wd4, int step, const int* step_dev, float beta1,
+                  float beta2, float eps, float grad_scale, hipStream_t stream);
+int tvts_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream);
+int tvts_transpose_bf16_batched(const void* src, void* dst, const void* tiles, int ntiles, hipStream_t stream);
+int tvts_probe_tr16(const void* in, void* out, hipStream_t stream);
+
+/* ---- timing helper for bench.py: HIP events on the stream the kernels run on */
+int tvts_event_create(void** ev);
+int tvts_event_record(void* ev, hipStream_t stream);
+int tvts_event_elapsed_ms(void* start, void* stop, float* ms);
+int tvts_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,64 @@
+"""World-size-2 gloo test of the data-parallel exchange steps (tvts_amd/dist.py) on CPU tensors, with the
+oracle as the compute, against the reference's own 2-rank run (tests/golden/ddp2_tiny.npz)."""
+import os
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ddp2_tiny.npz")
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import tvts_oracle as O
+    from tvts_amd import dist as D
+    f = np.load(GOLD)
+    arch = O.tiny_arch()
+    P = {k: v.clone().requires_grad_(True) for k, v in O.synth_params(arch, seed=int(f["seed"])).items()}
+    batch = O.synth_batch(arch, B=int(f["B"]), T=int(f["T"]), seed=int(f[f"batch_seed{rank}"]), caption_len=int(f["caption_len"]))
+    te, ve, pred = O.model_forward(P, batch, arch)
+    B = ve.shape[0]
+    assert D.world() == (world, rank)
+    v_all, t_all = D.allgather_embeds(ve.detach(), te.detach())
+    v_all.requires_grad_(True); t_all.requires_grad_(True)
+    loss1 = O.norm_softmax_loss(O.sim_matrix(v_all, t_all))
+    loss1.backward()
+    # AllGather_multi.backward: local rows only, no reduction
+    loss2 = O.sorting_ce(pred, batch["label"])
+    torch.autograd.backward([ve, te, loss2], [D.local_rows(v_all.grad, B), D.local_rows(t_all.grad, B), torch.ones(())])
+    # flat gradient buffer + asynchronous range reductions, 1/W applied afterwards
+    names = [k for k in P if P[k].grad is not None]
+    sizes = [P[k].numel() for k in names]
+    flat = torch.cat([P[k].grad.reshape(-1) for k in names])
+    sync = D.GradSync(flat, bucket_bytes=64 << 10)
+    cut = flat.numel() // 3
+    sync.reduce_range(cut, flat.numel())
+    sync.reduce_range(0, cut)
+    flat.mul_(sync.finish())
+    out, o = {}, 0
+    for k, n in zip(names, sizes):
+        out[k] = flat[o:o + n].view_as(P[k]).clone().numpy(); o += n
+    q.put((rank, float(loss1), float(loss2), float(flat.norm()), {k: out[k] for k in out if "g_" + k in f.files}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_matches_reference_ddp():
+    f = np.load(GOLD)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    [p.join() for p in procs]
+    for r in range(2):
+        assert abs(res[r][1] - float(f["loss1"][r])) < 1e-5   # every rank sees the same global InfoNCE
+        assert abs(res[r][2] - float(f["loss2"][r])) < 1e-5   # the sorting loss is local
+        assert abs(res[r][3] - float(f["grad_norm"])) < 1e-4 * float(f["grad_norm"])
+        for k, g in res[r][4].items():
+            ref = f["g_" + k]
+            assert np.linalg.norm(g - ref) < 1e-4 * np.linalg.norm(ref), k

@@ -1,0 +1,433 @@
+"""GPU parity of every C-ABI kernel against plain fp32 torch-CPU / oracle restatements (run with -m gpu)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tvts_oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tvts_amd import hip
+    return hip
+
+
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ probes
+def test_tr16_read_semantics(K):
+    """ds_read_b64_tr_b16: lane (l&15) of each 16-lane group receives column (l&15) of that group's 4x16 block."""
+    x = torch.arange(16 * 64, dtype=torch.float32).reshape(16, 64) % 251
+    out = torch.zeros(64 * 4, dtype=torch.bfloat16, device=DEV)
+    K.probe_tr16(bf(x).to(DEV), out)
+    got = out.float().cpu().reshape(64, 4)
+    exp = torch.empty(64, 4)
+    for l in range(64):
+        for e in range(4):
+            exp[l, e] = bf(x)[(l >> 4) * 4 + e, l & 15].float()
+    assert torch.equal(got, exp), (got[:20], exp[:20])
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (300, 256, 128), (1000, 768, 768), (77, 2304, 256), (9420, 768, 3072)])
+def test_gemm_nt_plain(K, M, N, K_):
+    a, b = bf(rnd(M, K_, seed=1)), bf(rnd(N, K_, seed=2) * K_ ** -0.5)
+    ref = a.float() @ b.float().t()
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 4e-3)):
+        out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+        K.gemm_nt(a.to(DEV), b.to(DEV), out)
+        assert rel(out.float(), ref) < tol, (dt, rel(out.float(), ref))
+
+
+def test_gemm_nt_transpose_detecting(K):
+    """A = [I | 0] with an asymmetric B: catches swapped rows/cols in the C write."""
+    M = N = 128
+    K_ = 128
+    a = torch.zeros(M, K_); a[:, :M] = torch.eye(M)
+    b = rnd(N, K_, seed=3)
+    out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    K.gemm_nt(bf(a).to(DEV), bf(b).to(DEV), out)
+    assert rel(out, bf(b).float()[:, :M].t()) < 1e-6
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_gemm_nt_epilogues(K, act):
+    M, N, K_ = 333, 512, 256
+    a, b = bf(rnd(M, K_, seed=4)), bf(rnd(N, K_, seed=5) * K_ ** -0.5)
+    bias, res = rnd(N, seed=6), rnd(M, N, seed=7)
+    fn = O.quick_gelu if act == "quick_gelu" else O.gelu_erf
+    pre = a.float() @ b.float().t() + bias
+    # bias + activation + pre-activation side output
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    h = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt(a.to(DEV), b.to(DEV), out, bias=bias.to(DEV), act=act, preact=h)
+    assert rel(h.float(), pre) < 4e-3 and rel(out.float(), fn(pre)) < 5e-3
+    # bias + fp32 residual, fp32 out
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    K.gemm_nt(a.to(DEV), b.to(DEV), out32, bias=bias.to(DEV), residual=res.to(DEV))
+    assert rel(out32, pre + res) < 2e-5
+    # activation-gradient gate: out = (a b^T) * act'(h)
+    hh = bf(rnd(M, N, seed=8))
+    x = hh.float().clone().requires_grad_(True)
+    fn(x).sum().backward()
+    g = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt(a.to(DEV), b.to(DEV), g, gate_h=hh.to(DEV), gate_act=act)
+    assert rel(g.float(), (a.float() @ b.float().t()) * x.grad) < 5e-3
+
+
+@pytest.mark.parametrize("M,Na,Nb", [(64, 128, 128), (200, 256, 128), (1000, 768, 256), (9420, 768, 768), (37, 512, 128)])
+def test_gemm_tn(K, M, Na, Nb):
+    p, q = bf(rnd(M, Na, seed=9)), bf(rnd(M, Nb, seed=10))
+    ref = p.float().t() @ q.float()
+    out = torch.full((Na, Nb), 7.0, dtype=torch.float32, device=DEV)
+    K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=False)
+    assert rel(out, ref) < 3e-5, rel(out, ref)
+    K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True)
+    assert rel(out, 2 * ref) < 3e-5
+
+
+def test_gemm_tn_views(K):
+    """P and Q as column slices of wider buffers (leading dimension != width)."""
+    M = 500
+    big = bf(rnd(M, 768, seed=11))
+    p, q = big[:, 128:384], big[:, 512:640]
+    out = torch.zeros(256, 128, dtype=torch.float32, device=DEV)
+    bd = big.to(DEV)
+    K.gemm_tn(bd[:, 128:384], bd[:, 512:640], out, accumulate=False)
+    assert rel(out, p.float().t() @ q.float()) < 3e-5
+
+
+def test_gemm_small_and_colsum(K):
+    a, b = rnd(37, 50, seed=12), rnd(50, 23, seed=13)
+    out = torch.zeros(37, 23, device=DEV)
+    K.gemm_small(a.to(DEV), b.to(DEV), out, M=37, N=23, K=50, sa=(50, 1), sb=(23, 1), alpha=0.5)
+    assert rel(out, 0.5 * a @ b) < 1e-5
+    out2 = torch.ones(50, 23, device=DEV)  # A^T via strides, accumulate
+    c = rnd(37, 23, seed=14)
+    K.gemm_small(a.to(DEV), c.to(DEV), out2, M=50, N=23, K=37, sa=(1, 50), sb=(23, 1), accumulate=True)
+    assert rel(out2, 1 + a.t() @ c) < 1e-5
+    x = bf(rnd(1001, 512, seed=15))
+    s = torch.ones(512, device=DEV)
+    K.colsum(x.to(DEV), s)
+    assert rel(s, 1 + x.float().sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("W,eps", [(768, 1e-5), (512, 1e-6), (128, 1e-5), (1280, 1e-5)])
+def test_layernorm(K, W, eps):
+    M = 301
+    x = rnd(M, W, seed=16) * 2 + 0.3
+    g, b = 1 + 0.1 * rnd(W, seed=17), 0.1 * rnd(W, seed=18)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = O.layer_norm(xr, gr, br, eps)
+    dy = bf(rnd(M, W, seed=19))
+    res = rnd(M, W, seed=20)
+    y.backward(dy.float())
+    yd = torch.empty(M, W, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    K.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), eps, yd, mean, rstd)
+    assert rel(yd.float(), y) < 4e-3
+    y32 = torch.empty(M, W, device=DEV)
+    K.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), eps, y32)
+    assert rel(y32, y) < 1e-5
+    dx, dxb = torch.empty(M, W, device=DEV), torch.empty(M, W, dtype=torch.bfloat16, device=DEV)
+    dg, db = torch.zeros(W, device=DEV), torch.zeros(W, device=DEV)
+    K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), dx, dx_bf16=dxb, res1=res.to(DEV), res2=res.to(DEV),
+                    dgamma=dg, dbeta=db)
+    assert rel(dx, xr.grad + 2 * res) < 1e-5
+    assert rel(dxb.float(), xr.grad + 2 * res) < 4e-3
+    assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+
+
+def test_layernorm_rows(K):
+    """Gathered rows (ln_final on the EOT rows, sort-head norm on the caption rows) and the scatter in backward."""
+    M, W, R = 40, 128, 6
+    x = rnd(M, W, seed=21)
+    rows = torch.tensor([3, 9, 10, 22, 39, 0], dtype=torch.int32)
+    g, b = 1 + 0.1 * rnd(W, seed=22), 0.1 * rnd(W, seed=23)
+    xr = x.clone().requires_grad_(True)
+    y = O.layer_norm(xr[rows.long()], g, b, 1e-5)
+    dy = rnd(R, W, seed=24)
+    y.backward(dy)
+    y32 = torch.empty(R, W, device=DEV)
+    mean, rstd = torch.empty(R, device=DEV), torch.empty(R, device=DEV)
+    K.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, y32, mean, rstd, rows=rows.to(DEV))
+    assert rel(y32, y) < 1e-5
+    dx = torch.zeros(M, W, device=DEV)
+    K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), dx, rows=rows.to(DEV))
+    assert rel(dx, xr.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _ref_divided(qkv, heads, mode, T, n, dO):
+    """Oracle divided attention on a given packed qkv (identity projections), + grads wrt qkv."""
+    B, S, W3 = qkv.shape
+    W = W3 // 3
+    x = qkv.clone().requires_grad_(True)
+    out = O.divided_attention(x, torch.eye(W3), torch.zeros(W3), torch.eye(W), torch.zeros(W), heads, mode, T, n)
+    out.backward(dO)
+    return out.detach(), x.grad
+
+
+@pytest.mark.parametrize("tr", [True, False])
+@pytest.mark.parametrize("mode,B,heads,T,n", [("time", 2, 2, 8, 5), ("space", 2, 2, 3, 21), ("space", 1, 3, 2, 98),
+                                              ("time", 1, 4, 12, 3), ("space", 2, 1, 8, 49)])
+def test_divided_attention(K, mode, B, heads, T, n, tr):
+    K.attn_set_transpose_read(tr)
+    try:
+        S, W = 1 + T * n, heads * 64
+        qkv = bf(rnd(B, S, 3 * W, seed=25))
+        dO = bf(rnd(B, S, W, seed=26))
+        ref_out, ref_dqkv = _ref_divided(qkv.float(), heads, mode, T, n, dO.float())
+        qd = qkv.reshape(B * S, 3 * W).to(DEV)
+        out = torch.full((B * S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B * S, heads, device=DEV)
+        K.attn_fwd(mode, qd, out, lse, B=B, heads=heads, S=S, T=T, n=n)
+        K.attn_fwd("cls", qd, out, lse, B=B, heads=heads, S=S, T=T, n=n)
+        assert rel(out.float().view(B, S, W), ref_out) < 8e-3, rel(out.float().view(B, S, W), ref_out)
+        dOd = dO.reshape(B * S, W).to(DEV)
+        delta = torch.empty(B * S, heads, device=DEV)
+        dqkv = torch.full((B * S, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        acc = torch.zeros(B, heads, 2, 64, device=DEV)
+        K.attn_delta(dOd, out, delta, rows=B * S, heads=heads)
+        K.attn_bwd_dq(mode, qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n)
+        K.attn_bwd_dq("cls", qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n)
+        K.attn_bwd_dkv(mode, qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n, cls_acc=acc)
+        K.attn_cls_finalize(acc, dqkv, B=B, heads=heads, S=S)
+        got = dqkv.float().view(B, S, 3 * W).cpu()
+        assert torch.isfinite(got).all()
+        for nm, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
+            assert rel(got[..., sl], ref_dqkv[..., sl]) < 2e-2, (nm, rel(got[..., sl], ref_dqkv[..., sl]))
+            # CLS rows separately: they are the cross-group sums
+            assert rel(got[:, 0, sl], ref_dqkv[:, 0, sl]) < 2e-2, (nm + "_cls", rel(got[:, 0, sl], ref_dqkv[:, 0, sl]))
+    finally:
+        K.attn_set_transpose_read(True)
+
+
+def _ref_full(qkv, heads, causal, dO):
+    B, S, W3 = qkv.shape
+    W, dh = W3 // 3, 64
+    x = qkv.clone().requires_grad_(True)
+    t = x.reshape(B, S, 3, heads, dh)
+    q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    s = (q * dh ** -0.5) @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((S, S), float("-inf")).triu(1)
+    o = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, S, W)
+    o.backward(dO)
+    return o.detach(), x.grad
+
+
+@pytest.mark.parametrize("tr", [True, False])
+@pytest.mark.parametrize("B,heads,S,causal", [(3, 2, 32, True), (2, 2, 77, True), (2, 2, 197, False), (1, 8, 789, False),
+                                              (4, 1, 9, True)])
+def test_full_attention(K, B, heads, S, causal, tr):
+    K.attn_set_transpose_read(tr)
+    try:
+        W = heads * 64
+        qkv, dO = bf(rnd(B, S, 3 * W, seed=27)), bf(rnd(B, S, W, seed=28))
+        ref_out, ref_d = _ref_full(qkv.float(), heads, causal, dO.float())
+        qd, dOd = qkv.reshape(B * S, 3 * W).to(DEV), dO.reshape(B * S, W).to(DEV)
+        out = torch.full((B * S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lse, delta = torch.empty(B * S, heads, device=DEV), torch.empty(B * S, heads, device=DEV)
+        K.attn_fwd("full", qd, out, lse, B=B, heads=heads, S=S, causal=causal)
+        assert rel(out.float().view(B, S, W), ref_out) < 8e-3
+        dqkv = torch.full((B * S, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        K.attn_delta(dOd, out, delta, rows=B * S, heads=heads)
+        K.attn_bwd_dq("full", qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, causal=causal)
+        K.attn_bwd_dkv("full", qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, causal=causal)
+        got = dqkv.float().view(B, S, 3 * W).cpu()
+        assert torch.isfinite(got).all()
+        for nm, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
+            assert rel(got[..., sl], ref_d[..., sl]) < 2e-2, (nm, rel(got[..., sl], ref_d[..., sl]))
+    finally:
+        K.attn_set_transpose_read(True)
+
+
+def test_attention_softmax_spike(K):
+    """Online-softmax rescale across key tiles: one key far above the rest in a late tile."""
+    B, heads, S = 1, 1, 200
+    qkv = bf(rnd(B, S, 192, seed=29))
+    qkv[0, 5, 0:64] = 6.0
+    qkv[0, 150, 64:128] = 6.0   # q5 . k150 = 2304/8 = 288 >> others
+    dO = bf(rnd(B, S, 64, seed=30))
+    ref_out, _ = _ref_full(qkv.float(), heads, False, dO.float())
+    out = torch.empty(S, 64, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(S, 1, device=DEV)
+    K.attn_fwd("full", qkv.reshape(S, 192).to(DEV), out, lse, B=1, heads=1, S=S)
+    assert rel(out.float().view(1, S, 64), ref_out) < 8e-3
+    assert rel(out.float()[5], ref_out[0, 5]) < 8e-3
+
+
+# ------------------------------------------------------------------------------------------------ embed kernels
+def test_patch_embed_and_assemble(K):
+    from tvts_amd import arch as A
+    arch = A.small_arch()
+    oarch = O.tiny_arch(**{k: arch[k] for k in ("image", "patch", "width", "heads", "layers", "embed", "mask_ratio")})
+    B, T = 2, 3
+    P = O.synth_params(oarch, seed=31)
+    batch = O.synth_batch(oarch, B=B, T=T, seed=32)
+    n, W, p = batch["keep_ind"].shape[1], arch["width"], arch["patch"]
+    keep = batch["keep_ind"].to(torch.int32).to(DEV)
+    cols = torch.empty(B * T * n, 3 * p * p, dtype=torch.bfloat16, device=DEV)
+    K.patch_gather(batch["video"].to(DEV), keep, cols, B=B, T=T, n=n, img=arch["image"], patch=p)
+    g = arch["image"] // p
+    pix = batch["video"].reshape(B, T, 3, g, p, g, p).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, T, g * g, 3 * p * p)
+    ref_cols = torch.gather(pix, 2, batch["keep_ind"][:, None, :, None].expand(B, T, n, 3 * p * p)).reshape(-1, 3 * p * p)
+    assert torch.equal(cols.float().cpu(), bf(ref_cols).float())
+    # assemble + ln_pre against the oracle's token embedding (with a bf16 conv GEMM in between)
+    wconv = P["video_model.conv1.weight"].reshape(W, -1)
+    pe = torch.empty(B * T * n, W, device=DEV)
+    K.gemm_nt(cols, bf(wconv).to(DEV), pe)
+    tok = torch.empty(B * (1 + T * n), W, device=DEV)
+    K.vit_assemble(pe, P["video_model.class_embedding"].to(DEV), P["video_model.positional_embedding"].to(DEV),
+                   P["video_model.temporal_embedding"].to(DEV), keep, tok, B=B, T=T, n=n)
+    x = torch.empty_like(tok)
+    K.layernorm_fwd(tok, P["video_model.ln_pre.weight"].to(DEV), P["video_model.ln_pre.bias"].to(DEV), 1e-5, x)
+    ref = O.video_embed_tokens(P, batch["video"], batch["keep_ind"], oarch).reshape(-1, W)
+    assert rel(x, ref) < 5e-3
+    # backward scatter
+    dtok = rnd(B * (1 + T * n), W, seed=33)
+    tokr = {k: P[k].clone().requires_grad_(True) for k in ("video_model.class_embedding", "video_model.positional_embedding",
+                                                           "video_model.temporal_embedding")}
+    S = 1 + T * n
+    pos = tokr["video_model.positional_embedding"]
+    patch_in = torch.zeros(B, T, n, W, requires_grad=True)
+    tk = patch_in + pos[1:][batch["keep_ind"]][:, None] + tokr["video_model.temporal_embedding"][:T][None, :, None]
+    full = torch.cat([(tokr["video_model.class_embedding"] + pos[0]).expand(B, 1, W), tk.reshape(B, T * n, W)], 1)
+    full.backward(dtok.view(B, S, W))
+    dpatch = torch.empty(B * T * n, W, dtype=torch.bfloat16, device=DEV)
+    dcls, dpos, dtmp = torch.zeros(W, device=DEV), torch.zeros(g * g + 1, W, device=DEV), torch.zeros(12, W, device=DEV)
+    K.vit_assemble_bwd(dtok.to(DEV), keep, dpatch, dcls, dpos, dtmp, B=B, T=T, n=n)
+    assert rel(dpatch.float(), patch_in.grad.reshape(-1, W)) < 4e-3
+    assert rel(dcls, tokr["video_model.class_embedding"].grad) < 1e-5
+    assert rel(dpos, pos.grad) < 1e-5
+    assert rel(dtmp, tokr["video_model.temporal_embedding"].grad) < 1e-5
+
+
+def test_text_embed_mean_sort_assemble(K):
+    N, L, Wt, V, ctx = 6, 7, 128, 50, 12
+    ids = torch.randint(0, V, (N, ctx), generator=torch.Generator().manual_seed(34), dtype=torch.int32)
+    emb, pos = rnd(V, Wt, seed=35), rnd(ctx, Wt, seed=36)
+    x = torch.empty(N * L, Wt, device=DEV)
+    K.text_embed(ids.to(DEV), emb.to(DEV), pos.to(DEV), x, N=N, L=L)
+    ref = emb[ids[:, :L].long()] + pos[:L]
+    assert rel(x, ref.reshape(-1, Wt)) < 1e-6
+    dx = rnd(N * L, Wt, seed=37)
+    demb, dpos = torch.zeros(V, Wt, device=DEV), torch.zeros(ctx, Wt, device=DEV)
+    K.text_embed_bwd(dx.to(DEV), ids.to(DEV), demb, dpos, N=N, L=L)
+    e2 = emb.clone().requires_grad_(True); p2 = pos.clone().requires_grad_(True)
+    (e2[ids[:, :L].long()] + p2[:L]).backward(dx.view(N, L, Wt))
+    assert rel(demb, e2.grad) < 1e-5 and rel(dpos, p2.grad) < 1e-5
+    # caption mean (clip-major) and its backward
+    NT, B, E = 4, 3, 128
+    t = rnd(NT * B, E, seed=38)
+    mean, before = torch.empty(B, E, device=DEV), torch.empty(B, NT, E, device=DEV)
+    K.text_mean(t.to(DEV), mean, before, NT=NT, B=B)
+    assert rel(mean, t.view(NT, B, E).mean(0)) < 1e-6 and rel(before, t.view(NT, B, E).permute(1, 0, 2)) < 1e-7
+    dmean = rnd(B, E, seed=39)
+    dt = torch.empty(NT * B, E, device=DEV)
+    K.text_mean_bwd(dmean.to(DEV), dt, NT=NT, B=B)
+    assert rel(dt, (dmean / NT).repeat(NT, 1)) < 1e-6
+    # sort-head assemble / backward
+    S = 5
+    tok, txt, ty = rnd(B * S, E, seed=40), rnd(B, NT, E, seed=41), rnd(2, E, seed=42)
+    xs = torch.empty(B * (S + NT), E, device=DEV)
+    K.sort_assemble(tok.to(DEV), txt.to(DEV), ty.to(DEV), xs, B=B, S=S, off=0, Sv=S, NT=NT)
+    ref = torch.cat([tok.view(B, S, E) + ty[0], txt + ty[1]], 1)
+    assert rel(xs, ref.reshape(-1, E)) < 1e-6
+    dxs, dvid = rnd(B * (S + NT), E, seed=43), rnd(B, E, seed=44)
+    dout = torch.empty(B * S, E, dtype=torch.bfloat16, device=DEV)
+    dty = torch.zeros(2, E, device=DEV)
+    K.sort_assemble_bwd(dxs.to(DEV), dvid.to(DEV), dout, dty, B=B, S=S, off=0, Sv=S, NT=NT)
+    d3 = dxs.view(B, S + NT, E)
+    rd = d3[:, :S].clone(); rd[:, 0] += dvid
+    assert rel(dout.float(), rd.reshape(-1, E)) < 4e-3
+    assert rel(dty, torch.stack([d3[:, :S].sum((0, 1)), d3[:, S:].sum((0, 1))])) < 1e-5
+    K.sort_assemble_bwd(None, dvid.to(DEV), dout, None, B=B, S=S, off=0, Sv=S, NT=NT)
+    rd = torch.zeros(B, S, E); rd[:, 0] = dvid
+    assert rel(dout.float(), rd.reshape(-1, E)) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize("G", [6, 96, 200])
+def test_losses(K, G):
+    from tvts_amd.engine import LossHead
+    E = 128
+    v, t = rnd(G, E, seed=45), rnd(G, E, seed=46)
+    vr, tr_ = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    ref = O.norm_softmax_loss(O.sim_matrix(vr, tr_))
+    ref.backward()
+    head = LossHead(torch.device(DEV))
+    loss, dv, dt = head.contrastive(v.to(DEV), t.to(DEV))
+    assert abs(float(loss) - float(ref)) < 2e-5 * max(1, abs(float(ref)))
+    assert rel(dv, vr.grad) < 1e-4 and rel(dt, tr_.grad) < 1e-4
+    pred = rnd(G, 4, seed=47).requires_grad_(True)
+    lab = torch.arange(4).repeat(G // 4 + 1)[:G]
+    r2 = O.sorting_ce(pred, lab)
+    r2.backward()
+    l2, dp = head.sorting(pred.detach().to(DEV), lab.to(torch.int32).to(DEV))
+    assert abs(float(l2) - float(r2)) < 1e-5 and rel(dp, pred.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_adamw_and_shadows(K):
+    n = 4096 * 3
+    p, g = rnd(n, seed=48), rnd(n, seed=49) * 0.1
+    m, v = torch.zeros(n), torch.zeros(n)
+    groups = torch.tensor([0] * 4 + [3] * 4 + [255] * 4, dtype=torch.uint8)
+    lr4, wd4 = [1e-2, 0, 0, 1e-3], [0.05, 0, 0, 0.0]
+    pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    sh = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    step_dev = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for step in (1, 2, 3):
+        gs = g * step
+        if step < 3:
+            K.adamw_hf(pd, gs.to(DEV), md, vd, sh, groups.to(DEV), lr4, wd4, step, grad_scale=0.5)
+        else:  # device-side step counter (graph-replay form)
+            step_dev.fill_(3)
+            K.adamw_hf(pd, gs.to(DEV), md, vd, sh, groups.to(DEV), lr4, wd4, 0, grad_scale=0.5, step_dev=step_dev)
+        for lo, hi, gi in ((0, 4096, 0), (4096, 8192, 3)):
+            O.hf_adamw_step(pr[lo:hi], 0.5 * gs[lo:hi], mr[lo:hi], vr[lo:hi], step, lr4[gi], wd4[gi])
+    assert rel(pd, pr) < 1e-6 and rel(md, mr) < 1e-6 and rel(vd, vr) < 1e-6
+    assert torch.equal(pd[8192:].cpu(), p[8192:])  # frozen chunks untouched
+    assert torch.equal(sh[:8192].float().cpu(), bf(pd[:8192].cpu()).float())
+    c = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    K.cast_f32_bf16(pd, c)
+    assert torch.equal(c.float().cpu(), bf(pd.cpu()).float())
+
+
+def test_param_store_shadows(K):
+    from tvts_amd import arch as A
+    from tvts_amd.engine import ParamStore
+    st = ParamStore(A.small_arch(), torch.device(DEV))
+    st.flat.copy_(torch.randn(st.total, generator=torch.Generator().manual_seed(50)))
+    st.refresh_shadows()
+    for name in ("video_model.conv1.weight", "video_model.proj", "text_model.resblocks.1.mlp.c_fc.weight",
+                 "pred_model.blocks.0.attn.qkv.weight"):
+        w = st.p(name).reshape(st.shapes[name][0], -1)
+        assert torch.equal(st.w(name).float(), w.to(torch.bfloat16).float())
+        assert torch.equal(st.wt(name).float(), w.t().to(torch.bfloat16).float())

@@ -1,0 +1,145 @@
+"""Architecture tables and the parameter inventory (reference state-dict names).
+
+Constructor arguments follow v2/model/model_dist_TVTSv2_ViT_{B_32,B_16,H_14}.py; the key order is the
+reference's ``state_dict()`` order, which the checkpoint's optimizer state indexes into.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+ARCHS = {
+    "B_32": dict(name="B_32", image=224, patch=32, width=768, heads=12, layers=12, embed=512,
+                 text_width=512, text_heads=8, text_layers=12, text_tune_from=9, vocab=49408, context=77,
+                 act="quick_gelu", tail="all_tokens", num_frames=12, mask_ratio=0.0,
+                 sort_heads=8, sort_depth=2, n_trans=4),
+    "B_16": dict(name="B_16", image=224, patch=16, width=768, heads=12, layers=12, embed=512,
+                 text_width=512, text_heads=8, text_layers=12, text_tune_from=9, vocab=49408, context=77,
+                 act="quick_gelu", tail="all_tokens", num_frames=12, mask_ratio=0.5,
+                 sort_heads=8, sort_depth=2, n_trans=4),
+    "H_14": dict(name="H_14", image=224, patch=14, width=1280, heads=16, layers=32, embed=1024,
+                 text_width=1024, text_heads=16, text_layers=24, text_tune_from=18, vocab=49408, context=77,
+                 act="gelu", tail="pooled_and_patches", num_frames=12, mask_ratio=0.7,
+                 sort_heads=16, sort_depth=2, n_trans=4),
+}
+
+
+def small_arch(**over) -> dict:
+    """A reduced architecture whose every dimension satisfies the HIP kernels' tiling constraints
+    (head dim 64, GEMM K % 64 == 0, patch % 8 == 0); used by the GPU parity tests and smoke()."""
+    a = dict(name="small", image=64, patch=16, width=256, heads=4, layers=2, embed=128,
+             text_width=128, text_heads=2, text_layers=3, text_tune_from=1, vocab=512, context=16,
+             act="quick_gelu", tail="all_tokens", num_frames=12, mask_ratio=0.5,
+             sort_heads=2, sort_depth=2, n_trans=4)
+    a.update(over)
+    return a
+
+
+def patches_per_frame(arch) -> int:
+    return (arch["image"] // arch["patch"]) ** 2
+
+
+def n_keep(arch) -> int:
+    # same float expression as v2/model/video_encoder_ViT_B_16.py:220
+    return int(patches_per_frame(arch) * (1 - arch["mask_ratio"]))
+
+
+def param_shapes(arch) -> "OrderedDict[str, Tuple[int, ...]]":
+    W, E, Wt, p = arch["width"], arch["embed"], arch["text_width"], arch["patch"]
+    o: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    o["text_positional_embedding"] = (arch["context"], Wt)
+    o["text_projection"] = (Wt, E)
+    for i in range(arch["text_layers"]):
+        pre = f"text_model.resblocks.{i}."
+        o[pre + "attn.in_proj_weight"] = (3 * Wt, Wt)
+        o[pre + "attn.in_proj_bias"] = (3 * Wt,)
+        o[pre + "attn.out_proj.weight"] = (Wt, Wt)
+        o[pre + "attn.out_proj.bias"] = (Wt,)
+        o[pre + "ln_1.weight"] = (Wt,)
+        o[pre + "ln_1.bias"] = (Wt,)
+        o[pre + "mlp.c_fc.weight"] = (4 * Wt, Wt)
+        o[pre + "mlp.c_fc.bias"] = (4 * Wt,)
+        o[pre + "mlp.c_proj.weight"] = (Wt, 4 * Wt)
+        o[pre + "mlp.c_proj.bias"] = (Wt,)
+        o[pre + "ln_2.weight"] = (Wt,)
+        o[pre + "ln_2.bias"] = (Wt,)
+    o["text_token_embedding.weight"] = (arch["vocab"], Wt)
+    o["text_ln_final.weight"] = (Wt,)
+    o["text_ln_final.bias"] = (Wt,)
+    o["video_model.class_embedding"] = (W,)
+    o["video_model.positional_embedding"] = (patches_per_frame(arch) + 1, W)
+    o["video_model.proj"] = (W, E)
+    o["video_model.temporal_embedding"] = (arch["num_frames"], W)
+    o["video_model.conv1.weight"] = (W, 3, p, p)
+    o["video_model.ln_pre.weight"] = (W,)
+    o["video_model.ln_pre.bias"] = (W,)
+    for i in range(arch["layers"]):
+        pre = f"video_model.transformer.resblocks.{i}."
+        for a in ("attn", "timeattn"):
+            o[pre + a + ".qkv.weight"] = (3 * W, W)
+            o[pre + a + ".qkv.bias"] = (3 * W,)
+            o[pre + a + ".proj.weight"] = (W, W)
+            o[pre + a + ".proj.bias"] = (W,)
+        o[pre + "ln_3.weight"] = (W,)
+        o[pre + "ln_3.bias"] = (W,)
+        o[pre + "ln_1.weight"] = (W,)
+        o[pre + "ln_1.bias"] = (W,)
+        o[pre + "mlp.c_fc.weight"] = (4 * W, W)
+        o[pre + "mlp.c_fc.bias"] = (4 * W,)
+        o[pre + "mlp.c_proj.weight"] = (W, 4 * W)
+        o[pre + "mlp.c_proj.bias"] = (W,)
+        o[pre + "ln_2.weight"] = (W,)
+        o[pre + "ln_2.bias"] = (W,)
+    o["video_model.ln_post.weight"] = (W,)
+    o["video_model.ln_post.bias"] = (W,)
+    o["pred_model.type_embed"] = (1, 2, E)
+    for i in range(arch["sort_depth"]):
+        pre = f"pred_model.blocks.{i}."
+        o[pre + "norm1.weight"] = (E,)
+        o[pre + "norm1.bias"] = (E,)
+        o[pre + "attn.qkv.weight"] = (3 * E, E)
+        o[pre + "attn.qkv.bias"] = (3 * E,)
+        o[pre + "attn.proj.weight"] = (E, E)
+        o[pre + "attn.proj.bias"] = (E,)
+        o[pre + "norm2.weight"] = (E,)
+        o[pre + "norm2.bias"] = (E,)
+        o[pre + "mlp.fc1.weight"] = (4 * E, E)
+        o[pre + "mlp.fc1.bias"] = (4 * E,)
+        o[pre + "mlp.fc2.weight"] = (E, 4 * E)
+        o[pre + "mlp.fc2.bias"] = (E,)
+    o["pred_model.norm.weight"] = (E,)
+    o["pred_model.norm.bias"] = (E,)
+    o["pred_model.head.weight"] = (arch["n_trans"], E)
+    o["pred_model.head.bias"] = (arch["n_trans"],)
+    return o
+
+
+def is_mfma_weight(name: str, shape) -> bool:
+    """Parameters consumed by the bf16 MFMA GEMMs (they get bf16 shadows, plain and transposed)."""
+    if name in ("video_model.proj", "video_model.conv1.weight"):
+        return True
+    if name.startswith("pred_model.head"):
+        return False
+    return len(shape) == 2 and name.endswith(("weight", "in_proj_weight")) and "embedding" not in name
+
+
+# optimizer grouping: v2/train_dist_TVTSv2_ViT_B_16.py:66-107 (H/14: train_dist_TVTSv2_ViT_H_14.py:68-71)
+GROUP_HPARAMS = ((1e-4, 0.05), (1e-4, 0.0), (1e-7, 0.05), (1e-7, 0.0))
+
+
+def param_group_of(name: str, arch) -> int:
+    """0 new-decay, 1 new-nodecay, 2 clip-decay, 3 clip-nodecay, -1 frozen (requires_grad False)."""
+    no_decay = ["bias", "LayerNorm", "ln_", "norm"]
+    if arch["name"] == "H_14":
+        no_decay += ["ls_", "LayerScale"]
+    nd = any(s in name for s in no_decay)
+    if "video_model" in name:
+        new = "timeattn" in name or "ln_3" in name
+        return (0 if new else 2) + int(nd)
+    if "text" in name:
+        if "resblocks" in name:
+            tune = ["resblocks.%d." % i for i in range(arch["text_tune_from"], arch["text_layers"])]
+            if not any(t in name for t in tune):
+                return -1
+        return 2 + int(nd)
+    return int(nd)

@@ -1,0 +1,546 @@
+// Fused softmax attention (forward, dQ, dK/dV) for every attention site of the TVTSv2 step, head dim 64.
+//
+// One kernel family, four token-index geometries over a packed qkv buffer [rows, 3*W] (q | k | v, heads
+// contiguous inside each third -- the layout of VarAttention.qkv, nn.MultiheadAttention.in_proj and
+// SelfAttention.qkv alike):
+//   FULL  : group (b,h); queries = keys = rows b*S .. b*S+S-1; optional causal mask
+//           (CLIP text tower v2/CLIP/clip/model.py:185-187,330-336; sort head v2/model/sort_transformer.py:45-53)
+//   SPACE : group (b,h,f); queries = the n patch tokens of frame f; keys = CLS token + those n tokens
+//   TIME  : group (b,h,p); queries = the T tokens at patch slot p; keys = CLS token + those T tokens
+//   CLS   : group (b,h); query = CLS token; keys = all S tokens
+//           (divided space-time attention, v2/model/video_encoder_ViT_B_16.py:38-76: q scaled by dh^-0.5
+//            before the CLS split :45-51, CLS k/v prepended to every group :56-60)
+// Nothing is regrouped in memory: the einops rearrange / repeat / cat of the reference become index math.
+//
+// MFMA formulation (wave64, v_mfma_f32_16x16x32_bf16): scores are computed TRANSPOSED, S^T = K Q^T, so
+// a lane holds 4 consecutive keys of ONE query (C layout: col = query = lane&15, rows = keys).  The
+// softmax reduction over keys is then in-lane + 2 cross-lane steps, and exp(S^T) converts in-lane into
+// the B operand of O^T = V^T P^T by choosing the MFMA k-slot <-> key permutation
+//   slot (l>>4)*8 + j  <->  key 32u + 16*(j>>2) + 4*(l>>4) + (j&3)
+// on both operands.  The matching V^T A-operand is gathered from an LDS image of the V tile with the
+// transposing read ds_read_b64_tr_b16.  Q/K/V/dO fragments that are k-contiguous are loaded straight from
+// global memory (16 B per lane) -- no LDS round trip, no P matrix in memory.
+// Backward recomputes P from the saved log-sum-exp (flash-attention style): one pass over key tiles for
+// dQ, one pass over query tiles for dK/dV.  In SPACE/TIME geometry the dK/dV pass also folds in the CLS
+// query (which attends every token), so each dqkv element is written exactly once; the CLS key/value
+// gradient is the only cross-group sum and goes through fp32 atomics + a tiny finalize kernel.
+#include "common.h"
+
+enum { MODE_FULL = 0, MODE_SPACE = 1, MODE_TIME = 2, MODE_CLS = 3 };
+#define DH 64
+#define VSTRIDE 160  // bytes per LDS row of a [rows][64] bf16 tile (128 + 32: conflict-free b64_tr reads)
+
+struct AttnGeom {
+    int B, heads, S, T, n;  // S tokens per sample (FULL: sequence length); T,n only for SPACE/TIME
+    int causal;
+    int ld;                 // qkv row stride (elements)
+    int W;                  // heads * 64
+    float scale2;           // dh^-0.5 * log2(e)
+    float scale;            // dh^-0.5
+};
+
+struct Grp { int b, h, sub, nq, nk; };
+
+template <int MODE>
+__device__ __forceinline__ int n_groups(const AttnGeom& g) {
+    if (MODE == MODE_SPACE) return g.B * g.heads * g.T;
+    if (MODE == MODE_TIME) return g.B * g.heads * g.n;
+    return g.B * g.heads;
+}
+template <int MODE>
+__device__ __forceinline__ Grp decode(const AttnGeom& g, int gid) {
+    Grp r;
+    if (MODE == MODE_SPACE) { r.sub = gid % g.T; gid /= g.T; r.nq = g.n; r.nk = g.n + 1; }
+    else if (MODE == MODE_TIME) { r.sub = gid % g.n; gid /= g.n; r.nq = g.T; r.nk = g.T + 1; }
+    else if (MODE == MODE_CLS) { r.sub = 0; r.nq = 1; r.nk = g.S; }
+    else { r.sub = 0; r.nq = g.S; r.nk = g.S; }
+    r.h = gid % g.heads;
+    r.b = gid / g.heads;
+    return r;
+}
+// token row of query i / key j of a group
+template <int MODE>
+__device__ __forceinline__ int q_row(const AttnGeom& g, const Grp& r, int i) {
+    const int base = r.b * g.S;
+    if (MODE == MODE_SPACE) return base + 1 + r.sub * g.n + i;
+    if (MODE == MODE_TIME) return base + 1 + i * g.n + r.sub;
+    if (MODE == MODE_CLS) return base;
+    return base + i;
+}
+template <int MODE>
+__device__ __forceinline__ int k_row(const AttnGeom& g, const Grp& r, int j) {
+    const int base = r.b * g.S;
+    if (MODE == MODE_SPACE) return j == 0 ? base : base + r.sub * g.n + j;
+    if (MODE == MODE_TIME) return j == 0 ? base : base + 1 + (j - 1) * g.n + r.sub;
+    return base + j;
+}
+// queries with the CLS query prepended (SPACE/TIME dK/dV pass)
+template <int MODE>
+__device__ __forceinline__ int qx_row(const AttnGeom& g, const Grp& r, int i) {
+    if (MODE == MODE_SPACE || MODE == MODE_TIME) return i == 0 ? r.b * g.S : q_row<MODE>(g, r, i - 1);
+    return q_row<MODE>(g, r, i);
+}
+
+__device__ __forceinline__ bf16x8 ldg8(const bf16* p) { return *(const bf16x8*)p; }
+
+// stage `nrows` (<= 64) rows x 64 bf16 (rows given by a functor) into a wave-private LDS tile
+template <typename RowFn>
+__device__ __forceinline__ void stage_tile(char* tile, int nrows, int lane, const bf16* base, int ld, int col0, RowFn rowfn) {
+    for (int c = lane; c < nrows * 8; c += 64) {
+        const int r = c >> 3, ch = c & 7;
+        const bf16x8 v = ldg8(base + (size_t)rowfn(r) * ld + col0 + ch * 8);
+        *(bf16x8*)(tile + r * VSTRIDE + ch * 16) = v;
+    }
+}
+
+// A-operand fragment of X^T (rows = 16 columns d of block dt, k-slots = tile rows of k-step u) from a
+// row-major LDS tile: two transposing reads, each a [4 rows][16 cols] block per 16-lane group.
+template <bool TR>
+__device__ __forceinline__ bf16x8 frag_T(const char* tile, int u, int dt, int lane) {
+    const int gq = lane >> 4, i = lane & 15;
+    bf16x8 out;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row0 = u * 32 + half * 16 + gq * 4;
+        if (TR) {
+            const char* p = tile + (row0 + (i >> 2)) * VSTRIDE + dt * 32 + (i & 3) * 8;
+            const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))p);
+            const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[half * 4 + e] = tb[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[half * 4 + e] = *(const bf16*)(tile + (row0 + e) * VSTRIDE + (dt * 16 + i) * 2);
+        }
+    }
+    return out;
+}
+
+__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups holding one query/key column
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int MODE, bool TR>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                       int ldo, float* __restrict__ lse2) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * VSTRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* vt = smem + wave * 64 * VSTRIDE;
+    const int nq_max = (MODE == MODE_SPACE) ? g.n : (MODE == MODE_TIME) ? g.T : (MODE == MODE_CLS) ? 1 : g.S;
+    const int qtiles = (nq_max + 15) >> 4;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= n_groups<MODE>(g) * qtiles) return;
+    const Grp r = decode<MODE>(g, item / qtiles);
+    const int q0 = (item % qtiles) * 16;
+    const int gq = lane >> 4, li = lane & 15;
+    const int hcol = r.h * DH;
+
+    const int qi = q0 + li;                       // this lane's query (column of S^T)
+    const int qi_c = qi < r.nq ? qi : r.nq - 1;
+    const bf16* qp = qkv + (size_t)q_row<MODE>(g, r, qi_c) * g.ld + hcol;
+    bf16x8 qf[2];
+    qf[0] = ldg8(qp + gq * 8);
+    qf[1] = ldg8(qp + 32 + gq * 8);
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
+
+    int nk_eff = r.nk;
+    if (MODE == MODE_FULL && g.causal) { const int lim = q0 + 16; nk_eff = lim < r.nk ? lim : r.nk; }
+
+    for (int kt0 = 0; kt0 < nk_eff; kt0 += 64) {
+        const int rows = (nk_eff - kt0) < 64 ? (nk_eff - kt0) : 64;
+        stage_tile(vt, 64, lane, qkv, g.ld, 2 * g.W + hcol, [&](int rr) {
+            int j = kt0 + rr; j = j < r.nk ? j : r.nk - 1; return k_row<MODE>(g, r, j); });
+        f32x4 st[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            st[t] = (f32x4){0, 0, 0, 0};
+            if (t * 16 < rows) {
+                int kj = kt0 + t * 16 + li; kj = kj < r.nk ? kj : r.nk - 1;
+                const bf16* kp = qkv + (size_t)k_row<MODE>(g, r, kj) * g.ld + g.W + hcol;
+                const bf16x8 k0 = ldg8(kp + gq * 8), k1 = ldg8(kp + 32 + gq * 8);
+                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[0], st[t], 0, 0, 0);
+                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[1], st[t], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = kt0 + t * 16 + gq * 4 + e;
+                const bool ok = key < r.nk && !(MODE == MODE_FULL && g.causal && key > qi);
+                const float s = ok ? st[t][e] * g.scale2 : -INFINITY;
+                st[t][e] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = group_max(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = exp2f(st[t][e] - m_new);
+                st[t][e] = p;
+                rs += p;
+            }
+        rs = group_sum(rs);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u * 32 < rows) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 vf = frag_T<TR>(vt, u, dt, lane);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (qi < r.nq) {
+        const float inv = 1.0f / l_run;
+        const int row = q_row<MODE>(g, r, qi);
+        bf16* op = out + (size_t)row * ldo + hcol;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x4 v = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
+            *(bf16x4*)(op + dt * 16 + gq * 4) = v;
+        }
+        if (gq == 0) lse2[(size_t)row * g.heads + r.h] = m_run + log2f(l_run);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ D = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ dO, int lddo, const bf16* __restrict__ O,
+                                                         int ldo, int rows, int heads, float* __restrict__ delta) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (row, head, chunk of 8)
+    const long total = (long)rows * heads * 8;
+    float s = 0.f;
+    long rh = idx >> 3;
+    if (idx < total) {
+        const int row = (int)(rh / heads), h = (int)(rh % heads), ch = (int)(idx & 7);
+        const bf16x8 a = ldg8(dO + (size_t)row * lddo + h * DH + ch * 8);
+        const bf16x8 b = ldg8(O + (size_t)row * ldo + h * DH + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)b[e];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (idx < total && (idx & 7) == 0) delta[rh] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <int MODE, bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnGeom g, const bf16* __restrict__ qkv,
+                                                          const bf16* __restrict__ dO, int lddo,
+                                                          const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                          bf16* __restrict__ dqkv, int lddq) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * VSTRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* kt_lds = smem + wave * 64 * VSTRIDE;
+    const int nq_max = (MODE == MODE_SPACE) ? g.n : (MODE == MODE_TIME) ? g.T : (MODE == MODE_CLS) ? 1 : g.S;
+    const int qtiles = (nq_max + 15) >> 4;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= n_groups<MODE>(g) * qtiles) return;
+    const Grp r = decode<MODE>(g, item / qtiles);
+    const int q0 = (item % qtiles) * 16;
+    const int gq = lane >> 4, li = lane & 15;
+    const int hcol = r.h * DH;
+
+    const int qi = q0 + li;
+    const int qi_c = qi < r.nq ? qi : r.nq - 1;
+    const int qrow = q_row<MODE>(g, r, qi_c);
+    const bf16* qp = qkv + (size_t)qrow * g.ld + hcol;
+    const bf16* dop = dO + (size_t)qrow * lddo + hcol;
+    bf16x8 qf[2], dof[2];
+    qf[0] = ldg8(qp + gq * 8); qf[1] = ldg8(qp + 32 + gq * 8);
+    dof[0] = ldg8(dop + gq * 8); dof[1] = ldg8(dop + 32 + gq * 8);
+    const float lse = lse2[(size_t)qrow * g.heads + r.h];
+    const float dlt = delta[(size_t)qrow * g.heads + r.h];
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0, 0, 0, 0};
+    int nk_eff = r.nk;
+    if (MODE == MODE_FULL && g.causal) { const int lim = q0 + 16; nk_eff = lim < r.nk ? lim : r.nk; }
+
+    for (int kt0 = 0; kt0 < nk_eff; kt0 += 64) {
+        const int rows = (nk_eff - kt0) < 64 ? (nk_eff - kt0) : 64;
+        stage_tile(kt_lds, 64, lane, qkv, g.ld, g.W + hcol, [&](int rr) {
+            int j = kt0 + rr; j = j < r.nk ? j : r.nk - 1; return k_row<MODE>(g, r, j); });
+        f32x4 ds[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ds[t] = (f32x4){0, 0, 0, 0};
+            if (t * 16 < rows) {
+                int kj = kt0 + t * 16 + li; kj = kj < r.nk ? kj : r.nk - 1;
+                const size_t krow = (size_t)k_row<MODE>(g, r, kj) * g.ld;
+                const bf16* kp = qkv + krow + g.W + hcol;
+                const bf16* vp = qkv + krow + 2 * g.W + hcol;
+                f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(kp + gq * 8), qf[0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(kp + 32 + gq * 8), qf[1], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp + gq * 8), dof[0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp + 32 + gq * 8), dof[1], dp, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = kt0 + t * 16 + gq * 4 + e;
+                    const bool ok = key < r.nk && !(MODE == MODE_FULL && g.causal && key > qi);
+                    const float p = ok ? exp2f(s[e] * g.scale2 - lse) : 0.f;
+                    ds[t][e] = p * (dp[e] - dlt) * g.scale;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u * 32 < rows) {
+                bf16x8 dsf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsf[j] = (bf16)ds[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(kt_lds, u, dt, lane), dsf, acc[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (qi < r.nq) {
+        bf16* dq = dqkv + (size_t)qrow * lddq + hcol;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x4 v = {(bf16)acc[dt][0], (bf16)acc[dt][1], (bf16)acc[dt][2], (bf16)acc[dt][3]};
+            *(bf16x4*)(dq + dt * 16 + gq * 4) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <int MODE, bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnGeom g, const bf16* __restrict__ qkv,
+                                                           const bf16* __restrict__ dO, int lddo,
+                                                           const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                           bf16* __restrict__ dqkv, int lddq, float* __restrict__ cls_acc) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 2 * 32 * VSTRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* q_lds = smem + wave * 2 * 32 * VSTRIDE;
+    char* do_lds = q_lds + 32 * VSTRIDE;
+    constexpr bool EXT = (MODE == MODE_SPACE || MODE == MODE_TIME);
+    const int nk_max = (MODE == MODE_SPACE) ? g.n + 1 : (MODE == MODE_TIME) ? g.T + 1 : g.S;
+    const int ktiles = (nk_max + 15) >> 4;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= n_groups<MODE>(g) * ktiles) return;
+    const Grp r = decode<MODE>(g, item / ktiles);
+    const int k0 = (item % ktiles) * 16;
+    const int gq = lane >> 4, li = lane & 15;
+    const int hcol = r.h * DH;
+    const int nqx = EXT ? r.nq + 1 : r.nq;
+
+    const int kj = k0 + li;                      // this lane's key (column)
+    const int kj_c = kj < r.nk ? kj : r.nk - 1;
+    const int krow = k_row<MODE>(g, r, kj_c);
+    const bf16* kp = qkv + (size_t)krow * g.ld + g.W + hcol;
+    const bf16* vp = qkv + (size_t)krow * g.ld + 2 * g.W + hcol;
+    bf16x8 kb[2], vb[2];
+    kb[0] = ldg8(kp + gq * 8); kb[1] = ldg8(kp + 32 + gq * 8);
+    vb[0] = ldg8(vp + gq * 8); vb[1] = ldg8(vp + 32 + gq * 8);
+
+    f32x4 dv[4], dk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
+
+    int q_begin = 0;
+    if (MODE == MODE_FULL && g.causal) q_begin = k0 & ~31;  // queries before the first key of the tile see none of it
+
+    for (int qt0 = q_begin; qt0 < nqx; qt0 += 32) {
+        auto rowfn = [&](int rr) { int i = qt0 + rr; i = i < nqx ? i : nqx - 1; return qx_row<MODE>(g, r, i); };
+        stage_tile(q_lds, 32, lane, qkv, g.ld, hcol, rowfn);
+        stage_tile(do_lds, 32, lane, dO, lddo, hcol, rowfn);
+        bf16x8 pf, dsf;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+            const char* qa = q_lds + (t * 16 + li) * VSTRIDE + gq * 16;
+            const char* da = do_lds + (t * 16 + li) * VSTRIDE + gq * 16;
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)qa, kb[0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(qa + 64), kb[1], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)da, vb[0], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(da + 64), vb[1], dp, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int qi = qt0 + t * 16 + gq * 4 + e;  // (extended) query index of this row
+                bool ok = qi < nqx && kj < r.nk;
+                if (MODE == MODE_FULL && g.causal) ok = ok && kj <= qi;
+                if (EXT) ok = ok && !(qi == 0 && kj == 0 && r.sub != 0);  // CLS query x CLS key counted once
+                float p = 0.f, d = 0.f;
+                if (ok) {
+                    const int qrow = qx_row<MODE>(g, r, qi);
+                    const float lse = lse2[(size_t)qrow * g.heads + r.h];
+                    const float dlt = delta[(size_t)qrow * g.heads + r.h];
+                    p = exp2f(s[e] * g.scale2 - lse);
+                    d = p * (dp[e] - dlt) * g.scale;
+                }
+                pf[t * 4 + e] = (bf16)p;
+                dsf[t * 4 + e] = (bf16)d;
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(do_lds, 0, dt, lane), pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(q_lds, 0, dt, lane), dsf, dk[dt], 0, 0, 0);
+        }
+    }
+    if (kj < r.nk) {
+        if (EXT && kj == 0) {  // CLS key/value: summed over all groups of (b,h)
+            float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 2) * DH;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(a + dt * 16 + gq * 4 + e, dk[dt][e]);
+                    atomicAdd(a + DH + dt * 16 + gq * 4 + e, dv[dt][e]);
+                }
+        } else {
+            bf16* dkp = dqkv + (size_t)krow * lddq + g.W + hcol;
+            bf16* dvp = dqkv + (size_t)krow * lddq + 2 * g.W + hcol;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *(bf16x4*)(dkp + dt * 16 + gq * 4) = (bf16x4){(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
+                *(bf16x4*)(dvp + dt * 16 + gq * 4) = (bf16x4){(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
+            }
+        }
+    }
+}
+
+__global__ void attn_cls_finalize_kernel(const float* __restrict__ cls_acc, int B, int heads, int S, int W,
+                                         bf16* __restrict__ dqkv, int lddq) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b, h, kv, d)
+    if (idx >= B * heads * 2 * DH) return;
+    const int d = idx % DH, kv = (idx / DH) % 2, h = (idx / (2 * DH)) % heads, b = idx / (2 * DH * heads);
+    dqkv[(size_t)(b * S) * lddq + (1 + kv) * W + h * DH + d] = (bf16)cls_acc[idx];
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static int g_use_tr = 1;
+extern "C" void tvts_attn_set_transpose_read(int on) { g_use_tr = on ? 1 : 0; }
+
+static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int n, int causal, int ld) {
+    if (B <= 0 || heads <= 0 || S <= 0 || ld % 8) return TVTS_EINVAL;
+    if ((mode == MODE_SPACE || mode == MODE_TIME) && (T <= 0 || n <= 0 || S != 1 + T * n)) return TVTS_EINVAL;
+    if (mode < MODE_FULL || mode > MODE_CLS) return TVTS_EINVAL;
+    g.B = B; g.heads = heads; g.S = S; g.T = T; g.n = n; g.causal = causal; g.ld = ld; g.W = heads * DH;
+    g.scale = 0.125f;
+    g.scale2 = 0.125f * 1.4426950408889634f;
+    return TVTS_OK;
+}
+static int items_q(const AttnGeom& g, int mode) {
+    const int nq = mode == MODE_SPACE ? g.n : mode == MODE_TIME ? g.T : mode == MODE_CLS ? 1 : g.S;
+    const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : mode == MODE_TIME ? g.B * g.heads * g.n : g.B * g.heads;
+    return groups * ceil_div(nq, 16);
+}
+static int items_k(const AttnGeom& g, int mode) {
+    const int nk = mode == MODE_SPACE ? g.n + 1 : mode == MODE_TIME ? g.T + 1 : g.S;
+    const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : mode == MODE_TIME ? g.B * g.heads * g.n : g.B * g.heads;
+    return groups * ceil_div(nk, 16);
+}
+
+#define DISPATCH_MODE(KERNEL, mode, ...)                                                        \
+    do {                                                                                        \
+        if (g_use_tr) {                                                                         \
+            switch (mode) {                                                                     \
+                case MODE_FULL: hipLaunchKernelGGL((KERNEL<MODE_FULL, true>), __VA_ARGS__); break;   \
+                case MODE_SPACE: hipLaunchKernelGGL((KERNEL<MODE_SPACE, true>), __VA_ARGS__); break; \
+                case MODE_TIME: hipLaunchKernelGGL((KERNEL<MODE_TIME, true>), __VA_ARGS__); break;   \
+                case MODE_CLS: hipLaunchKernelGGL((KERNEL<MODE_CLS, true>), __VA_ARGS__); break;     \
+                default: return TVTS_EINVAL;                                                    \
+            }                                                                                   \
+        } else {                                                                                \
+            switch (mode) {                                                                     \
+                case MODE_FULL: hipLaunchKernelGGL((KERNEL<MODE_FULL, false>), __VA_ARGS__); break;   \
+                case MODE_SPACE: hipLaunchKernelGGL((KERNEL<MODE_SPACE, false>), __VA_ARGS__); break; \
+                case MODE_TIME: hipLaunchKernelGGL((KERNEL<MODE_TIME, false>), __VA_ARGS__); break;   \
+                case MODE_CLS: hipLaunchKernelGGL((KERNEL<MODE_CLS, false>), __VA_ARGS__); break;     \
+                default: return TVTS_EINVAL;                                                    \
+            }                                                                                   \
+        }                                                                                       \
+    } while (0)
+
+// out[rows, ldo] (heads merged, the layout the output projection consumes), lse2[rows, heads]
+extern "C" int tvts_attn_fwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+                             void* out, int ldo, float* lse2, hipStream_t stream) {
+    AttnGeom g;
+    int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
+    if (rc) return rc;
+    if (ldo % 4) return TVTS_EINVAL;
+    const int blocks = ceil_div(items_q(g, mode), 4);
+    DISPATCH_MODE(attn_fwd_kernel, mode, dim3(blocks), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+extern "C" int tvts_attn_delta(const void* dO, int lddo, const void* O, int ldo, int rows, int heads, float* delta,
+                               hipStream_t stream) {
+    if (rows <= 0 || heads <= 0 || lddo % 8 || ldo % 8) return TVTS_EINVAL;
+    const long total = (long)rows * heads * 8;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16*)dO, lddo,
+                       (const bf16*)O, ldo, rows, heads, delta);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+extern "C" int tvts_attn_bwd_dq(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+                                const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
+                                hipStream_t stream) {
+    AttnGeom g;
+    int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
+    if (rc) return rc;
+    if (lddo % 8 || lddq % 4) return TVTS_EINVAL;
+    const int blocks = ceil_div(items_q(g, mode), 4);
+    DISPATCH_MODE(attn_bwd_dq_kernel, mode, dim3(blocks), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo,
+                  lse2, delta, (bf16*)dqkv, lddq);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// cls_acc: fp32 [B, heads, 2, 64], zeroed by the caller before the SPACE/TIME pass, consumed by
+// tvts_attn_cls_finalize afterwards (unused for FULL).
+extern "C" int tvts_attn_bwd_dkv(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+                                 const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
+                                 float* cls_acc, hipStream_t stream) {
+    AttnGeom g;
+    if (mode == MODE_CLS) return TVTS_EINVAL;  // the CLS query is folded into the SPACE/TIME pass
+    int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
+    if (rc) return rc;
+    if (lddo % 8 || lddq % 4) return TVTS_EINVAL;
+    if ((mode == MODE_SPACE || mode == MODE_TIME) && !cls_acc) return TVTS_EINVAL;
+    const int blocks = ceil_div(items_k(g, mode), 4);
+    DISPATCH_MODE(attn_bwd_dkv_kernel, mode, dim3(blocks), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo,
+                  lse2, delta, (bf16*)dqkv, lddq, cls_acc);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+extern "C" int tvts_attn_cls_finalize(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq,
+                                      hipStream_t stream) {
+    const int total = B * heads * 2 * DH;
+    hipLaunchKernelGGL(attn_cls_finalize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, cls_acc, B, heads, S,
+                       heads * DH, (bf16*)dqkv, lddq);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}

@@ -1,0 +1,64 @@
+// Shared device helpers for the TVTSv2 gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+#define GLB_PTR(T) __attribute__((address_space(1))) T*
+
+#define TVTS_OK 0
+#define TVTS_EINVAL (-22)
+
+#define TVTS_LAUNCH_CHECK()                                  \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return (int)e__;              \
+    } while (0)
+
+enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU_ERF = 2 };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    if (act == ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));
+    if (act == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    return x;
+}
+// d act(x) / dx
+__device__ __forceinline__ float act_bwd(float x, int act) {
+    if (act == ACT_QUICK_GELU) {
+        float s = 1.0f / (1.0f + __expf(-1.702f * x));
+        return s * (1.0f + 1.702f * x * (1.0f - s));
+    }
+    if (act == ACT_GELU_ERF) {
+        float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    }
+    return 1.0f;
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks that land on one XCD (bid % 8) get a
+// contiguous range of logical ids, so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,243 @@
+// Token-assembly kernels around the transformer stacks (all HBM-bound gathers / scatters, fp32 unless noted).
+//
+//  tvts_patch_gather        kept patches of every frame -> bf16 im2col rows [B*T*n, 3*p*p] in conv-weight order
+//                           (v2/model/video_encoder_ViT_B_16.py:180-184 + tube-mask gather :201-215; only kept
+//                           patches are embedded -- output-equivalent)
+//  tvts_vit_assemble(+_bwd) CLS + patch embedding + spatial/temporal position (:185-198) -> tokens [B*S, W]
+//  tvts_text_embed(+_bwd)   token embedding gather + positional add (model_dist_TVTSv2_ViT_B_16.py:98-100)
+//  tvts_text_mean(+_bwd)    clip-major captions [NT*B,E] -> mean over NT and the [B,NT,E] copy for the sort head (:69-76)
+//  tvts_sort_assemble(+_bwd) video tokens + type_embed[0] | caption embeddings + type_embed[1]
+//                           (v2/model/sort_transformer.py:124-128)
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------- patch gather
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ video, const int* __restrict__ keep,
+                                                           int B, int T, int n, int img, int p, bf16* __restrict__ out,
+                                                           int ldo) {
+    const int K = 3 * p * p;
+    const int row = blockIdx.x;  // (b, f, i)
+    const int i = row % n, f = (row / n) % T, b = row / (n * T);
+    const int g = img / p;
+    const int pi = keep[b * n + i];
+    const int gy = pi / g, gx = pi % g;
+    const float* fr = video + ((size_t)(b * T + f) * 3) * img * img;
+    for (int c8 = threadIdx.x * 8; c8 < K; c8 += 256 * 8) {
+        const int ch = c8 / (p * p), rem = c8 % (p * p), py = rem / p, px = rem % p;  // px multiple of 8
+        const float* src = fr + ((size_t)ch * img + gy * p + py) * img + gx * p + px;
+        const f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + 4);
+        bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)c[0], (bf16)c[1], (bf16)c[2], (bf16)c[3]};
+        *(bf16x8*)(out + (size_t)row * ldo + c8) = o;
+    }
+}
+
+extern "C" int tvts_patch_gather(const float* video, const int* keep, int B, int T, int n, int img, int patch, void* out,
+                                 int ldo, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || n <= 0 || patch % 8 || img % patch || ldo % 8) return TVTS_EINVAL;
+    hipLaunchKernelGGL(patch_gather_kernel, dim3(B * T * n), dim3(256), 0, stream, video, keep, B, T, n, img, patch,
+                       (bf16*)out, ldo);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- ViT token assemble
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch, int ldp,
+                                                           const float* __restrict__ cls, const float* __restrict__ pos,
+                                                           const float* __restrict__ temporal, const int* __restrict__ keep,
+                                                           int B, int T, int n, int W, float* __restrict__ tok, int ldt) {
+    const int S = 1 + T * n;
+    const int row = blockIdx.x;  // b*S + s
+    const int b = row / S, s = row % S;
+    for (int c = threadIdx.x * 4; c < W; c += 1024) {
+        f32x4 v;
+        if (s == 0) {
+            v = *(const f32x4*)(cls + c) + *(const f32x4*)(pos + c);
+        } else {
+            const int f = (s - 1) / n, i = (s - 1) % n;
+            v = *(const f32x4*)(patch + (size_t)((b * T + f) * n + i) * ldp + c) +
+                *(const f32x4*)(pos + (size_t)(1 + keep[b * n + i]) * W + c) + *(const f32x4*)(temporal + (size_t)f * W + c);
+        }
+        *(f32x4*)(tok + (size_t)row * ldt + c) = v;
+    }
+}
+
+extern "C" int tvts_vit_assemble(const float* patch, int ldp, const float* cls, const float* pos, const float* temporal,
+                                 const int* keep, int B, int T, int n, int W, float* tok, int ldt, hipStream_t stream) {
+    if (W % 4 || ldp % 4 || ldt % 4) return TVTS_EINVAL;
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(B * (1 + T * n)), dim3(256), 0, stream, patch, ldp, cls, pos, temporal,
+                       keep, B, T, n, W, tok, ldt);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// one block per (b, f): d_patch rows (bf16, compact im2col row order), dpos scatter, dtemporal / dcls sums
+__global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __restrict__ dtok, int ldt,
+                                                               const int* __restrict__ keep, int B, int T, int n, int W,
+                                                               bf16* __restrict__ dpatch, int ldp, float* __restrict__ dcls,
+                                                               float* __restrict__ dpos, float* __restrict__ dtemporal) {
+    const int S = 1 + T * n;
+    const int b = blockIdx.x / T, f = blockIdx.x % T;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        float ts = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float v = dtok[(size_t)(b * S + 1 + f * n + i) * ldt + c];
+            dpatch[(size_t)((b * T + f) * n + i) * ldp + c] = (bf16)v;
+            atomicAdd(dpos + (size_t)(1 + keep[b * n + i]) * W + c, v);
+            ts += v;
+        }
+        atomicAdd(dtemporal + (size_t)f * W + c, ts);
+        if (f == 0) {
+            const float v0 = dtok[(size_t)(b * S) * ldt + c];
+            atomicAdd(dcls + c, v0);
+            atomicAdd(dpos + c, v0);
+        }
+    }
+}
+
+extern "C" int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int B, int T, int n, int W, void* dpatch,
+                                     int ldp, float* dcls, float* dpos, float* dtemporal, hipStream_t stream) {
+    hipLaunchKernelGGL(vit_assemble_bwd_kernel, dim3(B * T), dim3(256), 0, stream, dtok, ldt, keep, B, T, n, W,
+                       (bf16*)dpatch, ldp, dcls, dpos, dtemporal);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- text embedding
+__global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__ ids, int ld_ids, int N, int L,
+                                                         const float* __restrict__ emb, const float* __restrict__ pos,
+                                                         int Wt, float* __restrict__ x, int ldx) {
+    const int row = blockIdx.x;  // n*L + l
+    const int nn = row / L, l = row % L;
+    const int id = ids[(size_t)nn * ld_ids + l];
+    for (int c = threadIdx.x * 4; c < Wt; c += 1024)
+        *(f32x4*)(x + (size_t)row * ldx + c) = *(const f32x4*)(emb + (size_t)id * Wt + c) + *(const f32x4*)(pos + (size_t)l * Wt + c);
+}
+extern "C" int tvts_text_embed(const int* ids, int ld_ids, int N, int L, const float* emb, const float* pos, int Wt,
+                               float* x, int ldx, hipStream_t stream) {
+    if (Wt % 4 || ldx % 4) return TVTS_EINVAL;
+    hipLaunchKernelGGL(text_embed_kernel, dim3(N * L), dim3(256), 0, stream, ids, ld_ids, N, L, emb, pos, Wt, x, ldx);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __restrict__ dx, int ldx, const int* __restrict__ ids,
+                                                             int ld_ids, int N, int L, int Wt, float* __restrict__ demb,
+                                                             float* __restrict__ dpos) {
+    const int row = blockIdx.x;
+    const int nn = row / L, l = row % L;
+    const int id = ids[(size_t)nn * ld_ids + l];
+    for (int c = threadIdx.x; c < Wt; c += 256) {
+        const float v = dx[(size_t)row * ldx + c];
+        if (v != 0.f) {
+            atomicAdd(demb + (size_t)id * Wt + c, v);
+            atomicAdd(dpos + (size_t)l * Wt + c, v);
+        }
+    }
+}
+extern "C" int tvts_text_embed_bwd(const float* dx, int ldx, const int* ids, int ld_ids, int N, int L, int Wt, float* demb,
+                                   float* dpos, hipStream_t stream) {
+    hipLaunchKernelGGL(text_embed_bwd_kernel, dim3(N * L), dim3(256), 0, stream, dx, ldx, ids, ld_ids, N, L, Wt, demb, dpos);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- caption mean
+__global__ void text_mean_kernel(const float* __restrict__ t, int NT, int B, int E, float* __restrict__ mean,
+                                 float* __restrict__ before) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b, e)
+    if (idx >= B * E) return;
+    const int b = idx / E, e = idx % E;
+    float s = 0.f;
+    for (int i = 0; i < NT; ++i) {
+        const float v = t[(size_t)(i * B + b) * E + e];
+        s += v;
+        if (before) before[((size_t)b * NT + i) * E + e] = v;
+    }
+    mean[idx] = s / (float)NT;
+}
+extern "C" int tvts_text_mean(const float* t, int NT, int B, int E, float* mean, float* before, hipStream_t stream) {
+    hipLaunchKernelGGL(text_mean_kernel, dim3(ceil_div(B * E, 256)), dim3(256), 0, stream, t, NT, B, E, mean, before);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+__global__ void text_mean_bwd_kernel(const float* __restrict__ dmean, int NT, int B, int E, float* __restrict__ dt) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (i, b, e)
+    if (idx >= NT * B * E) return;
+    const int e = idx % E, b = (idx / E) % B;
+    dt[idx] = dmean[(size_t)b * E + e] / (float)NT;
+}
+extern "C" int tvts_text_mean_bwd(const float* dmean, int NT, int B, int E, float* dt, hipStream_t stream) {
+    hipLaunchKernelGGL(text_mean_bwd_kernel, dim3(ceil_div(NT * B * E, 256)), dim3(256), 0, stream, dmean, NT, B, E, dt);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- sort head input
+// xs[b, s] = tok[b*S + off + s] + type[0]  (s < Sv);  xs[b, Sv + i] = text[b, i] + type[1]
+__global__ __launch_bounds__(256) void sort_assemble_kernel(const float* __restrict__ tok, int ldt, int S, int off, int Sv,
+                                                            const float* __restrict__ text, int NT,
+                                                            const float* __restrict__ type, int E, float* __restrict__ xs,
+                                                            int ldx) {
+    const int So = Sv + NT;
+    const int row = blockIdx.x;
+    const int b = row / So, s = row % So;
+    const float* src = s < Sv ? tok + (size_t)(b * S + off + s) * ldt : text + ((size_t)b * NT + (s - Sv)) * E;
+    const float* ty = type + (s < Sv ? 0 : E);
+    for (int c = threadIdx.x * 4; c < E; c += 1024)
+        *(f32x4*)(xs + (size_t)row * ldx + c) = *(const f32x4*)(src + c) + *(const f32x4*)(ty + c);
+}
+extern "C" int tvts_sort_assemble(const float* tok, int ldt, int B, int S, int off, int Sv, const float* text, int NT,
+                                  const float* type, int E, float* xs, int ldx, hipStream_t stream) {
+    if (E % 4 || ldt % 4 || ldx % 4) return TVTS_EINVAL;
+    hipLaunchKernelGGL(sort_assemble_kernel, dim3(B * (Sv + NT)), dim3(256), 0, stream, tok, ldt, S, off, Sv, text, NT, type,
+                       E, xs, ldx);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+// d_out[b*S + r] (bf16, feeds the output-projection dgrad/wgrad) = [r >= off ? dxs[b, r-off] : 0] + [r == 0 ? dvid[b] : 0]
+// dtype[0] += sum over video rows, dtype[1] += sum over caption rows.  One block per sample.
+__global__ __launch_bounds__(256) void sort_assemble_bwd_kernel(const float* __restrict__ dxs, int ldx, int S, int off, int Sv,
+                                                                int NT, const float* __restrict__ dvid, int E,
+                                                                bf16* __restrict__ dout, int ldo, float* __restrict__ dtype) {
+    const int So = Sv + NT;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < E; c += 256) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int r = 0; r < S; ++r) {
+            float v = 0.f;
+            if (dxs && r >= off) {
+                v = dxs[(size_t)(b * So + r - off) * ldx + c];
+                s0 += v;
+            }
+            if (r == 0 && dvid) v += dvid[(size_t)b * E + c];
+            dout[(size_t)(b * S + r) * ldo + c] = (bf16)v;
+        }
+        if (dxs) {
+            for (int i = 0; i < NT; ++i) s1 += dxs[(size_t)(b * So + Sv + i) * ldx + c];
+            atomicAdd(dtype + c, s0);
+            atomicAdd(dtype + E + c, s1);
+        }
+    }
+}
+extern "C" int tvts_sort_assemble_bwd(const float* dxs, int ldx, int B, int S, int off, int Sv, int NT, const float* dvid,
+                                      int E, void* dout, int ldo, float* dtype, hipStream_t stream) {
+    hipLaunchKernelGGL(sort_assemble_bwd_kernel, dim3(B), dim3(256), 0, stream, dxs, ldx, S, off, Sv, NT, dvid, E,
+                       (bf16*)dout, ldo, dtype);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- row gather/scatter (fp32)
+// dst[r] = src[rows[r]]   (gather)   or   dst[rows[r]] += src[r]   (scatter_add)
+__global__ void rows_gather_kernel(const float* __restrict__ src, int lds_, const int* __restrict__ rows, int R, int W,
+                                   float* __restrict__ dst, int ldd, int scatter) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < W; c += blockDim.x) {
+        if (scatter) dst[(size_t)rows[r] * ldd + c] += src[(size_t)r * lds_ + c];
+        else dst[(size_t)r * ldd + c] = src[(size_t)rows[r] * lds_ + c];
+    }
+}
+extern "C" int tvts_rows_gather(const float* src, int ld_src, const int* rows, int R, int W, float* dst, int ld_dst,
+                                int scatter_add, hipStream_t stream) {
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(R), dim3(256), 0, stream, src, ld_src, rows, R, W, dst, ld_dst, scatter_add);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}

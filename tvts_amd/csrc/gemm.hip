@@ -1,0 +1,401 @@
+// bf16 MFMA GEMMs for the TVTSv2 step on gfx950.
+//
+//   tvts_gemm_nt_bf16   : C[M,N] = epi(A[M,K] . B[N,K]^T)   (nn.Linear forward; dgrad with the [K,N] weight copy)
+//   tvts_gemm_tn_bf16   : C[Na,Nb] (+)= P[M,Na]^T . Q[M,Nb]  (weight gradient, contraction over the token rows)
+//   tvts_gemm_small_f32 : strided fp32 fallback for the handful of tiny matmuls (heads, projections of [B,E] rows)
+//   tvts_colsum_bf16    : bias gradient, column sums of a bf16 [M,N] matrix accumulated into fp32
+//
+// Tiling (both MFMA kernels): 128x128 output tile, 64-deep stage, 256 threads = 4 waves in 2x2, each wave
+// a 64x64 sub-tile as 4x4 v_mfma_f32_16x16x32_bf16 tiles.  Operands go HBM -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip), double buffered.  The LDS image is lane-linear as the
+// DMA demands; bank conflicts are removed by XOR-swizzling the per-lane SOURCE address and applying the
+// same involution on the ds_read side.
+//
+// MFMA roles are swapped (weights feed the A operand, activations the B operand) so that a lane ends up
+// with 4 consecutive output columns of one output row: 8-byte bf16 / 16-byte fp32 epilogue accesses with
+// bias, activation, activation-gradient gate and fp32 residual fused.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define NTHREADS 256
+
+struct GemmNT {
+    const bf16* A; int lda;
+    const bf16* B; int ldb;
+    int M, N, K;
+    const float* bias;
+    const float* residual; int ldr;
+    int act;
+    bf16* preact; int ldp;
+    const bf16* gate_h; int ldh; int gate_act;
+    void* out; int ldc; int out_f32;
+    int tiles_n;
+};
+
+// --- one [128 rows][64 k] bf16 tile: 16 KiB, rows of 128 B, 16-B chunk c of row r stored at chunk c^(r&7)
+__device__ __forceinline__ void stage_rows128(const bf16* __restrict__ base, int ld, int row0, int row_max,
+                                              int k0, char* lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r0 = (t * 4 + wave) * 8;
+        const int row = r0 + (lane >> 3);
+        const int slot = lane & 7;
+        const int chunk = slot ^ (row & 7);
+        int grow = row0 + row;
+        grow = grow < row_max ? grow : row_max;
+        const bf16* src = base + (size_t)grow * ld + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const GLB_PTR(void))src, (LDS_PTR(void))(lds_tile + r0 * 128), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8 frag_rows128(const char* lds_tile, int row, int chunk) {
+    return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+template <int ACT, int GATE>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmNT g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = lid / g.tiles_n, tile_n = lid % g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    stage_rows128(g.A, g.lda, m0, g.M - 1, 0, smem, wave, lane);
+    stage_rows128(g.B, g.ldb, n0, g.N - 1, 0, smem + 16384, wave, lane);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * 32768;
+        if (kt + 1 < nk) {
+            char* nxt = smem + ((kt + 1) & 1) * 32768;
+            stage_rows128(g.A, g.lda, m0, g.M - 1, (kt + 1) * BK, nxt, wave, lane);
+            stage_rows128(g.B, g.ldb, n0, g.N - 1, (kt + 1) * BK, nxt + 16384, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag_rows128(cur, wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bfr[j] = frag_rows128(cur + 16384, wn * 64 + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane owns row m (column of the swapped MFMA) and 4 consecutive n
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= g.N) continue;
+            f32x4 v = acc[j][i];
+            if (g.bias) {
+                const f32x4 b = *(const f32x4*)(g.bias + n);
+                v += b;
+            }
+            if (ACT != ACT_NONE) {
+                if (g.preact) {
+                    bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = h;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
+            }
+            if (GATE != ACT_NONE) {
+                const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
+            }
+            if (g.residual) {
+                const f32x4 r = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
+                v += r;
+            }
+            if (g.out_f32) {
+                *(f32x4*)((float*)g.out + (size_t)m * g.ldc + n) = v;
+            } else {
+                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *(bf16x4*)((bf16*)g.out + (size_t)m * g.ldc + n) = o;
+            }
+        }
+    }
+}
+
+extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                                 const float* bias, const float* residual, int ldr, int act, void* preact,
+                                 int ldp, const void* gate_h, int ldh, int gate_act, void* out, int ldc,
+                                 int out_f32, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return TVTS_EINVAL;
+    if (K % BK != 0 || N % 4 != 0 || lda % 8 != 0 || ldb % 8 != 0) return TVTS_EINVAL;
+    if ((ldc % 4) || (residual && (ldr % 4)) || (preact && (ldp % 4)) || (gate_h && (ldh % 4))) return TVTS_EINVAL;
+    GemmNT g;
+    g.A = (const bf16*)A; g.lda = lda; g.B = (const bf16*)B; g.ldb = ldb;
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
+    g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
+    g.out = out; g.ldc = ldc; g.out_f32 = out_f32;
+    g.tiles_n = ceil_div(N, BN);
+    const int tiles = ceil_div(M, BM) * g.tiles_n;
+    void (*kern)(GemmNT) = nullptr;
+    if (gate_h) {
+        if (act != ACT_NONE) return TVTS_EINVAL;
+        kern = gate_act == ACT_QUICK_GELU ? gemm_nt_kernel<0, 1> : gate_act == ACT_GELU_ERF ? gemm_nt_kernel<0, 2> : nullptr;
+    } else {
+        kern = act == ACT_NONE ? gemm_nt_kernel<0, 0> : act == ACT_QUICK_GELU ? gemm_nt_kernel<1, 0>
+             : act == ACT_GELU_ERF ? gemm_nt_kernel<2, 0> : nullptr;
+    }
+    if (!kern) return TVTS_EINVAL;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), 65536, stream, g);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN: C[Na,Nb] (+)= sum_m P[m,Na] * Q[m,Nb].  Both operands are "contraction-strided", so the MFMA
+// fragments come from LDS through the transposing read ds_read_b64_tr_b16 (4 rows x 16 columns per
+// 16-lane group; lane (l&15) receives column l&15 of those 4 rows).  The MFMA k-slot <-> m mapping is
+// the same permutation for both operands: slot (l>>4)*8+j <-> m = 32u + 16*(j>>2) + 4*(l>>4) + (j&3).
+// LDS tile: [64 m][128 cols] bf16 = 16 KiB, rows of 256 B, 32-B chunk c of row r stored at c^(r&7).
+// ------------------------------------------------------------------------------------------------
+struct GemmTN {
+    const bf16* P; int ldp;
+    const bf16* Q; int ldq;
+    int M, Na, Nb;
+    float* out; int ldo;
+    int tiles_b, tiles_ab, m_per_split;
+    int atomic;
+};
+
+__device__ __forceinline__ void stage_cols128(const bf16* __restrict__ base, int ld, int m0, int m_max, int c0,
+                                              int c_max, char* lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r0 = (t * 4 + wave) * 4;  // 4 rows of 256 B per wave-issue
+        const int row = r0 + (lane >> 4);
+        const int s16 = lane & 15;
+        const int chunk32 = (s16 >> 1) ^ (row & 7);
+        int gm = m0 + row;
+        gm = gm < m_max ? gm : m_max;
+        int col = c0 + chunk32 * 16 + (s16 & 1) * 8;
+        col = col < c_max ? col : c_max;
+        const bf16* src = base + (size_t)gm * ld + col;
+        __builtin_amdgcn_global_load_lds((const GLB_PTR(void))src, (LDS_PTR(void))(lds_tile + r0 * 256), 16, 0, 0);
+    }
+}
+
+// 8 k-slots (one MFMA k-step u) of column block ct (16 columns) for this lane
+__device__ __forceinline__ bf16x8 frag_tr(const char* lds_tile, int u, int ct, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    bf16x8 out;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row = u * 32 + half * 16 + g * 4 + (i >> 2);
+        const int chunk32 = ct ^ (row & 7);
+        const char* p = lds_tile + row * 256 + chunk32 * 32 + (i & 3) * 8;
+        s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))p);
+        bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+        out[half * 4 + 0] = tb[0]; out[half * 4 + 1] = tb[1]; out[half * 4 + 2] = tb[2]; out[half * 4 + 3] = tb[3];
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmTN g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][P 16K | Q 16K]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave >> 1, wb = wave & 1;
+
+    const int bid = blockIdx.x;
+    const int split = bid / g.tiles_ab;
+    const int t = bid % g.tiles_ab;
+    const int a0 = (t / g.tiles_b) * 128, b0 = (t % g.tiles_b) * 128;
+    const int m_begin = split * g.m_per_split;
+    int m_end = m_begin + g.m_per_split;
+    m_end = m_end < g.M ? m_end : g.M;
+    if (m_begin >= m_end) return;
+    const int nk = (m_end - m_begin + 63) / 64;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // rows >= M are read clamped: the caller guarantees rows [M, round_up(M,64)) of P are ZERO or that
+    // m_end is a multiple of 64 (see tvts_gemm_tn_bf16); we additionally zero the contribution by
+    // clamping to row M-1 only when the caller says pad rows are valid (pad_ok), so here: plain clamp.
+    stage_cols128(g.P, g.ldp, m_begin, g.M - 1, a0, g.Na - 8, smem, wave, lane);
+    stage_cols128(g.Q, g.ldq, m_begin, g.M - 1, b0, g.Nb - 8, smem + 16384, wave, lane);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * 32768;
+        if (kt + 1 < nk) {
+            char* nxt = smem + ((kt + 1) & 1) * 32768;
+            stage_cols128(g.P, g.ldp, m_begin + (kt + 1) * 64, g.M - 1, a0, g.Na - 8, nxt, wave, lane);
+            stage_cols128(g.Q, g.ldq, m_begin + (kt + 1) * 64, g.M - 1, b0, g.Nb - 8, nxt + 16384, wave, lane);
+        }
+        // valid m in this stage (tail rows beyond m_end must not contribute)
+        const int valid = m_end - (m_begin + kt * 64);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 pf[4], qf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[i] = frag_tr(cur, u, wa * 4 + i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qf[j] = frag_tr(cur + 16384, u, wb * 4 + j, lane);
+            if (valid < 64) {  // zero k-slots whose m is past the end (uniform branch, tail stage only)
+                const int gq = lane >> 4;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int m = u * 32 + (e >> 2) * 16 + gq * 4 + (e & 3);
+                    if (m >= valid) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pf[i][e] = (bf16)0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // acc[i][j]: MFMA A-operand = Q (rows = b within tile j), B-operand = P (cols = a within tile i)
+    // lane: col = a = l&15, rows = b = (l>>4)*4 + r  -> 4 consecutive b for one a: 16-B fp32 access
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int a = a0 + wa * 64 + i * 16 + (lane & 15);
+        if (a >= g.Na) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = b0 + wb * 64 + j * 16 + (lane >> 4) * 4;
+            if (b >= g.Nb) continue;
+            float* dst = g.out + (size_t)a * g.ldo + b;
+            if (g.atomic) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[i][j][e]);
+            } else {
+                *(f32x4*)dst = acc[i][j];
+            }
+        }
+    }
+}
+
+extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb,
+                                 float* out, int ldo, int accumulate, hipStream_t stream) {
+    if (M <= 0 || Na <= 0 || Nb <= 0) return TVTS_EINVAL;
+    if (Na % 8 || Nb % 8 || ldp % 8 || ldq % 8 || ldo % 4) return TVTS_EINVAL;
+    GemmTN g;
+    g.P = (const bf16*)P; g.ldp = ldp; g.Q = (const bf16*)Q; g.ldq = ldq; g.M = M; g.Na = Na; g.Nb = Nb;
+    g.out = out; g.ldo = ldo;
+    const int tiles_a = ceil_div(Na, 128);
+    g.tiles_b = ceil_div(Nb, 128);
+    g.tiles_ab = tiles_a * g.tiles_b;
+    // split the contraction so the grid fills 256 CUs a few times over
+    int splits = ceil_div(1024, g.tiles_ab);
+    int max_splits = ceil_div(M, 256);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (!accumulate && splits > 1) {
+        hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)Nb * 4, Na, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    g.m_per_split = ceil_div(ceil_div(M, splits), 64) * 64;
+    splits = ceil_div(M, g.m_per_split);
+    g.atomic = (accumulate || splits > 1) ? 1 : 0;
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e2 != hipSuccess) return (int)e2;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(g.tiles_ab * splits), dim3(NTHREADS), 65536, stream, g);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tiny strided fp32 matmul: C[i,j] (+)= alpha * sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj]  (16x16 LDS tiles)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_small_kernel(const float* __restrict__ A, long sai, long sak,
+                                                         const float* __restrict__ B, long sbk, long sbj,
+                                                         int M, int N, int K, float alpha, const float* bias,
+                                                         float* C, long ldc, int accumulate) {
+    __shared__ float As[16][17], Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const int ka = k0 + tx, kb = k0 + ty;
+        As[ty][tx] = (i < M && ka < K) ? A[i * sai + ka * sak] : 0.f;
+        Bs[ty][tx] = (kb < K && j < N) ? B[kb * sbk + j * sbj] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += As[ty][k] * Bs[k][tx];
+        __syncthreads();
+    }
+    if (i < M && j < N) {
+        float v = alpha * acc + (bias ? bias[j] : 0.f);
+        if (accumulate) C[i * ldc + j] += v; else C[i * ldc + j] = v;
+    }
+}
+
+extern "C" int tvts_gemm_small_f32(const float* A, long sai, long sak, const float* B, long sbk, long sbj,
+                                   int M, int N, int K, float alpha, const float* bias, float* C, long ldc,
+                                   int accumulate, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return TVTS_EINVAL;
+    hipLaunchKernelGGL(gemm_small_kernel, dim3(ceil_div(N, 16), ceil_div(M, 16)), dim3(256), 0, stream, A, sai,
+                       sak, B, sbk, sbj, M, N, K, alpha, bias, C, ldc, accumulate);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bias gradient: out[n] += sum_m X[m,n]  (bf16 in, fp32 atomics; 8 columns per lane, rows strided by blocks)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, int ld, int M, int N,
+                                                     float* __restrict__ out, int rows_per_block) {
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (col >= N) return;
+    const int r0 = blockIdx.y * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    r1 = r1 < M ? r1 : M;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = r0; r < r1; ++r) {
+        const bf16x8 v = *(const bf16x8*)(X + (size_t)r * ld + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(out + col + e, s[e]);
+}
+
+extern "C" int tvts_colsum_bf16(const void* X, int ld, int M, int N, float* out, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || N % 8 || ld % 8) return TVTS_EINVAL;
+    const int rows_per_block = 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 2048), ceil_div(M, rows_per_block)), dim3(256), 0, stream,
+                       (const bf16*)X, ld, M, N, out, rows_per_block);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}

@@ -1,0 +1,124 @@
+// Optimizer-side kernels over the FLAT fp32 parameter / gradient / moment buffers.
+//
+//   tvts_adamw_hf        multi-tensor AdamW with Hugging Face semantics (transformers==4.10.2 `AdamW`, the optimizer
+//                        the reference builds at v2/train_dist_TVTSv2_ViT_B_16.py:118-125): bias-corrected step,
+//                        eps added OUTSIDE the correction, decoupled decay `p -= lr*wd*p` AFTER the Adam update.
+//                        One launch for all ~400 tensors: the flat buffers are cut into 1024-element chunks and a
+//                        byte table gives each chunk its parameter group (255 = frozen / padding).  The same pass
+//                        applies the data-parallel 1/world gradient scale and refreshes the bf16 weight shadow.
+//   tvts_cast_f32_bf16   shadow refresh when an external optimizer owned the update (drop-in path)
+//   tvts_transpose_bf16_batched   [N,K] -> [K,N] copies of every GEMM weight (dgrad operand), one launch
+#include "common.h"
+
+struct AdamGroups { float lr[4]; float wd[4]; float step_size[4]; };
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16* __restrict__ shadow,
+                                                    const unsigned char* __restrict__ chunk_group, AdamGroups hp, float beta1,
+                                                    float beta2, float eps, float grad_scale,
+                                                    const int* __restrict__ step_dev) {
+    const int grp = chunk_group[blockIdx.x];
+    if (grp > 3) return;
+    if (step_dev) {  // step counter lives in device memory (hipGraph replay): bias correction computed here
+        const double st = (double)step_dev[0];
+        const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
+        hp.step_size[grp] = (float)((double)hp.lr[grp] * sqrt(bc2) / bc1);
+    }
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    f32x4 pv = *(f32x4*)(p + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+    const f32x4 gv = *(const f32x4*)(g + i);
+    const float lr = hp.lr[grp], wd = hp.wd[grp], ss = hp.step_size[grp];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float gg = gv[e] * grad_scale;
+        mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
+        vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
+        pv[e] -= ss * mv[e] / (sqrtf(vv[e]) + eps);
+        if (wd > 0.f) pv[e] -= lr * wd * pv[e];
+    }
+    *(f32x4*)(p + i) = pv;
+    *(f32x4*)(m + i) = mv;
+    *(f32x4*)(v + i) = vv;
+    if (shadow) *(bf16x4*)(shadow + i) = (bf16x4){(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
+}
+
+extern "C" int tvts_adamw_hf(float* p, const float* g, float* m, float* v, void* shadow_bf16,
+                             const unsigned char* chunk_group, int nchunks, const float* lr4, const float* wd4, int step,
+                             const int* step_dev, float beta1, float beta2, float eps, float grad_scale,
+                             hipStream_t stream) {
+    if (nchunks <= 0 || (step <= 0 && !step_dev)) return TVTS_EINVAL;
+    if (step <= 0) step = 1;
+    AdamGroups hp;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    for (int i = 0; i < 4; ++i) {
+        hp.lr[i] = lr4[i];
+        hp.wd[i] = wd4[i];
+        hp.step_size[i] = (float)((double)lr4[i] * sqrt(bc2) / bc1);
+    }
+    hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, stream, p, g, m, v, (bf16*)shadow_bf16, chunk_group, hp,
+                       beta1, beta2, eps, grad_scale, step_dev);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(src + i * 4);
+        *(bf16x4*)(dst + i * 4) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    }
+}
+extern "C" int tvts_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream) {
+    if (n <= 0 || n % 4) return TVTS_EINVAL;
+    const size_t n4 = (size_t)n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, (bf16*)dst, n4);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// tile table entry: {src_off, dst_off (elements, as two int32 halves each), R, C, tile_r, tile_c}
+struct TrTile { long long src_off, dst_off; int R, C, tr, tc; };
+
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
+                                                                const TrTile* __restrict__ tiles) {
+    __shared__ bf16 t[64][66];
+    const TrTile e = tiles[blockIdx.x];
+    const bf16* s = src + e.src_off;
+    bf16* d = dst + e.dst_off;
+    const int r0 = e.tr * 64, c0 = e.tc * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        if (r0 + r < e.R && c0 + c < e.C) t[r][c] = s[(size_t)(r0 + r) * e.C + c0 + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (r0 + r < e.R && c0 + c < e.C) d[(size_t)(c0 + c) * e.R + r0 + r] = t[r][c];
+    }
+}
+extern "C" int tvts_transpose_bf16_batched(const void* src, void* dst, const void* tiles, int ntiles, hipStream_t stream) {
+    if (ntiles <= 0) return TVTS_EINVAL;
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(ntiles), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst,
+                       (const TrTile*)tiles);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// probe used by tests: what does ds_read_b64_tr_b16 return?  in: 16 x 64 bf16 row-major tile (row stride 160 B in LDS)
+__global__ void probe_tr16_kernel(const bf16* __restrict__ in, bf16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char tile[16 * 160];
+    const int lane = threadIdx.x;
+    for (int c = lane; c < 16 * 8; c += 64) *(bf16x8*)(tile + (c >> 3) * 160 + (c & 7) * 16) = *(const bf16x8*)(in + (c >> 3) * 64 + (c & 7) * 8);
+    __syncthreads();
+    const int gq = lane >> 4, i = lane & 15;
+    const char* p = tile + (gq * 4 + (i >> 2)) * 160 + (i & 3) * 8;
+    const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))p);
+    const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+    for (int e = 0; e < 4; ++e) out[lane * 4 + e] = tb[e];
+}
+extern "C" int tvts_probe_tr16(const void* in, void* out, hipStream_t stream) {
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, stream, (const bf16*)in, (bf16*)out);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}

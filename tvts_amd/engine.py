@@ -1,0 +1,532 @@
+"""Step engine: explicit forward / backward of the TVTSv2 model over hand-written HIP kernels.
+
+No autograd graph is built here: every activation that the backward pass needs is kept in a named
+workspace buffer and the backward is written out by hand, kernel by kernel (tvts_amd.hip).  The
+module classes in tvts_amd/model wrap this engine behind the reference's nn.Module surface.
+
+Numerics: bf16 MFMA operands with fp32 accumulation; the residual stream, LayerNorm statistics,
+embeddings, losses, gradients of parameters, master weights and optimizer state are fp32.
+
+Reference being restated (file:line under v2/):
+  forward wiring            model/model_dist_TVTSv2_ViT_B_16.py:61-116
+  space-time ViT            model/video_encoder_ViT_B_16.py:94-124,176-235
+  CLIP text tower           CLIP/clip/model.py:171-203,345-358
+  transcript sorting head   model/sort_transformer.py:61-80,124-142
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import hip as K
+from .arch import is_mfma_weight, n_keep, param_shapes, patches_per_frame
+
+CH = 1024  # flat-buffer alignment / optimizer chunk (elements)
+
+
+class ParamStore:
+    """All parameters in ONE flat fp32 buffer (+ flat grad, bf16 shadow, transposed bf16 shadow).
+
+    nn.Parameters handed to the outside world are views into ``flat``; ``grad`` views are installed as
+    ``.grad`` so an external optimizer (the reference entrypoint builds transformers.AdamW) sees them.
+    """
+
+    def __init__(self, arch: dict, device: torch.device):
+        self.arch = arch
+        self.device = device
+        self.shapes = param_shapes(arch)
+        self.off: Dict[str, int] = {}
+        off = 0
+        for name, shape in self.shapes.items():
+            self.off[name] = off
+            off += -(-int(np.prod(shape)) // CH) * CH
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        # transposed copies of the MFMA weights
+        self.toff: Dict[str, int] = {}
+        toff, tiles = 0, []
+        for name, shape in self.shapes.items():
+            if not is_mfma_weight(name, shape):
+                continue
+            R, C = shape[0], int(np.prod(shape[1:]))
+            self.toff[name] = toff
+            for tr in range(-(-R // 64)):
+                for tc in range(-(-C // 64)):
+                    tiles.append((self.off[name], toff, R, C, tr, tc))
+            toff += -(-R * C // CH) * CH
+        self.shadow_t = torch.zeros(max(toff, 8), dtype=torch.bfloat16, device=device)
+        rec = np.zeros(len(tiles), dtype=[("s", "<i8"), ("d", "<i8"), ("R", "<i4"), ("C", "<i4"), ("tr", "<i4"), ("tc", "<i4")])
+        for i, t in enumerate(tiles):
+            rec[i] = t
+        self.n_tiles = len(tiles)
+        self.tile_table = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+        self.m: Optional[torch.Tensor] = None
+        self.v: Optional[torch.Tensor] = None
+        self.shadow_version = -1
+        self._views: Dict[str, torch.Tensor] = {}
+        self._gviews: Dict[str, torch.Tensor] = {}
+
+    def _n(self, name):
+        return int(np.prod(self.shapes[name]))
+
+    def p(self, name) -> torch.Tensor:
+        v = self._views.get(name)
+        if v is None:
+            o = self.off[name]
+            v = self._views[name] = self.flat[o:o + self._n(name)].view(self.shapes[name])
+        return v
+
+    def g(self, name) -> torch.Tensor:
+        v = self._gviews.get(name)
+        if v is None:
+            o = self.off[name]
+            v = self._gviews[name] = self.grad[o:o + self._n(name)].view(self.shapes[name])
+        return v
+
+    def g2d(self, name) -> torch.Tensor:
+        s = self.shapes[name]
+        return self.g(name).view(s[0], -1)
+
+    def w(self, name) -> torch.Tensor:
+        """bf16 shadow, 2-D [shape[0], rest] as stored."""
+        o, s = self.off[name], self.shapes[name]
+        return self.shadow[o:o + self._n(name)].view(s[0], -1)
+
+    def wt(self, name) -> torch.Tensor:
+        """bf16 shadow transposed, [rest, shape[0]]."""
+        o, s = self.toff[name], self.shapes[name]
+        return self.shadow_t[o:o + self._n(name)].view(-1, s[0])
+
+    def refresh_shadows(self, cast: bool = True):
+        """fp32 master -> bf16 shadow (+ transposed copies).  cast=False when the fused AdamW kernel
+        already wrote the plain shadow."""
+        if cast:
+            K.cast_f32_bf16(self.flat, self.shadow)
+        if self.n_tiles:
+            K.transpose_batched(self.shadow, self.shadow_t, self.tile_table, self.n_tiles)
+
+
+_TEXT_NAMES = dict(ln1="ln_1", qkv_w="attn.in_proj_weight", qkv_b="attn.in_proj_bias", o_w="attn.out_proj.weight",
+                   o_b="attn.out_proj.bias", ln2="ln_2", fc_w="mlp.c_fc.weight", fc_b="mlp.c_fc.bias",
+                   pj_w="mlp.c_proj.weight", pj_b="mlp.c_proj.bias")
+_SORT_NAMES = dict(ln1="norm1", qkv_w="attn.qkv.weight", qkv_b="attn.qkv.bias", o_w="attn.proj.weight",
+                   o_b="attn.proj.bias", ln2="norm2", fc_w="mlp.fc1.weight", fc_b="mlp.fc1.bias",
+                   pj_w="mlp.fc2.weight", pj_b="mlp.fc2.bias")
+
+
+class Engine:
+    def __init__(self, store: ParamStore):
+        self.P = store
+        self.arch = store.arch
+        a = self.arch
+        if a["tail"] != "all_tokens":
+            raise NotImplementedError("tail 'pooled_and_patches' (H/14) is not built yet")
+        if a["width"] // a["heads"] != 64 or a["text_width"] // a["text_heads"] != 64 or a["embed"] // a["sort_heads"] != 64:
+            raise NotImplementedError("attention kernels are built for head dim 64")
+        self.dev = store.device
+        self.buf: Dict[str, torch.Tensor] = {}
+        self.requires_grad = {name: True for name in store.shapes}
+        self.ctx: dict = {}
+        self.grad_ready = None  # optional callback(start, end): flat grad range is final (GradSync.reduce_range)
+
+    def _ready(self, first: str, last: str):
+        if self.grad_ready is not None:
+            P = self.P
+            self.grad_ready(P.off[first], P.off[last] + -(-P._n(last) // CH) * CH)
+
+    # ------------------------------------------------------------------ workspace
+    def _b(self, name, shape, dtype=torch.bfloat16, zero=False):
+        t = self.buf.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.zeros(shape, dtype=dtype, device=self.dev) if zero else torch.empty(shape, dtype=dtype, device=self.dev)
+            self.buf[name] = t
+        elif zero:
+            t.zero_()
+        return t
+
+    def _f(self, name, shape, zero=False):
+        return self._b(name, shape, torch.float32, zero)
+
+    # ------------------------------------------------------------------ linear helpers
+    def _lin(self, a, wname, bname, out, M, **epi):
+        K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
+
+    def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, **epi):
+        """dW += dy^T a_in, db += colsum(dy) (if trainable); d_in = dy W (optional, with epilogue)."""
+        if self.requires_grad[wname]:
+            K.gemm_tn(dy, a_in, self.P.g2d(wname), M=M, accumulate=True)
+        if bname and self.requires_grad[bname]:
+            K.colsum(dy, self.P.g(bname), M=M)
+        if d_in is not None:
+            K.gemm_nt(dy, self.P.wt(wname), d_in, M=M, **epi)
+
+    def _ln(self, x, name, eps, y, tag, rows=None, M=None):
+        M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
+        mean, rstd = self._f(tag + ".mean", (M,)), self._f(tag + ".rstd", (M,))
+        K.layernorm_fwd(x, self.P.p(name + ".weight"), self.P.p(name + ".bias"), eps, y, mean, rstd, rows=rows, M=M)
+
+    def _ln_bwd(self, dy, x, name, tag, dx, dx_bf16=None, res1=None, res2=None, rows=None, M=None):
+        tr = self.requires_grad[name + ".weight"]
+        K.layernorm_bwd(dy, x, self.buf[tag + ".mean"], self.buf[tag + ".rstd"], self.P.p(name + ".weight"), dx,
+                        dx_bf16=dx_bf16, res1=res1, res2=res2, dgamma=self.P.g(name + ".weight") if tr else None,
+                        dbeta=self.P.g(name + ".bias") if tr else None, rows=rows, M=M)
+
+    # ------------------------------------------------------------------ generic pre-LN block (text tower, sort head)
+    def _block_fwd(self, pre, nm, x_in, x_out, tag, M, Wd, heads, Bn, S, causal, act, eps):
+        ln1 = self._b(tag + ".ln1", (M, Wd))
+        self._ln(x_in, pre + nm["ln1"], eps, ln1, tag + ".ln1")
+        qkv = self._b(tag + ".qkv", (M, 3 * Wd))
+        self._lin(ln1, pre + nm["qkv_w"], pre + nm["qkv_b"], qkv, M)
+        att = self._b(tag + ".att", (M, Wd))
+        lse = self._f(tag + ".lse", (M, heads))
+        K.attn_fwd("full", qkv, att, lse, B=Bn, heads=heads, S=S, causal=causal)
+        mid = self._f(tag + ".mid", (M, Wd))
+        self._lin(att, pre + nm["o_w"], pre + nm["o_b"], mid, M, residual=x_in)
+        ln2 = self._b(tag + ".ln2", (M, Wd))
+        self._ln(mid, pre + nm["ln2"], eps, ln2, tag + ".ln2")
+        h = self._b(tag + ".h", (M, 4 * Wd))
+        a = self._b(tag + ".a", (M, 4 * Wd))
+        self._lin(ln2, pre + nm["fc_w"], pre + nm["fc_b"], a, M, act=act, preact=h)
+        self._lin(a, pre + nm["pj_w"], pre + nm["pj_b"], x_out, M, residual=mid)
+
+    def _block_bwd(self, pre, nm, x_in, dx, dxb, dx_in, dxb_in, tag, M, Wd, heads, Bn, S, causal, act, scr):
+        """dx/dxb: grad wrt block output (fp32 / bf16).  Writes grad wrt block input to dx_in/dxb_in."""
+        B_ = self.buf
+        dh = self._b(scr + ".dh", (M, 4 * Wd))
+        dln = self._b(scr + ".dln", (M, Wd))
+        self._lin_bwd(dxb, B_[tag + ".a"], pre + nm["pj_w"], pre + nm["pj_b"], dh, M, gate_h=B_[tag + ".h"], gate_act=act)
+        self._lin_bwd(dh, B_[tag + ".ln2"], pre + nm["fc_w"], pre + nm["fc_b"], dln, M)
+        dmid = self._f(scr + ".dmid", (M, Wd))
+        dmidb = self._b(scr + ".dmidb", (M, Wd))
+        self._ln_bwd(dln, B_[tag + ".mid"], pre + nm["ln2"], tag + ".ln2", dmid, dx_bf16=dmidb, res1=dx)
+        datt = self._b(scr + ".datt", (M, Wd))
+        self._lin_bwd(dmidb, B_[tag + ".att"], pre + nm["o_w"], pre + nm["o_b"], datt, M)
+        dqkv = self._b(scr + ".dqkv", (M, 3 * Wd))
+        delta = self._f(scr + ".delta", (M, heads))
+        qkv, lse = B_[tag + ".qkv"], B_[tag + ".lse"]
+        K.attn_delta(datt, B_[tag + ".att"], delta, rows=M, heads=heads)
+        K.attn_bwd_dq("full", qkv, datt, lse, delta, dqkv, B=Bn, heads=heads, S=S, causal=causal)
+        K.attn_bwd_dkv("full", qkv, datt, lse, delta, dqkv, B=Bn, heads=heads, S=S, causal=causal)
+        self._lin_bwd(dqkv, B_[tag + ".ln1"], pre + nm["qkv_w"], pre + nm["qkv_b"], dln, M)
+        self._ln_bwd(dln, x_in, pre + nm["ln1"], tag + ".ln1", dx_in, dx_bf16=dxb_in, res1=dmid)
+
+    # ------------------------------------------------------------------ text tower
+    def text_forward(self, ids_dev, eot_rows, N, L):
+        a = self.arch
+        Wt, M = a["text_width"], N * L
+        x = self._f("txt.x0", (M, Wt))
+        K.text_embed(ids_dev, self.P.p("text_token_embedding.weight"), self.P.p("text_positional_embedding"), x, N=N, L=L)
+        for l in range(a["text_layers"]):
+            xo = self._f(f"txt.x{l + 1}", (M, Wt))
+            self._block_fwd(f"text_model.resblocks.{l}.", _TEXT_NAMES, x, xo, f"txt{l}", M, Wt, a["text_heads"], N, L, True,
+                            a["act"], 1e-5)
+            x = xo
+        lnf = self._f("txt.lnf", (N, Wt))
+        self._ln(x, "text_ln_final", 1e-5, lnf, "txt.lnf", rows=eot_rows)
+        t = self._f("txt.t", (N, a["embed"]))
+        K.gemm_small(lnf, self.P.p("text_projection"), t, M=N, N=a["embed"], K=Wt, sa=(Wt, 1), sb=(a["embed"], 1))
+        return t
+
+    def text_backward(self, dt, ids_dev, eot_rows, N, L):
+        a = self.arch
+        Wt, E, M = a["text_width"], a["embed"], N * L
+        lnf = self.buf["txt.lnf"]
+        if self.requires_grad["text_projection"]:  # dproj[Wt,E] += lnf^T dt
+            K.gemm_small(lnf, dt, self.P.g("text_projection"), M=Wt, N=E, K=N, sa=(1, Wt), sb=(E, 1), accumulate=True)
+        dlnf = self._f("txt.dlnf", (N, Wt))
+        K.gemm_small(dt, self.P.p("text_projection"), dlnf, M=N, N=Wt, K=E, sa=(E, 1), sb=(1, E))
+        dx = self._f("txt.dxA", (M, Wt), zero=True)
+        dxb = self._b("txt.dxbA", (M, Wt), zero=True)
+        self._ln_bwd(dlnf, self.buf[f"txt.x{a['text_layers']}"], "text_ln_final", "txt.lnf", dx, dx_bf16=dxb, rows=eot_rows)
+        for l in reversed(range(a["text_layers"])):
+            nx = "B" if (a["text_layers"] - l) % 2 == 1 else "A"
+            dxi = self._f("txt.dx" + nx, (M, Wt))
+            dxbi = self._b("txt.dxb" + nx, (M, Wt))
+            self._block_bwd(f"text_model.resblocks.{l}.", _TEXT_NAMES, self.buf[f"txt.x{l}"], dx, dxb, dxi, dxbi, f"txt{l}",
+                            M, Wt, a["text_heads"], N, L, True, a["act"], "txt.s")
+            dx, dxb = dxi, dxbi
+        if self.requires_grad["text_token_embedding.weight"] or self.requires_grad["text_positional_embedding"]:
+            K.text_embed_bwd(dx, ids_dev, self.P.g("text_token_embedding.weight"), self.P.g("text_positional_embedding"),
+                             N=N, L=L)
+
+    # ------------------------------------------------------------------ video tower
+    def _st_attention_fwd(self, qkv, att, lse, mode, B, T, n):
+        h, S = self.arch["heads"], 1 + T * n
+        K.attn_fwd(mode, qkv, att, lse, B=B, heads=h, S=S, T=T, n=n)
+        K.attn_fwd("cls", qkv, att, lse, B=B, heads=h, S=S, T=T, n=n)
+
+    def _st_attention_bwd(self, qkv, att, datt, lse, dqkv, mode, B, T, n, scr):
+        h, S = self.arch["heads"], 1 + T * n
+        M = B * S
+        delta = self._f(scr + ".delta", (M, h))
+        cls_acc = self._f(scr + ".clsacc", (B, h, 2, 64), zero=True)
+        K.attn_delta(datt, att, delta, rows=M, heads=h)
+        K.attn_bwd_dq(mode, qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n)
+        K.attn_bwd_dq("cls", qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n)
+        K.attn_bwd_dkv(mode, qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, cls_acc=cls_acc)
+        K.attn_cls_finalize(cls_acc, dqkv, B=B, heads=h, S=S)
+
+    def video_forward(self, video, keep_dev, B, T):
+        a = self.arch
+        W, E, p = a["width"], a["embed"], a["patch"]
+        n = keep_dev.shape[1]
+        S = 1 + T * n
+        M, Mp, Kp = B * S, B * T * n, 3 * p * p
+        cols = self._b("vit.im2col", (Mp, Kp))
+        K.patch_gather(video, keep_dev, cols, B=B, T=T, n=n, img=a["image"], patch=p)
+        pe = self._f("vit.patch", (Mp, W))
+        K.gemm_nt(cols, self.P.w("video_model.conv1.weight"), pe, M=Mp)
+        tok = self._f("vit.tok", (M, W))
+        K.vit_assemble(pe, self.P.p("video_model.class_embedding"), self.P.p("video_model.positional_embedding"),
+                       self.P.p("video_model.temporal_embedding"), keep_dev, tok, B=B, T=T, n=n)
+        x = self._f("vit.x0", (M, W))
+        self._ln(tok, "video_model.ln_pre", 1e-5, x, "vit.lnpre")
+        for l in range(a["layers"]):
+            pre, tg = f"video_model.transformer.resblocks.{l}.", f"vit{l}"
+            ln3 = self._b(tg + ".ln3", (M, W))
+            self._ln(x, pre + "ln_3", 1e-5, ln3, tg + ".ln3")
+            qkv_t = self._b(tg + ".qkv_t", (M, 3 * W))
+            self._lin(ln3, pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", qkv_t, M)
+            att_t, lse_t = self._b(tg + ".att_t", (M, W)), self._f(tg + ".lse_t", (M, a["heads"]))
+            self._st_attention_fwd(qkv_t, att_t, lse_t, "time", B, T, n)
+            t_res = self._f(tg + ".t_res", (M, W))
+            self._lin(att_t, pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", t_res, M, residual=x)
+            ln1 = self._b(tg + ".ln1", (M, W))
+            self._ln(t_res, pre + "ln_1", 1e-5, ln1, tg + ".ln1")
+            qkv_s = self._b(tg + ".qkv_s", (M, 3 * W))
+            self._lin(ln1, pre + "attn.qkv.weight", pre + "attn.qkv.bias", qkv_s, M)
+            att_s, lse_s = self._b(tg + ".att_s", (M, W)), self._f(tg + ".lse_s", (M, a["heads"]))
+            self._st_attention_fwd(qkv_s, att_s, lse_s, "space", B, T, n)
+            s_res = self._f(tg + ".s_res", (M, W))  # residual from the block INPUT x (video_encoder_ViT_B_16.py:121)
+            self._lin(att_s, pre + "attn.proj.weight", pre + "attn.proj.bias", s_res, M, residual=x)
+            ln2 = self._b(tg + ".ln2", (M, W))
+            self._ln(s_res, pre + "ln_2", 1e-5, ln2, tg + ".ln2")
+            h, act = self._b(tg + ".h", (M, 4 * W)), self._b(tg + ".a", (M, 4 * W))
+            self._lin(ln2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", act, M, act=a["act"], preact=h)
+            xo = self._f(f"vit.x{l + 1}", (M, W))
+            self._lin(act, pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", xo, M, residual=s_res)
+            x = xo
+        lnp = self._b("vit.lnpost", (M, W))
+        self._ln(x, "video_model.ln_post", 1e-5, lnp, "vit.lnpost")
+        out = self._f("vit.out", (M, E))
+        K.gemm_nt(lnp, self.P.wt("video_model.proj"), out, M=M)  # x @ proj, proj stored [W,E]
+        return out
+
+    def video_backward(self, dout_b, keep_dev, B, T):
+        """dout_b: bf16 [B*S, E] grad of the projected tokens (CLS rows carry the embedding grad)."""
+        a, B_ = self.arch, self.buf
+        W, E, p = a["width"], a["embed"], a["patch"]
+        n = keep_dev.shape[1]
+        S = 1 + T * n
+        M, Mp = B * S, B * T * n
+        rg = self.requires_grad
+        if rg["video_model.proj"]:  # dproj[W,E] += lnpost^T dout
+            K.gemm_tn(B_["vit.lnpost"], dout_b, self.P.g("video_model.proj"), M=M, accumulate=True)
+        dln = self._b("vit.s.dln", (M, W))
+        K.gemm_nt(dout_b, self.P.w("video_model.proj"), dln, M=M)
+        dx, dxb = self._f("vit.dxA", (M, W)), self._b("vit.dxbA", (M, W))
+        self._ln_bwd(dln, B_[f"vit.x{a['layers']}"], "video_model.ln_post", "vit.lnpost", dx, dx_bf16=dxb)
+        dh = self._b("vit.s.dh", (M, 4 * W))
+        datt = self._b("vit.s.datt", (M, W))
+        dqkv = self._b("vit.s.dqkv", (M, 3 * W))
+        dsr, dsrb = self._f("vit.s.dsres", (M, W)), self._b("vit.s.dsresb", (M, W))
+        dtr, dtrb = self._f("vit.s.dtres", (M, W)), self._b("vit.s.dtresb", (M, W))
+        for l in reversed(range(a["layers"])):
+            pre, tg = f"video_model.transformer.resblocks.{l}.", f"vit{l}"
+            x_in = B_[f"vit.x{l}"]
+            self._lin_bwd(dxb, B_[tg + ".a"], pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dh, M,
+                          gate_h=B_[tg + ".h"], gate_act=a["act"])
+            self._lin_bwd(dh, B_[tg + ".ln2"], pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", dln, M)
+            self._ln_bwd(dln, B_[tg + ".s_res"], pre + "ln_2", tg + ".ln2", dsr, dx_bf16=dsrb, res1=dx)
+            # spatial attention branch
+            self._lin_bwd(dsrb, B_[tg + ".att_s"], pre + "attn.proj.weight", pre + "attn.proj.bias", datt, M)
+            self._st_attention_bwd(B_[tg + ".qkv_s"], B_[tg + ".att_s"], datt, B_[tg + ".lse_s"], dqkv, "space", B, T, n, "vit.s")
+            self._lin_bwd(dqkv, B_[tg + ".ln1"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", dln, M)
+            self._ln_bwd(dln, B_[tg + ".t_res"], pre + "ln_1", tg + ".ln1", dtr, dx_bf16=dtrb)
+            # temporal attention branch
+            self._lin_bwd(dtrb, B_[tg + ".att_t"], pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", datt, M)
+            self._st_attention_bwd(B_[tg + ".qkv_t"], B_[tg + ".att_t"], datt, B_[tg + ".lse_t"], dqkv, "time", B, T, n, "vit.s")
+            self._lin_bwd(dqkv, B_[tg + ".ln3"], pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", dln, M)
+            nx = "B" if (a["layers"] - l) % 2 == 1 else "A"
+            dxi, dxbi = self._f("vit.dx" + nx, (M, W)), self._b("vit.dxb" + nx, (M, W))
+            # x feeds ln_3, the time residual and the space residual
+            self._ln_bwd(dln, x_in, pre + "ln_3", tg + ".ln3", dxi, dx_bf16=dxbi, res1=dsr, res2=dtr)
+            dx, dxb = dxi, dxbi
+            self._ready(pre + "attn.qkv.weight", pre + "ln_2.bias")
+        dtok = self._f("vit.dtok", (M, W))
+        self._ln_bwd(dx, B_["vit.tok"], "video_model.ln_pre", "vit.lnpre", dtok)
+        dpatch = self._b("vit.dpatch", (Mp, W))
+        K.vit_assemble_bwd(dtok, keep_dev, dpatch, self.P.g("video_model.class_embedding"),
+                           self.P.g("video_model.positional_embedding"), self.P.g("video_model.temporal_embedding"),
+                           B=B, T=T, n=n)
+        if rg["video_model.conv1.weight"]:
+            K.gemm_tn(dpatch, B_["vit.im2col"], self.P.g2d("video_model.conv1.weight"), M=Mp, accumulate=True)
+        self._ready("video_model.class_embedding", "video_model.ln_pre.bias")
+        self._ready("video_model.ln_post.weight", "video_model.ln_post.bias")
+
+    # ------------------------------------------------------------------ sort head
+    def sort_forward(self, out, text_before, B, S, NT):
+        a = self.arch
+        E, hs = a["embed"], a["sort_heads"]
+        So = S + NT
+        Mo = B * So
+        xs = self._f("srt.x0", (Mo, E))
+        K.sort_assemble(out, text_before, self.P.p("pred_model.type_embed").view(2, E), xs, B=B, S=S, off=0, Sv=S, NT=NT)
+        x = xs
+        for l in range(a["sort_depth"]):
+            xo = self._f(f"srt.x{l + 1}", (Mo, E))
+            self._block_fwd(f"pred_model.blocks.{l}.", _SORT_NAMES, x, xo, f"srt{l}", Mo, E, hs, B, So, False, "gelu", 1e-6)
+            x = xo
+        rows = self.ctx["sort_rows"]
+        nf = self._f("srt.nf", (B * NT, E))
+        self._ln(x, "pred_model.norm", 1e-6, nf, "srt.norm", rows=rows)
+        pred = self._f("srt.pred", (B * NT, a["n_trans"]))
+        C = a["n_trans"]
+        K.gemm_small(nf, self.P.p("pred_model.head.weight"), pred, M=B * NT, N=C, K=E, sa=(E, 1), sb=(1, E),
+                     bias=self.P.p("pred_model.head.bias"))
+        return pred
+
+    def sort_backward(self, dpred, B, S, NT):
+        """-> fp32 grad of the sort-head input xs [B*So, E]."""
+        a, B_ = self.arch, self.buf
+        E, hs, C = a["embed"], a["sort_heads"], a["n_trans"]
+        So = S + NT
+        Mo, R = B * So, B * NT
+        nf = B_["srt.nf"]
+        K.gemm_small(dpred, nf, self.P.g("pred_model.head.weight"), M=C, N=E, K=R, sa=(1, C), sb=(E, 1), accumulate=True)
+        ones = self._f("srt.ones", (R,))
+        ones.fill_(1.0)
+        K.gemm_small(ones, dpred, self.P.g("pred_model.head.bias").view(1, C), M=1, N=C, K=R, sa=(0, 1), sb=(C, 1),
+                     accumulate=True)
+        dnf = self._f("srt.dnf", (R, E))
+        K.gemm_small(dpred, self.P.p("pred_model.head.weight"), dnf, M=R, N=E, K=C, sa=(C, 1), sb=(E, 1))
+        dx = self._f("srt.dxA", (Mo, E), zero=True)
+        dxb = self._b("srt.dxbA", (Mo, E), zero=True)
+        self._ln_bwd(dnf, B_[f"srt.x{a['sort_depth']}"], "pred_model.norm", "srt.norm", dx, dx_bf16=dxb, rows=self.ctx["sort_rows"])
+        for l in reversed(range(a["sort_depth"])):
+            nx = "B" if (a["sort_depth"] - l) % 2 == 1 else "A"
+            dxi, dxbi = self._f("srt.dx" + nx, (Mo, E)), self._b("srt.dxb" + nx, (Mo, E))
+            self._block_bwd(f"pred_model.blocks.{l}.", _SORT_NAMES, B_[f"srt.x{l}"], dx, dxb, dxi, dxbi, f"srt{l}", Mo, E,
+                            hs, B, So, False, "gelu", "srt.s")
+            dx, dxb = dxi, dxbi
+        return dx
+
+    # ------------------------------------------------------------------ whole model
+    def prepare_batch(self, data: dict):
+        """Host-side (plumbing): dtype/device normalisation of the reference batch dict."""
+        a = self.arch
+        video = data["video"]
+        if video.dim() == 4:
+            video = video.unsqueeze(1)
+        video = video.to(self.dev, torch.float32).contiguous()
+        B, T = video.shape[:2]
+        ids = data["text"]
+        ids_cpu = ids.detach().to("cpu", torch.int64)
+        eot = ids_cpu.argmax(dim=-1)
+        L = int(eot.max()) + 1
+        N = ids_cpu.shape[0]
+        NT = N // B
+        eot_rows = (torch.arange(N) * L + eot).to(torch.int32).to(self.dev)
+        ids_dev = ids_cpu[:, :L].to(torch.int32).contiguous().to(self.dev)
+        keep = data["keep_ind"].to(torch.int32).contiguous().to(self.dev)
+        n = keep.shape[1]
+        S = 1 + T * n
+        So = S + NT
+        sort_rows = (torch.arange(B)[:, None] * So + S + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev)
+        vid_rows = (torch.arange(B) * S).to(torch.int32).to(self.dev)
+        return dict(video=video, ids=ids_dev, eot_rows=eot_rows, keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
+                    sort_rows=sort_rows, vid_rows=vid_rows)
+
+    def forward(self, pb: dict):
+        """-> (text_emb [B,E], video_emb [B,E], pred [B*NT, n_trans] | None); all fp32 workspace tensors."""
+        a = self.arch
+        self.ctx = pb
+        B, T, N, NT, L, S, E = pb["B"], pb["T"], pb["N"], pb["NT"], pb["L"], pb["S"], a["embed"]
+        t = self.text_forward(pb["ids"], pb["eot_rows"], N, L)
+        text_emb = self._f("mdl.text_emb", (B, E))
+        text_before = self._f("mdl.text_before", (B, NT, E))
+        K.text_mean(t, text_emb, text_before, NT=NT, B=B)
+        out = self.video_forward(pb["video"], pb["keep"], B, T)
+        video_emb = self._f("mdl.video_emb", (B, E))
+        K.rows_gather(out, pb["vid_rows"], video_emb)
+        pred = self.sort_forward(out, text_before, B, S, NT) if NT != 1 else None
+        return text_emb, video_emb, pred
+
+    def backward(self, d_text, d_video, d_pred):
+        """Accumulates parameter gradients into the flat grad buffer (+=).  d_* are fp32 GPU tensors (or None)."""
+        a, pb = self.arch, self.ctx
+        B, T, N, NT, L, S, E = pb["B"], pb["T"], pb["N"], pb["NT"], pb["L"], pb["S"], a["embed"]
+        dout = self._b("mdl.dout", (B * S, E))
+        if d_pred is not None:
+            dxs = self.sort_backward(d_pred, B, S, NT)
+            K.sort_assemble_bwd(dxs, d_video, dout, self.P.g("pred_model.type_embed").view(2, E), B=B, S=S, off=0, Sv=S, NT=NT)
+            self._ready("pred_model.type_embed", "pred_model.head.bias")
+        else:
+            K.sort_assemble_bwd(None, d_video, dout, None, B=B, S=S, off=0, Sv=S, NT=NT)
+        self.video_backward(dout, pb["keep"], B, T)
+        if d_text is not None:
+            dt = self._f("mdl.dt", (N, E))
+            K.text_mean_bwd(d_text, dt, NT=NT, B=B)
+            self.text_backward(dt, pb["ids"], pb["eot_rows"], N, L)
+            self._ready("text_positional_embedding", "text_ln_final.bias")
+
+
+class LossHead:
+    """sim_matrix + NormSoftmaxLoss (+ sorting CE) forward AND backward on the GPU, fp32.
+
+    model/model_dist_TVTSv2_ViT_B_16.py:119-127, model/loss.py:13-25, trainer/trainer.py:484-496."""
+
+    def __init__(self, device, temperature=0.05):
+        self.dev, self.temp = device, temperature
+        self.buf: Dict[str, torch.Tensor] = {}
+
+    def _f(self, name, shape, zero=False):
+        t = self.buf.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape:
+            t = self.buf[name] = torch.zeros(shape, dtype=torch.float32, device=self.dev)
+        elif zero:
+            t.zero_()
+        return t
+
+    def sim(self, a, b, eps=1e-8):
+        G, E = a.shape
+        an, bn = self._f("an", (G, E)), self._f("bn", (b.shape[0], E))
+        ai, bi = self._f("ai", (G,)), self._f("bi", (b.shape[0],))
+        K.l2norm_rows(a, an, ai, eps)
+        K.l2norm_rows(b, bn, bi, eps)
+        return an, bn, ai, bi
+
+    def contrastive(self, video_all, text_all, need_grad=True):
+        """-> (loss1 scalar tensor, d_video_all, d_text_all).  Rows of the similarity are videos (trainer.py:484)."""
+        G, E = video_all.shape
+        vn, tn, vi, ti = self.sim(video_all, text_all)
+        x = self._f("x", (G, G))
+        K.gemm_small(vn, tn, x, M=G, N=G, K=E, sa=(E, 1), sb=(1, E), alpha=1.0 / self.temp)
+        lse = self._f("lse", (2 * G,))
+        loss = self._f("loss1", (1,), zero=True)
+        dx = self._f("dx", (G, G)) if need_grad else None
+        K.infonce(x, lse, dx, loss)
+        if not need_grad:
+            return loss, None, None
+        dvn, dtn = self._f("dvn", (G, E)), self._f("dtn", (G, E))
+        K.gemm_small(dx, tn, dvn, M=G, N=E, K=G, sa=(G, 1), sb=(E, 1), alpha=1.0 / self.temp)
+        K.gemm_small(dx, vn, dtn, M=G, N=E, K=G, sa=(1, G), sb=(E, 1), alpha=1.0 / self.temp)
+        dv, dt = self._f("dv", (G, E)), self._f("dt", (G, E))
+        K.l2norm_rows_bwd(dvn, vn, vi, dv)
+        K.l2norm_rows_bwd(dtn, tn, ti, dt)
+        return loss, dv, dt
+
+    def sorting(self, pred, labels_i32, need_grad=True):
+        """2 * CrossEntropy (trainer.py:487-492) -> (loss2, dpred)."""
+        loss = self._f("loss2", (1,), zero=True)
+        dp = self._f("dpred", pred.shape) if need_grad else None
+        K.cross_entropy(pred, labels_i32, 2.0, dp, loss)
+        return loss, dp

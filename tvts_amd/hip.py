@@ -1,0 +1,281 @@
+"""Thin tensor-level wrappers over the C ABI (include/tvts_hip.h).
+
+PyTorch is used for device memory and the current HIP stream only; every function here launches a
+hand-written gfx950 kernel.  Tensors must live on the GPU; a CPU tensor raises (no fallback).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+GEMM_PROFILE = None  # bench.py: list collecting (kind, flops, start_event, end_event) per MFMA GEMM launch
+
+ACT = {"none": 0, None: 0, "quick_gelu": 1, "gelu": 2}
+MODE = {"full": 0, "space": 1, "time": 2, "cls": 3}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _chk(rc: int, name: str):
+    if rc != 0:
+        raise HipError(f"{name} failed with code {rc}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("tvts_amd kernels need GPU tensors (no CPU path)")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor"
+    return t.stride(0)
+
+
+def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None):
+    """out[M,N] = [act'(gate_h) *] act(a[M,K] @ b[N,K]^T + bias) [+ residual]; a, b bf16; out bf16 or fp32."""
+    lib = _lib.load()
+    M = a.shape[0] if M is None else M
+    N, K = b.shape
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape[1] == K
+    assert out.shape[1] == N and out.dtype in (torch.bfloat16, torch.float32)
+    if GEMM_PROFILE is not None:
+        ev0, ev1 = Event(), Event()
+        ev0.record()
+    rc = lib.tvts_gemm_nt_bf16(_p(a), _ld(a), _p(b), _ld(b), M, N, K, _p(bias), _p(residual),
+                               _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
+                               _ld(preact) if preact is not None else 0, _p(gate_h),
+                               _ld(gate_h) if gate_h is not None else 0, ACT[gate_act], _p(out), _ld(out),
+                               1 if out.dtype == torch.float32 else 0, _stream())
+    _chk(rc, "tvts_gemm_nt_bf16")
+    if GEMM_PROFILE is not None:
+        ev1.record()
+        GEMM_PROFILE.append(("gemm_nt", 2.0 * M * N * K, ev0, ev1))
+
+
+def gemm_tn(p, q, out, *, M=None, accumulate=True):
+    """out[Na,Nb] (+)= p[M,Na]^T @ q[M,Nb]; p, q bf16; out fp32."""
+    lib = _lib.load()
+    M = p.shape[0] if M is None else M
+    assert p.dtype == torch.bfloat16 and q.dtype == torch.bfloat16 and out.dtype == torch.float32
+    if GEMM_PROFILE is not None:
+        ev0, ev1 = Event(), Event()
+        ev0.record()
+    rc = lib.tvts_gemm_tn_bf16(_p(p), _ld(p), _p(q), _ld(q), M, p.shape[1], q.shape[1], _p(out), _ld(out),
+                               1 if accumulate else 0, _stream())
+    _chk(rc, "tvts_gemm_tn_bf16")
+    if GEMM_PROFILE is not None:
+        ev1.record()
+        GEMM_PROFILE.append(("gemm_tn", 2.0 * M * p.shape[1] * q.shape[1], ev0, ev1))
+
+
+def gemm_small(a, b, out, *, M, N, K, sa, sb, alpha=1.0, bias=None, accumulate=False):
+    """out[i,j] (+)= alpha * sum_k a[i*sa[0]+k*sa[1]] * b[k*sb[0]+j*sb[1]] + bias[j] (fp32)."""
+    lib = _lib.load()
+    assert a.dtype == b.dtype == out.dtype == torch.float32
+    rc = lib.tvts_gemm_small_f32(_p(a), sa[0], sa[1], _p(b), sb[0], sb[1], M, N, K, alpha, _p(bias), _p(out),
+                                 out.stride(0), 1 if accumulate else 0, _stream())
+    _chk(rc, "tvts_gemm_small_f32")
+
+
+def colsum(x, out, *, M=None):
+    lib = _lib.load()
+    M = x.shape[0] if M is None else M
+    _chk(lib.tvts_colsum_bf16(_p(x), _ld(x), M, x.shape[1], _p(out), _stream()), "tvts_colsum_bf16")
+
+
+def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=None):
+    lib = _lib.load()
+    M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
+    rc = lib.tvts_layernorm_fwd(_p(x), _ld(x), _p(rows), _p(gamma), _p(beta), eps, M, x.shape[1], _p(y), _ld(y),
+                                1 if y.dtype == torch.float32 else 0, _p(mean), _p(rstd), _stream())
+    _chk(rc, "tvts_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2=None, dgamma=None, dbeta=None,
+                  rows=None, M=None):
+    lib = _lib.load()
+    M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
+    ldr = _ld(res1) if res1 is not None else (_ld(res2) if res2 is not None else 0)
+    rc = lib.tvts_layernorm_bwd(_p(dy), _ld(dy), 1 if dy.dtype == torch.float32 else 0, _p(x), _ld(x), _p(rows),
+                                _p(mean), _p(rstd), _p(gamma), _p(res1), _p(res2), ldr, M, x.shape[1], _p(dx), _ld(dx),
+                                _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0, _p(dgamma), _p(dbeta),
+                                _stream())
+    _chk(rc, "tvts_layernorm_bwd")
+
+
+def attn_fwd(mode, qkv, out, lse2, *, B, heads, S, T=0, n=0, causal=False):
+    lib = _lib.load()
+    rc = lib.tvts_attn_fwd(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(out), _ld(out), _p(lse2),
+                           _stream())
+    _chk(rc, "tvts_attn_fwd")
+
+
+def attn_delta(dO, O, delta, *, rows, heads):
+    lib = _lib.load()
+    _chk(lib.tvts_attn_delta(_p(dO), _ld(dO), _p(O), _ld(O), rows, heads, _p(delta), _stream()), "tvts_attn_delta")
+
+
+def attn_bwd_dq(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False):
+    lib = _lib.load()
+    rc = lib.tvts_attn_bwd_dq(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO), _p(lse2),
+                              _p(delta), _p(dqkv), _ld(dqkv), _stream())
+    _chk(rc, "tvts_attn_bwd_dq")
+
+
+def attn_bwd_dkv(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None):
+    lib = _lib.load()
+    rc = lib.tvts_attn_bwd_dkv(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO),
+                               _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc), _stream())
+    _chk(rc, "tvts_attn_bwd_dkv")
+
+
+def attn_cls_finalize(cls_acc, dqkv, *, B, heads, S):
+    lib = _lib.load()
+    _chk(lib.tvts_attn_cls_finalize(_p(cls_acc), B, heads, S, _p(dqkv), _ld(dqkv), _stream()), "tvts_attn_cls_finalize")
+
+
+def attn_set_transpose_read(on: bool):
+    _lib.load().tvts_attn_set_transpose_read(int(on))
+
+
+def patch_gather(video, keep, out, *, B, T, n, img, patch):
+    lib = _lib.load()
+    assert video.dtype == torch.float32 and keep.dtype == torch.int32 and video.is_contiguous()
+    _chk(lib.tvts_patch_gather(_p(video), _p(keep), B, T, n, img, patch, _p(out), _ld(out), _stream()), "tvts_patch_gather")
+
+
+def vit_assemble(patch, cls, pos, temporal, keep, tok, *, B, T, n):
+    lib = _lib.load()
+    _chk(lib.tvts_vit_assemble(_p(patch), _ld(patch), _p(cls), _p(pos), _p(temporal), _p(keep), B, T, n, tok.shape[1],
+                               _p(tok), _ld(tok), _stream()), "tvts_vit_assemble")
+
+
+def vit_assemble_bwd(dtok, keep, dpatch, dcls, dpos, dtemporal, *, B, T, n):
+    lib = _lib.load()
+    _chk(lib.tvts_vit_assemble_bwd(_p(dtok), _ld(dtok), _p(keep), B, T, n, dtok.shape[1], _p(dpatch), _ld(dpatch),
+                                   _p(dcls), _p(dpos), _p(dtemporal), _stream()), "tvts_vit_assemble_bwd")
+
+
+def text_embed(ids, emb, pos, x, *, N, L):
+    lib = _lib.load()
+    assert ids.dtype == torch.int32
+    _chk(lib.tvts_text_embed(_p(ids), ids.stride(0), N, L, _p(emb), _p(pos), emb.shape[1], _p(x), _ld(x), _stream()),
+         "tvts_text_embed")
+
+
+def text_embed_bwd(dx, ids, demb, dpos, *, N, L):
+    lib = _lib.load()
+    _chk(lib.tvts_text_embed_bwd(_p(dx), _ld(dx), _p(ids), ids.stride(0), N, L, dx.shape[1], _p(demb), _p(dpos),
+                                 _stream()), "tvts_text_embed_bwd")
+
+
+def text_mean(t, mean, before, *, NT, B):
+    lib = _lib.load()
+    _chk(lib.tvts_text_mean(_p(t), NT, B, t.shape[1], _p(mean), _p(before), _stream()), "tvts_text_mean")
+
+
+def text_mean_bwd(dmean, dt, *, NT, B):
+    lib = _lib.load()
+    _chk(lib.tvts_text_mean_bwd(_p(dmean), NT, B, dmean.shape[1], _p(dt), _stream()), "tvts_text_mean_bwd")
+
+
+def sort_assemble(tok, text, type_embed, xs, *, B, S, off, Sv, NT):
+    lib = _lib.load()
+    _chk(lib.tvts_sort_assemble(_p(tok), _ld(tok), B, S, off, Sv, _p(text), NT, _p(type_embed), xs.shape[1], _p(xs),
+                                _ld(xs), _stream()), "tvts_sort_assemble")
+
+
+def sort_assemble_bwd(dxs, dvid, dout, dtype, *, B, S, off, Sv, NT):
+    lib = _lib.load()
+    E = dout.shape[1]
+    _chk(lib.tvts_sort_assemble_bwd(_p(dxs), _ld(dxs) if dxs is not None else 0, B, S, off, Sv, NT, _p(dvid), E,
+                                    _p(dout), _ld(dout), _p(dtype), _stream()), "tvts_sort_assemble_bwd")
+
+
+def rows_gather(src, rows, dst, *, scatter_add=False):
+    lib = _lib.load()
+    _chk(lib.tvts_rows_gather(_p(src), _ld(src), _p(rows), rows.numel(), src.shape[1], _p(dst), _ld(dst),
+                              int(scatter_add), _stream()), "tvts_rows_gather")
+
+
+def l2norm_rows(x, xn, inv, eps=1e-8):
+    lib = _lib.load()
+    _chk(lib.tvts_l2norm_rows(_p(x), x.shape[0], x.shape[1], eps, _p(xn), _p(inv), _stream()), "tvts_l2norm_rows")
+
+
+def l2norm_rows_bwd(dxn, xn, inv, dx):
+    lib = _lib.load()
+    _chk(lib.tvts_l2norm_rows_bwd(_p(dxn), _p(xn), _p(inv), xn.shape[0], xn.shape[1], _p(dx), _stream()),
+         "tvts_l2norm_rows_bwd")
+
+
+def infonce(x, lse, dx, loss):
+    lib = _lib.load()
+    _chk(lib.tvts_infonce(_p(x), x.shape[0], _p(lse), _p(dx), _p(loss), _stream()), "tvts_infonce")
+
+
+def cross_entropy(logits, labels, scale, dlogits, loss):
+    lib = _lib.load()
+    assert labels.dtype == torch.int32
+    _chk(lib.tvts_cross_entropy(_p(logits), _p(labels), logits.shape[0], logits.shape[1], scale, _p(dlogits), _p(loss),
+                                _stream()), "tvts_cross_entropy")
+
+
+def adamw_hf(p, g, m, v, shadow, chunk_group, lr4, wd4, step, beta1=0.9, beta2=0.999, eps=1e-6, grad_scale=1.0,
+             step_dev=None):
+    lib = _lib.load()
+    lr = (ctypes.c_float * 4)(*lr4)
+    wd = (ctypes.c_float * 4)(*wd4)
+    _chk(lib.tvts_adamw_hf(_p(p), _p(g), _p(m), _p(v), _p(shadow), _p(chunk_group), chunk_group.numel(),
+                           ctypes.cast(lr, ctypes.c_void_p), ctypes.cast(wd, ctypes.c_void_p), step, _p(step_dev), beta1, beta2, eps,
+                           grad_scale, _stream()), "tvts_adamw_hf")
+
+
+def cast_f32_bf16(src, dst):
+    lib = _lib.load()
+    _chk(lib.tvts_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "tvts_cast_f32_bf16")
+
+
+def transpose_batched(src, dst, tiles, ntiles):
+    lib = _lib.load()
+    _chk(lib.tvts_transpose_bf16_batched(_p(src), _p(dst), _p(tiles), ntiles, _stream()), "tvts_transpose_bf16_batched")
+
+
+def probe_tr16(inp, out):
+    lib = _lib.load()
+    _chk(lib.tvts_probe_tr16(_p(inp), _p(out), _stream()), "tvts_probe_tr16")
+
+
+class Event:
+    """HIP event on the launch stream (torch.cuda.Event would do too; this one goes through the C ABI)."""
+
+    def __init__(self):
+        self._e = ctypes.c_void_p()
+        _chk(_lib.load().tvts_event_create(ctypes.byref(self._e)), "tvts_event_create")
+
+    def record(self):
+        _chk(_lib.load().tvts_event_record(self._e, _stream()), "tvts_event_record")
+
+    def elapsed_ms(self, end: "Event") -> float:
+        ms = ctypes.c_float()
+        _chk(_lib.load().tvts_event_elapsed_ms(self._e, end._e, ctypes.byref(ms)), "tvts_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            _lib.load().tvts_event_destroy(self._e)
+        except Exception:
+            pass

@@ -1,0 +1,10 @@
+"""Drop-in for v2/model/model_dist_TVTSv2_ViT_B_16.py: same class name, ctor and forward contract."""
+from ._common import TVTSv2Base, sim_matrix  # noqa: F401
+
+
+class TVTSv2_B_16(TVTSv2Base):
+    ARCH_NAME = "B_16"
+
+
+if __name__ == "__main__":
+    pass

@@ -1,0 +1,90 @@
+"""Fused multi-tensor AdamW with Hugging Face semantics over the flat parameter store.
+
+Replaces ``transformers.AdamW(params=optimizer_grouped_parameters)`` built at
+v2/train_dist_TVTSv2_ViT_B_16.py:118-125 (defaults betas (0.9, 0.999), eps 1e-6, correct_bias=True).
+It is a ``torch.optim.Optimizer`` so param_groups / state_dict keep the reference checkpoint layout
+(``state[p] = {step, exp_avg, exp_avg_sq}``), but ``step()`` is ONE kernel launch over the flat buffers.
+
+Gradient handling follows the reference's pinned torch 1.11 ``zero_grad()`` (grads zeroed, not set to
+None): every trainable tensor is updated every step, tensors that received no gradient see g = 0.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hip as K
+from .engine import CH, ParamStore
+
+
+class FusedHFAdamW(torch.optim.Optimizer):
+    def __init__(self, params, store: ParamStore, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0,
+                 correct_bias=True, model=None):
+        if not correct_bias:
+            raise NotImplementedError("correct_bias=False is not built")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)
+        super().__init__(params, defaults)
+        if len(self.param_groups) > 4:
+            raise ValueError("the fused kernel supports up to 4 parameter groups (the reference uses 4)")
+        self.store, self.model = store, model
+        dev = store.device
+        if store.m is None:
+            store.m = torch.zeros_like(store.flat)
+            store.v = torch.zeros_like(store.flat)
+        ptr2name = {store.p(n).data_ptr(): n for n in store.shapes}
+        table = torch.full((store.total // CH,), 255, dtype=torch.uint8)
+        self._names = []
+        for gi, group in enumerate(self.param_groups):
+            names = []
+            for p in group["params"]:
+                name = ptr2name.get(p.data_ptr())
+                if name is None:
+                    raise ValueError("FusedHFAdamW only handles parameters of the flat store")
+                names.append(name)
+                o, n = store.off[name], p.numel()
+                table[o // CH:(o + n + CH - 1) // CH] = gi
+                o2 = store.off[name]
+                self.state[p] = dict(step=0, exp_avg=store.m[o2:o2 + n].view(p.shape), exp_avg_sq=store.v[o2:o2 + n].view(p.shape))
+            self._names.append(names)
+        self.chunk_group = table.to(dev)
+        self.global_step = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.store.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None, device_step: bool = False):
+        """device_step=True keeps the step counter in device memory (hipGraph replay)."""
+        b1, b2 = self.param_groups[0]["betas"]
+        eps = self.param_groups[0]["eps"]
+        lr4 = [g["lr"] for g in self.param_groups] + [0.0] * (4 - len(self.param_groups))
+        wd4 = [g["weight_decay"] for g in self.param_groups] + [0.0] * (4 - len(self.param_groups))
+        self.global_step += 1
+        if device_step:
+            self.step_dev.add_(1)
+        K.adamw_hf(self.store.flat, self.store.grad, self.store.m, self.store.v, self.store.shadow, self.chunk_group,
+                   lr4, wd4, self.global_step, b1, b2, eps, self.grad_scale, step_dev=self.step_dev if device_step else None)
+        self.store.refresh_shadows(cast=False)
+        if self.model is not None:
+            self.model.mark_shadows_fresh()
+        if not device_step:
+            for st in self.state.values():
+                st["step"] = self.global_step
+
+    def load_state_dict(self, state_dict):
+        """Accepts the HF-AdamW / torch layout: state keyed by the running parameter index."""
+        sd_groups, sd_state = state_dict["param_groups"], state_dict["state"]
+        for g, sg in zip(self.param_groups, sd_groups):
+            for k, v in sg.items():
+                if k != "params":
+                    g[k] = v
+            for p, idx in zip(g["params"], sg["params"]):
+                st = sd_state.get(idx)
+                if st is None:
+                    continue
+                self.state[p]["exp_avg"].copy_(st["exp_avg"])
+                self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
+                self.state[p]["step"] = int(st["step"])
+                self.global_step = max(self.global_step, int(st["step"]))
+        self.step_dev.fill_(self.global_step)

@@ -1,0 +1,178 @@
+"""Drop-in for v2/trainer/trainer.py: Trainer_TVTSv2_{B_32,B_16,H_14} with the reference's constructor and
+``train()`` contract, running each optimisation step on the HIP engine (tvts_amd.step.StepRunner).
+
+Kept from the reference's ``_train_epoch`` (:419-525): the YT loader drives the loop, the other loaders are
+cycled with fresh iterators (:438-461); per loop iteration one optimizer step per loader (:463); captions
+arrive as a list of NT lists and are flattened clip-major before tokenising (:465-473, ``truncate=True`` for
+the B models, none for H/14 :767); loss = InfoNCE + 2*CE (:485-496); the debug log line and its cadence
+``int(sqrt(batch_size))`` (:384,505-512); LR x0.1 at the ``--schedule`` epochs, applied at epoch end (:402-417).
+AllGather / AllGather_multi are exported with the same names and semantics for callers that import them.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..base import Multi_BaseTrainer_dist
+from ..model._common import sim_matrix  # noqa: F401  (the reference re-exports it at module scope)
+from ..step import StepRunner
+
+__all__ = ["AllGather", "AllGather_multi", "Trainer_TVTSv2_B_32", "Trainer_TVTSv2_B_16", "Trainer_TVTSv2_H_14"]
+
+
+class AllGather_multi(torch.autograd.Function):
+    """all_gather forward, local-row-slice backward, no reduction (v2/trainer/trainer.py:41-57)."""
+
+    @staticmethod
+    def forward(ctx, tensor, n_gpu, args):
+        ctx.rank, ctx.batch_size = args.rank, tensor.shape[0]
+        if args.world_size == 1:
+            return tensor.clone()
+        out = torch.empty((args.world_size * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype,
+                          device=tensor.device)
+        dist.all_gather_into_tensor(out, tensor.contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output[ctx.batch_size * ctx.rank: ctx.batch_size * (ctx.rank + 1)], None, None
+
+
+class AllGather(AllGather_multi):
+    """Single-node variant (:22-38): identical except that it indexes with local_rank."""
+
+    @staticmethod
+    def forward(ctx, tensor, n_gpu, args):
+        out = AllGather_multi.forward(ctx, tensor, n_gpu, args)
+        ctx.rank = args.local_rank
+        return out
+
+
+class _TrainerBase(Multi_BaseTrainer_dist):
+    TRUNCATE = True
+
+    def __init__(self, args, model, loss, metrics, optimizer, config, data_loader, valid_data_loader=None,
+                 lr_scheduler=None, len_epoch=None, writer=None, visualizer=None, tokenizer=None,
+                 max_samples_per_epoch=50000):
+        super().__init__(args, model, loss, metrics, optimizer, config, writer)
+        self.config, self.args = config, args
+        self.data_loader = data_loader
+        if len_epoch is None:
+            self.len_epoch = None
+            for x in data_loader:
+                if x.dataset_name.startswith("YT"):
+                    self.len_epoch = len(x)
+            if self.len_epoch is None:
+                self.len_epoch = len(data_loader[0])
+        else:
+            self.len_epoch = len_epoch
+        self.valid_data_loader = valid_data_loader
+        self.do_validation = bool(valid_data_loader)
+        self.lr_scheduler, self.visualizer = lr_scheduler, visualizer
+        self.batch_size = self.data_loader[0].batch_size
+        self.log_step = max(1, int(np.sqrt(self.batch_size)))
+        self.total_batch_sum = sum(x.batch_size for x in self.data_loader)
+        self.tokenizer = tokenizer
+        self.max_samples_per_epoch = max_samples_per_epoch
+        self.n_gpu = self.args.world_size
+        self.allgather = AllGather_multi.apply
+        self.num_clips = self.n_trans = 4
+        self.base_lr = [g["lr"] for g in optimizer.param_groups]
+        self.runner = StepRunner(model, optimizer)
+
+    def _adjust_learning_rate(self, optimizer, epoch, args):
+        lr_rate = 1.0
+        for milestone in getattr(args, "schedule", []):
+            if epoch == milestone:
+                lr_rate = 0.1
+        for group in optimizer.param_groups:
+            group["lr"] = group["lr"] * lr_rate
+
+    def _progress(self, batch_idx, dl_idx):
+        current = batch_idx * self.data_loader[dl_idx].batch_size
+        total = getattr(self.data_loader[dl_idx], "n_samples", self.len_epoch * self.data_loader[dl_idx].batch_size)
+        return "[{}/{} ({:.0f}%)]".format(current, total, 100.0 * current / max(total, 1))
+
+    def _tokenize(self, data):
+        if self.tokenizer is not None and not torch.is_tensor(data["text"]):
+            text_all = []
+            for clip_texts in data["text"]:  # list over the NT clips, each a list of B strings -> clip-major
+                text_all = text_all + list(clip_texts)
+            data["text"] = self.tokenizer(text_all, truncate=True) if self.TRUNCATE else self.tokenizer(text_all)
+        return data
+
+    def _train_epoch(self, epoch):
+        total_loss = [0.0] * len(self.data_loader)
+        for loader in self.data_loader:
+            if hasattr(loader, "train_sampler") and loader.train_sampler is not None:
+                loader.train_sampler.set_epoch(epoch)
+        iter_dl = [None] * len(self.data_loader)
+        loop_dl, loop_dl_idx = None, 0
+        for dl_idx, dl in enumerate(self.data_loader):
+            if loop_dl is None and len(dl) == self.len_epoch:
+                loop_dl, loop_dl_idx = dl, dl_idx
+            else:
+                iter_dl[dl_idx] = iter(dl)
+        for batch_idx, loop_dl_data in enumerate(loop_dl):
+            data_li = [None] * len(self.data_loader)
+            for dl_idx in range(len(iter_dl)):
+                if dl_idx != loop_dl_idx:
+                    try:
+                        data_li[dl_idx] = next(iter_dl[dl_idx])
+                    except StopIteration:
+                        iter_dl[dl_idx] = iter(self.data_loader[dl_idx])
+                        data_li[dl_idx] = next(iter_dl[dl_idx])
+            data_li[loop_dl_idx] = loop_dl_data
+            for dl_idx, data in enumerate(data_li):
+                out = self.runner.step(self._tokenize(data))
+                log_now = batch_idx % self.log_step == 0 and self.args.local_rank == 0
+                l1 = out["loss1"]
+                l2 = out["loss2"] if out["loss2"] is not None else torch.zeros_like(l1)
+                loss = float(l1 + l2)  # the reference syncs once per step as well (trainer.py:503)
+                total_loss[dl_idx] += loss
+                if log_now:
+                    self.logger.debug("Train Epoch: {} dl{} {} Loss_ct: {:.6f} Loss_ce: {:.6f} Loss: {:.6f}".format(
+                        epoch, dl_idx, self._progress(batch_idx, dl_idx), float(l1), float(l2), loss))
+            if (batch_idx + 1) * self.batch_size * self.n_gpu >= self.max_samples_per_epoch:
+                break
+        log = {f"loss_{dl_idx}": total_loss[dl_idx] / self.len_epoch for dl_idx in range(len(self.data_loader))}
+        if self.do_validation:
+            val_log = self._valid_epoch(epoch)
+            if self.args.rank == 0:
+                log.update(val_log)
+        self._adjust_learning_rate(self.optimizer, epoch, self.args)
+        return log
+
+    @torch.no_grad()
+    def _valid_epoch(self, epoch):
+        """Sorting accuracy + contrastive loss on the validation loaders (a reduced form of trainer.py:527-635;
+        the numpy retrieval metrics of model/metric.py stay out of scope)."""
+        res = {}
+        for dl_idx, dl in enumerate(self.valid_data_loader):
+            correct, count = 0, 0
+            for data in dl:
+                data = self._tokenize(data)
+                te, ve, pred = self.model(data, return_embeds=True)
+                if pred is not None and "label" in data:
+                    lab = data["label"].to(pred.device)
+                    correct += int((pred.argmax(-1) == lab).sum())
+                    count += lab.numel()
+            if count:
+                t = torch.tensor([correct, count], dtype=torch.float64, device=self.device)
+                if self.args.world_size > 1:
+                    dist.all_reduce(t)
+                res[f"val_loss_{dl_idx}"] = float(t[0] / t[1])  # (sic) the reference logs accuracy under this key (:585-588,630)
+        return res
+
+
+class Trainer_TVTSv2_B_32(_TrainerBase):
+    TRUNCATE = True
+
+
+class Trainer_TVTSv2_B_16(_TrainerBase):
+    TRUNCATE = True
+
+
+class Trainer_TVTSv2_H_14(_TrainerBase):
+    TRUNCATE = False
