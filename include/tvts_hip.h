@@ -84,8 +84,8 @@ int tvts_cross_entropy(const float* logits, const int* labels, int R, int C, flo
 
 /* ---- optimizer (optim.hip): transformers.AdamW as built at train_dist_TVTSv2_ViT_B_16.py:118-125 */
 int tvts_adamw_hf(float* p, const float* g, float* m, float* v, void* shadow_bf16, const unsigned char* chunk_group,
-                  int nchunks, const float* lr4, const float* wd4, int step, const int* step_dev, float beta1,
-                  float beta2, float eps, float grad_scale, hipStream_t stream);
+                  int nchunks, const float* lr4, const float* wd4, int step, const int* step_dev, double beta1,
+                  double beta2, double eps, float grad_scale, hipStream_t stream);
 int tvts_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream);
 int tvts_transpose_bf16_batched(const void* src, void* dst, const void* tiles, int ntiles, hipStream_t stream);
 int tvts_probe_tr16(const void* in, void* out, hipStream_t stream);

@@ -269,9 +269,16 @@ def divided_attention(x: Tensor, wqkv: Tensor, bqkv: Tensor, wo: Tensor, bo: Ten
     token (f, i) attends {CLS} + {(f, i')}.  The CLS query attends all tokens.  q is scaled by
     dh^-0.5 before the CLS split (:45-51); CLS k/v are key 0 of every group (:56-60).
     """
-    B, S, W = x.shape
+    out = divided_attention_core(linear(x, wqkv, bqkv), heads, mode, T, n)
+    return linear(out, wo, bo)
+
+
+def divided_attention_core(qkv_packed: Tensor, heads: int, mode: str, T: int, n: int) -> Tensor:
+    """The attention proper on a packed [B, S, 3W] (q | k | v) tensor -> merged heads [B, S, W]."""
+    B, S, W3 = qkv_packed.shape
+    W = W3 // 3
     dh = W // heads
-    qkv = linear(x, wqkv, bqkv).reshape(B, S, 3, heads, dh)
+    qkv = qkv_packed.reshape(B, S, 3, heads, dh)
     q = qkv[:, :, 0].permute(0, 2, 1, 3) * dh ** -0.5  # [B,h,S,dh]
     k = qkv[:, :, 1].permute(0, 2, 1, 3)
     v = qkv[:, :, 2].permute(0, 2, 1, 3)
@@ -290,8 +297,7 @@ def divided_attention(x: Tensor, wqkv: Tensor, bqkv: Tensor, wo: Tensor, bo: Ten
     if mode == "time":
         out = out.transpose(2, 3)
     out = torch.cat([cls_out, out.reshape(B, heads, T * n, dh)], 2)  # [B,h,S,dh]
-    out = out.permute(0, 2, 1, 3).reshape(B, S, W)
-    return linear(out, wo, bo)
+    return out.permute(0, 2, 1, 3).reshape(B, S, W)
 
 
 def st_block(x: Tensor, P: Params, pre: str, arch, T: int, n: int) -> Tensor:

@@ -183,10 +183,8 @@ def test_layernorm_rows(K):
 # ------------------------------------------------------------------------------------------------ attention
 def _ref_divided(qkv, heads, mode, T, n, dO):
     """Oracle divided attention on a given packed qkv (identity projections), + grads wrt qkv."""
-    B, S, W3 = qkv.shape
-    W = W3 // 3
     x = qkv.clone().requires_grad_(True)
-    out = O.divided_attention(x, torch.eye(W3), torch.zeros(W3), torch.eye(W), torch.zeros(W), heads, mode, T, n)
+    out = O.divided_attention_core(x, heads, mode, T, n)
     out.backward(dO)
     return out.detach(), x.grad
 

@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, "libtvts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tvts_hip.h")
 
 _CTYPES = {
-    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "hipStream_t": ctypes.c_void_p,
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+    "hipStream_t": ctypes.c_void_p,
 }
 
 
@@ -52,6 +53,7 @@ def load():
     global _lib, _protos
     if _lib is not None:
         return _lib
+    import torch  # noqa: F401  -- load PyTorch-ROCm's HIP runtime first so both sides share ONE libamdhip64
     if not os.path.exists(LIB_PATH):
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -15,7 +15,7 @@ struct AdamGroups { float lr[4]; float wd[4]; float step_size[4]; };
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ shadow,
                                                     const unsigned char* __restrict__ chunk_group, AdamGroups hp, float beta1,
-                                                    float beta2, float eps, float grad_scale,
+                                                    float beta2, float omb1, float omb2, float eps, float grad_scale,
                                                     const int* __restrict__ step_dev) {
     const int grp = chunk_group[blockIdx.x];
     if (grp > 3) return;
@@ -31,8 +31,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float gg = gv[e] * grad_scale;
-        mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
-        vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
+        mv[e] = beta1 * mv[e] + omb1 * gg;
+        vv[e] = beta2 * vv[e] + omb2 * gg * gg;
         pv[e] -= ss * mv[e] / (sqrtf(vv[e]) + eps);
         if (wd > 0.f) pv[e] -= lr * wd * pv[e];
     }
@@ -44,19 +44,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 extern "C" int tvts_adamw_hf(float* p, const float* g, float* m, float* v, void* shadow_bf16,
                              const unsigned char* chunk_group, int nchunks, const float* lr4, const float* wd4, int step,
-                             const int* step_dev, float beta1, float beta2, float eps, float grad_scale,
+                             const int* step_dev, double beta1, double beta2, double eps, float grad_scale,
                              hipStream_t stream) {
     if (nchunks <= 0 || (step <= 0 && !step_dev)) return TVTS_EINVAL;
     if (step <= 0) step = 1;
     AdamGroups hp;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     for (int i = 0; i < 4; ++i) {
         hp.lr[i] = lr4[i];
         hp.wd[i] = wd4[i];
         hp.step_size[i] = (float)((double)lr4[i] * sqrt(bc2) / bc1);
     }
     hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, stream, p, g, m, v, (bf16*)shadow_bf16, chunk_group, hp,
-                       beta1, beta2, eps, grad_scale, step_dev);
+                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, grad_scale, step_dev);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
