@@ -103,8 +103,10 @@ def test_gemm_tn(K, M, Na, Nb):
     out = torch.full((Na, Nb), 7.0, dtype=torch.float32, device=DEV)
     K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=False)
     assert rel(out, ref) < 3e-5, rel(out, ref)
-    K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True)
+    cs = torch.ones(Na, device=DEV)
+    K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True, colsum=cs)
     assert rel(out, 2 * ref) < 3e-5
+    assert rel(cs, 1 + p.float().sum(0)) < 1e-5, rel(cs, 1 + p.float().sum(0))
 
 
 def test_gemm_tn_views(K):

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
     char* vt = smem + wave * 64 * VSTRIDE;
     const int nq_max = (MODE == MODE_SPACE) ? g.n : (MODE == MODE_TIME) ? g.T : (MODE == MODE_CLS) ? 1 : g.S;
     const int qtiles = (nq_max + 15) >> 4;
-    const int item = blockIdx.x * 4 + wave;
+    constexpr bool SPLIT = (MODE == MODE_CLS);    // one group per block, key tiles dealt round-robin to the waves
+    const int item = SPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
     if (item >= n_groups<MODE>(g) * qtiles) return;
     const Grp r = decode<MODE>(g, item / qtiles);
     const int q0 = (item % qtiles) * 16;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
     qf[0] = ldg8(qp + gq * 8);
     qf[1] = ldg8(qp + 32 + gq * 8);
 
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = SPLIT ? -1e30f : -INFINITY, l_run = 0.f;
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
     int nk_eff = r.nk;
     if (MODE == MODE_FULL && g.causal) { const int lim = q0 + 16; nk_eff = lim < r.nk ? lim : r.nk; }
 
-    for (int kt0 = 0; kt0 < nk_eff; kt0 += 64) {
+    for (int kt0 = SPLIT ? wave * 64 : 0; kt0 < nk_eff; kt0 += SPLIT ? 256 : 64) {
         const int rows = (nk_eff - kt0) < 64 ? (nk_eff - kt0) : 64;
         stage_tile(vt, 64, lane, qkv, g.ld, 2 * g.W + hcol, [&](int rr) {
             int j = kt0 + rr; j = j < r.nk ? j : r.nk - 1; return k_row<MODE>(g, r, j); });
@@ -214,6 +215,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
             }
         }
     }
+    if (SPLIT) {  // merge the 4 partial softmax states (m, l, O) through LDS; wave 0 writes the result
+        __syncthreads();
+        float* red = (float*)smem;  // [wave][18][64]
+        red[(wave * 18 + 0) * 64 + lane] = m_run;
+        red[(wave * 18 + 1) * 64 + lane] = l_run;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(wave * 18 + 2 + dt * 4 + e) * 64 + lane] = o[dt][e];
+        __syncthreads();
+        if (wave != 0) return;
+        float mm = m_run;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) mm = fmaxf(mm, red[(w * 18 + 0) * 64 + lane]);
+        float ll = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = exp2f(red[(w * 18 + 0) * 64 + lane] - mm);
+            ll += red[(w * 18 + 1) * 64 + lane] * sc;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[dt][e] += red[(w * 18 + 2 + dt * 4 + e) * 64 + lane] * sc;
+        }
+        m_run = mm;
+        l_run = ll;
+    }
     if (qi < r.nq) {
         const float inv = 1.0f / l_run;
         const int row = q_row<MODE>(g, r, qi);
@@ -258,7 +288,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnGeom g, const bf16
     char* kt_lds = smem + wave * 64 * VSTRIDE;
     const int nq_max = (MODE == MODE_SPACE) ? g.n : (MODE == MODE_TIME) ? g.T : (MODE == MODE_CLS) ? 1 : g.S;
     const int qtiles = (nq_max + 15) >> 4;
-    const int item = blockIdx.x * 4 + wave;
+    constexpr bool SPLIT = (MODE == MODE_CLS);
+    const int item = SPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
     if (item >= n_groups<MODE>(g) * qtiles) return;
     const Grp r = decode<MODE>(g, item / qtiles);
     const int q0 = (item % qtiles) * 16;
@@ -282,7 +313,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnGeom g, const bf16
     int nk_eff = r.nk;
     if (MODE == MODE_FULL && g.causal) { const int lim = q0 + 16; nk_eff = lim < r.nk ? lim : r.nk; }
 
-    for (int kt0 = 0; kt0 < nk_eff; kt0 += 64) {
+    for (int kt0 = SPLIT ? wave * 64 : 0; kt0 < nk_eff; kt0 += SPLIT ? 256 : 64) {
         const int rows = (nk_eff - kt0) < 64 ? (nk_eff - kt0) : 64;
         stage_tile(kt_lds, 64, lane, qkv, g.ld, g.W + hcol, [&](int rr) {
             int j = kt0 + rr; j = j < r.nk ? j : r.nk - 1; return k_row<MODE>(g, r, j); });
@@ -320,6 +351,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnGeom g, const bf16
                     acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(kt_lds, u, dt, lane), dsf, acc[dt], 0, 0, 0);
             }
         }
+    }
+    if (SPLIT) {  // sum the 4 partial dQ accumulators through LDS
+        __syncthreads();
+        float* red = (float*)smem;  // [wave][16][64]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(wave * 16 + dt * 4 + e) * 64 + lane] = acc[dt][e];
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[dt][e] += red[(w * 16 + dt * 4 + e) * 64 + lane];
     }
     if (qi < r.nq) {
         bf16* dq = dqkv + (size_t)qrow * lddq + hcol;
@@ -488,7 +535,7 @@ extern "C" int tvts_attn_fwd(int mode, const void* qkv, int ld, int B, int heads
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     if (ldo % 4) return TVTS_EINVAL;
-    const int blocks = ceil_div(items_q(g, mode), 4);
+    const int blocks = mode == MODE_CLS ? items_q(g, mode) : ceil_div(items_q(g, mode), 4);
     DISPATCH_MODE(attn_fwd_kernel, mode, dim3(blocks), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
@@ -511,7 +558,7 @@ extern "C" int tvts_attn_bwd_dq(int mode, const void* qkv, int ld, int B, int he
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     if (lddo % 8 || lddq % 4) return TVTS_EINVAL;
-    const int blocks = ceil_div(items_q(g, mode), 4);
+    const int blocks = mode == MODE_CLS ? items_q(g, mode) : ceil_div(items_q(g, mode), 4);
     DISPATCH_MODE(attn_bwd_dq_kernel, mode, dim3(blocks), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo,
                   lse2, delta, (bf16*)dqkv, lddq);
     TVTS_LAUNCH_CHECK();

@@ -186,6 +186,7 @@ struct GemmTN {
     float* out; int ldo;
     int tiles_b, tiles_ab, m_per_split;
     int atomic;
+    float* colsum;  // optional: colsum[a] += sum_m P[m,a]  (bias gradient fused into the weight gradient)
 };
 
 __device__ __forceinline__ void stage_cols128(const bf16* __restrict__ base, int ld, int m0, int m_max, int c0,
@@ -208,17 +209,17 @@ __device__ __forceinline__ void stage_cols128(const bf16* __restrict__ base, int
 // 8 k-slots (one MFMA k-step u) of column block ct (16 columns) for this lane
 __device__ __forceinline__ bf16x8 frag_tr(const char* lds_tile, int u, int ct, int lane) {
     const int g = lane >> 4, i = lane & 15;
-    bf16x8 out;
+    s16x4 h[2];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int row = u * 32 + half * 16 + g * 4 + (i >> 2);
         const int chunk32 = ct ^ (row & 7);
         const char* p = lds_tile + row * 256 + chunk32 * 32 + (i & 3) * 8;
-        s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))p);
-        bf16x4 tb = __builtin_bit_cast(bf16x4, t);
-        out[half * 4 + 0] = tb[0]; out[half * 4 + 1] = tb[1]; out[half * 4 + 2] = tb[2]; out[half * 4 + 3] = tb[3];
+        h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))p);
     }
-    return out;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 both = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
 }
 
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmTN g) {
@@ -237,6 +238,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmTN g) {
     m_end = m_end < g.M ? m_end : g.M;
     if (m_begin >= m_end) return;
     const int nk = (m_end - m_begin + 63) / 64;
+    const bool do_cs = g.colsum != nullptr && (t % g.tiles_b) == 0 && wb == 0;  // wave-uniform
+    f32x4 cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -282,8 +290,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmTN g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0);
+            if (do_cs) {  // every row of ones . P is the column sum of this stage
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[i], cs[i], 0, 0, 0);
+            }
         }
         __syncthreads();
+    }
+    if (do_cs && lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a = a0 + wa * 64 + i * 16 + lane;
+            if (a < g.Na) atomicAdd(g.colsum + a, cs[i][0]);
+        }
     }
     // acc[i][j]: MFMA A-operand = Q (rows = b within tile j), B-operand = P (cols = a within tile i)
     // lane: col = a = l&15, rows = b = (l>>4)*4 + r  -> 4 consecutive b for one a: 16-B fp32 access
@@ -307,26 +326,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmTN g) {
 }
 
 extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb,
-                                 float* out, int ldo, int accumulate, hipStream_t stream) {
+                                 float* out, int ldo, int accumulate, float* colsum, hipStream_t stream) {
     if (M <= 0 || Na <= 0 || Nb <= 0) return TVTS_EINVAL;
     if (Na % 8 || Nb % 8 || ldp % 8 || ldq % 8 || ldo % 4) return TVTS_EINVAL;
     GemmTN g;
     g.P = (const bf16*)P; g.ldp = ldp; g.Q = (const bf16*)Q; g.ldq = ldq; g.M = M; g.Na = Na; g.Nb = Nb;
-    g.out = out; g.ldo = ldo;
+    g.out = out; g.ldo = ldo; g.colsum = colsum;
     const int tiles_a = ceil_div(Na, 128);
     g.tiles_b = ceil_div(Nb, 128);
     g.tiles_ab = tiles_a * g.tiles_b;
-    // split the contraction so the grid fills 256 CUs a few times over
-    int splits = ceil_div(1024, g.tiles_ab);
-    int max_splits = ceil_div(M, 256);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
+    // split the contraction so that the grid fills whole rounds of 2 blocks x 256 CUs
+    const int slots = 512;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= 32; ++s) {
+        if (s > 1 && M / s < 512) break;
+        const long blocks = (long)g.tiles_ab * s;
+        const double eff = (double)blocks / (double)(slots * ((blocks + slots - 1) / slots));
+        if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+    }
+    int splits = best;
+    g.m_per_split = ceil_div(ceil_div(M, splits), 64) * 64;
+    splits = ceil_div(M, g.m_per_split);
     if (!accumulate && splits > 1) {
         hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)Nb * 4, Na, stream);
         if (e != hipSuccess) return (int)e;
     }
-    g.m_per_split = ceil_div(ceil_div(M, splits), 64) * 64;
-    splits = ceil_div(M, g.m_per_split);
     g.atomic = (accumulate || splits > 1) ? 1 : 0;
     hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     if (e2 != hipSuccess) return (int)e2;

@@ -160,9 +160,10 @@ class Engine:
 
     def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, **epi):
         """dW += dy^T a_in, db += colsum(dy) (if trainable); d_in = dy W (optional, with epilogue)."""
-        if self.requires_grad[wname]:
-            K.gemm_tn(dy, a_in, self.P.g2d(wname), M=M, accumulate=True)
-        if bname and self.requires_grad[bname]:
+        want_b = bool(bname) and self.requires_grad[bname]
+        if self.requires_grad[wname]:  # bias gradient (column sums of dy) rides along in the same kernel
+            K.gemm_tn(dy, a_in, self.P.g2d(wname), M=M, accumulate=True, colsum=self.P.g(bname) if want_b else None)
+        elif want_b:
             K.colsum(dy, self.P.g(bname), M=M)
         if d_in is not None:
             K.gemm_nt(dy, self.P.wt(wname), d_in, M=M, **epi)

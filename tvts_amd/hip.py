@@ -65,7 +65,7 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
         GEMM_PROFILE.append(("gemm_nt", 2.0 * M * N * K, ev0, ev1))
 
 
-def gemm_tn(p, q, out, *, M=None, accumulate=True):
+def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None):
     """out[Na,Nb] (+)= p[M,Na]^T @ q[M,Nb]; p, q bf16; out fp32."""
     lib = _lib.load()
     M = p.shape[0] if M is None else M
@@ -74,7 +74,7 @@ def gemm_tn(p, q, out, *, M=None, accumulate=True):
         ev0, ev1 = Event(), Event()
         ev0.record()
     rc = lib.tvts_gemm_tn_bf16(_p(p), _ld(p), _p(q), _ld(q), M, p.shape[1], q.shape[1], _p(out), _ld(out),
-                               1 if accumulate else 0, _stream())
+                               1 if accumulate else 0, _p(colsum), _stream())
     _chk(rc, "tvts_gemm_tn_bf16")
     if GEMM_PROFILE is not None:
         ev1.record()
