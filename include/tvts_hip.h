@@ -22,6 +22,8 @@ enum { TVTS_ATTN_FULL = 0, TVTS_ATTN_SPACE = 1, TVTS_ATTN_TIME = 2, TVTS_ATTN_CL
 int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                       const float* residual, int ldr, int act, void* preact, int ldp, const void* gate_h, int ldh,
                       int gate_act, void* out, int ldc, int out_f32, hipStream_t stream);
+/* tile selection override for tools/gemm_bench.py: 0 auto, 128, 256 */
+void tvts_gemm_set_nt_tile(int t);
 /* weight gradient: out[Na,Nb] (+)= P[M,Na]^T . Q[M,Nb], bf16 in, fp32 out (autograd of the Linear sites above) */
 /* colsum (optional): colsum[a] += sum_m P[m,a] -- the bias gradient, fused into the same pass */
 int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb, float* out, int ldo,

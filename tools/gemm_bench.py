@@ -29,6 +29,16 @@ def timeit(fn, iters=20):
 
 def main():
     dev = "cuda:0"
+    from tvts_amd import _lib
+    for tile in [int(x) for x in os.environ.get('TILES', '256,512').split(',')]:
+        _lib.load().tvts_gemm_set_nt_tile(tile)
+        print(f"--- NT tile {tile}")
+        nt(dev)
+    _lib.load().tvts_gemm_set_nt_tile(0)
+    tn(dev)
+
+
+def nt(dev):
     tot_f, tot_t = 0.0, 0.0
     for (m, n, k) in NT_SHAPES:
         a = torch.randn(m, k, device=dev).bfloat16()
@@ -36,13 +46,16 @@ def main():
         bias = torch.randn(n, device=dev)
         out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
         K.gemm_nt(a, b, out, bias=bias)
-        ref = (a[:512].float() @ b.float().t() + bias)
-        err = float((out[:512].float() - ref).norm() / ref.norm())
+        ref = (a[-512:].float() @ b.float().t() + bias)
+        err = float((out[-512:].float() - ref).norm() / ref.norm())
         ms = timeit(lambda: K.gemm_nt(a, b, out, bias=bias))
         fl = 2.0 * m * n * k
         tot_f += fl; tot_t += ms
         print(f"NT {m:6d} x {n:5d} x {k:5d}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF  relerr {err:.1e}")
     print(f"NT total {tot_f/tot_t/1e9:.1f} TF")
+
+
+def tn(dev):
     tot_f, tot_t = 0.0, 0.0
     for (m, na, nb) in TN_SHAPES:
         p = torch.randn(m, na, device=dev).bfloat16()

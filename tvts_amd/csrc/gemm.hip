@@ -31,7 +31,7 @@ struct GemmNT {
     bf16* preact; int ldp;
     const bf16* gate_h; int ldh; int gate_act;
     void* out; int ldc; int out_f32;
-    int tiles_n;
+    int tiles_m, tiles_n;
 };
 
 // --- one [128 rows][64 k] bf16 tile: 16 KiB, rows of 128 B, 16-B chunk c of row r stored at chunk c^(r&7)
@@ -55,62 +55,320 @@ __device__ __forceinline__ bf16x8 frag_rows128(const char* lds_tile, int row, in
 }
 
 template <int ACT, int GATE>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmNT g) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNT g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = lid / g.tiles_n, tile_n = lid % g.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+    // Persistent blocks.  XCD x (= blockIdx % 8, see xcd note in common.h) owns a contiguous range of tiles; its
+    // blocks walk that range with stride (blocks per XCD), n fastest, so co-resident blocks of one XCD share the
+    // A row-panels and the whole weight panel in that XCD's L2.
+    const int total = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int q = total >> 3, rem = total & 7;
+    const int range_lo = xcd * q + (xcd < rem ? xcd : rem);
+    const int range_n = q + (xcd < rem ? 1 : 0);
     const int nk = g.K / BK;
+
+    int t = slot;  // index inside this XCD's range
+    if (t >= range_n) return;
+    int tile = range_lo + t;
+    int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
     stage_rows128(g.A, g.lda, m0, g.M - 1, 0, smem, wave, lane);
     stage_rows128(g.B, g.ldb, n0, g.N - 1, 0, smem + 16384, wave, lane);
     __syncthreads();
+    int stage = 0;
+    while (true) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int t_next = t + per_xcd;
+        const bool has_next = t_next < range_n;
+        const int tile_n = range_lo + t_next;
+        const int m0n = (tile_n / g.tiles_n) * BM, n0n = (tile_n % g.tiles_n) * BN;
 
-    for (int kt = 0; kt < nk; ++kt) {
-        char* cur = smem + (kt & 1) * 32768;
-        if (kt + 1 < nk) {
-            char* nxt = smem + ((kt + 1) & 1) * 32768;
-            stage_rows128(g.A, g.lda, m0, g.M - 1, (kt + 1) * BK, nxt, wave, lane);
-            stage_rows128(g.B, g.ldb, n0, g.N - 1, (kt + 1) * BK, nxt + 16384, wave, lane);
+        for (int kt = 0; kt < nk; ++kt) {
+            char* cur = smem + stage * 32768;
+            char* nxt = smem + (stage ^ 1) * 32768;
+            if (kt + 1 < nk) {
+                stage_rows128(g.A, g.lda, m0, g.M - 1, (kt + 1) * BK, nxt, wave, lane);
+                stage_rows128(g.B, g.ldb, n0, g.N - 1, (kt + 1) * BK, nxt + 16384, wave, lane);
+            } else if (has_next) {  // first stage of the NEXT tile flies under this tile's last MFMAs + epilogue
+                stage_rows128(g.A, g.lda, m0n, g.M - 1, 0, nxt, wave, lane);
+                stage_rows128(g.B, g.ldb, n0n, g.N - 1, 0, nxt + 16384, wave, lane);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[4], bfr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = frag_rows128(cur, wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    bfr[j] = frag_rows128(cur + 16384, wn * 64 + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+            }
+            stage ^= 1;
+            if (kt + 1 < nk) __syncthreads();
         }
+
+        // epilogue: lane owns row m (column of the swapped MFMA) and 4 consecutive n
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[4];
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            if (m >= g.M) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = frag_rows128(cur, wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+                if (n >= g.N) continue;
+                f32x4 v = acc[j][i];
+                if (g.bias) {
+                    const f32x4 b = *(const f32x4*)(g.bias + n);
+                    v += b;
+                }
+                if (ACT != ACT_NONE) {
+                    if (g.preact) {
+                        bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = h;
+                    }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                bfr[j] = frag_rows128(cur + 16384, wn * 64 + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
+                }
+                if (GATE != ACT_NONE) {
+                    const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
+                }
+                if (g.residual) {
+                    const f32x4 r = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
+                    v += r;
+                }
+                if (g.out_f32) {
+                    *(f32x4*)((float*)g.out + (size_t)m * g.ldc + n) = v;
+                } else {
+                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *(bf16x4*)((bf16*)g.out + (size_t)m * g.ldc + n) = o;
+                }
+            }
         }
-        __syncthreads();
+        if (!has_next) break;
+        __syncthreads();  // next tile's first stage has landed (vmcnt(0)) and every wave is done with `cur`
+        t = t_next; m0 = m0n; n0 = n0n;
     }
+}
 
-    // epilogue: lane owns row m (column of the swapped MFMA) and 4 consecutive n
+// ------------------------------------------------------------------------------------------------
+// 256x256 tile variant: 512 threads = 8 waves as 2(M) x 4(N), each wave a 128x64 sub-tile (8x4 MFMA tiles,
+// 128 accumulator registers).  Per 64-deep stage a wave issues the same 8 LDS-DMA pieces and 24 ds_read_b128
+// as in the 128x128 kernel but feeds 64 MFMAs instead of 32, which is what lifts the MFMA duty cycle.
+// LDS: 2 stages x (A 32 KiB + B 32 KiB) = 128 KiB, one block (2 waves per SIMD) per CU; persistent over tiles.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_rows256(const bf16* __restrict__ base, int ld, int row0, int row_max,
+                                              int k0, char* lds_tile, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-        if (m >= g.M) continue;
+    for (int t = 0; t < 4; ++t) {
+        const int r0 = (t * 8 + wave) * 8;
+        const int row = r0 + (lane >> 3);
+        const int slot = lane & 7;
+        const int chunk = slot ^ (row & 7);
+        int grow = row0 + row;
+        grow = grow < row_max ? grow : row_max;
+        const bf16* src = base + (size_t)grow * ld + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const GLB_PTR(void))src, (LDS_PTR(void))(lds_tile + r0 * 128), 16, 0, 0);
+    }
+}
+
+// Epilogue of a 128x64 wave sub-tile through a wave-private LDS patch: the MFMA layout (16 rows x 8 B per
+// store instruction = sixteen 32-byte fragments of sixteen cache lines) is re-read as whole rows, so every store
+// / residual load / gate load instruction covers full 128-B (bf16) or 256-B (fp32) row segments.
+// patch: 16 rows x 272 B (64 fp32 + 16 B pad), one 16-row slab (MFMA tile row i) per pass.
+template <int ACT, int GATE>
+__device__ __forceinline__ void epilogue256_lds(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn,
+                                                int lane, char* patch) {
+    const int nb = n0 + wn * 64;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nb + j * 16 + (lane >> 4) * 4;
+        bias4[j] = (g.bias && n < g.N) ? *(const f32x4*)(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(f32x4*)(patch + (lane & 15) * 272 + (j * 16 + (lane >> 4) * 4) * 4) = acc[j][i] + bias4[j];
+            acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (g.out_f32) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int idx = lane + 64 * t, r = idx >> 4, c16 = idx & 15;
+                f32x4 v = *(const f32x4*)(patch + r * 272 + c16 * 16);
+                const int m = m0 + wm * 128 + i * 16 + r, n = nb + c16 * 4;
+                if (m >= g.M || n >= g.N) continue;
+                if (ACT != ACT_NONE) {
+                    if (g.preact) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
+                }
+                if (GATE != ACT_NONE) {
+                    const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
+                }
+                if (g.residual) v += *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
+                *(f32x4*)((float*)g.out + (size_t)m * g.ldc + n) = v;
+            }
+        } else {  // bf16 out: 8 columns (16 bytes) per lane
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int idx = lane + 64 * t, r = idx >> 3, c8 = idx & 7;
+                const f32x4 v0 = *(const f32x4*)(patch + r * 272 + c8 * 32), v1 = *(const f32x4*)(patch + r * 272 + c8 * 32 + 16);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const int m = m0 + wm * 128 + i * 16 + r, n = nb + c8 * 8;
+                if (m >= g.M || n >= g.N) continue;
+                if (ACT != ACT_NONE) {
+                    if (g.preact) {
+                        bf16x8 h;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = (bf16)v[e];
+                        *(bf16x8*)(g.preact + (size_t)m * g.ldp + n) = h;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], ACT);
+                }
+                if (GATE != ACT_NONE) {
+                    const bf16x8 h = *(const bf16x8*)(g.gate_h + (size_t)m * g.ldh + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= act_bwd((float)h[e], GATE);
+                }
+                if (g.residual) {
+                    const f32x4 r0 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n), r1 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *(bf16x8*)((bf16*)g.out + (size_t)m * g.ldc + n) = o;
+            }
+        }
+    }
+}
+
+template <int ACT, int GATE>
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNT g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 32K | B 32K]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int total = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int q = total >> 3, rem = total & 7;
+    const int range_lo = xcd * q + (xcd < rem ? xcd : rem);
+    const int range_n = q + (xcd < rem ? 1 : 0);
+    const int nk = g.K / BK;
+
+    int t = slot;
+    if (t >= range_n) return;
+    int tile = range_lo + t;
+    int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 256;
+    stage_rows256(g.A, g.lda, m0, g.M - 1, 0, smem, wave, lane);
+    stage_rows256(g.B, g.ldb, n0, g.N - 1, 0, smem + 32768, wave, lane);
+    __syncthreads();
+    int stage = 0;
+    while (true) {
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int t_next = t + per_xcd;
+        const bool has_next = t_next < range_n;
+        const int tile_n = range_lo + t_next;
+        const int m0n = (tile_n / g.tiles_n) * 256, n0n = (tile_n % g.tiles_n) * 256;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            char* cur = smem + stage * 65536;
+            char* nxt = smem + (stage ^ 1) * 65536;
+            if (kt + 1 < nk) {
+                stage_rows256(g.A, g.lda, m0, g.M - 1, (kt + 1) * BK, nxt, wave, lane);
+                stage_rows256(g.B, g.ldb, n0, g.N - 1, (kt + 1) * BK, nxt + 32768, wave, lane);
+            } else if (has_next) {
+                stage_rows256(g.A, g.lda, m0n, g.M - 1, 0, nxt, wave, lane);
+                stage_rows256(g.B, g.ldb, n0n, g.N - 1, 0, nxt + 32768, wave, lane);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[8], bfr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    bfr[j] = frag_rows128(cur + 32768, wn * 64 + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[i] = frag_rows128(cur, wm * 128 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+            }
+            stage ^= 1;
+            if (kt + 1 < nk) __syncthreads();
+        }
+
+        // all waves are done reading the last stage (its buffer hosts the epilogue patches); a raw barrier keeps the
+        // next tile's first-stage DMA in flight (a __syncthreads would drain it here)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        epilogue256_lds<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, smem + (stage ^ 1) * 65536 + wave * 8192);
+        if (!has_next) break;
+        __syncthreads();
+        t = t_next; m0 = m0n; n0 = n0n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256x256 tile, ANTI-PHASE wave groups.  The 8 waves form two groups (wm = 0 / 1); a SIMD hosts one wave of
+// each.  Group 1 runs one s_barrier behind group 0, so in every barrier-to-barrier interval one group issues its
+// LDS reads / LDS-DMA while the other issues 32 MFMAs: the matrix pipe of each SIMD always has a wave feeding it
+// instead of all waves loading, then all waves multiplying.  Per 64-deep K-tile and wave:
+//   I0  12 ds_read_b128 (k 0..31) + the 8 LDS-DMA pieces of the NEXT K-tile | barrier
+//   I1  32 MFMA                                                             | barrier
+//   I2  12 ds_read_b128 (k 32..63)                 [group 1: vmcnt(0)]      | barrier
+//   I3  32 MFMA   [group 0: vmcnt(0)]  [last K-tile of an output tile: epilogue] | barrier
+// The DMA of K-tile t+1 is issued 3 intervals before its first reader; raw s_barrier + hand-placed waitcnts keep
+// it in flight across barriers (a __syncthreads would drain it).  K-tiles form one flat sequence across the
+// block's persistent list of output tiles, so the next tile's first K-tile is fetched under the epilogue.
+// ------------------------------------------------------------------------------------------------
+#define RAW_BARRIER()                         \
+    do {                                      \
+        asm volatile("" ::: "memory");        \
+        __builtin_amdgcn_s_barrier();         \
+        asm volatile("" ::: "memory");        \
+    } while (0)
+
+template <int ACT, int GATE>
+__device__ __forceinline__ void epilogue256(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn, int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + (lane & 15);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            if (n >= g.N) continue;
             f32x4 v = acc[j][i];
+            acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (m >= g.M || n >= g.N) continue;
             if (g.bias) {
                 const f32x4 b = *(const f32x4*)(g.bias + n);
                 v += b;
@@ -142,6 +400,222 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmNT g) {
     }
 }
 
+template <int ACT, int GATE>
+__global__ __launch_bounds__(512, 2) void gemm_nt256s_kernel(GemmNT g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 K-tiles][A 32K | B 32K]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int total = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int q = total >> 3, rem = total & 7;
+    const int range_lo = xcd * q + (xcd < rem ? xcd : rem);
+    const int range_n = q + (xcd < rem ? 1 : 0);
+    const int nk = g.K / BK;
+    if (slot >= range_n) return;  // whole block
+    const int ntl = (range_n - slot + per_xcd - 1) / per_xcd;
+    const int total_it = ntl * nk;
+
+    int tile = range_lo + slot;
+    int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 256;
+    stage_rows256(g.A, g.lda, m0, g.M - 1, 0, smem, wave, lane);
+    stage_rows256(g.B, g.ldb, n0, g.N - 1, 0, smem + 32768, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RAW_BARRIER();
+    if (wm == 1) RAW_BARRIER();  // group 1 trails by one interval from here on
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int kt = 0, tl = 0;
+    for (int it = 0; it < total_it; ++it) {
+        char* cur = smem + (it & 1) * 65536;
+        char* nxt = smem + ((it + 1) & 1) * 65536;
+        bf16x8 af[8], bfr[4];
+        // ---- I0: fragments of k 0..31, DMA of the next K-tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = frag_rows128(cur + 32768, wn * 64 + j * 16 + (lane & 15), (lane >> 4));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = frag_rows128(cur, wm * 128 + i * 16 + (lane & 15), (lane >> 4));
+        if (it + 1 < total_it) {
+            int nm0 = m0, nn0 = n0, nk0 = (kt + 1) * BK;
+            if (kt + 1 == nk) {
+                const int tn = range_lo + slot + (tl + 1) * per_xcd;
+                nm0 = (tn / g.tiles_n) * 256; nn0 = (tn % g.tiles_n) * 256; nk0 = 0;
+            }
+            stage_rows256(g.A, g.lda, nm0, g.M - 1, nk0, nxt, wave, lane);
+            stage_rows256(g.B, g.ldb, nn0, g.N - 1, nk0, nxt + 32768, wave, lane);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RAW_BARRIER();
+        // ---- I1
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        RAW_BARRIER();
+        // ---- I2: fragments of k 32..63
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = frag_rows128(cur + 32768, wn * 64 + j * 16 + (lane & 15), 4 + (lane >> 4));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = frag_rows128(cur, wm * 128 + i * 16 + (lane & 15), 4 + (lane >> 4));
+        if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RAW_BARRIER();
+        // ---- I3
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 1 == nk) {
+            epilogue256<ACT, GATE>(g, acc, m0, n0, wm, wn, lane);
+            kt = 0; ++tl;
+            const int tn = range_lo + slot + tl * per_xcd;
+            m0 = (tn / g.tiles_n) * 256; n0 = (tn % g.tiles_n) * 256;
+        } else {
+            ++kt;
+        }
+        RAW_BARRIER();
+    }
+    if (wm == 0) RAW_BARRIER();
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256x256 tile, DEEP RING: 32-deep stages in an NS-slot LDS ring (NS x 32 KiB), NS-1 stages of LDS-DMA in
+// flight at all times.  PMC on the 2-stage kernels shows the matrix pipe 36 % busy and the waves parked on
+// vmcnt/barrier 41 % of the time: with one K-tile of prefetch the K-tile time stretches to the L2/MALL
+// latency under load (~13 B/clk/CU delivered).  More bytes in flight per CU is the lever, so the stage is
+// halved (BK 32) and the ring deepened; waits are COUNTED (s_waitcnt vmcnt(4*(NS-2))) with raw s_barrier so
+// the younger stages stay in flight across the barrier.
+// Stage layout: A [256 rows][32 k] bf16 = rows of 64 B (16 KiB) | B the same; 16-B chunk c of row r is stored
+// at chunk c ^ ((r >> 2) & 3)  (conflict-free ds_read_b128 for 16 consecutive rows at one chunk).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_rows256_k32(const bf16* __restrict__ base, int ld, int row0, int row_max,
+                                                  int k0, char* lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int r0 = (t * 8 + wave) * 16;
+        const int row = r0 + (lane >> 2);
+        const int slot = lane & 3;
+        const int chunk = slot ^ ((row >> 2) & 3);
+        int grow = row0 + row;
+        grow = grow < row_max ? grow : row_max;
+        const bf16* src = base + (size_t)grow * ld + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const GLB_PTR(void))src, (LDS_PTR(void))(lds_tile + r0 * 64), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ bf16x8 frag_rows_k32(const char* lds_tile, int row, int chunk) {
+    return *(const bf16x8*)(lds_tile + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int ACT, int GATE, int NS>
+__global__ __launch_bounds__(512, 2) void gemm_nt256r_kernel(GemmNT g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NS][A 16K | B 16K]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int total = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int q = total >> 3, rem = total & 7;
+    const int range_lo = xcd * q + (xcd < rem ? xcd : rem);
+    const int range_n = q + (xcd < rem ? 1 : 0);
+    const int nk = g.K / 32;
+    if (slot >= range_n) return;
+    const int ntl = (range_n - slot + per_xcd - 1) / per_xcd;
+    const int total_st = ntl * nk;
+
+    // issue cursor (stage to be loaded next) and compute cursor
+    int i_st = 0, i_kt = 0, i_tl = 0;
+    int i_m0, i_n0;
+    {
+        const int tile = range_lo + slot;
+        i_m0 = (tile / g.tiles_n) * 256; i_n0 = (tile % g.tiles_n) * 256;
+    }
+    auto issue = [&]() {
+        char* dst = smem + (i_st % NS) * 32768;
+        stage_rows256_k32(g.A, g.lda, i_m0, g.M - 1, i_kt * 32, dst, wave, lane);
+        stage_rows256_k32(g.B, g.ldb, i_n0, g.N - 1, i_kt * 32, dst + 16384, wave, lane);
+        ++i_st;
+        if (++i_kt == nk) {
+            i_kt = 0; ++i_tl;
+            const int tile = range_lo + slot + i_tl * per_xcd;
+            i_m0 = (tile / g.tiles_n) * 256; i_n0 = (tile % g.tiles_n) * 256;
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (i_st < total_st) issue();
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int kt = 0, tl = 0;
+    int m0, n0;
+    {
+        const int tile = range_lo + slot;
+        m0 = (tile / g.tiles_n) * 256; n0 = (tile % g.tiles_n) * 256;
+    }
+    for (int st = 0; st < total_st; ++st) {
+        // stage `st` must have landed: stages issued after it may stay in flight (4 DMA pieces each)
+        const int younger = i_st - st - 1;  // 0 .. NS-2
+        if (younger >= NS - 2) wait_vmcnt<4 * (NS - 2)>();
+        else if (younger == 2) wait_vmcnt<8>();
+        else if (younger == 1) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        RAW_BARRIER();
+        if (i_st < total_st) issue();  // into the slot whose last reader finished before the barrier
+        const char* cur = smem + (st % NS) * 32768;
+        bf16x8 af[8], bfr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = frag_rows_k32(cur + 16384, wn * 64 + j * 16 + (lane & 15), (lane >> 4));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = frag_rows_k32(cur, wm * 128 + i * 16 + (lane & 15), (lane >> 4));
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (++kt == nk) {
+            epilogue256<ACT, GATE>(g, acc, m0, n0, wm, wn, lane);
+            kt = 0; ++tl;
+            const int tile = range_lo + slot + tl * per_xcd;
+            m0 = (tile / g.tiles_n) * 256; n0 = (tile % g.tiles_n) * 256;
+        }
+    }
+}
+
+#include <stdlib.h>
+static int nt_tile_env() { const char* e = getenv("TVTS_NT_TILE"); return e ? atoi(e) : 0; }
+static int g_nt_tile = nt_tile_env();  // 0 = auto, 128 / 256 / 512 (= 256 anti-phase) forced (tools/gemm_bench.py)
+extern "C" void tvts_gemm_set_nt_tile(int t) { g_nt_tile = t; }
+
 extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                                  const float* bias, const float* residual, int ldr, int act, void* preact,
                                  int ldp, const void* gate_h, int ldh, int gate_act, void* out, int ldc,
@@ -154,8 +628,46 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32;
+    const bool stag = g_nt_tile == 512;
+    const int ring = g_nt_tile == 1024 ? 4 : g_nt_tile == 1280 ? 5 : 0;
+    if ((g_nt_tile >= 256) && (N % 8 || ldc % 8 || (preact && ldp % 8) || (gate_h && ldh % 8))) return TVTS_EINVAL;
+    const bool big = stag || ring || (g_nt_tile == 256) || (g_nt_tile == 0 && N % 256 == 0 && M >= 4096);
+    if (big) {
+        g.tiles_n = ceil_div(N, 256);
+        g.tiles_m = ceil_div(M, 256);
+        const int total_tiles = g.tiles_m * g.tiles_n;
+        const int grid = total_tiles < 256 ? ((total_tiles + 7) / 8) * 8 : 256;
+        void (*kern)(GemmNT) = nullptr;
+        if (gate_h) {
+            if (act != ACT_NONE) return TVTS_EINVAL;
+            kern = gate_act == ACT_QUICK_GELU ? (stag ? gemm_nt256s_kernel<0, 1> : gemm_nt256_kernel<0, 1>)
+                 : gate_act == ACT_GELU_ERF ? (stag ? gemm_nt256s_kernel<0, 2> : gemm_nt256_kernel<0, 2>) : nullptr;
+        } else {
+            kern = act == ACT_NONE ? (stag ? gemm_nt256s_kernel<0, 0> : gemm_nt256_kernel<0, 0>)
+                 : act == ACT_QUICK_GELU ? (stag ? gemm_nt256s_kernel<1, 0> : gemm_nt256_kernel<1, 0>)
+                 : act == ACT_GELU_ERF ? (stag ? gemm_nt256s_kernel<2, 0> : gemm_nt256_kernel<2, 0>) : nullptr;
+        }
+        int lds_bytes = 131072;
+        if (ring) {
+            if (K % 32) return TVTS_EINVAL;
+            lds_bytes = ring * 32768;
+            if (gate_h) kern = gate_act == ACT_QUICK_GELU ? (ring == 4 ? gemm_nt256r_kernel<0, 1, 4> : gemm_nt256r_kernel<0, 1, 5>)
+                             : (ring == 4 ? gemm_nt256r_kernel<0, 2, 4> : gemm_nt256r_kernel<0, 2, 5>);
+            else kern = act == ACT_NONE ? (ring == 4 ? gemm_nt256r_kernel<0, 0, 4> : gemm_nt256r_kernel<0, 0, 5>)
+                      : act == ACT_QUICK_GELU ? (ring == 4 ? gemm_nt256r_kernel<1, 0, 4> : gemm_nt256r_kernel<1, 0, 5>)
+                      : (ring == 4 ? gemm_nt256r_kernel<2, 0, 4> : gemm_nt256r_kernel<2, 0, 5>);
+        }
+        if (!kern) return TVTS_EINVAL;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, stream, g);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
     g.tiles_n = ceil_div(N, BN);
-    const int tiles = ceil_div(M, BM) * g.tiles_n;
+    g.tiles_m = ceil_div(M, BM);
+    const int total_tiles = g.tiles_m * g.tiles_n;
+    int tiles = total_tiles < 512 ? ((total_tiles + 7) / 8) * 8 : 512;  // persistent grid: 2 blocks x 256 CUs, multiple of 8
     void (*kern)(GemmNT) = nullptr;
     if (gate_h) {
         if (act != ACT_NONE) return TVTS_EINVAL;
@@ -184,7 +696,7 @@ struct GemmTN {
     const bf16* Q; int ldq;
     int M, Na, Nb;
     float* out; int ldo;
-    int tiles_b, tiles_ab, m_per_split;
+    int tiles_b, tiles_ab, m_per_split, n_items;
     int atomic;
     float* colsum;  // optional: colsum[a] += sum_m P[m,a]  (bias gradient fused into the weight gradient)
 };
@@ -222,16 +734,21 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* lds_tile, int u, int ct, i
     return __builtin_bit_cast(bf16x8, both);
 }
 
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmTN g) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][P 16K | Q 16K]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave >> 1, wb = wave & 1;
 
-    const int bid = blockIdx.x;
-    const int split = bid / g.tiles_ab;
-    const int t = bid % g.tiles_ab;
+    // Work items are (m-range, output tile) pairs in range-major order; XCD x (= blockIdx % 8) takes the x-th
+    // contiguous eighth of that list, so the P/Q rows of an m-range are pulled into ONE XCD's L2 (two at a
+    // boundary) and shared there by all output tiles, instead of being fetched by all eight L2s.
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int item = xcd * per + jx;
+    if (item >= g.n_items) return;
+    const int split = item / g.tiles_ab;
+    const int t = item % g.tiles_ab;
     const int a0 = (t / g.tiles_b) * 128, b0 = (t % g.tiles_b) * 128;
     const int m_begin = split * g.m_per_split;
     int m_end = m_begin + g.m_per_split;
@@ -260,20 +777,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmTN g) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         char* cur = smem + (kt & 1) * 32768;
+        // All transposing reads of this stage first: hipcc drains vmcnt(0) in front of a ds_read_tr that follows
+        // an LDS-DMA issue, which would serialise the next stage's loads behind this stage's MFMAs.
+        bf16x8 pf[2][4], qf[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[u][i] = frag_tr(cur, u, wa * 4 + i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qf[u][j] = frag_tr(cur + 16384, u, wb * 4 + j, lane);
+        }
         if (kt + 1 < nk) {
             char* nxt = smem + ((kt + 1) & 1) * 32768;
             stage_cols128(g.P, g.ldp, m_begin + (kt + 1) * 64, g.M - 1, a0, g.Na - 8, nxt, wave, lane);
             stage_cols128(g.Q, g.ldq, m_begin + (kt + 1) * 64, g.M - 1, b0, g.Nb - 8, nxt + 16384, wave, lane);
         }
-        // valid m in this stage (tail rows beyond m_end must not contribute)
-        const int valid = m_end - (m_begin + kt * 64);
+        const int valid = m_end - (m_begin + kt * 64);  // tail rows beyond m_end must not contribute
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            bf16x8 pf[4], qf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pf[i] = frag_tr(cur, u, wa * 4 + i, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) qf[j] = frag_tr(cur + 16384, u, wb * 4 + j, lane);
             if (valid < 64) {  // zero k-slots whose m is past the end (uniform branch, tail stage only)
                 const int gq = lane >> 4;
 #pragma unroll
@@ -281,7 +802,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmTN g) {
                     const int m = u * 32 + (e >> 2) * 16 + gq * 4 + (e & 3);
                     if (m >= valid) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) pf[i][e] = (bf16)0.f;
+                        for (int i = 0; i < 4; ++i) pf[u][i][e] = (bf16)0.f;
                     }
                 }
             }
@@ -289,10 +810,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmTN g) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[u][j], pf[u][i], acc[i][j], 0, 0, 0);
             if (do_cs) {  // every row of ones . P is the column sum of this stage
 #pragma unroll
-                for (int i = 0; i < 4; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[i], cs[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[u][i], cs[i], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -335,17 +856,19 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     const int tiles_a = ceil_div(Na, 128);
     g.tiles_b = ceil_div(Nb, 128);
     g.tiles_ab = tiles_a * g.tiles_b;
-    // split the contraction so that the grid fills whole rounds of 2 blocks x 256 CUs
-    const int slots = 512;
-    int best = 1;
-    double best_eff = 0.0;
-    for (int s = 1; s <= 32; ++s) {
-        if (s > 1 && M / s < 512) break;
-        const long blocks = (long)g.tiles_ab * s;
-        const double eff = (double)blocks / (double)(slots * ((blocks + slots - 1) / slots));
-        if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+    // split the contraction over M into S ranges (range s lives on XCD s % 8, see the kernel).  S is chosen for
+    // whole rounds of 2 blocks x 256 CUs: the smallest S reaching >= 93 % round efficiency, else the best one.
+    int splits = 1;
+    {
+        double best = 0.0;
+        for (int sp = 1; sp <= 64; ++sp) {
+            if (sp > 1 && M / sp < 768) break;
+            const long blocks = (long)g.tiles_ab * sp;
+            const double eff = (double)blocks / (512.0 * (double)((blocks + 511) / 512));
+            if (eff > best + 1e-9) { best = eff; splits = sp; }
+            if (eff >= 0.93) { splits = sp; break; }
+        }
     }
-    int splits = best;
     g.m_per_split = ceil_div(ceil_div(M, splits), 64) * 64;
     splits = ceil_div(M, g.m_per_split);
     if (!accumulate && splits > 1) {
@@ -355,7 +878,9 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     g.atomic = (accumulate || splits > 1) ? 1 : 0;
     hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     if (e2 != hipSuccess) return (int)e2;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(g.tiles_ab * splits), dim3(NTHREADS), 65536, stream, g);
+    g.n_items = g.tiles_ab * splits;
+    const int grid = ceil_div(g.n_items, 8) * 8;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(NTHREADS), 65536, stream, g);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
