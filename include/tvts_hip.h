@@ -56,6 +56,7 @@ int tvts_attn_bwd_dkv(int mode, const void* qkv, int ld, int B, int heads, int S
                       hipStream_t stream);
 int tvts_attn_cls_finalize(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq, hipStream_t stream);
 void tvts_attn_set_transpose_read(int on);
+void tvts_attn_set_shared(int on);
 
 /* ---- token assembly (embed.hip): video_encoder_ViT_B_16.py:176-216; model_dist..B_16.py:69-76,98-100;
  *      sort_transformer.py:124-128 */

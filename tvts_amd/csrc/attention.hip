@@ -83,13 +83,21 @@ __device__ __forceinline__ int qx_row(const AttnGeom& g, const Grp& r, int i) {
 
 __device__ __forceinline__ bf16x8 ldg8(const bf16* p) { return *(const bf16x8*)p; }
 
-// stage `nrows` (<= 64) rows x 64 bf16 (rows given by a functor) into a wave-private LDS tile
+// stage `nrows` (<= 64, multiple of 16) rows x 64 bf16 (rows given by a functor) into a wave-private LDS tile;
+// rows [nrows, round_up(nrows, 32)) are ZERO-filled: the MFMA k-step that covers them multiplies by P = 0, and
+// stale LDS bits could be NaN.
 template <typename RowFn>
 __device__ __forceinline__ void stage_tile(char* tile, int nrows, int lane, const bf16* base, int ld, int col0, RowFn rowfn) {
     for (int c = lane; c < nrows * 8; c += 64) {
         const int r = c >> 3, ch = c & 7;
         const bf16x8 v = ldg8(base + (size_t)rowfn(r) * ld + col0 + ch * 8);
         *(bf16x8*)(tile + r * VSTRIDE + ch * 16) = v;
+    }
+    if (nrows & 16) {
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+        for (int c = lane; c < 16 * 8; c += 64) *(bf16x8*)(tile + (nrows + (c >> 3)) * VSTRIDE + (c & 7) * 16) = z;
     }
 }
 
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
 
     for (int kt0 = SPLIT ? wave * 64 : 0; kt0 < nk_eff; kt0 += SPLIT ? 256 : 64) {
         const int rows = (nk_eff - kt0) < 64 ? (nk_eff - kt0) : 64;
-        stage_tile(vt, 64, lane, qkv, g.ld, 2 * g.W + hcol, [&](int rr) {
+        stage_tile(vt, (rows + 15) & ~15, lane, qkv, g.ld, 2 * g.W + hcol, [&](int rr) {
             int j = kt0 + rr; j = j < r.nk ? j : r.nk - 1; return k_row<MODE>(g, r, j); });
         f32x4 st[4];
 #pragma unroll
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnGeom g, const bf16
 
     for (int kt0 = SPLIT ? wave * 64 : 0; kt0 < nk_eff; kt0 += SPLIT ? 256 : 64) {
         const int rows = (nk_eff - kt0) < 64 ? (nk_eff - kt0) : 64;
-        stage_tile(kt_lds, 64, lane, qkv, g.ld, g.W + hcol, [&](int rr) {
+        stage_tile(kt_lds, (rows + 15) & ~15, lane, qkv, g.ld, g.W + hcol, [&](int rr) {
             int j = kt0 + rr; j = j < r.nk ? j : r.nk - 1; return k_row<MODE>(g, r, j); });
         f32x4 ds[4];
 #pragma unroll
@@ -417,18 +425,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnGeom g, const bf1
 
     for (int qt0 = q_begin; qt0 < nqx; qt0 += 32) {
         auto rowfn = [&](int rr) { int i = qt0 + rr; i = i < nqx ? i : nqx - 1; return qx_row<MODE>(g, r, i); };
-        stage_tile(q_lds, 32, lane, qkv, g.ld, hcol, rowfn);
-        stage_tile(do_lds, 32, lane, dO, lddo, hcol, rowfn);
+        const int qrows = (nqx - qt0) > 16 ? 32 : 16;
+        stage_tile(q_lds, qrows, lane, qkv, g.ld, hcol, rowfn);
+        stage_tile(do_lds, qrows, lane, dO, lddo, hcol, rowfn);
         bf16x8 pf, dsf;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
             const char* qa = q_lds + (t * 16 + li) * VSTRIDE + gq * 16;
             const char* da = do_lds + (t * 16 + li) * VSTRIDE + gq * 16;
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)qa, kb[0], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(qa + 64), kb[1], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)da, vb[0], dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(da + 64), vb[1], dp, 0, 0, 0);
+            if (t * 16 < qrows) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)qa, kb[0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(qa + 64), kb[1], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)da, vb[0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(da + 64), vb[1], dp, 0, 0, 0);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int qi = qt0 + t * 16 + gq * 4 + e;  // (extended) query index of this row
@@ -475,6 +486,510 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnGeom g, const bf1
     }
 }
 
+// ================================================================================================
+// BLOCK-SHARED variants for the geometries whose groups span several 16-row tiles (FULL, SPACE): the four
+// waves of a block take four consecutive query (or key) tiles of ONE group and share the K/V (or Q/dO) tiles,
+// which are staged once per block -- global -> registers at the top of an iteration, registers -> LDS at its
+// bottom (async-stage split), double-buffered, one __syncthreads per tile.  K/Q/dO fragments then come from
+// LDS (ds_read_b128) instead of four redundant global fetches.
+// ================================================================================================
+struct Stage2 { bf16x8 v[2]; };
+template <typename RowFn>
+__device__ __forceinline__ void stage_load64(Stage2& r, int nrows, int tid, const bf16* base, int ld, int col0, RowFn rowfn) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+        if (row < nrows) r.v[i] = ldg8(base + (size_t)rowfn(row) * ld + col0 + ch * 8);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r.v[i][e] = (bf16)0.f;
+        }
+    }
+}
+__device__ __forceinline__ void stage_store64(const Stage2& r, char* tile, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i;
+        *(bf16x8*)(tile + (c >> 3) * VSTRIDE + (c & 7) * 16) = r.v[i];
+    }
+}
+template <typename RowFn>
+__device__ __forceinline__ bf16x8 stage_load32(int nrows, int tid, const bf16* base, int ld, int col0, RowFn rowfn) {
+    const int row = tid >> 3, ch = tid & 7;
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+    return row < nrows ? ldg8(base + (size_t)rowfn(row) * ld + col0 + ch * 8) : z;
+}
+__device__ __forceinline__ void stage_store32(bf16x8 v, char* tile, int tid) {
+    *(bf16x8*)(tile + (tid >> 3) * VSTRIDE + (tid & 7) * 16) = v;
+}
+__device__ __forceinline__ bf16x8 frag_row(const char* tile, int row, int ks, int gq) {  // k-contiguous fragment
+    return *(const bf16x8*)(tile + row * VSTRIDE + ks * 64 + gq * 16);
+}
+
+#define TILE_B (64 * VSTRIDE)
+
+template <int MODE, bool TR>
+__global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                              int ldo, float* __restrict__ lse2) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [buf][K | V]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq_max = (MODE == MODE_SPACE) ? g.n : g.S;
+    const int qblocks = (((nq_max + 15) >> 4) + 3) >> 2;
+    const Grp r = decode<MODE>(g, blockIdx.x / qblocks);
+    const int qb = blockIdx.x % qblocks;
+    const int q0 = (qb * 4 + wave) * 16;
+    const bool active = q0 < r.nq;
+    const int gq = lane >> 4, li = lane & 15;
+    const int hcol = r.h * DH;
+    const int qi = q0 + li;
+    const int qi_c = qi < r.nq ? qi : r.nq - 1;
+    const bf16* qp = qkv + (size_t)q_row<MODE>(g, r, qi_c) * g.ld + hcol;
+    const bf16x8 qf0 = ldg8(qp + gq * 8), qf1 = ldg8(qp + 32 + gq * 8);
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
+    const bool causal = (MODE == MODE_FULL) && g.causal;
+    int nk_blk = r.nk, nk_w = r.nk;
+    if (causal) {
+        const int limb = (qb * 4 + 4) * 16, limw = q0 + 16;
+        nk_blk = limb < r.nk ? limb : r.nk;
+        nk_w = limw < r.nk ? limw : r.nk;
+    }
+    auto krow = [&](int kt0) { return [&, kt0](int rr) { return k_row<MODE>(g, r, kt0 + rr); }; };
+    Stage2 sk, sv;
+    {
+        const int rows = nk_blk < 64 ? nk_blk : 64;
+        stage_load64(sk, rows, tid, qkv, g.ld, g.W + hcol, krow(0));
+        stage_load64(sv, rows, tid, qkv, g.ld, 2 * g.W + hcol, krow(0));
+        stage_store64(sk, smem, tid);
+        stage_store64(sv, smem + TILE_B, tid);
+    }
+    int buf = 0;
+    for (int kt0 = 0; kt0 < nk_blk; kt0 += 64, buf ^= 1) {
+        __syncthreads();
+        const char* kt_ = smem + buf * 2 * TILE_B;
+        const char* vt = kt_ + TILE_B;
+        const bool more = kt0 + 64 < nk_blk;
+        if (more) {
+            const int rows = (nk_blk - kt0 - 64) < 64 ? (nk_blk - kt0 - 64) : 64;
+            stage_load64(sk, rows, tid, qkv, g.ld, g.W + hcol, krow(kt0 + 64));
+            stage_load64(sv, rows, tid, qkv, g.ld, 2 * g.W + hcol, krow(kt0 + 64));
+        }
+        if (active && kt0 < nk_w) {
+            const int rows = (nk_w - kt0) < 64 ? (nk_w - kt0) : 64;
+            f32x4 st[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                st[t] = (f32x4){0, 0, 0, 0};
+                if (t * 16 < rows) {
+                    st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, 0, gq), qf0, st[t], 0, 0, 0);
+                    st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, 1, gq), qf1, st[t], 0, 0, 0);
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = kt0 + t * 16 + gq * 4 + e;
+                    const bool ok = key < r.nk && !(causal && key > qi);
+                    const float sv_ = ok ? st[t][e] * g.scale2 : -INFINITY;
+                    st[t][e] = sv_;
+                    mx = fmaxf(mx, sv_);
+                }
+            mx = group_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f(m_run - m_new);
+            float rs = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = exp2f(st[t][e] - m_new);
+                    st[t][e] = p;
+                    rs += p;
+                }
+            rs = group_sum(rs);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u * 32 < rows) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(vt, u, dt, lane), pf, o[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            char* nb = smem + (buf ^ 1) * 2 * TILE_B;
+            stage_store64(sk, nb, tid);
+            stage_store64(sv, nb + TILE_B, tid);
+        }
+    }
+    if (active && qi < r.nq) {
+        const float inv = 1.0f / l_run;
+        const int row = q_row<MODE>(g, r, qi);
+        bf16* op = out + (size_t)row * ldo + hcol;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x4 v = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
+            *(bf16x4*)(op + dt * 16 + gq * 4) = v;
+        }
+        if (gq == 0) lse2[(size_t)row * g.heads + r.h] = m_run + log2f(l_run);
+    }
+}
+
+template <int MODE, bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_dq_shared_kernel(AttnGeom g, const bf16* __restrict__ qkv,
+                                                                 const bf16* __restrict__ dO, int lddo,
+                                                                 const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                                 bf16* __restrict__ dqkv, int lddq) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [buf][K | V]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq_max = (MODE == MODE_SPACE) ? g.n : g.S;
+    const int qblocks = (((nq_max + 15) >> 4) + 3) >> 2;
+    const Grp r = decode<MODE>(g, blockIdx.x / qblocks);
+    const int qb = blockIdx.x % qblocks;
+    const int q0 = (qb * 4 + wave) * 16;
+    const bool active = q0 < r.nq;
+    const int gq = lane >> 4, li = lane & 15;
+    const int hcol = r.h * DH;
+    const int qi = q0 + li;
+    const int qi_c = qi < r.nq ? qi : r.nq - 1;
+    const int qrow = q_row<MODE>(g, r, qi_c);
+    const bf16* qp = qkv + (size_t)qrow * g.ld + hcol;
+    const bf16* dop = dO + (size_t)qrow * lddo + hcol;
+    const bf16x8 qf0 = ldg8(qp + gq * 8), qf1 = ldg8(qp + 32 + gq * 8);
+    const bf16x8 dof0 = ldg8(dop + gq * 8), dof1 = ldg8(dop + 32 + gq * 8);
+    const float lse = lse2[(size_t)qrow * g.heads + r.h];
+    const float dlt = delta[(size_t)qrow * g.heads + r.h];
+    f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0, 0, 0, 0};
+    const bool causal = (MODE == MODE_FULL) && g.causal;
+    int nk_blk = r.nk, nk_w = r.nk;
+    if (causal) {
+        const int limb = (qb * 4 + 4) * 16, limw = q0 + 16;
+        nk_blk = limb < r.nk ? limb : r.nk;
+        nk_w = limw < r.nk ? limw : r.nk;
+    }
+    auto krow = [&](int kt0) { return [&, kt0](int rr) { return k_row<MODE>(g, r, kt0 + rr); }; };
+    Stage2 sk, sv;
+    {
+        const int rows = nk_blk < 64 ? nk_blk : 64;
+        stage_load64(sk, rows, tid, qkv, g.ld, g.W + hcol, krow(0));
+        stage_load64(sv, rows, tid, qkv, g.ld, 2 * g.W + hcol, krow(0));
+        stage_store64(sk, smem, tid);
+        stage_store64(sv, smem + TILE_B, tid);
+    }
+    int buf = 0;
+    for (int kt0 = 0; kt0 < nk_blk; kt0 += 64, buf ^= 1) {
+        __syncthreads();
+        const char* kt_ = smem + buf * 2 * TILE_B;
+        const char* vt = kt_ + TILE_B;
+        const bool more = kt0 + 64 < nk_blk;
+        if (more) {
+            const int rows = (nk_blk - kt0 - 64) < 64 ? (nk_blk - kt0 - 64) : 64;
+            stage_load64(sk, rows, tid, qkv, g.ld, g.W + hcol, krow(kt0 + 64));
+            stage_load64(sv, rows, tid, qkv, g.ld, 2 * g.W + hcol, krow(kt0 + 64));
+        }
+        if (active && kt0 < nk_w) {
+            const int rows = (nk_w - kt0) < 64 ? (nk_w - kt0) : 64;
+            f32x4 ds[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ds[t] = (f32x4){0, 0, 0, 0};
+                if (t * 16 < rows) {
+                    f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, 0, gq), qf0, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, 1, gq), qf1, s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(vt, t * 16 + li, 0, gq), dof0, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(vt, t * 16 + li, 1, gq), dof1, dp, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = kt0 + t * 16 + gq * 4 + e;
+                        const bool ok = key < r.nk && !(causal && key > qi);
+                        const float p = ok ? exp2f(s[e] * g.scale2 - lse) : 0.f;
+                        ds[t][e] = p * (dp[e] - dlt) * g.scale;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u * 32 < rows) {
+                    bf16x8 dsf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dsf[j] = (bf16)ds[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(kt_, u, dt, lane), dsf, acc[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            char* nb = smem + (buf ^ 1) * 2 * TILE_B;
+            stage_store64(sk, nb, tid);
+            stage_store64(sv, nb + TILE_B, tid);
+        }
+    }
+    if (active && qi < r.nq) {
+        bf16* dq = dqkv + (size_t)qrow * lddq + hcol;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *(bf16x4*)(dq + dt * 16 + gq * 4) = (bf16x4){(bf16)acc[dt][0], (bf16)acc[dt][1], (bf16)acc[dt][2], (bf16)acc[dt][3]};
+    }
+}
+
+template <int MODE, bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, const bf16* __restrict__ qkv,
+                                                                  const bf16* __restrict__ dO, int lddo,
+                                                                  const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                                  bf16* __restrict__ dqkv, int lddq, float* __restrict__ cls_acc) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 32 * VSTRIDE];  // [buf][Q | dO] of 32 rows
+    __shared__ float stat[2][2][32];                                      // [buf][lse2 | delta][query]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr bool EXT = (MODE == MODE_SPACE);
+    constexpr int HT = 32 * VSTRIDE;
+    const int nk_max = (MODE == MODE_SPACE) ? g.n + 1 : g.S;
+    const int kblocks = (((nk_max + 15) >> 4) + 3) >> 2;
+    const Grp r = decode<MODE>(g, blockIdx.x / kblocks);
+    const int kb_ = blockIdx.x % kblocks;
+    const int k0 = (kb_ * 4 + wave) * 16;
+    const bool active = k0 < r.nk;
+    const int gq = lane >> 4, li = lane & 15;
+    const int hcol = r.h * DH;
+    const int nqx = EXT ? r.nq + 1 : r.nq;
+    const int kj = k0 + li;
+    const int kj_c = kj < r.nk ? kj : r.nk - 1;
+    const int krow_ = k_row<MODE>(g, r, kj_c);
+    const bf16* kp = qkv + (size_t)krow_ * g.ld + g.W + hcol;
+    const bf16* vp = qkv + (size_t)krow_ * g.ld + 2 * g.W + hcol;
+    const bf16x8 kb0 = ldg8(kp + gq * 8), kb1 = ldg8(kp + 32 + gq * 8);
+    const bf16x8 vb0 = ldg8(vp + gq * 8), vb1 = ldg8(vp + 32 + gq * 8);
+    f32x4 dv[4], dk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
+    const bool causal = (MODE == MODE_FULL) && g.causal;
+    const int q_begin = causal ? ((kb_ * 64) & ~31) : 0;  // queries before the block's first key see none of its keys
+    auto qrowf = [&](int qt0) { return [&, qt0](int rr) { return qx_row<MODE>(g, r, qt0 + rr); }; };
+    bf16x8 sq, sd;
+    {
+        const int rows = (nqx - q_begin) < 32 ? (nqx - q_begin) : 32;
+        sq = stage_load32(rows, tid, qkv, g.ld, hcol, qrowf(q_begin));
+        sd = stage_load32(rows, tid, dO, lddo, hcol, qrowf(q_begin));
+        stage_store32(sq, smem, tid);
+        stage_store32(sd, smem + HT, tid);
+        if (tid < 64) {
+            const int qi = q_begin + (tid & 31);
+            const size_t o = (size_t)qx_row<MODE>(g, r, qi < nqx ? qi : nqx - 1) * g.heads + r.h;
+            stat[0][tid >> 5][tid & 31] = (tid < 32) ? lse2[o] : delta[o];
+        }
+    }
+    float sstat = 0.f;
+    int buf = 0;
+    for (int qt0 = q_begin; qt0 < nqx; qt0 += 32, buf ^= 1) {
+        __syncthreads();
+        const char* q_lds = smem + buf * 2 * HT;
+        const char* do_lds = q_lds + HT;
+        const bool more = qt0 + 32 < nqx;
+        if (more) {
+            const int rows = (nqx - qt0 - 32) < 32 ? (nqx - qt0 - 32) : 32;
+            sq = stage_load32(rows, tid, qkv, g.ld, hcol, qrowf(qt0 + 32));
+            sd = stage_load32(rows, tid, dO, lddo, hcol, qrowf(qt0 + 32));
+            if (tid < 64) {
+                const int qi = qt0 + 32 + (tid & 31);
+                const size_t o = (size_t)qx_row<MODE>(g, r, qi < nqx ? qi : nqx - 1) * g.heads + r.h;
+                sstat = (tid < 32) ? lse2[o] : delta[o];
+            }
+        }
+        if (active && !(causal && qt0 + 32 <= k0)) {
+            const int qrows = (nqx - qt0) > 16 ? 32 : 16;
+            bf16x8 pf, dsf;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+                if (t * 16 < qrows) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, 0, gq), kb0, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, 1, gq), kb1, s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, 0, gq), vb0, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, 1, gq), vb1, dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qi = qt0 + t * 16 + gq * 4 + e;
+                    bool ok = qi < nqx && kj < r.nk;
+                    if (causal) ok = ok && kj <= qi;
+                    if (EXT) ok = ok && !(qi == 0 && kj == 0 && r.sub != 0);
+                    float p = 0.f, d = 0.f;
+                    if (ok) {
+                        const int ql = t * 16 + gq * 4 + e;
+                        p = exp2f(s[e] * g.scale2 - stat[buf][0][ql]);
+                        d = p * (dp[e] - stat[buf][1][ql]) * g.scale;
+                    }
+                    pf[t * 4 + e] = (bf16)p;
+                    dsf[t * 4 + e] = (bf16)d;
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(do_lds, 0, dt, lane), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(q_lds, 0, dt, lane), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+        if (more) {
+            char* nb = smem + (buf ^ 1) * 2 * HT;
+            stage_store32(sq, nb, tid);
+            stage_store32(sd, nb + HT, tid);
+            if (tid < 64) stat[buf ^ 1][tid >> 5][tid & 31] = sstat;
+        }
+    }
+    if (active && kj < r.nk) {
+        if (EXT && kj == 0) {
+            float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 2) * DH;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(a + dt * 16 + gq * 4 + e, dk[dt][e]);
+                    atomicAdd(a + DH + dt * 16 + gq * 4 + e, dv[dt][e]);
+                }
+        } else {
+            bf16* dkp = dqkv + (size_t)krow_ * lddq + g.W + hcol;
+            bf16* dvp = dqkv + (size_t)krow_ * lddq + 2 * g.W + hcol;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *(bf16x4*)(dkp + dt * 16 + gq * 4) = (bf16x4){(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
+                *(bf16x4*)(dvp + dt * 16 + gq * 4) = (bf16x4){(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
+            }
+        }
+    }
+}
+
+// TIME geometry dK/dV: the groups are tiny (T queries x T+1 keys) and very many (B*h*n).  A block takes one
+// (b,h) and a CHUNK of patch slots; each wave walks its share of the slots, keeps the CLS key/value gradient of
+// all of them in registers, the four waves combine through LDS and ONE set of fp32 atomics per block goes out
+// (n/CHUNK per address instead of n).
+#define TIME_CHUNK 28
+template <bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, const bf16* __restrict__ qkv,
+                                                                const bf16* __restrict__ dO, int lddo,
+                                                                const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                                bf16* __restrict__ dqkv, int lddq, float* __restrict__ cls_acc) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 2 * 32 * VSTRIDE];
+    __shared__ float stat[4][2][32];
+    __shared__ float red[4][2][DH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* q_lds = smem + wave * 2 * 32 * VSTRIDE;
+    char* do_lds = q_lds + 32 * VSTRIDE;
+    const int chunks = (g.n + TIME_CHUNK - 1) / TIME_CHUNK;
+    const int c = blockIdx.x % chunks, bh = blockIdx.x / chunks;
+    Grp r;
+    r.h = bh % g.heads; r.b = bh / g.heads; r.nq = g.T; r.nk = g.T + 1;
+    const int p_end = (c + 1) * TIME_CHUNK < g.n ? (c + 1) * TIME_CHUNK : g.n;
+    const int gq = lane >> 4, li = lane & 15;
+    const int hcol = r.h * DH;
+    const int nqx = r.nq + 1;
+    const int ktiles = (r.nk + 15) >> 4;
+    f32x4 cdk[4], cdv[4];  // CLS key/value gradient (valid in the lanes whose key column is 0)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { cdk[dt] = (f32x4){0, 0, 0, 0}; cdv[dt] = (f32x4){0, 0, 0, 0}; }
+
+    for (int p = c * TIME_CHUNK + wave; p < p_end; p += 4) {
+        r.sub = p;
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int k0 = kt * 16;
+            const int kj = k0 + li;
+            const int kj_c = kj < r.nk ? kj : r.nk - 1;
+            const int krow = k_row<MODE_TIME>(g, r, kj_c);
+            const bf16* kp = qkv + (size_t)krow * g.ld + g.W + hcol;
+            const bf16* vp = qkv + (size_t)krow * g.ld + 2 * g.W + hcol;
+            const bf16x8 kb0 = ldg8(kp + gq * 8), kb1 = ldg8(kp + 32 + gq * 8);
+            const bf16x8 vb0 = ldg8(vp + gq * 8), vb1 = ldg8(vp + 32 + gq * 8);
+            f32x4 dv[4], dk[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
+            for (int qt0 = 0; qt0 < nqx; qt0 += 32) {
+                auto rowfn = [&](int rr) { int i = qt0 + rr; i = i < nqx ? i : nqx - 1; return qx_row<MODE_TIME>(g, r, i); };
+                const int qrows = (nqx - qt0) > 16 ? 32 : 16;
+                stage_tile(q_lds, qrows, lane, qkv, g.ld, hcol, rowfn);
+                stage_tile(do_lds, qrows, lane, dO, lddo, hcol, rowfn);
+                {
+                    const size_t o = (size_t)rowfn(lane & 31) * g.heads + r.h;
+                    stat[wave][lane >> 5][lane & 31] = (lane < 32) ? lse2[o] : delta[o];
+                }
+                bf16x8 pf, dsf;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+                    if (t * 16 < qrows) {
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, 0, gq), kb0, s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, 1, gq), kb1, s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, 0, gq), vb0, dp, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, 1, gq), vb1, dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ql = t * 16 + gq * 4 + e, qi = qt0 + ql;
+                        const bool ok = qi < nqx && kj < r.nk && !(qi == 0 && kj == 0 && p != 0);  // CLS x CLS once
+                        float pp = 0.f, d = 0.f;
+                        if (ok) {
+                            pp = exp2f(s[e] * g.scale2 - stat[wave][0][ql]);
+                            d = pp * (dp[e] - stat[wave][1][ql]) * g.scale;
+                        }
+                        pf[t * 4 + e] = (bf16)pp;
+                        dsf[t * 4 + e] = (bf16)d;
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(do_lds, 0, dt, lane), pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(q_lds, 0, dt, lane), dsf, dk[dt], 0, 0, 0);
+                }
+            }
+            if (kj < r.nk) {
+                if (kj == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) { cdk[dt] += dk[dt]; cdv[dt] += dv[dt]; }
+                } else {
+                    bf16* dkp = dqkv + (size_t)krow * lddq + g.W + hcol;
+                    bf16* dvp = dqkv + (size_t)krow * lddq + 2 * g.W + hcol;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        *(bf16x4*)(dkp + dt * 16 + gq * 4) = (bf16x4){(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
+                        *(bf16x4*)(dvp + dt * 16 + gq * 4) = (bf16x4){(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
+                    }
+                }
+            }
+        }
+    }
+    // combine the four waves' CLS partials (held by lanes with li == 0: d = dt*16 + gq*4 + e)
+    if (li == 0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[wave][0][dt * 16 + gq * 4 + e] = cdk[dt][e];
+                red[wave][1][dt * 16 + gq * 4 + e] = cdv[dt][e];
+            }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * DH) {
+        const int kv = threadIdx.x / DH, d = threadIdx.x % DH;
+        const float v = red[0][kv][d] + red[1][kv][d] + red[2][kv][d] + red[3][kv][d];
+        atomicAdd(cls_acc + ((size_t)(r.b * g.heads + r.h) * 2 + kv) * DH + d, v);
+    }
+}
+
 __global__ void attn_cls_finalize_kernel(const float* __restrict__ cls_acc, int B, int heads, int S, int W,
                                          bf16* __restrict__ dqkv, int lddq) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b, h, kv, d)
@@ -485,6 +1000,8 @@ __global__ void attn_cls_finalize_kernel(const float* __restrict__ cls_acc, int 
 
 // ------------------------------------------------------------------------------------------------ C ABI
 static int g_use_tr = 1;
+static int g_shared = 1;  // block-shared K/V (Q/dO) staging for FULL and SPACE geometry
+extern "C" void tvts_attn_set_shared(int on) { g_shared = on ? 1 : 0; }
 extern "C" void tvts_attn_set_transpose_read(int on) { g_use_tr = on ? 1 : 0; }
 
 static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int n, int causal, int ld) {
@@ -535,6 +1052,17 @@ extern "C" int tvts_attn_fwd(int mode, const void* qkv, int ld, int B, int heads
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     if (ldo % 4) return TVTS_EINVAL;
+    if (g_shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
+        const int nq = mode == MODE_SPACE ? g.n : g.S;
+        const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : g.B * g.heads;
+        const int nb = groups * ceil_div(ceil_div(nq, 16), 4);
+        if (mode == MODE_FULL) { if (g_use_tr) hipLaunchKernelGGL((attn_fwd_shared_kernel<MODE_FULL, true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
+                                 else hipLaunchKernelGGL((attn_fwd_shared_kernel<MODE_FULL, false>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2); }
+        else { if (g_use_tr) hipLaunchKernelGGL((attn_fwd_shared_kernel<MODE_SPACE, true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
+               else hipLaunchKernelGGL((attn_fwd_shared_kernel<MODE_SPACE, false>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2); }
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
     const int blocks = mode == MODE_CLS ? items_q(g, mode) : ceil_div(items_q(g, mode), 4);
     DISPATCH_MODE(attn_fwd_kernel, mode, dim3(blocks), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
     TVTS_LAUNCH_CHECK();
@@ -558,6 +1086,18 @@ extern "C" int tvts_attn_bwd_dq(int mode, const void* qkv, int ld, int B, int he
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     if (lddo % 8 || lddq % 4) return TVTS_EINVAL;
+    if (g_shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
+        const int nq = mode == MODE_SPACE ? g.n : g.S;
+        const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : g.B * g.heads;
+        const int nb = groups * ceil_div(ceil_div(nq, 16), 4);
+#define DQ_ARGS dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo, lse2, delta, (bf16*)dqkv, lddq
+        if (mode == MODE_FULL) { if (g_use_tr) hipLaunchKernelGGL((attn_bwd_dq_shared_kernel<MODE_FULL, true>), DQ_ARGS);
+                                 else hipLaunchKernelGGL((attn_bwd_dq_shared_kernel<MODE_FULL, false>), DQ_ARGS); }
+        else { if (g_use_tr) hipLaunchKernelGGL((attn_bwd_dq_shared_kernel<MODE_SPACE, true>), DQ_ARGS);
+               else hipLaunchKernelGGL((attn_bwd_dq_shared_kernel<MODE_SPACE, false>), DQ_ARGS); }
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
     const int blocks = mode == MODE_CLS ? items_q(g, mode) : ceil_div(items_q(g, mode), 4);
     DISPATCH_MODE(attn_bwd_dq_kernel, mode, dim3(blocks), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo,
                   lse2, delta, (bf16*)dqkv, lddq);
@@ -576,6 +1116,25 @@ extern "C" int tvts_attn_bwd_dkv(int mode, const void* qkv, int ld, int B, int h
     if (rc) return rc;
     if (lddo % 8 || lddq % 4) return TVTS_EINVAL;
     if ((mode == MODE_SPACE || mode == MODE_TIME) && !cls_acc) return TVTS_EINVAL;
+    if (g_shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
+        const int nk = mode == MODE_SPACE ? g.n + 1 : g.S;
+        const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : g.B * g.heads;
+        const int nb = groups * ceil_div(ceil_div(nk, 16), 4);
+#define DKV_ARGS dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo, lse2, delta, (bf16*)dqkv, lddq, cls_acc
+        if (mode == MODE_FULL) { if (g_use_tr) hipLaunchKernelGGL((attn_bwd_dkv_shared_kernel<MODE_FULL, true>), DKV_ARGS);
+                                 else hipLaunchKernelGGL((attn_bwd_dkv_shared_kernel<MODE_FULL, false>), DKV_ARGS); }
+        else { if (g_use_tr) hipLaunchKernelGGL((attn_bwd_dkv_shared_kernel<MODE_SPACE, true>), DKV_ARGS);
+               else hipLaunchKernelGGL((attn_bwd_dkv_shared_kernel<MODE_SPACE, false>), DKV_ARGS); }
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
+    if (g_shared && mode == MODE_TIME) {
+        const int nb = g.B * g.heads * ceil_div(g.n, TIME_CHUNK);
+        if (g_use_tr) hipLaunchKernelGGL((attn_bwd_dkv_time_kernel<true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo, lse2, delta, (bf16*)dqkv, lddq, cls_acc);
+        else hipLaunchKernelGGL((attn_bwd_dkv_time_kernel<false>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo, lse2, delta, (bf16*)dqkv, lddq, cls_acc);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
     const int blocks = ceil_div(items_k(g, mode), 4);
     DISPATCH_MODE(attn_bwd_dkv_kernel, mode, dim3(blocks), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo,
                   lse2, delta, (bf16*)dqkv, lddq, cls_acc);
