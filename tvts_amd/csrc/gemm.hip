@@ -15,6 +15,7 @@
 // with 4 consecutive output columns of one output row: 8-byte bf16 / 16-byte fp32 epilogue accesses with
 // bias, activation, activation-gradient gate and fp32 residual fused.
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -32,6 +33,8 @@ struct GemmNT {
     const bf16* gate_h; int ldh; int gate_act;
     void* out; int ldc; int out_f32;
     int tiles_m, tiles_n;
+    int ablate;  // experiment knob TVTS_NT_ABLATE: 1 skip MFMA, 2 skip DMA in the K loop, 4 skip fragment reads, 8 skip epilogue
+    int swz;  // XOR mask of the LDS chunk swizzle (7; 0 = linear image, experiment knob TVTS_NT_SWZ)
 };
 
 // --- one [128 rows][64 k] bf16 tile: 16 KiB, rows of 128 B, 16-B chunk c of row r stored at chunk c^(r&7)
@@ -50,8 +53,8 @@ __device__ __forceinline__ void stage_rows128(const bf16* __restrict__ base, int
     }
 }
 
-__device__ __forceinline__ bf16x8 frag_rows128(const char* lds_tile, int row, int chunk) {
-    return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+__device__ __forceinline__ bf16x8 frag_rows128(const char* lds_tile, int row, int chunk, int swz = 7) {
+    return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ (row & swz)) << 4));
 }
 
 template <int ACT, int GATE>
@@ -171,13 +174,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNT g) {
 // LDS: 2 stages x (A 32 KiB + B 32 KiB) = 128 KiB, one block (2 waves per SIMD) per CU; persistent over tiles.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void stage_rows256(const bf16* __restrict__ base, int ld, int row0, int row_max,
-                                              int k0, char* lds_tile, int wave, int lane) {
+                                              int k0, char* lds_tile, int wave, int lane, int swz = 7) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int r0 = (t * 8 + wave) * 8;
         const int row = r0 + (lane >> 3);
         const int slot = lane & 7;
-        const int chunk = slot ^ (row & 7);
+        const int chunk = slot ^ (row & swz);
         int grow = row0 + row;
         grow = grow < row_max ? grow : row_max;
         const bf16* src = base + (size_t)grow * ld + k0 + chunk * 8;
@@ -263,6 +266,32 @@ __device__ __forceinline__ void epilogue256_lds(const GemmNT& g, f32x4 (&acc)[4]
     }
 }
 
+struct StageOff256 { unsigned off[4]; };
+// byte offset (from the tile's first row, k = 0) of the 16-B chunk this lane fetches in DMA piece t; rows past
+// the matrix end are clamped to its last row.  Invariant along k, so the K loop only bumps a scalar base pointer.
+__device__ __forceinline__ void stage_offsets256(StageOff256& o, int ld, int row0, int row_max, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = (t * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        int grow = row0 + row;
+        grow = grow < row_max ? grow : row_max;
+        o.off[t] = (unsigned)(grow - row0) * (unsigned)ld * 2u + (unsigned)chunk * 16u;
+    }
+}
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {  // make wave-uniformity provable: SGPR base
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void stage_issue256(const StageOff256& o, const bf16* ubase_, char* lds_tile, int wave) {
+    const char* ubase = uniform_ptr(ubase_);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        __builtin_amdgcn_global_load_lds((const GLB_PTR(void))((const char*)ubase + o.off[t]),
+                                         (LDS_PTR(void))(lds_tile + (t * 8 + wave) * 1024), 16, 0, 0);
+}
+
 template <int ACT, int GATE>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNT g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 32K | B 32K]
@@ -282,8 +311,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNT g) {
     if (t >= range_n) return;
     int tile = range_lo + t;
     int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 256;
-    stage_rows256(g.A, g.lda, m0, g.M - 1, 0, smem, wave, lane);
-    stage_rows256(g.B, g.ldb, n0, g.N - 1, 0, smem + 32768, wave, lane);
+    StageOff256 oa, ob;  // per-lane byte offsets of this tile's DMA pieces (k-invariant)
+    stage_offsets256(oa, g.lda, m0, g.M - 1, wave, lane);
+    stage_offsets256(ob, g.ldb, n0, g.N - 1, wave, lane);
+    stage_issue256(oa, g.A + (size_t)m0 * g.lda, smem, wave);
+    stage_issue256(ob, g.B + (size_t)n0 * g.ldb, smem + 32768, wave);
     __syncthreads();
     int stage = 0;
     while (true) {
@@ -300,26 +332,43 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNT g) {
         for (int kt = 0; kt < nk; ++kt) {
             char* cur = smem + stage * 65536;
             char* nxt = smem + (stage ^ 1) * 65536;
-            if (kt + 1 < nk) {
-                stage_rows256(g.A, g.lda, m0, g.M - 1, (kt + 1) * BK, nxt, wave, lane);
-                stage_rows256(g.B, g.ldb, n0, g.N - 1, (kt + 1) * BK, nxt + 32768, wave, lane);
+            if (g.ablate & 2) {
+            } else if (kt + 1 < nk) {
+                stage_issue256(oa, g.A + (size_t)m0 * g.lda + (kt + 1) * BK, nxt, wave);
+                stage_issue256(ob, g.B + (size_t)n0 * g.ldb + (kt + 1) * BK, nxt + 32768, wave);
             } else if (has_next) {
-                stage_rows256(g.A, g.lda, m0n, g.M - 1, 0, nxt, wave, lane);
-                stage_rows256(g.B, g.ldb, n0n, g.N - 1, 0, nxt + 32768, wave, lane);
+                stage_offsets256(oa, g.lda, m0n, g.M - 1, wave, lane);
+                stage_offsets256(ob, g.ldb, n0n, g.N - 1, wave, lane);
+                stage_issue256(oa, g.A + (size_t)m0n * g.lda, nxt, wave);
+                stage_issue256(ob, g.B + (size_t)n0n * g.ldb, nxt + 32768, wave);
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 af[8], bfr[4];
+                if (g.ablate & 4) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    bfr[j] = frag_rows128(cur + 32768, wn * 64 + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+                    for (int j = 0; j < 4; ++j) { bf16x8 z; for (int e = 0; e < 8; ++e) z[e] = (bf16)(float)(lane + j); bfr[j] = z; }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) af[i] = frag_rows128(cur, wm * 128 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
+                    for (int i = 0; i < 8; ++i) { bf16x8 z; for (int e = 0; e < 8; ++e) z[e] = (bf16)(float)(lane + i); af[i] = z; }
+                } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+                        bfr[j] = frag_rows128(cur + 32768, wn * 64 + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) af[i] = frag_rows128(cur, wm * 128 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+                }
+                if (g.ablate & 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(af[i]));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(bfr[j]));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+                }
             }
             stage ^= 1;
             if (kt + 1 < nk) __syncthreads();
@@ -331,7 +380,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNT g) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        epilogue256_lds<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, smem + (stage ^ 1) * 65536 + wave * 8192);
+        if (!(g.ablate & 8)) epilogue256_lds<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, smem + (stage ^ 1) * 65536 + wave * 8192);
+        else if (lane == 0 && m0 == 123457) *(float*)g.out = acc[0][0][0] + acc[3][7][3];
         if (!has_next) break;
         __syncthreads();
         t = t_next; m0 = m0n; n0 = n0n;
@@ -493,6 +543,203 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256s_kernel(GemmNT g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256x256 tile, SOFTWARE-PIPELINED fragments (the production NT kernel).  An ablation of the plain 256x256
+// kernel (TVTS_NT_ABLATE) showed its three phases -- LDS-DMA wait, 24 ds_read_b128 per wave, 64 MFMAs per
+// wave -- running back to back: MFMA alone 105 us, DMA + reads alone 95 us, epilogue 53 us, together 237 us
+// (M 50240, N 2304, K 768).  Here the fragment registers are double-buffered so that the reads of the next
+// half K-step are in flight while the matrix pipe works on the current one, and the DMA of stage s+2 is issued
+// right after the barrier that frees its buffer, a full stage ahead of its consumer:
+//     F1 <- ds_read k 32..63 (cur) | MFMA(F0) | vmcnt(0) lgkmcnt(0) barrier | DMA(s+2 -> cur) |
+//     F0 <- ds_read k 0..31 (nxt)  | MFMA(F1) | [tile end: epilogue]
+// Stages form one flat sequence over the block's persistent tile list.  LDS: 2 x 64 KiB stages + 8 x 4 KiB
+// XOR-swizzled epilogue patches = 160 KiB exactly.
+// ------------------------------------------------------------------------------------------------
+template <int ACT, int GATE>
+__device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn,
+                                                  int lane, char* patch) {
+    // patch: 16 rows x 256 B (64 fp32), 16-B chunk c of row r stored at chunk c ^ r
+    const int nb = n0 + wn * 64;
+    const int li = lane & 15, gq = lane >> 4;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nb + j * 16 + gq * 4;
+        bias4[j] = (g.bias && n < g.N) ? *(const f32x4*)(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i] + bias4[j];
+            acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (g.out_f32) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int idx = lane + 64 * t, r = idx >> 4, c16 = idx & 15;
+                f32x4 v = *(const f32x4*)(patch + r * 256 + ((c16 ^ r) << 4));
+                const int m = m0 + wm * 128 + i * 16 + r, n = nb + c16 * 4;
+                if (m >= g.M || n >= g.N) continue;
+                if (ACT != ACT_NONE) {
+                    if (g.preact) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
+                }
+                if (GATE != ACT_NONE) {
+                    const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
+                }
+                if (g.residual) v += *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
+                *(f32x4*)((float*)g.out + (size_t)m * g.ldc + n) = v;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int idx = lane + 64 * t, r = idx >> 3, c8 = idx & 7;
+                const f32x4 v0 = *(const f32x4*)(patch + r * 256 + (((2 * c8) ^ r) << 4));
+                const f32x4 v1 = *(const f32x4*)(patch + r * 256 + (((2 * c8 + 1) ^ r) << 4));
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const int m = m0 + wm * 128 + i * 16 + r, n = nb + c8 * 8;
+                if (m >= g.M || n >= g.N) continue;
+                if (ACT != ACT_NONE) {
+                    if (g.preact) {
+                        bf16x8 h;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = (bf16)v[e];
+                        *(bf16x8*)(g.preact + (size_t)m * g.ldp + n) = h;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], ACT);
+                }
+                if (GATE != ACT_NONE) {
+                    const bf16x8 h = *(const bf16x8*)(g.gate_h + (size_t)m * g.ldh + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= act_bwd((float)h[e], GATE);
+                }
+                if (g.residual) {
+                    const f32x4 r0 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n), r1 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *(bf16x8*)((bf16*)g.out + (size_t)m * g.ldc + n) = o;
+            }
+        }
+    }
+}
+
+#define RAW_BARRIER_P()                       \
+    do {                                      \
+        asm volatile("" ::: "memory");        \
+        __builtin_amdgcn_s_barrier();         \
+        asm volatile("" ::: "memory");        \
+    } while (0)
+
+template <int ACT, int GATE>
+__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 32K | B 32K] + 8 x 4K patches
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    char* patch = smem + 131072 + wave * 4096;
+
+    const int total = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int q = total >> 3, rem = total & 7;
+    const int range_lo = xcd * q + (xcd < rem ? xcd : rem);
+    const int range_n = q + (xcd < rem ? 1 : 0);
+    const int nk = g.K / BK;
+    if (slot >= range_n) return;
+    const int ntl = (range_n - slot + per_xcd - 1) / per_xcd;
+    const int total_st = ntl * nk;
+
+    // DMA cursor
+    int i_st = 0, i_kt = 0, i_tl = 0, i_m0, i_n0;
+    StageOff256 oa, ob;
+    {
+        const int tile = range_lo + slot;
+        i_m0 = (tile / g.tiles_n) * 256; i_n0 = (tile % g.tiles_n) * 256;
+        stage_offsets256(oa, g.lda, i_m0, g.M - 1, wave, lane);
+        stage_offsets256(ob, g.ldb, i_n0, g.N - 1, wave, lane);
+    }
+    auto issue = [&]() {
+        char* dst = smem + (i_st & 1) * 65536;
+        stage_issue256(oa, g.A + (size_t)i_m0 * g.lda + i_kt * BK, dst, wave);
+        stage_issue256(ob, g.B + (size_t)i_n0 * g.ldb + i_kt * BK, dst + 32768, wave);
+        ++i_st;
+        if (++i_kt == nk) {
+            i_kt = 0; ++i_tl;
+            const int tile = range_lo + slot + i_tl * per_xcd;
+            i_m0 = (tile / g.tiles_n) * 256; i_n0 = (tile % g.tiles_n) * 256;
+            stage_offsets256(oa, g.lda, i_m0, g.M - 1, wave, lane);
+            stage_offsets256(ob, g.ldb, i_n0, g.N - 1, wave, lane);
+        }
+    };
+    issue();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RAW_BARRIER_P();
+    if (i_st < total_st) issue();
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int kt = 0, tl = 0, m0, n0;
+    {
+        const int tile = range_lo + slot;
+        m0 = (tile / g.tiles_n) * 256; n0 = (tile % g.tiles_n) * 256;
+    }
+    const int arow = wm * 128 + (lane & 15), brow = wn * 64 + (lane & 15), gq = lane >> 4;
+    // fragment registers: two A half-sets (4 MFMA row-tiles each) and two B sets, refilled while the matrix pipe
+    // works on the other one
+    bf16x8 aF[2][4], bF[2][4];
+#define LOAD_A(dst, buf, ks, h)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) dst[i] = frag_rows128(buf, arow + ((h) * 4 + i) * 16, (ks) * 4 + gq)
+#define LOAD_B(dst, buf, ks)                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) dst[j] = frag_rows128((buf) + 32768, brow + j * 16, (ks) * 4 + gq)
+#define MFMA16(av, bv, h)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+            acc[j][(h) * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[j], av[i], acc[j][(h) * 4 + i], 0, 0, 0)
+    LOAD_B(bF[0], smem, 0);
+    LOAD_A(aF[0], smem, 0, 0);
+
+    for (int st = 0; st < total_st; ++st) {
+        const char* cur = smem + (st & 1) * 65536;
+        const char* nxt = smem + ((st + 1) & 1) * 65536;
+        LOAD_A(aF[1], cur, 0, 1);
+        MFMA16(aF[0], bF[0], 0);
+        LOAD_B(bF[1], cur, 1);
+        LOAD_A(aF[0], cur, 1, 0);
+        MFMA16(aF[1], bF[0], 1);
+        LOAD_A(aF[1], cur, 1, 1);
+        MFMA16(aF[0], bF[1], 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        RAW_BARRIER_P();
+        if (i_st < total_st) issue();  // stage st+2 into the buffer every wave has just finished reading
+        if (st + 1 < total_st) {
+            LOAD_B(bF[0], nxt, 0);
+            LOAD_A(aF[0], nxt, 0, 0);
+        }
+        MFMA16(aF[1], bF[1], 1);
+        if (++kt == nk) {
+            epilogue256_patch<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, patch);
+            kt = 0; ++tl;
+            const int tile = range_lo + slot + tl * per_xcd;
+            m0 = (tile / g.tiles_n) * 256; n0 = (tile % g.tiles_n) * 256;
+        }
+    }
+#undef LOAD_A
+#undef LOAD_B
+#undef MFMA16
+}
+
+// ------------------------------------------------------------------------------------------------
 // 256x256 tile, DEEP RING: 32-deep stages in an NS-slot LDS ring (NS x 32 KiB), NS-1 stages of LDS-DMA in
 // flight at all times.  PMC on the 2-stage kernels shows the matrix pipe 36 % busy and the waves parked on
 // vmcnt/barrier 41 % of the time: with one K-tile of prefetch the K-tile time stretches to the L2/MALL
@@ -628,10 +875,13 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32;
+    { static const char* e = getenv("TVTS_NT_SWZ"); g.swz = e ? atoi(e) : 7; }
+    { static const char* e = getenv("TVTS_NT_ABLATE"); g.ablate = e ? atoi(e) : 0; }
+    const bool pipe = g_nt_tile == 768 || (g_nt_tile == 0);
     const bool stag = g_nt_tile == 512;
     const int ring = g_nt_tile == 1024 ? 4 : g_nt_tile == 1280 ? 5 : 0;
     if ((g_nt_tile >= 256) && (N % 8 || ldc % 8 || (preact && ldp % 8) || (gate_h && ldh % 8))) return TVTS_EINVAL;
-    const bool big = stag || ring || (g_nt_tile == 256) || (g_nt_tile == 0 && N % 256 == 0 && M >= 4096);
+    const bool big = stag || ring || g_nt_tile == 768 || (g_nt_tile == 256) || (g_nt_tile == 0 && N % 256 == 0 && M >= 4096);
     if (big) {
         g.tiles_n = ceil_div(N, 256);
         g.tiles_m = ceil_div(M, 256);
@@ -648,6 +898,11 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
                  : act == ACT_GELU_ERF ? (stag ? gemm_nt256s_kernel<2, 0> : gemm_nt256_kernel<2, 0>) : nullptr;
         }
         int lds_bytes = 131072;
+        if (pipe && !stag && !ring && g_nt_tile != 256) {
+            lds_bytes = 163840;
+            if (gate_h) kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1> : gemm_nt256p_kernel<0, 2>;
+            else kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0> : gemm_nt256p_kernel<2, 0>;
+        }
         if (ring) {
             if (K % 32) return TVTS_EINVAL;
             lds_bytes = ring * 32768;
