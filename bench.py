@@ -183,11 +183,16 @@ def main():
         one_step(0, device_step=False)
         torch.cuda.synchronize()
         recs, K.GEMM_PROFILE = K.GEMM_PROFILE, None
-        tot_ms = sum(s.elapsed_ms(e) for _, _, s, e in recs)
-        tot_fl = sum(f for _, f, _, _ in recs)
+        tot_ms = sum(r[2].elapsed_ms(r[3]) for r in recs)
+        tot_fl = sum(r[1] for r in recs)
         by = {}
-        for kind, f, s, e in recs:
+        shapes = {}
+        for kind, f, s, e, shp in recs:
             d = by.setdefault(kind, [0, 0.0, 0.0]); d[0] += 1; d[1] += f; d[2] += s.elapsed_ms(e)
+            d2 = shapes.setdefault((kind,) + tuple(shp), [0, 0.0, 0.0]); d2[0] += 1; d2[1] += f; d2[2] += s.elapsed_ms(e)
+        if os.environ.get('TVTS_BENCH_SHAPES'):
+            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][2])[:24]:
+                print(f'[shape] {v[2]:7.2f} ms n={v[0]:3d} {v[1] / (v[2] * 1e-3) / 1e12:7.1f} TF  {k}', file=sys.stderr)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,

@@ -16,6 +16,7 @@
 // bias, activation, activation-gradient gate and fp32 residual fused.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define BM 128
 #define BN 128
@@ -954,6 +955,7 @@ struct GemmTN {
     int tiles_b, tiles_ab, m_per_split, n_items;
     int atomic;
     float* colsum;  // optional: colsum[a] += sum_m P[m,a]  (bias gradient fused into the weight gradient)
+    int ablate;     // experiment knob TVTS_TN_ABLATE: 1 skip MFMA, 2 skip DMA after the prologue, 4 skip fragment reads, 8 skip epilogue
 };
 
 __device__ __forceinline__ void stage_cols128(const bf16* __restrict__ base, int ld, int m0, int m_max, int c0,
@@ -1101,6 +1103,267 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN, 256x256 tile, software-pipelined (the production weight-gradient kernel for large outputs).
+// Same skeleton as gemm_nt256p_kernel: 8 waves (2 x 4), wave tile 128(a) x 64(b), two 64-row stages in LDS,
+// fragment registers double-buffered in four chunks per stage, DMA of stage s+2 issued right after the barrier
+// that frees its buffer.  Differences: the contraction runs over token rows, so stages advance along m and the
+// fragments are gathered with ds_read_b64_tr_b16 from [64 m][256 cols] tiles (512-B rows, 32-B chunk c of row r
+// at c ^ (r & 7)).  hipcc parks an s_waitcnt vmcnt(0) in front of every transposing read that follows an LDS-DMA
+// builtin, which would drain the prefetch, so the DMA is issued from inline asm (M0 saved/restored) and waited
+// for by hand.  The bias gradient (column sums of P) is accumulated on the VALU from the P fragments.
+// Work items = (m-range, tile) in range-major order, one contiguous eighth per XCD, one round of 256 blocks.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16_asm(unsigned voff, const char* sbase, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+struct StageOffTN { unsigned off[4]; };
+__device__ __forceinline__ void tn_offsets(StageOffTN& o, int ld, int rows_valid, int c_max, int c0, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = 2 * (t * 8 + wave) + (lane >> 5);
+        const int s16 = lane & 31;
+        const int c32 = (s16 >> 1) ^ (row & 7);
+        int col = c0 + c32 * 16 + (s16 & 1) * 8;
+        col = col < c_max ? col : c_max;
+        const int r = row < rows_valid ? row : rows_valid - 1;
+        o.off[t] = ((unsigned)r * (unsigned)ld + (unsigned)col) * 2u;
+    }
+}
+__device__ __forceinline__ void tn_issue(const StageOffTN& o, const bf16* ubase_, unsigned lds_tile, int wave) {
+    const char* ubase = uniform_ptr(ubase_);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) glds16_asm(o.off[t], ubase, lds_tile + (unsigned)(t * 8 + wave) * 1024u);
+}
+__device__ __forceinline__ bf16x8 frag_tr512(const char* lds_tile, int u, int ct, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    s16x4 h[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row = u * 32 + half * 16 + g * 4 + (i >> 2);
+        const char* p = lds_tile + row * 512 + ((ct ^ (row & 7)) << 5) + (i & 3) * 8;
+        h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))p);
+    }
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 both = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+// DMA piece offsets for a 32-row stage: piece t of wave w covers rows 2*(t*8+w), +1  (t = 0,1)
+struct StageOffTN32 { unsigned off[2]; };
+// 32-row stage of one operand = 4 column blocks of [32 rows][64 cols] (128-B rows, 4 KiB each).  A DMA piece is
+// 8 rows x 128 B of one column block (the request shape of the NT kernels: eight different rows per wave
+// instruction); piece p = cb*4 + rg, wave w issues pieces w and w+8.  32-B chunk c of row r sits at c ^ ((r>>1)&3).
+__device__ __forceinline__ void tn_offsets32(StageOffTN32& o, int ld, int rows_valid, int c_max, int c0, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int piece = t * 8 + wave, cb = piece >> 2, rg = piece & 3;
+        const int row = rg * 8 + (lane >> 3);
+        const int s16 = lane & 7;
+        const int c4 = (s16 >> 1) ^ ((row >> 1) & 3);
+        int col = c0 + cb * 64 + c4 * 16 + (s16 & 1) * 8;
+        col = col < c_max ? col : c_max;
+        const int r = row < rows_valid ? row : rows_valid - 1;
+        o.off[t] = ((unsigned)r * (unsigned)ld + (unsigned)col) * 2u;
+    }
+}
+__device__ __forceinline__ void tn_issue32(const StageOffTN32& o, const bf16* ubase_, unsigned lds_tile, int wave, bool use_builtin = false) {
+    const char* ubase = uniform_ptr(ubase_);
+    if (use_builtin) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            __builtin_amdgcn_global_load_lds((const GLB_PTR(void))(ubase + o.off[t]), (LDS_PTR(void))(size_t)(lds_tile + (unsigned)(t * 8 + wave) * 1024u), 16, 0, 0);
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) glds16_asm(o.off[t], ubase, lds_tile + (unsigned)(t * 8 + wave) * 1024u);
+}
+// fragment of 16-column block ct (0..15) over the 32 rows of the stage
+__device__ __forceinline__ bf16x8 frag_tr_cb(const char* lds_tile, int ct, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    s16x4 h[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row = half * 16 + g * 4 + (i >> 2);
+        const char* p = lds_tile + (ct >> 2) * 4096 + row * 128 + (((ct & 3) ^ ((row >> 1) & 3)) << 5) + (i & 3) * 8;
+        h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))p);
+    }
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 both = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+template <int N> __device__ __forceinline__ void wait_vm_lgkm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// Stages are 32 token rows ([32][256] bf16 per operand, 16 KiB each) in an NS-slot ring: NS-1 stages of LDS-DMA
+// stay in flight (the weight-gradient operands are streamed once from HBM with no reuse along the contraction,
+// so the loop is bound by miss latency x bytes in flight, not by L2 bandwidth).
+template <bool CS, int NS>
+__device__ __forceinline__ void tn256_body(const GemmTN& g, char* smem, unsigned lds0, int wave, int lane, int a0, int b0,
+                                           int m_begin, int m_end) {
+    const int wa = wave >> 2, wb = wave & 3;
+    const int nst = (m_end - m_begin + 31) / 32;
+    const int tail_rows = (m_end - m_begin) - (nst - 1) * 32;  // 1..32
+    const int nfull = tail_rows == 32 ? nst : nst - 1;
+
+    const int rot = (g.ablate & 64) ? 0 : (nfull > 0 ? (int)(((unsigned)(a0 / 256) * 7u + (unsigned)(b0 / 256) * 3u) % (unsigned)nfull) : 0);
+    StageOffTN32 op, oq;
+    tn_offsets32(op, g.ldp, 32, g.Na - 8, a0, wave, lane);
+    tn_offsets32(oq, g.ldq, 32, g.Nb - 8, b0, wave, lane);
+    int i_st = 0;
+    auto issue = [&]() {
+        const unsigned dst = lds0 + (unsigned)(i_st % NS) * 32768u;
+        // blocks that share operand panels start at different stages (rotation over the full stages), so the
+        // eight-or-so CUs reading one line do not all ask the same L2 channel in the same microsecond
+        const int ph = (i_st < nfull) ? (i_st + rot) % nfull : i_st;
+        const size_t mrow = (size_t)(m_begin + ph * 32);
+        if (i_st == nst - 1 && tail_rows < 32) {
+            StageOffTN32 opt, oqt;
+            tn_offsets32(opt, g.ldp, tail_rows, g.Na - 8, a0, wave, lane);
+            tn_offsets32(oqt, g.ldq, tail_rows, g.Nb - 8, b0, wave, lane);
+            tn_issue32(opt, g.P + mrow * g.ldp, dst, wave);
+            tn_issue32(oqt, g.Q + mrow * g.ldq, dst + 16384u, wave);
+        } else {
+            if (!(g.ablate & 16)) tn_issue32(op, g.P + mrow * g.ldp, dst, wave, (g.ablate & 128) != 0);
+            if (!(g.ablate & 32)) tn_issue32(oq, g.Q + mrow * g.ldq, dst + 16384u, wave, (g.ablate & 128) != 0);
+        }
+        ++i_st;
+    };
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (i_st < nst && !((g.ablate & 2) && p > 0)) issue();
+    auto wait_stage = [&](int st) {  // stage `st` landed; younger stages may stay in flight (4 pieces each)
+        const int younger = i_st - st - 1;
+        if (younger >= 3) wait_vm_lgkm<12>();
+        else if (younger == 2) wait_vm_lgkm<8>();
+        else if (younger == 1) wait_vm_lgkm<4>();
+        else wait_vm_lgkm<0>();
+    };
+    wait_stage(0);
+    RAW_BARRIER_P();
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 csacc = {0.f, 0.f, 0.f, 0.f};  // bias gradient: row i of this tile = column sums of a-tile i (selector MFMA)
+
+    bf16x8 pF[2][4], qF[2][4];
+    if (g.ablate & 4) { for (int x = 0; x < 2; ++x) for (int y = 0; y < 4; ++y) for (int e = 0; e < 8; ++e) { pF[x][y][e] = (bf16)(float)(lane + y); qF[x][y][e] = (bf16)(float)(lane - y); } }
+#define TN_LOAD_P(dst, buf, h) if (!(g.ablate & 4)) { _Pragma("unroll") for (int i = 0; i < 4; ++i) dst[i] = frag_tr_cb(buf, wa * 8 + (h) * 4 + i, lane); }
+#define TN_LOAD_Q(dst, buf) if (!(g.ablate & 4)) { _Pragma("unroll") for (int j = 0; j < 4; ++j) dst[j] = frag_tr_cb((buf) + 16384, wb * 4 + j, lane); }
+#define TN_MFMA16(pv, qv, h)                                                                              \
+    if (g.ablate & 1) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(pv[i])); asm volatile("" :: "v"(qv[i])); } } else \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+            acc[(h) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qv[j], pv[i], acc[(h) * 4 + i][j], 0, 0, 0); \
+        if (CS) {                                                                                         \
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;                                   \
+            const unsigned pat = ((lane & 15) == (h) * 4 + i) ? 0x3f803f80u : 0u;                          \
+            const bf16x8 sel = __builtin_bit_cast(bf16x8, (u32x4){pat, pat, pat, pat});                    \
+            csacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, pv[i], csacc, 0, 0, 0);                  \
+        }                                                                                                 \
+    }
+    if (nfull > 0) {
+        TN_LOAD_Q(qF[0], smem);
+        TN_LOAD_P(pF[0], smem, 0);
+    }
+    // stage st uses qF[st & 1]; the loop is unrolled by two so the fragment sets are indexed statically
+    auto step = [&](int st, auto parity) {
+        constexpr int PQ = decltype(parity)::value;
+        const char* cur = smem + (st % NS) * 32768;
+        const char* nxt = smem + ((st + 1) % NS) * 32768;
+        TN_LOAD_P(pF[1], cur, 1);
+        TN_MFMA16(pF[0], qF[PQ], 0);
+        if (st + 1 < nst) wait_stage(st + 1); else wait_vm_lgkm<0>();
+        RAW_BARRIER_P();
+        if (i_st < nst && !(g.ablate & 2)) issue();  // into the slot of stage st, which every wave has finished reading
+        if (st + 1 < nfull) {
+            TN_LOAD_Q(qF[PQ ^ 1], nxt);
+            TN_LOAD_P(pF[0], nxt, 0);
+        }
+        TN_MFMA16(pF[1], qF[PQ], 1);
+    };
+    int st = 0;
+    for (; st + 1 < nfull; st += 2) {
+        step(st, std::integral_constant<int, 0>{});
+        step(st + 1, std::integral_constant<int, 1>{});
+    }
+    if (st < nfull) { step(st, std::integral_constant<int, 0>{}); ++st; }
+    if (nfull < nst) {  // short last stage (landed: the last step waited for it, or the prologue did)
+        const char* cur = smem + (nfull % NS) * 32768;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            TN_LOAD_Q(qF[0], cur);
+            TN_LOAD_P(pF[0], cur, h);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = (e >> 2) * 16 + (lane >> 4) * 4 + (e & 3) < tail_rows;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pF[0][i][e] = ok ? pF[0][i][e] : (bf16)0.f;
+            }
+            if (h == 0) { TN_MFMA16(pF[0], qF[0], 0); } else { TN_MFMA16(pF[0], qF[0], 1); }
+        }
+    }
+#undef TN_LOAD_P
+#undef TN_LOAD_Q
+#undef TN_MFMA16
+    if (CS && wb == 0 && lane < 32) {  // csacc[r] in lane (gq, li): a-tile i = gq*4 + r, column li
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = a0 + wa * 128 + ((lane >> 4) * 4 + r) * 16 + (lane & 15);
+            if (a < g.Na) atomicAdd(g.colsum + a, csacc[r]);
+        }
+    }
+    if (g.ablate & 8) { if (lane == 0 && a0 == 123457) g.out[0] = acc[0][0][0] + acc[7][3][3]; return; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int a = a0 + wa * 128 + i * 16 + (lane & 15);
+        if (a >= g.Na) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = b0 + wb * 64 + j * 16 + (lane >> 4) * 4;
+            if (b >= g.Nb) continue;
+            float* dst = g.out + (size_t)a * g.ldo + b;
+            if (g.atomic) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[i][j][e]);
+            } else {
+                *(f32x4*)dst = acc[i][j];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmTN g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // ring of [P 16K | Q 16K] stages
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(LDS_PTR(char))smem;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int item = xcd * per + jx;
+    if (item >= g.n_items) return;
+    const int split = item / g.tiles_ab, t = item % g.tiles_ab;
+    const int a0 = (t / g.tiles_b) * 256, b0 = (t % g.tiles_b) * 256;
+    const int m_begin = split * g.m_per_split;
+    int m_end = m_begin + g.m_per_split;
+    m_end = m_end < g.M ? m_end : g.M;
+    if (m_begin >= m_end) return;
+    if (g.colsum != nullptr && (t % g.tiles_b) == 0) tn256_body<true, 5>(g, smem, lds0, wave, lane, a0, b0, m_begin, m_end);
+    else tn256_body<false, 5>(g, smem, lds0, wave, lane, a0, b0, m_begin, m_end);
+}
+
+static int tn_tile_env() { const char* e = getenv("TVTS_TN_TILE"); return e ? atoi(e) : 0; }
+static int g_tn_tile = tn_tile_env();  // 0 auto, 128, 256
+
 extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb,
                                  float* out, int ldo, int accumulate, float* colsum, hipStream_t stream) {
     if (M <= 0 || Na <= 0 || Nb <= 0) return TVTS_EINVAL;
@@ -1108,6 +1371,31 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     GemmTN g;
     g.P = (const bf16*)P; g.ldp = ldp; g.Q = (const bf16*)Q; g.ldq = ldq; g.M = M; g.Na = Na; g.Nb = Nb;
     g.out = out; g.ldo = ldo; g.colsum = colsum;
+    { static const char* e = getenv("TVTS_TN_ABLATE"); g.ablate = e ? atoi(e) : 0; }
+    // the 256x256 ring variant is correct but not faster than the 128x128 kernel yet (its LDS-DMA stream delivers
+    // ~4.5 TB/s whatever the ring depth): opt-in via TVTS_TN_TILE=256
+    const bool big = Na % 256 == 0 && Nb % 256 == 0 && g_tn_tile == 256;
+    if (big) {
+        g.tiles_b = Nb / 256;
+        g.tiles_ab = (Na / 256) * g.tiles_b;
+        int splits = 256 / g.tiles_ab;  // one round of 256 blocks (1 per CU)
+        if (splits < 1) splits = 1;
+        while (splits > 1 && M / splits < 512) --splits;
+        g.m_per_split = ceil_div(ceil_div(M, splits), 32) * 32;
+        splits = ceil_div(M, g.m_per_split);
+        if (!accumulate && splits > 1) {
+            hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)Nb * 4, Na, stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        g.atomic = (accumulate || splits > 1) ? 1 : 0;
+        g.n_items = g.tiles_ab * splits;
+        const int grid = ceil_div(g.n_items, 8) * 8;
+        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tn256p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if (e2 != hipSuccess) return (int)e2;
+        hipLaunchKernelGGL(gemm_tn256p_kernel, dim3(grid), dim3(512), 163840, stream, g);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
     const int tiles_a = ceil_div(Na, 128);
     g.tiles_b = ceil_div(Nb, 128);
     g.tiles_ab = tiles_a * g.tiles_b;

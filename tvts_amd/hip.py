@@ -62,7 +62,7 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
     _chk(rc, "tvts_gemm_nt_bf16")
     if GEMM_PROFILE is not None:
         ev1.record()
-        GEMM_PROFILE.append(("gemm_nt", 2.0 * M * N * K, ev0, ev1))
+        GEMM_PROFILE.append(("gemm_nt", 2.0 * M * N * K, ev0, ev1, (M, N, K, "f32" if out.dtype == torch.float32 else "bf16", "res" if residual is not None else "", str(act or ""), "gate" if gate_h is not None else "")))
 
 
 def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None):
@@ -78,7 +78,7 @@ def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None):
     _chk(rc, "tvts_gemm_tn_bf16")
     if GEMM_PROFILE is not None:
         ev1.record()
-        GEMM_PROFILE.append(("gemm_tn", 2.0 * M * p.shape[1] * q.shape[1], ev0, ev1))
+        GEMM_PROFILE.append(("gemm_tn", 2.0 * M * p.shape[1] * q.shape[1], ev0, ev1, (M, p.shape[1], q.shape[1], "cs" if colsum is not None else "")))
 
 
 def gemm_small(a, b, out, *, M, N, K, sa, sb, alpha=1.0, bias=None, accumulate=False):
