@@ -35,20 +35,25 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// QuickGELU x*sigmoid(1.702x) and its derivative on the fast transcendental path (v_exp_f32 + v_rcp_f32, ~1 ulp):
+// the epilogue evaluates 64 K of these per output tile while the matrix pipe waits.
+__device__ __forceinline__ float fast_sigmoid(float z) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
 __device__ __forceinline__ float act_fwd(float x, int act) {
-    if (act == ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));
+    if (act == ACT_QUICK_GELU) return x * fast_sigmoid(1.702f * x);
     if (act == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
     return x;
 }
 // d act(x) / dx
 __device__ __forceinline__ float act_bwd(float x, int act) {
     if (act == ACT_QUICK_GELU) {
-        float s = 1.0f / (1.0f + __expf(-1.702f * x));
+        const float s = fast_sigmoid(1.702f * x);
         return s * (1.0f + 1.702f * x * (1.0f - s));
     }
     if (act == ACT_GELU_ERF) {
         float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-        return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+        return cdf + x * 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.5f * 1.4426950408889634f * x * x);
     }
     return 1.0f;
 }

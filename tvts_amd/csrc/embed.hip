@@ -193,15 +193,19 @@ extern "C" int tvts_sort_assemble(const float* tok, int ldt, int B, int S, int o
     return TVTS_OK;
 }
 // d_out[b*S + r] (bf16, feeds the output-projection dgrad/wgrad) = [r >= off ? dxs[b, r-off] : 0] + [r == 0 ? dvid[b] : 0]
-// dtype[0] += sum over video rows, dtype[1] += sum over caption rows.  One block per sample.
+// dtype[0] += sum over video rows, dtype[1] += sum over caption rows.
+// grid (B, row chunks of 32): each block converts its rows and adds its partial column sums with atomics.
 __global__ __launch_bounds__(256) void sort_assemble_bwd_kernel(const float* __restrict__ dxs, int ldx, int S, int off, int Sv,
                                                                 int NT, const float* __restrict__ dvid, int E,
                                                                 bf16* __restrict__ dout, int ldo, float* __restrict__ dtype) {
     const int So = Sv + NT;
     const int b = blockIdx.x;
+    const int r0 = blockIdx.y * 32;
+    int r1 = r0 + 32;
+    r1 = r1 < S ? r1 : S;
     for (int c = threadIdx.x; c < E; c += 256) {
         float s0 = 0.f, s1 = 0.f;
-        for (int r = 0; r < S; ++r) {
+        for (int r = r0; r < r1; ++r) {
             float v = 0.f;
             if (dxs && r >= off) {
                 v = dxs[(size_t)(b * So + r - off) * ldx + c];
@@ -211,16 +215,17 @@ __global__ __launch_bounds__(256) void sort_assemble_bwd_kernel(const float* __r
             dout[(size_t)(b * S + r) * ldo + c] = (bf16)v;
         }
         if (dxs) {
-            for (int i = 0; i < NT; ++i) s1 += dxs[(size_t)(b * So + Sv + i) * ldx + c];
+            if (blockIdx.y == 0)
+                for (int i = 0; i < NT; ++i) s1 += dxs[(size_t)(b * So + Sv + i) * ldx + c];
             atomicAdd(dtype + c, s0);
-            atomicAdd(dtype + E + c, s1);
+            if (blockIdx.y == 0) atomicAdd(dtype + E + c, s1);
         }
     }
 }
 extern "C" int tvts_sort_assemble_bwd(const float* dxs, int ldx, int B, int S, int off, int Sv, int NT, const float* dvid,
                                       int E, void* dout, int ldo, float* dtype, hipStream_t stream) {
-    hipLaunchKernelGGL(sort_assemble_bwd_kernel, dim3(B), dim3(256), 0, stream, dxs, ldx, S, off, Sv, NT, dvid, E,
-                       (bf16*)dout, ldo, dtype);
+    hipLaunchKernelGGL(sort_assemble_bwd_kernel, dim3(B, ceil_div(S, 32)), dim3(256), 0, stream, dxs, ldx, S, off, Sv, NT, dvid,
+                       E, (bf16*)dout, ldo, dtype);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

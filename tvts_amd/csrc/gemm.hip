@@ -882,7 +882,7 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     const bool stag = g_nt_tile == 512;
     const int ring = g_nt_tile == 1024 ? 4 : g_nt_tile == 1280 ? 5 : 0;
     if ((g_nt_tile >= 256) && (N % 8 || ldc % 8 || (preact && ldp % 8) || (gate_h && ldh % 8))) return TVTS_EINVAL;
-    const bool big = stag || ring || g_nt_tile == 768 || (g_nt_tile == 256) || (g_nt_tile == 0 && N % 256 == 0 && M >= 4096);
+    const bool big = stag || ring || g_nt_tile == 768 || (g_nt_tile == 256) || (g_nt_tile == 0 && N % 256 == 0 && (long)ceil_div(M, 256) * (N / 256) >= 200);
     if (big) {
         g.tiles_n = ceil_div(N, 256);
         g.tiles_m = ceil_div(M, 256);
