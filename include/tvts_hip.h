@@ -25,9 +25,11 @@ int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int
 /* tile selection override for tools/gemm_bench.py: 0 auto, 128, 256 */
 void tvts_gemm_set_nt_tile(int t);
 /* weight gradient: out[Na,Nb] (+)= P[M,Na]^T . Q[M,Nb], bf16 in, fp32 out (autograd of the Linear sites above) */
-/* colsum (optional): colsum[a] += sum_m P[m,a] -- the bias gradient, fused into the same pass */
+/* colsum (optional): colsum[a] += sum_m P[m,a] -- the bias gradient, fused into the same pass.
+ * workspace (optional, workspace_elems floats): scratch for the split-M partials; with it the kernel stores
+ * partials and a reduce pass combines them (deterministic), without it the partials meet through fp32 atomics. */
 int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb, float* out, int ldo,
-                      int accumulate, float* colsum, hipStream_t stream);
+                      int accumulate, float* colsum, float* workspace, long workspace_elems, hipStream_t stream);
 /* strided fp32 matmul for the tiny products (text_projection model_dist..B_16.py:108, head sort_transformer.py:113,
  * sim_matrix model_dist..B_16.py:126): C[i,j] (+)= alpha * sum_k A[i*sai+k*sak] * B[k*sbk+j*sbj] + bias[j] */
 int tvts_gemm_small_f32(const float* A, long sai, long sak, const float* B, long sbk, long sbj, int M, int N, int K,

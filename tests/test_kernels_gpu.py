@@ -107,6 +107,10 @@ def test_gemm_tn(K, M, Na, Nb):
     K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True, colsum=cs)
     assert rel(out, 2 * ref) < 3e-5
     assert rel(cs, 1 + p.float().sum(0)) < 1e-5, rel(cs, 1 + p.float().sum(0))
+    K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True, workspace=False)  # fp32-atomic fallback (no workspace)
+    assert rel(out, 3 * ref) < 3e-5
+    K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=False, workspace=False)
+    assert rel(out, ref) < 3e-5
 
 
 def test_gemm_tn_views(K):

@@ -954,6 +954,7 @@ struct GemmTN {
     float* out; int ldo;
     int tiles_b, tiles_ab, m_per_split, n_items;
     int atomic;
+    float* ws;      // split partials [splits][Na][Nb] (plain stores, reduced by tn_reduce_kernel) or nullptr -> fp32 atomics
     float* colsum;  // optional: colsum[a] += sum_m P[m,a]  (bias gradient fused into the weight gradient)
     int ablate;     // experiment knob TVTS_TN_ABLATE: 1 skip MFMA, 2 skip DMA after the prologue, 4 skip fragment reads, 8 skip epilogue
 };
@@ -1084,6 +1085,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
     }
     // acc[i][j]: MFMA A-operand = Q (rows = b within tile j), B-operand = P (cols = a within tile i)
     // lane: col = a = l&15, rows = b = (l>>4)*4 + r  -> 4 consecutive b for one a: 16-B fp32 access
+    float* obase = g.ws ? g.ws + (size_t)split * g.Na * g.Nb : g.out;
+    const int old_ = g.ws ? g.Nb : g.ldo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int a = a0 + wa * 64 + i * 16 + (lane & 15);
@@ -1092,14 +1095,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
         for (int j = 0; j < 4; ++j) {
             const int b = b0 + wb * 64 + j * 16 + (lane >> 4) * 4;
             if (b >= g.Nb) continue;
-            float* dst = g.out + (size_t)a * g.ldo + b;
-            if (g.atomic) {
+            float* dst = obase + (size_t)a * old_ + b;
+            if (g.atomic && !g.ws) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[i][j][e]);
             } else {
                 *(f32x4*)dst = acc[i][j];
             }
         }
+    }
+}
+
+// out[a,b] = (accumulate ? out[a,b] : 0) + sum_s ws[s][a][b]
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, int Na, int Nb,
+                                                        float* __restrict__ out, int ldo, int accumulate) {
+    const size_t n4 = (size_t)Na * Nb / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t e = i * 4;
+        const int a = (int)(e / Nb), b = (int)(e % Nb);
+        f32x4 s = accumulate ? *(const f32x4*)(out + (size_t)a * ldo + b) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < splits; ++k) s += *(const f32x4*)(ws + (size_t)k * Na * Nb + e);
+        *(f32x4*)(out + (size_t)a * ldo + b) = s;
     }
 }
 
@@ -1365,10 +1381,12 @@ static int tn_tile_env() { const char* e = getenv("TVTS_TN_TILE"); return e ? at
 static int g_tn_tile = tn_tile_env();  // 0 auto, 128, 256
 
 extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb,
-                                 float* out, int ldo, int accumulate, float* colsum, hipStream_t stream) {
+                                 float* out, int ldo, int accumulate, float* colsum, float* workspace,
+                                 long workspace_elems, hipStream_t stream) {
     if (M <= 0 || Na <= 0 || Nb <= 0) return TVTS_EINVAL;
     if (Na % 8 || Nb % 8 || ldp % 8 || ldq % 8 || ldo % 4) return TVTS_EINVAL;
     GemmTN g;
+    g.ws = nullptr;
     g.P = (const bf16*)P; g.ldp = ldp; g.Q = (const bf16*)Q; g.ldq = ldq; g.M = M; g.Na = Na; g.Nb = Nb;
     g.out = out; g.ldo = ldo; g.colsum = colsum;
     { static const char* e = getenv("TVTS_TN_ABLATE"); g.ablate = e ? atoi(e) : 0; }
@@ -1414,7 +1432,11 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     }
     g.m_per_split = ceil_div(ceil_div(M, splits), 64) * 64;
     splits = ceil_div(M, g.m_per_split);
-    if (!accumulate && splits > 1) {
+    // split partials: plain stores into the caller's workspace + one reduce pass (an fp32 atomic epilogue costs
+    // ~190 us per launch whatever M is: 16 M scattered L2 atomics); atomics remain the fallback without workspace
+    const bool use_ws = workspace != nullptr && splits > 1 && (long)splits * Na * Nb <= workspace_elems && Nb % 4 == 0;
+    if (use_ws) g.ws = workspace;
+    if (!use_ws && !accumulate && splits > 1) {
         hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)Nb * 4, Na, stream);
         if (e != hipSuccess) return (int)e;
     }
@@ -1424,6 +1446,12 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     g.n_items = g.tiles_ab * splits;
     const int grid = ceil_div(g.n_items, 8) * 8;
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(NTHREADS), 65536, stream, g);
+    if (use_ws) {
+        const long n4 = (long)Na * Nb / 4;
+        int rb = (int)((n4 + 255) / 256);
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(rb), dim3(256), 0, stream, workspace, splits, Na, Nb, out, ldo, accumulate);
+    }
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

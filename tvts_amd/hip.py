@@ -65,16 +65,27 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
         GEMM_PROFILE.append(("gemm_nt", 2.0 * M * N * K, ev0, ev1, (M, N, K, "f32" if out.dtype == torch.float32 else "bf16", "res" if residual is not None else "", str(act or ""), "gate" if gate_h is not None else "")))
 
 
-def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None):
+TN_WORKSPACE = None  # fp32 scratch tensor for the split partials of gemm_tn (allocated lazily, 96 MiB)
+
+
+def _tn_workspace(dev):
+    global TN_WORKSPACE
+    if TN_WORKSPACE is None or TN_WORKSPACE.device != dev:
+        TN_WORKSPACE = torch.empty(24 * 1024 * 1024, dtype=torch.float32, device=dev)
+    return TN_WORKSPACE
+
+
+def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True):
     """out[Na,Nb] (+)= p[M,Na]^T @ q[M,Nb]; p, q bf16; out fp32."""
     lib = _lib.load()
     M = p.shape[0] if M is None else M
     assert p.dtype == torch.bfloat16 and q.dtype == torch.bfloat16 and out.dtype == torch.float32
+    ws = _tn_workspace(p.device) if workspace else None
     if GEMM_PROFILE is not None:
         ev0, ev1 = Event(), Event()
         ev0.record()
     rc = lib.tvts_gemm_tn_bf16(_p(p), _ld(p), _p(q), _ld(q), M, p.shape[1], q.shape[1], _p(out), _ld(out),
-                               1 if accumulate else 0, _p(colsum), _stream())
+                               1 if accumulate else 0, _p(colsum), _p(ws), ws.numel() if ws is not None else 0, _stream())
     _chk(rc, "tvts_gemm_tn_bf16")
     if GEMM_PROFILE is not None:
         ev1.record()
