@@ -60,6 +60,20 @@ int tvts_attn_cls_finalize(const float* cls_acc, int B, int heads, int S, void* 
 void tvts_attn_set_transpose_read(int on);
 void tvts_attn_set_shared(int on);
 
+/* the same entry points for head dim 80 (ViT-H/14, 1280 / 16 heads); qkv is [rows, 3*heads*80] */
+int tvts_attn80_fwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, void* out, int ldo,
+                  float* lse2, hipStream_t stream);
+int tvts_attn80_delta(const void* dO, int lddo, const void* O, int ldo, int rows, int heads, float* delta,
+                    hipStream_t stream);
+int tvts_attn80_bwd_dq(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
+                     int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, hipStream_t stream);
+int tvts_attn80_bwd_dkv(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
+                      int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, float* cls_acc,
+                      hipStream_t stream);
+int tvts_attn80_cls_finalize(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq, hipStream_t stream);
+void tvts_attn80_set_transpose_read(int on);
+void tvts_attn80_set_shared(int on);
+
 /* ---- token assembly (embed.hip): video_encoder_ViT_B_16.py:176-216; model_dist..B_16.py:69-76,98-100;
  *      sort_transformer.py:124-128 */
 int tvts_patch_gather(const float* video, const int* keep, int B, int T, int n, int img, int patch, void* out, int ldo,

@@ -196,30 +196,32 @@ def _ref_divided(qkv, heads, mode, T, n, dO):
 
 
 @pytest.mark.parametrize("tr", [True, False])
+@pytest.mark.parametrize("dh", [64, 80])
 @pytest.mark.parametrize("mode,B,heads,T,n", [("time", 2, 2, 8, 5), ("space", 2, 2, 3, 21), ("space", 1, 3, 2, 98),
-                                              ("time", 1, 4, 12, 3), ("space", 2, 1, 8, 49)])
-def test_divided_attention(K, mode, B, heads, T, n, tr):
+                                              ("time", 1, 4, 12, 3), ("space", 2, 1, 8, 49), ("time", 1, 2, 16, 4),
+                                              ("space", 1, 2, 2, 76)])
+def test_divided_attention(K, mode, B, heads, T, n, tr, dh):
     K.attn_set_transpose_read(tr)
     try:
-        S, W = 1 + T * n, heads * 64
+        S, W = 1 + T * n, heads * dh
         qkv = bf(rnd(B, S, 3 * W, seed=25))
         dO = bf(rnd(B, S, W, seed=26))
         ref_out, ref_dqkv = _ref_divided(qkv.float(), heads, mode, T, n, dO.float())
         qd = qkv.reshape(B * S, 3 * W).to(DEV)
         out = torch.full((B * S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
         lse = torch.empty(B * S, heads, device=DEV)
-        K.attn_fwd(mode, qd, out, lse, B=B, heads=heads, S=S, T=T, n=n)
-        K.attn_fwd("cls", qd, out, lse, B=B, heads=heads, S=S, T=T, n=n)
+        K.attn_fwd(mode, qd, out, lse, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh)
+        K.attn_fwd("cls", qd, out, lse, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh)
         assert rel(out.float().view(B, S, W), ref_out) < 8e-3, rel(out.float().view(B, S, W), ref_out)
         dOd = dO.reshape(B * S, W).to(DEV)
         delta = torch.empty(B * S, heads, device=DEV)
         dqkv = torch.full((B * S, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
-        acc = torch.zeros(B, heads, 2, 64, device=DEV)
-        K.attn_delta(dOd, out, delta, rows=B * S, heads=heads)
-        K.attn_bwd_dq(mode, qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n)
-        K.attn_bwd_dq("cls", qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n)
-        K.attn_bwd_dkv(mode, qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n, cls_acc=acc)
-        K.attn_cls_finalize(acc, dqkv, B=B, heads=heads, S=S)
+        acc = torch.zeros(B, heads, 2, dh, device=DEV)
+        K.attn_delta(dOd, out, delta, rows=B * S, heads=heads, head_dim=dh)
+        K.attn_bwd_dq(mode, qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh)
+        K.attn_bwd_dq("cls", qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh)
+        K.attn_bwd_dkv(mode, qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n, cls_acc=acc, head_dim=dh)
+        K.attn_cls_finalize(acc, dqkv, B=B, heads=heads, S=S, head_dim=dh)
         got = dqkv.float().view(B, S, 3 * W).cpu()
         assert torch.isfinite(got).all()
         for nm, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
@@ -232,7 +234,8 @@ def test_divided_attention(K, mode, B, heads, T, n, tr):
 
 def _ref_full(qkv, heads, causal, dO):
     B, S, W3 = qkv.shape
-    W, dh = W3 // 3, 64
+    W = W3 // 3
+    dh = W // heads
     x = qkv.clone().requires_grad_(True)
     t = x.reshape(B, S, 3, heads, dh)
     q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))
@@ -245,23 +248,24 @@ def _ref_full(qkv, heads, causal, dO):
 
 
 @pytest.mark.parametrize("tr", [True, False])
+@pytest.mark.parametrize("dh", [64, 80])
 @pytest.mark.parametrize("B,heads,S,causal", [(3, 2, 32, True), (2, 2, 77, True), (2, 2, 197, False), (1, 8, 789, False),
                                               (4, 1, 9, True)])
-def test_full_attention(K, B, heads, S, causal, tr):
+def test_full_attention(K, B, heads, S, causal, tr, dh):
     K.attn_set_transpose_read(tr)
     try:
-        W = heads * 64
+        W = heads * dh
         qkv, dO = bf(rnd(B, S, 3 * W, seed=27)), bf(rnd(B, S, W, seed=28))
         ref_out, ref_d = _ref_full(qkv.float(), heads, causal, dO.float())
         qd, dOd = qkv.reshape(B * S, 3 * W).to(DEV), dO.reshape(B * S, W).to(DEV)
         out = torch.full((B * S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
         lse, delta = torch.empty(B * S, heads, device=DEV), torch.empty(B * S, heads, device=DEV)
-        K.attn_fwd("full", qd, out, lse, B=B, heads=heads, S=S, causal=causal)
+        K.attn_fwd("full", qd, out, lse, B=B, heads=heads, S=S, causal=causal, head_dim=dh)
         assert rel(out.float().view(B, S, W), ref_out) < 8e-3
         dqkv = torch.full((B * S, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
-        K.attn_delta(dOd, out, delta, rows=B * S, heads=heads)
-        K.attn_bwd_dq("full", qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, causal=causal)
-        K.attn_bwd_dkv("full", qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, causal=causal)
+        K.attn_delta(dOd, out, delta, rows=B * S, heads=heads, head_dim=dh)
+        K.attn_bwd_dq("full", qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, causal=causal, head_dim=dh)
+        K.attn_bwd_dkv("full", qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, causal=causal, head_dim=dh)
         got = dqkv.float().view(B, S, 3 * W).cpu()
         assert torch.isfinite(got).all()
         for nm, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):

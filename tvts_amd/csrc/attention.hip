@@ -27,8 +27,25 @@
 #include "common.h"
 
 enum { MODE_FULL = 0, MODE_SPACE = 1, MODE_TIME = 2, MODE_CLS = 3 };
-#define DH 64
-#define VSTRIDE 160  // bytes per LDS row of a [rows][64] bf16 tile (128 + 32: conflict-free b64_tr reads)
+// Head dimension is a compile-time constant of this translation unit: the file is compiled twice
+// (-DTVTS_DH=64 -> tvts_attn_*, -DTVTS_DH=80 -> tvts_attn80_*; ViT-H/14 has 1280/16 = 80).
+#ifndef TVTS_DH
+#define TVTS_DH 64
+#endif
+#define DH TVTS_DH
+#if TVTS_DH == 64
+#define NS_DH dh64
+#define ABI(name) tvts_attn_##name
+#define VSTRIDE 160  // bytes per LDS row of a [rows][DH] bf16 tile (128 + 32: conflict-free b64_tr reads)
+#else
+#define NS_DH dh80
+#define ABI(name) tvts_attn80_##name
+#define VSTRIDE 192
+#endif
+namespace NS_DH {
+constexpr int DT = DH / 16;         // 16-wide d tiles of the output
+constexpr int KS = (DH + 31) / 32;  // MFMA k-steps over d (the last one is half empty for DH = 80)
+constexpr int NCH = DH / 8;         // 16-byte chunks per head row
 
 struct AttnGeom {
     int B, heads, S, T, n;  // S tokens per sample (FULL: sequence length); T,n only for SPACE/TIME
@@ -49,13 +66,15 @@ __device__ __forceinline__ int n_groups(const AttnGeom& g) {
 }
 template <int MODE>
 __device__ __forceinline__ Grp decode(const AttnGeom& g, int gid) {
+    // head index fastest: neighbouring work items (waves of a block, consecutive blocks) touch neighbouring
+    // 128-byte head slices of the SAME token rows, so a row is opened once per pass instead of once per head
     Grp r;
-    if (MODE == MODE_SPACE) { r.sub = gid % g.T; gid /= g.T; r.nq = g.n; r.nk = g.n + 1; }
-    else if (MODE == MODE_TIME) { r.sub = gid % g.n; gid /= g.n; r.nq = g.T; r.nk = g.T + 1; }
-    else if (MODE == MODE_CLS) { r.sub = 0; r.nq = 1; r.nk = g.S; }
-    else { r.sub = 0; r.nq = g.S; r.nk = g.S; }
     r.h = gid % g.heads;
-    r.b = gid / g.heads;
+    gid /= g.heads;
+    if (MODE == MODE_SPACE) { r.sub = gid % g.T; r.b = gid / g.T; r.nq = g.n; r.nk = g.n + 1; }
+    else if (MODE == MODE_TIME) { r.sub = gid % g.n; r.b = gid / g.n; r.nq = g.T; r.nk = g.T + 1; }
+    else if (MODE == MODE_CLS) { r.sub = 0; r.b = gid; r.nq = 1; r.nk = g.S; }
+    else { r.sub = 0; r.b = gid; r.nq = g.S; r.nk = g.S; }
     return r;
 }
 // token row of query i / key j of a group
@@ -82,22 +101,40 @@ __device__ __forceinline__ int qx_row(const AttnGeom& g, const Grp& r, int i) {
 }
 
 __device__ __forceinline__ bf16x8 ldg8(const bf16* p) { return *(const bf16x8*)p; }
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+    return z;
+}
+// KS k-contiguous fragments of one head row (d = ks*32 + gq*8 ..); slots past DH are zero
+__device__ __forceinline__ void ld_frags(const bf16* p, int gq, bf16x8 (&f)[KS]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = ks * 32 + gq * 8;
+        f[ks] = (d0 + 8 <= DH) ? ldg8(p + d0) : zero8();
+    }
+}
+
+// k-contiguous fragment of tile row `row` (d = ks*32 + gq*8 ..); slots past DH are zero
+__device__ __forceinline__ bf16x8 frag_row(const char* tile, int row, int ks, int gq) {
+    const int d0 = ks * 32 + gq * 8;
+    return (d0 + 8 <= DH) ? *(const bf16x8*)(tile + row * VSTRIDE + d0 * 2) : zero8();
+}
 
 // stage `nrows` (<= 64, multiple of 16) rows x 64 bf16 (rows given by a functor) into a wave-private LDS tile;
 // rows [nrows, round_up(nrows, 32)) are ZERO-filled: the MFMA k-step that covers them multiplies by P = 0, and
 // stale LDS bits could be NaN.
 template <typename RowFn>
 __device__ __forceinline__ void stage_tile(char* tile, int nrows, int lane, const bf16* base, int ld, int col0, RowFn rowfn) {
-    for (int c = lane; c < nrows * 8; c += 64) {
-        const int r = c >> 3, ch = c & 7;
+    for (int c = lane; c < nrows * NCH; c += 64) {
+        const int r = c / NCH, ch = c % NCH;
         const bf16x8 v = ldg8(base + (size_t)rowfn(r) * ld + col0 + ch * 8);
         *(bf16x8*)(tile + r * VSTRIDE + ch * 16) = v;
     }
     if (nrows & 16) {
-        bf16x8 z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
-        for (int c = lane; c < 16 * 8; c += 64) *(bf16x8*)(tile + (nrows + (c >> 3)) * VSTRIDE + (c & 7) * 16) = z;
+        const bf16x8 z = zero8();
+        for (int c = lane; c < 16 * NCH; c += 64) *(bf16x8*)(tile + (nrows + c / NCH) * VSTRIDE + (c % NCH) * 16) = z;
     }
 }
 
@@ -153,14 +190,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
     const int qi = q0 + li;                       // this lane's query (column of S^T)
     const int qi_c = qi < r.nq ? qi : r.nq - 1;
     const bf16* qp = qkv + (size_t)q_row<MODE>(g, r, qi_c) * g.ld + hcol;
-    bf16x8 qf[2];
-    qf[0] = ldg8(qp + gq * 8);
-    qf[1] = ldg8(qp + 32 + gq * 8);
+    bf16x8 qf[KS];
+    ld_frags(qp, gq, qf);
 
     float m_run = SPLIT ? -1e30f : -INFINITY, l_run = 0.f;
-    f32x4 o[4];
+    f32x4 o[DT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
+    for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
 
     int nk_eff = r.nk;
     if (MODE == MODE_FULL && g.causal) { const int lim = q0 + 16; nk_eff = lim < r.nk ? lim : r.nk; }
@@ -176,9 +212,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
             if (t * 16 < rows) {
                 int kj = kt0 + t * 16 + li; kj = kj < r.nk ? kj : r.nk - 1;
                 const bf16* kp = qkv + (size_t)k_row<MODE>(g, r, kj) * g.ld + g.W + hcol;
-                const bf16x8 k0 = ldg8(kp + gq * 8), k1 = ldg8(kp + 32 + gq * 8);
-                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[0], st[t], 0, 0, 0);
-                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[1], st[t], 0, 0, 0);
+                bf16x8 kf[KS];
+                ld_frags(kp, gq, kf);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[ks], st[t], 0, 0, 0);
             }
         }
         float mx = -INFINITY;
@@ -208,7 +245,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
         l_run = l_run * alpha + rs;
         m_run = m_new;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+        for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u * 32 < rows) {
@@ -216,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[2 * u + (j >> 2)][j & 3];
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
+                for (int dt = 0; dt < DT; ++dt) {
                     const bf16x8 vf = frag_T<TR>(vt, u, dt, lane);
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
                 }
@@ -225,29 +262,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
     }
     if (SPLIT) {  // merge the 4 partial softmax states (m, l, O) through LDS; wave 0 writes the result
         __syncthreads();
-        float* red = (float*)smem;  // [wave][18][64]
-        red[(wave * 18 + 0) * 64 + lane] = m_run;
-        red[(wave * 18 + 1) * 64 + lane] = l_run;
+        float* red = (float*)smem;  // [wave][2 + DT*4][64]
+        red[(wave * (2 + DT * 4) + 0) * 64 + lane] = m_run;
+        red[(wave * (2 + DT * 4) + 1) * 64 + lane] = l_run;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) red[(wave * 18 + 2 + dt * 4 + e) * 64 + lane] = o[dt][e];
+            for (int e = 0; e < 4; ++e) red[(wave * (2 + DT * 4) + 2 + dt * 4 + e) * 64 + lane] = o[dt][e];
         __syncthreads();
         if (wave != 0) return;
         float mm = m_run;
 #pragma unroll
-        for (int w = 1; w < 4; ++w) mm = fmaxf(mm, red[(w * 18 + 0) * 64 + lane]);
+        for (int w = 1; w < 4; ++w) mm = fmaxf(mm, red[(w * (2 + DT * 4) + 0) * 64 + lane]);
         float ll = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
+        for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float sc = exp2f(red[(w * 18 + 0) * 64 + lane] - mm);
-            ll += red[(w * 18 + 1) * 64 + lane] * sc;
+            const float sc = exp2f(red[(w * (2 + DT * 4) + 0) * 64 + lane] - mm);
+            ll += red[(w * (2 + DT * 4) + 1) * 64 + lane] * sc;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[dt][e] += red[(w * 18 + 2 + dt * 4 + e) * 64 + lane] * sc;
+                for (int e = 0; e < 4; ++e) o[dt][e] += red[(w * (2 + DT * 4) + 2 + dt * 4 + e) * 64 + lane] * sc;
         }
         m_run = mm;
         l_run = ll;
@@ -257,7 +294,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
         const int row = q_row<MODE>(g, r, qi);
         bf16* op = out + (size_t)row * ldo + hcol;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             const bf16x4 v = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
             *(bf16x4*)(op + dt * 16 + gq * 4) = v;
         }
@@ -268,21 +305,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
 // ------------------------------------------------------------------------------------------------ D = rowsum(dO * O)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ dO, int lddo, const bf16* __restrict__ O,
                                                          int ldo, int rows, int heads, float* __restrict__ delta) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (row, head, chunk of 8)
-    const long total = (long)rows * heads * 8;
+    const long rh = (long)blockIdx.x * 256 + threadIdx.x;  // (row, head)
+    if (rh >= (long)rows * heads) return;
+    const int row = (int)(rh / heads), h = (int)(rh % heads);
     float s = 0.f;
-    long rh = idx >> 3;
-    if (idx < total) {
-        const int row = (int)(rh / heads), h = (int)(rh % heads), ch = (int)(idx & 7);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
         const bf16x8 a = ldg8(dO + (size_t)row * lddo + h * DH + ch * 8);
         const bf16x8 b = ldg8(O + (size_t)row * ldo + h * DH + ch * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)b[e];
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (idx < total && (idx & 7) == 0) delta[rh] = s;
+    delta[rh] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
@@ -309,15 +343,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnGeom g, const bf16
     const int qrow = q_row<MODE>(g, r, qi_c);
     const bf16* qp = qkv + (size_t)qrow * g.ld + hcol;
     const bf16* dop = dO + (size_t)qrow * lddo + hcol;
-    bf16x8 qf[2], dof[2];
-    qf[0] = ldg8(qp + gq * 8); qf[1] = ldg8(qp + 32 + gq * 8);
-    dof[0] = ldg8(dop + gq * 8); dof[1] = ldg8(dop + 32 + gq * 8);
+    bf16x8 qf[KS], dof[KS];
+    ld_frags(qp, gq, qf);
+    ld_frags(dop, gq, dof);
     const float lse = lse2[(size_t)qrow * g.heads + r.h];
     const float dlt = delta[(size_t)qrow * g.heads + r.h];
 
-    f32x4 acc[4];
+    f32x4 acc[DT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0, 0, 0, 0};
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0, 0, 0, 0};
     int nk_eff = r.nk;
     if (MODE == MODE_FULL && g.causal) { const int lim = q0 + 16; nk_eff = lim < r.nk ? lim : r.nk; }
 
@@ -335,10 +369,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnGeom g, const bf16
                 const bf16* kp = qkv + krow + g.W + hcol;
                 const bf16* vp = qkv + krow + 2 * g.W + hcol;
                 f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(kp + gq * 8), qf[0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(kp + 32 + gq * 8), qf[1], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp + gq * 8), dof[0], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldg8(vp + 32 + gq * 8), dof[1], dp, 0, 0, 0);
+                bf16x8 kf[KS], vf[KS];
+                ld_frags(kp, gq, kf);
+                ld_frags(vp, gq, vf);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks], dof[ks], dp, 0, 0, 0);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int key = kt0 + t * 16 + gq * 4 + e;
@@ -355,7 +393,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnGeom g, const bf16
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dsf[j] = (bf16)ds[2 * u + (j >> 2)][j & 3];
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
                     acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(kt_lds, u, dt, lane), dsf, acc[dt], 0, 0, 0);
             }
         }
@@ -364,22 +402,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnGeom g, const bf16
         __syncthreads();
         float* red = (float*)smem;  // [wave][16][64]
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) red[(wave * 16 + dt * 4 + e) * 64 + lane] = acc[dt][e];
+            for (int e = 0; e < 4; ++e) red[(wave * (DT * 4) + dt * 4 + e) * 64 + lane] = acc[dt][e];
         __syncthreads();
         if (wave != 0) return;
 #pragma unroll
         for (int w = 1; w < 4; ++w)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[dt][e] += red[(w * 16 + dt * 4 + e) * 64 + lane];
+                for (int e = 0; e < 4; ++e) acc[dt][e] += red[(w * (DT * 4) + dt * 4 + e) * 64 + lane];
     }
     if (qi < r.nq) {
         bf16* dq = dqkv + (size_t)qrow * lddq + hcol;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             const bf16x4 v = {(bf16)acc[dt][0], (bf16)acc[dt][1], (bf16)acc[dt][2], (bf16)acc[dt][3]};
             *(bf16x4*)(dq + dt * 16 + gq * 4) = v;
         }
@@ -412,13 +450,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnGeom g, const bf1
     const int krow = k_row<MODE>(g, r, kj_c);
     const bf16* kp = qkv + (size_t)krow * g.ld + g.W + hcol;
     const bf16* vp = qkv + (size_t)krow * g.ld + 2 * g.W + hcol;
-    bf16x8 kb[2], vb[2];
-    kb[0] = ldg8(kp + gq * 8); kb[1] = ldg8(kp + 32 + gq * 8);
-    vb[0] = ldg8(vp + gq * 8); vb[1] = ldg8(vp + 32 + gq * 8);
+    bf16x8 kb[KS], vb[KS];
+    ld_frags(kp, gq, kb);
+    ld_frags(vp, gq, vb);
 
-    f32x4 dv[4], dk[4];
+    f32x4 dv[DT], dk[DT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
+    for (int dt = 0; dt < DT; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
 
     int q_begin = 0;
     if (MODE == MODE_FULL && g.causal) q_begin = k0 & ~31;  // queries before the first key of the tile see none of it
@@ -432,13 +470,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnGeom g, const bf1
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
-            const char* qa = q_lds + (t * 16 + li) * VSTRIDE + gq * 16;
-            const char* da = do_lds + (t * 16 + li) * VSTRIDE + gq * 16;
             if (t * 16 < qrows) {
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)qa, kb[0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(qa + 64), kb[1], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)da, vb[0], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(da + 64), vb[1], dp, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, ks, gq), kb[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, ks, gq), vb[ks], dp, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -459,7 +496,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnGeom g, const bf1
             }
         }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(do_lds, 0, dt, lane), pf, dv[dt], 0, 0, 0);
             dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(q_lds, 0, dt, lane), dsf, dk[dt], 0, 0, 0);
         }
@@ -468,7 +505,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnGeom g, const bf1
         if (EXT && kj == 0) {  // CLS key/value: summed over all groups of (b,h)
             float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 2) * DH;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     atomicAdd(a + dt * 16 + gq * 4 + e, dk[dt][e]);
@@ -478,7 +515,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnGeom g, const bf1
             bf16* dkp = dqkv + (size_t)krow * lddq + g.W + hcol;
             bf16* dvp = dqkv + (size_t)krow * lddq + 2 * g.W + hcol;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 *(bf16x4*)(dkp + dt * 16 + gq * 4) = (bf16x4){(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
                 *(bf16x4*)(dvp + dt * 16 + gq * 4) = (bf16x4){(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
             }
@@ -493,41 +530,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnGeom g, const bf1
 // bottom (async-stage split), double-buffered, one __syncthreads per tile.  K/Q/dO fragments then come from
 // LDS (ds_read_b128) instead of four redundant global fetches.
 // ================================================================================================
-struct Stage2 { bf16x8 v[2]; };
+constexpr int ST64 = (64 * NCH + 255) / 256;  // 16-byte chunks per thread for a 64-row tile (2 for DH 64, 3 for DH 80)
+constexpr int ST32 = (32 * NCH + 255) / 256;  // ... for a 32-row tile
+struct Stage2 { bf16x8 v[ST64]; };
 template <typename RowFn>
 __device__ __forceinline__ void stage_load64(Stage2& r, int nrows, int tid, const bf16* base, int ld, int col0, RowFn rowfn) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-        if (row < nrows) r.v[i] = ldg8(base + (size_t)rowfn(row) * ld + col0 + ch * 8);
-        else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) r.v[i][e] = (bf16)0.f;
-        }
+    for (int i = 0; i < ST64; ++i) {
+        const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
+        r.v[i] = (row < nrows) ? ldg8(base + (size_t)rowfn(row) * ld + col0 + ch * 8) : zero8();
     }
 }
 __device__ __forceinline__ void stage_store64(const Stage2& r, char* tile, int tid) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < ST64; ++i) {
         const int c = tid + 256 * i;
-        *(bf16x8*)(tile + (c >> 3) * VSTRIDE + (c & 7) * 16) = r.v[i];
+        if (c < 64 * NCH) *(bf16x8*)(tile + (c / NCH) * VSTRIDE + (c % NCH) * 16) = r.v[i];
     }
 }
+struct Stage1 { bf16x8 v[ST32]; };
 template <typename RowFn>
-__device__ __forceinline__ bf16x8 stage_load32(int nrows, int tid, const bf16* base, int ld, int col0, RowFn rowfn) {
-    const int row = tid >> 3, ch = tid & 7;
-    bf16x8 z;
+__device__ __forceinline__ Stage1 stage_load32(int nrows, int tid, const bf16* base, int ld, int col0, RowFn rowfn) {
+    Stage1 r;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
-    return row < nrows ? ldg8(base + (size_t)rowfn(row) * ld + col0 + ch * 8) : z;
+    for (int i = 0; i < ST32; ++i) {
+        const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
+        r.v[i] = (row < nrows) ? ldg8(base + (size_t)rowfn(row) * ld + col0 + ch * 8) : zero8();
+    }
+    return r;
 }
-__device__ __forceinline__ void stage_store32(bf16x8 v, char* tile, int tid) {
-    *(bf16x8*)(tile + (tid >> 3) * VSTRIDE + (tid & 7) * 16) = v;
+__device__ __forceinline__ void stage_store32(const Stage1& r, char* tile, int tid) {
+#pragma unroll
+    for (int i = 0; i < ST32; ++i) {
+        const int c = tid + 256 * i;
+        if (c < 32 * NCH) *(bf16x8*)(tile + (c / NCH) * VSTRIDE + (c % NCH) * 16) = r.v[i];
+    }
 }
-__device__ __forceinline__ bf16x8 frag_row(const char* tile, int row, int ks, int gq) {  // k-contiguous fragment
-    return *(const bf16x8*)(tile + row * VSTRIDE + ks * 64 + gq * 16);
-}
-
 #define TILE_B (64 * VSTRIDE)
 
 template <int MODE, bool TR>
@@ -546,12 +584,13 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const 
     const int qi = q0 + li;
     const int qi_c = qi < r.nq ? qi : r.nq - 1;
     const bf16* qp = qkv + (size_t)q_row<MODE>(g, r, qi_c) * g.ld + hcol;
-    const bf16x8 qf0 = ldg8(qp + gq * 8), qf1 = ldg8(qp + 32 + gq * 8);
+    bf16x8 qf[KS];
+    ld_frags(qp, gq, qf);
 
     float m_run = -INFINITY, l_run = 0.f;
-    f32x4 o[4];
+    f32x4 o[DT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
+    for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
     const bool causal = (MODE == MODE_FULL) && g.causal;
     int nk_blk = r.nk, nk_w = r.nk;
     if (causal) {
@@ -586,8 +625,8 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const 
             for (int t = 0; t < 4; ++t) {
                 st[t] = (f32x4){0, 0, 0, 0};
                 if (t * 16 < rows) {
-                    st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, 0, gq), qf0, st[t], 0, 0, 0);
-                    st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, 1, gq), qf1, st[t], 0, 0, 0);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, ks, gq), qf[ks], st[t], 0, 0, 0);
                 }
             }
             float mx = -INFINITY;
@@ -617,7 +656,7 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const 
             l_run = l_run * alpha + rs;
             m_run = m_new;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+            for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (u * 32 < rows) {
@@ -625,7 +664,7 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const 
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[2 * u + (j >> 2)][j & 3];
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
+                    for (int dt = 0; dt < DT; ++dt)
                         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(vt, u, dt, lane), pf, o[dt], 0, 0, 0);
                 }
             }
@@ -641,7 +680,7 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const 
         const int row = q_row<MODE>(g, r, qi);
         bf16* op = out + (size_t)row * ldo + hcol;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             const bf16x4 v = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
             *(bf16x4*)(op + dt * 16 + gq * 4) = v;
         }
@@ -669,13 +708,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_shared_kernel(AttnGeom g, con
     const int qrow = q_row<MODE>(g, r, qi_c);
     const bf16* qp = qkv + (size_t)qrow * g.ld + hcol;
     const bf16* dop = dO + (size_t)qrow * lddo + hcol;
-    const bf16x8 qf0 = ldg8(qp + gq * 8), qf1 = ldg8(qp + 32 + gq * 8);
-    const bf16x8 dof0 = ldg8(dop + gq * 8), dof1 = ldg8(dop + 32 + gq * 8);
+    bf16x8 qf[KS], dof[KS];
+    ld_frags(qp, gq, qf);
+    ld_frags(dop, gq, dof);
     const float lse = lse2[(size_t)qrow * g.heads + r.h];
     const float dlt = delta[(size_t)qrow * g.heads + r.h];
-    f32x4 acc[4];
+    f32x4 acc[DT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0, 0, 0, 0};
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0, 0, 0, 0};
     const bool causal = (MODE == MODE_FULL) && g.causal;
     int nk_blk = r.nk, nk_w = r.nk;
     if (causal) {
@@ -711,10 +751,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_shared_kernel(AttnGeom g, con
                 ds[t] = (f32x4){0, 0, 0, 0};
                 if (t * 16 < rows) {
                     f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, 0, gq), qf0, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, 1, gq), qf1, s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(vt, t * 16 + li, 0, gq), dof0, dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(vt, t * 16 + li, 1, gq), dof1, dp, 0, 0, 0);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, ks, gq), qf[ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(vt, t * 16 + li, ks, gq), dof[ks], dp, 0, 0, 0);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int key = kt0 + t * 16 + gq * 4 + e;
@@ -731,7 +772,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_shared_kernel(AttnGeom g, con
 #pragma unroll
                     for (int j = 0; j < 8; ++j) dsf[j] = (bf16)ds[2 * u + (j >> 2)][j & 3];
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
+                    for (int dt = 0; dt < DT; ++dt)
                         acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(kt_, u, dt, lane), dsf, acc[dt], 0, 0, 0);
                 }
             }
@@ -745,7 +786,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_shared_kernel(AttnGeom g, con
     if (active && qi < r.nq) {
         bf16* dq = dqkv + (size_t)qrow * lddq + hcol;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
             *(bf16x4*)(dq + dt * 16 + gq * 4) = (bf16x4){(bf16)acc[dt][0], (bf16)acc[dt][1], (bf16)acc[dt][2], (bf16)acc[dt][3]};
     }
 }
@@ -774,15 +815,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
     const int krow_ = k_row<MODE>(g, r, kj_c);
     const bf16* kp = qkv + (size_t)krow_ * g.ld + g.W + hcol;
     const bf16* vp = qkv + (size_t)krow_ * g.ld + 2 * g.W + hcol;
-    const bf16x8 kb0 = ldg8(kp + gq * 8), kb1 = ldg8(kp + 32 + gq * 8);
-    const bf16x8 vb0 = ldg8(vp + gq * 8), vb1 = ldg8(vp + 32 + gq * 8);
-    f32x4 dv[4], dk[4];
+    bf16x8 kb[KS], vb[KS];
+    ld_frags(kp, gq, kb);
+    ld_frags(vp, gq, vb);
+    f32x4 dv[DT], dk[DT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
+    for (int dt = 0; dt < DT; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
     const bool causal = (MODE == MODE_FULL) && g.causal;
     const int q_begin = causal ? ((kb_ * 64) & ~31) : 0;  // queries before the block's first key see none of its keys
     auto qrowf = [&](int qt0) { return [&, qt0](int rr) { return qx_row<MODE>(g, r, qt0 + rr); }; };
-    bf16x8 sq, sd;
+    Stage1 sq, sd;
     {
         const int rows = (nqx - q_begin) < 32 ? (nqx - q_begin) : 32;
         sq = stage_load32(rows, tid, qkv, g.ld, hcol, qrowf(q_begin));
@@ -819,10 +861,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
             for (int t = 0; t < 2; ++t) {
                 f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
                 if (t * 16 < qrows) {
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, 0, gq), kb0, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, 1, gq), kb1, s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, 0, gq), vb0, dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, 1, gq), vb1, dp, 0, 0, 0);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, ks, gq), kb[ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, ks, gq), vb[ks], dp, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -841,7 +884,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
                 }
             }
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(do_lds, 0, dt, lane), pf, dv[dt], 0, 0, 0);
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(q_lds, 0, dt, lane), dsf, dk[dt], 0, 0, 0);
             }
@@ -857,7 +900,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
         if (EXT && kj == 0) {
             float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 2) * DH;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     atomicAdd(a + dt * 16 + gq * 4 + e, dk[dt][e]);
@@ -867,7 +910,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
             bf16* dkp = dqkv + (size_t)krow_ * lddq + g.W + hcol;
             bf16* dvp = dqkv + (size_t)krow_ * lddq + 2 * g.W + hcol;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 *(bf16x4*)(dkp + dt * 16 + gq * 4) = (bf16x4){(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
                 *(bf16x4*)(dvp + dt * 16 + gq * 4) = (bf16x4){(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
             }
@@ -892,17 +935,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, cons
     char* q_lds = smem + wave * 2 * 32 * VSTRIDE;
     char* do_lds = q_lds + 32 * VSTRIDE;
     const int chunks = (g.n + TIME_CHUNK - 1) / TIME_CHUNK;
-    const int c = blockIdx.x % chunks, bh = blockIdx.x / chunks;
-    Grp r;
-    r.h = bh % g.heads; r.b = bh / g.heads; r.nq = g.T; r.nk = g.T + 1;
+    Grp r;  // block order (b, chunk, h): the heads of one token range run next to each other
+    r.h = blockIdx.x % g.heads;
+    const int c = (blockIdx.x / g.heads) % chunks;
+    r.b = blockIdx.x / (g.heads * chunks); r.nq = g.T; r.nk = g.T + 1;
     const int p_end = (c + 1) * TIME_CHUNK < g.n ? (c + 1) * TIME_CHUNK : g.n;
     const int gq = lane >> 4, li = lane & 15;
     const int hcol = r.h * DH;
     const int nqx = r.nq + 1;
     const int ktiles = (r.nk + 15) >> 4;
-    f32x4 cdk[4], cdv[4];  // CLS key/value gradient (valid in the lanes whose key column is 0)
+    f32x4 cdk[DT], cdv[DT];  // CLS key/value gradient (valid in the lanes whose key column is 0)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { cdk[dt] = (f32x4){0, 0, 0, 0}; cdv[dt] = (f32x4){0, 0, 0, 0}; }
+    for (int dt = 0; dt < DT; ++dt) { cdk[dt] = (f32x4){0, 0, 0, 0}; cdv[dt] = (f32x4){0, 0, 0, 0}; }
 
     for (int p = c * TIME_CHUNK + wave; p < p_end; p += 4) {
         r.sub = p;
@@ -913,11 +957,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, cons
             const int krow = k_row<MODE_TIME>(g, r, kj_c);
             const bf16* kp = qkv + (size_t)krow * g.ld + g.W + hcol;
             const bf16* vp = qkv + (size_t)krow * g.ld + 2 * g.W + hcol;
-            const bf16x8 kb0 = ldg8(kp + gq * 8), kb1 = ldg8(kp + 32 + gq * 8);
-            const bf16x8 vb0 = ldg8(vp + gq * 8), vb1 = ldg8(vp + 32 + gq * 8);
-            f32x4 dv[4], dk[4];
+            bf16x8 kb[KS], vb[KS];
+            ld_frags(kp, gq, kb);
+            ld_frags(vp, gq, vb);
+            f32x4 dv[DT], dk[DT];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
+            for (int dt = 0; dt < DT; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
             for (int qt0 = 0; qt0 < nqx; qt0 += 32) {
                 auto rowfn = [&](int rr) { int i = qt0 + rr; i = i < nqx ? i : nqx - 1; return qx_row<MODE_TIME>(g, r, i); };
                 const int qrows = (nqx - qt0) > 16 ? 32 : 16;
@@ -932,10 +977,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, cons
                 for (int t = 0; t < 2; ++t) {
                     f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
                     if (t * 16 < qrows) {
-                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, 0, gq), kb0, s, 0, 0, 0);
-                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, 1, gq), kb1, s, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, 0, gq), vb0, dp, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, 1, gq), vb1, dp, 0, 0, 0);
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, ks, gq), kb[ks], s, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, ks, gq), vb[ks], dp, 0, 0, 0);
+                        }
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -951,7 +997,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, cons
                     }
                 }
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
+                for (int dt = 0; dt < DT; ++dt) {
                     dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(do_lds, 0, dt, lane), pf, dv[dt], 0, 0, 0);
                     dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(q_lds, 0, dt, lane), dsf, dk[dt], 0, 0, 0);
                 }
@@ -959,12 +1005,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, cons
             if (kj < r.nk) {
                 if (kj == 0) {
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) { cdk[dt] += dk[dt]; cdv[dt] += dv[dt]; }
+                    for (int dt = 0; dt < DT; ++dt) { cdk[dt] += dk[dt]; cdv[dt] += dv[dt]; }
                 } else {
                     bf16* dkp = dqkv + (size_t)krow * lddq + g.W + hcol;
                     bf16* dvp = dqkv + (size_t)krow * lddq + 2 * g.W + hcol;
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
+                    for (int dt = 0; dt < DT; ++dt) {
                         *(bf16x4*)(dkp + dt * 16 + gq * 4) = (bf16x4){(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
                         *(bf16x4*)(dvp + dt * 16 + gq * 4) = (bf16x4){(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
                     }
@@ -975,7 +1021,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, cons
     // combine the four waves' CLS partials (held by lanes with li == 0: d = dt*16 + gq*4 + e)
     if (li == 0) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 red[wave][0][dt * 16 + gq * 4 + e] = cdk[dt][e];
@@ -998,19 +1044,22 @@ __global__ void attn_cls_finalize_kernel(const float* __restrict__ cls_acc, int 
     dqkv[(size_t)(b * S) * lddq + (1 + kv) * W + h * DH + d] = (bf16)cls_acc[idx];
 }
 
+}  // namespace NS_DH
+using namespace NS_DH;
+
 // ------------------------------------------------------------------------------------------------ C ABI
 static int g_use_tr = 1;
 static int g_shared = 1;  // block-shared K/V (Q/dO) staging for FULL and SPACE geometry
-extern "C" void tvts_attn_set_shared(int on) { g_shared = on ? 1 : 0; }
-extern "C" void tvts_attn_set_transpose_read(int on) { g_use_tr = on ? 1 : 0; }
+extern "C" void ABI(set_shared)(int on) { g_shared = on ? 1 : 0; }
+extern "C" void ABI(set_transpose_read)(int on) { g_use_tr = on ? 1 : 0; }
 
 static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int n, int causal, int ld) {
     if (B <= 0 || heads <= 0 || S <= 0 || ld % 8) return TVTS_EINVAL;
     if ((mode == MODE_SPACE || mode == MODE_TIME) && (T <= 0 || n <= 0 || S != 1 + T * n)) return TVTS_EINVAL;
     if (mode < MODE_FULL || mode > MODE_CLS) return TVTS_EINVAL;
     g.B = B; g.heads = heads; g.S = S; g.T = T; g.n = n; g.causal = causal; g.ld = ld; g.W = heads * DH;
-    g.scale = 0.125f;
-    g.scale2 = 0.125f * 1.4426950408889634f;
+    g.scale = 1.0f / sqrtf((float)DH);
+    g.scale2 = g.scale * 1.4426950408889634f;
     return TVTS_OK;
 }
 static int items_q(const AttnGeom& g, int mode) {
@@ -1046,7 +1095,7 @@ static int items_k(const AttnGeom& g, int mode) {
     } while (0)
 
 // out[rows, ldo] (heads merged, the layout the output projection consumes), lse2[rows, heads]
-extern "C" int tvts_attn_fwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+extern "C" int ABI(fwd)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
                              void* out, int ldo, float* lse2, hipStream_t stream) {
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
@@ -1069,7 +1118,7 @@ extern "C" int tvts_attn_fwd(int mode, const void* qkv, int ld, int B, int heads
     return TVTS_OK;
 }
 
-extern "C" int tvts_attn_delta(const void* dO, int lddo, const void* O, int ldo, int rows, int heads, float* delta,
+extern "C" int ABI(delta)(const void* dO, int lddo, const void* O, int ldo, int rows, int heads, float* delta,
                                hipStream_t stream) {
     if (rows <= 0 || heads <= 0 || lddo % 8 || ldo % 8) return TVTS_EINVAL;
     const long total = (long)rows * heads * 8;
@@ -1079,7 +1128,7 @@ extern "C" int tvts_attn_delta(const void* dO, int lddo, const void* O, int ldo,
     return TVTS_OK;
 }
 
-extern "C" int tvts_attn_bwd_dq(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+extern "C" int ABI(bwd_dq)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
                                 const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
                                 hipStream_t stream) {
     AttnGeom g;
@@ -1107,7 +1156,7 @@ extern "C" int tvts_attn_bwd_dq(int mode, const void* qkv, int ld, int B, int he
 
 // cls_acc: fp32 [B, heads, 2, 64], zeroed by the caller before the SPACE/TIME pass, consumed by
 // tvts_attn_cls_finalize afterwards (unused for FULL).
-extern "C" int tvts_attn_bwd_dkv(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+extern "C" int ABI(bwd_dkv)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
                                  const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
                                  float* cls_acc, hipStream_t stream) {
     AttnGeom g;
@@ -1142,7 +1191,7 @@ extern "C" int tvts_attn_bwd_dkv(int mode, const void* qkv, int ld, int B, int h
     return TVTS_OK;
 }
 
-extern "C" int tvts_attn_cls_finalize(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq,
+extern "C" int ABI(cls_finalize)(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq,
                                       hipStream_t stream) {
     const int total = B * heads * 2 * DH;
     hipLaunchKernelGGL(attn_cls_finalize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, cls_acc, B, heads, S,

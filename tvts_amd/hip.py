@@ -127,39 +127,48 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2
     _chk(rc, "tvts_layernorm_bwd")
 
 
-def attn_fwd(mode, qkv, out, lse2, *, B, heads, S, T=0, n=0, causal=False):
+def _attn_fn(lib, name, head_dim):
+    if head_dim == 64:
+        return getattr(lib, "tvts_attn_" + name)
+    if head_dim == 80:
+        return getattr(lib, "tvts_attn80_" + name)
+    raise HipError(f"attention kernels are built for head dim 64 and 80, not {head_dim}")
+
+
+def attn_fwd(mode, qkv, out, lse2, *, B, heads, S, T=0, n=0, causal=False, head_dim=64):
     lib = _lib.load()
-    rc = lib.tvts_attn_fwd(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(out), _ld(out), _p(lse2),
+    rc = _attn_fn(lib, "fwd", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(out), _ld(out), _p(lse2),
                            _stream())
     _chk(rc, "tvts_attn_fwd")
 
 
-def attn_delta(dO, O, delta, *, rows, heads):
+def attn_delta(dO, O, delta, *, rows, heads, head_dim=64):
     lib = _lib.load()
-    _chk(lib.tvts_attn_delta(_p(dO), _ld(dO), _p(O), _ld(O), rows, heads, _p(delta), _stream()), "tvts_attn_delta")
+    _chk(_attn_fn(lib, "delta", head_dim)(_p(dO), _ld(dO), _p(O), _ld(O), rows, heads, _p(delta), _stream()), "tvts_attn_delta")
 
 
-def attn_bwd_dq(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False):
+def attn_bwd_dq(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, head_dim=64):
     lib = _lib.load()
-    rc = lib.tvts_attn_bwd_dq(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO), _p(lse2),
+    rc = _attn_fn(lib, "bwd_dq", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO), _p(lse2),
                               _p(delta), _p(dqkv), _ld(dqkv), _stream())
     _chk(rc, "tvts_attn_bwd_dq")
 
 
-def attn_bwd_dkv(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None):
+def attn_bwd_dkv(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None, head_dim=64):
     lib = _lib.load()
-    rc = lib.tvts_attn_bwd_dkv(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO),
+    rc = _attn_fn(lib, "bwd_dkv", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO),
                                _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc), _stream())
     _chk(rc, "tvts_attn_bwd_dkv")
 
 
-def attn_cls_finalize(cls_acc, dqkv, *, B, heads, S):
+def attn_cls_finalize(cls_acc, dqkv, *, B, heads, S, head_dim=64):
     lib = _lib.load()
-    _chk(lib.tvts_attn_cls_finalize(_p(cls_acc), B, heads, S, _p(dqkv), _ld(dqkv), _stream()), "tvts_attn_cls_finalize")
+    _chk(_attn_fn(lib, "cls_finalize", head_dim)(_p(cls_acc), B, heads, S, _p(dqkv), _ld(dqkv), _stream()), "tvts_attn_cls_finalize")
 
 
 def attn_set_transpose_read(on: bool):
     _lib.load().tvts_attn_set_transpose_read(int(on))
+    _lib.load().tvts_attn80_set_transpose_read(int(on))
 
 
 def patch_gather(video, keep, out, *, B, T, n, img, patch):
