@@ -52,7 +52,7 @@ ARCHS = {
     # v2/model/model_dist_TVTSv2_ViT_H_14.py:44-83, OpenCLIP/model_configs/ViT-H-14.json
     "H_14": dict(name="H_14", image=224, patch=14, width=1280, heads=16, layers=32, embed=1024,
                  text_width=1024, text_heads=16, text_layers=24, text_tune_from=18, vocab=49408, context=77,
-                 act="gelu", tail="pooled_and_patches", num_frames=12, mask_ratio=0.7,
+                 act="gelu", tail="pooled_and_patches", num_frames=12, mask_ratio=0.7, block_order="openclip",
                  sort_heads=16, sort_depth=2, n_trans=4),
 }
 
@@ -87,20 +87,19 @@ def param_shapes(arch) -> "Dict[str, Tuple[int, ...]]":
     out: Dict[str, Tuple[int, ...]] = {}
     out["text_positional_embedding"] = (arch["context"], Wt)
     out["text_projection"] = (Wt, E)
+    openclip = arch.get("block_order") == "openclip"  # H/14: OpenCLIP registration order (ln_1 first)
     for i in range(arch["text_layers"]):
         pre = f"text_model.resblocks.{i}."
-        out[pre + "attn.in_proj_weight"] = (3 * Wt, Wt)
-        out[pre + "attn.in_proj_bias"] = (3 * Wt,)
-        out[pre + "attn.out_proj.weight"] = (Wt, Wt)
-        out[pre + "attn.out_proj.bias"] = (Wt,)
-        out[pre + "ln_1.weight"] = (Wt,)
-        out[pre + "ln_1.bias"] = (Wt,)
-        out[pre + "mlp.c_fc.weight"] = (4 * Wt, Wt)
-        out[pre + "mlp.c_fc.bias"] = (4 * Wt,)
-        out[pre + "mlp.c_proj.weight"] = (Wt, 4 * Wt)
-        out[pre + "mlp.c_proj.bias"] = (Wt,)
-        out[pre + "ln_2.weight"] = (Wt,)
-        out[pre + "ln_2.bias"] = (Wt,)
+        blk = {"attn.in_proj_weight": (3 * Wt, Wt), "attn.in_proj_bias": (3 * Wt,), "attn.out_proj.weight": (Wt, Wt),
+               "attn.out_proj.bias": (Wt,), "ln_1.weight": (Wt,), "ln_1.bias": (Wt,), "mlp.c_fc.weight": (4 * Wt, Wt),
+               "mlp.c_fc.bias": (4 * Wt,), "mlp.c_proj.weight": (Wt, 4 * Wt), "mlp.c_proj.bias": (Wt,),
+               "ln_2.weight": (Wt,), "ln_2.bias": (Wt,)}
+        order = list(blk)
+        if openclip:  # v2/OpenCLIP/transformer.py:189-216: ln_1, attn, ln_2, mlp
+            order = ["ln_1.weight", "ln_1.bias"] + [k for k in order if k.startswith("attn.")] + \
+                    ["ln_2.weight", "ln_2.bias"] + [k for k in order if k.startswith("mlp.")]
+        for k in order:
+            out[pre + k] = blk[k]
     out["text_token_embedding.weight"] = (arch["vocab"], Wt)
     out["text_ln_final.weight"] = (Wt,)
     out["text_ln_final.bias"] = (Wt,)
@@ -113,21 +112,27 @@ def param_shapes(arch) -> "Dict[str, Tuple[int, ...]]":
     out["video_model.ln_pre.bias"] = (W,)
     for i in range(arch["layers"]):
         pre = f"video_model.transformer.resblocks.{i}."
+        blk = {}
         for a in ("attn", "timeattn"):
-            out[pre + a + ".qkv.weight"] = (3 * W, W)
-            out[pre + a + ".qkv.bias"] = (3 * W,)
-            out[pre + a + ".proj.weight"] = (W, W)
-            out[pre + a + ".proj.bias"] = (W,)
-        out[pre + "ln_3.weight"] = (W,)
-        out[pre + "ln_3.bias"] = (W,)
-        out[pre + "ln_1.weight"] = (W,)
-        out[pre + "ln_1.bias"] = (W,)
-        out[pre + "mlp.c_fc.weight"] = (4 * W, W)
-        out[pre + "mlp.c_fc.bias"] = (4 * W,)
-        out[pre + "mlp.c_proj.weight"] = (W, 4 * W)
-        out[pre + "mlp.c_proj.bias"] = (W,)
-        out[pre + "ln_2.weight"] = (W,)
-        out[pre + "ln_2.bias"] = (W,)
+            blk[a + ".qkv.weight"] = (3 * W, W)
+            blk[a + ".qkv.bias"] = (3 * W,)
+            blk[a + ".proj.weight"] = (W, W)
+            blk[a + ".proj.bias"] = (W,)
+        for ln in ("ln_3", "ln_1"):
+            blk[ln + ".weight"] = (W,)
+            blk[ln + ".bias"] = (W,)
+        blk["mlp.c_fc.weight"] = (4 * W, W)
+        blk["mlp.c_fc.bias"] = (4 * W,)
+        blk["mlp.c_proj.weight"] = (W, 4 * W)
+        blk["mlp.c_proj.bias"] = (W,)
+        blk["ln_2.weight"] = (W,)
+        blk["ln_2.bias"] = (W,)
+        order = list(blk)  # B models (video_encoder_ViT_B_16.py:98-111): attn, timeattn, ln_3, ln_1, mlp, ln_2
+        if openclip:       # H/14 (video_encoder_ViT_H_14.py:221-240): ln_1, attn, timeattn, ln_3, ln_2, mlp
+            pick = lambda pfx: [k for k in blk if k.startswith(pfx)]  # noqa: E731
+            order = pick("ln_1.") + pick("attn.") + pick("timeattn.") + pick("ln_3.") + pick("ln_2.") + pick("mlp.")
+        for k in order:
+            out[pre + k] = blk[k]
     out["video_model.ln_post.weight"] = (W,)
     out["video_model.ln_post.bias"] = (W,)
     out["pred_model.type_embed"] = (1, 2, E)

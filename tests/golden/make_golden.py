@@ -294,6 +294,84 @@ def gen_model_b32():
          batch_seed=0, B=2, T=4, gn_names=np.array(names), gn_vals=torch.stack(vals), **sel)
 
 
+def import_reference_h14():
+    """H/14 classes: video_encoder_ViT_H_14 + OpenCLIP/transformer.py + model_dist_TVTSv2_ViT_H_14 (the OpenCLIP
+    package __init__ pulls tokenizers/pretrained tables that are irrelevant here, so only its transformer/utils load)."""
+    ns = import_reference()
+    if hasattr(ns, "mh"):
+        return ns
+    oc = _stub("OpenCLIP")
+    oc.utils = _load("OpenCLIP.utils", os.path.join(REF, "OpenCLIP/utils.py"))
+    oc.transformer = _load("OpenCLIP.transformer", os.path.join(REF, "OpenCLIP/transformer.py"))
+    ns.oc = oc.transformer
+    ns.veh = _load("model.video_encoder_ViT_H_14", os.path.join(REF, "model/video_encoder_ViT_H_14.py"))
+    ns.mh = _load("model.model_dist_TVTSv2_ViT_H_14", os.path.join(REF, "model/model_dist_TVTSv2_ViT_H_14.py"))
+    return ns
+
+
+def h_tiny_arch():
+    return O.tiny_arch(name="H_14", image=28, patch=7, width=80, heads=2, layers=2, embed=32, text_width=32,
+                       text_heads=2, text_layers=3, text_tune_from=1, act="gelu", tail="pooled_and_patches",
+                       block_order="openclip", mask_ratio=0.7)
+
+
+class TinyRefModelH(torch.nn.Module):
+    """Reference H/14 sub-modules at a tiny size, wired by TVTSv2_H_14.forward / compute_text / compute_video."""
+
+    def __init__(self, ns, arch, P):
+        super().__init__()
+        a = arch
+        self.text_model = ns.oc.Transformer(width=a["text_width"], layers=a["text_layers"], heads=a["text_heads"],
+                                            act_layer=torch.nn.GELU, norm_layer=ns.oc.LayerNorm)
+        self.text_token_embedding = torch.nn.Embedding(a["vocab"], a["text_width"])
+        self.text_positional_embedding = torch.nn.Parameter(torch.empty(a["context"], a["text_width"]))
+        self.text_ln_final = ns.oc.LayerNorm(a["text_width"])
+        self.text_projection = torch.nn.Parameter(torch.empty(a["text_width"], a["embed"]))
+        # OpenCLIP/transformer.py:694-700 / model.py build_attention_mask: additive causal mask
+        self.text_attn_mask = torch.full((a["context"], a["context"]), float("-inf")).triu_(1)
+        self.video_model = ns.veh.VisionTransformer(
+            image_size=a["image"], patch_size=a["patch"], width=a["width"], layers=a["layers"], heads=a["heads"],
+            mlp_ratio=4.0, output_dim=a["embed"], act_layer=torch.nn.GELU, norm_layer=ns.veh.LayerNorm,
+            num_frames=a["num_frames"], mask_ratio=a["mask_ratio"])
+        self.pred_model = ns.sort.SortTransformer(num_classes=a["n_trans"], embed_dim=a["embed"],
+                                                  num_heads=a["sort_heads"])
+        self._ref = ns.mh.TVTSv2_H_14
+
+    def compute_text(self, t):
+        return self._ref.compute_text(self, t)
+
+    def compute_video(self, v, k):
+        return self._ref.compute_video(self, v, k)
+
+    def forward(self, data, return_embeds=True):
+        return self._ref.forward(self, data, return_embeds)
+
+
+def gen_model_h_tiny():
+    """H/14 structure: OpenCLIP text tower (GELU, un-truncated causal context), ln_post on CLS only, patch tokens
+    without CLS to the sort head, state-dict registration order."""
+    ns = import_reference_h14()
+    arch = h_tiny_arch()
+    m = TinyRefModelH(ns, arch, None)
+    names = list(m.state_dict().keys())
+    assert names == list(O.param_shapes(arch).keys()), [(a, b) for a, b in zip(names, O.param_shapes(arch)) if a != b][:5]
+    P = O.synth_params(arch, seed=21)
+    m.load_state_dict(P, strict=True)
+    batch = O.synth_batch(arch, B=3, T=3, seed=12, caption_len=10)
+    te, ve, pred = m(batch)
+    loss1, loss2 = ref_losses(ns, te, ve, pred, batch["label"])
+    (loss1 + loss2).backward()
+    gn = {k: v.grad.norm() for k, v in m.named_parameters() if v.grad is not None}
+    total = torch.sqrt(sum(v ** 2 for v in gn.values()))
+    sel = ["video_model.proj", "video_model.ln_post.weight", "video_model.transformer.resblocks.1.attn.qkv.weight",
+           "video_model.conv1.weight", "text_projection", "text_model.resblocks.2.mlp.c_fc.weight",
+           "pred_model.type_embed"]
+    grads = {"g_" + k: dict(m.named_parameters())[k].grad for k in sel}
+    save("model_h_tiny", te=te, ve=ve, pred=pred, loss1=loss1, loss2=loss2, grad_norm=total, seed=21, batch_seed=12,
+         B=3, T=3, caption_len=10, names=np.array(names), gn_names=np.array(list(gn.keys())),
+         gn_vals=torch.stack(list(gn.values())), **grads)
+
+
 def gen_groups():
     """Name -> optimizer group, by executing the reference entrypoint's own grouping statements
     (train_dist_TVTSv2_ViT_B_16.py:66-107) on a module exposing the A13 parameter names."""
@@ -364,7 +442,7 @@ def gen_ddp2():
 
 
 GENS = {"block": gen_block, "vit": gen_vit, "text": gen_text, "sort": gen_sort, "model_tiny": gen_model_tiny,
-        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2}
+        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -106,6 +106,33 @@ def test_model_tiny(golden):
             assert relerr(f[k], P[k[2:]].grad) < GTOL, k
 
 
+def h_tiny_arch():
+    # same dict as tests/golden/make_golden.py:h_tiny_arch
+    return O.tiny_arch(name="H_14", image=28, patch=7, width=80, heads=2, layers=2, embed=32, text_width=32,
+                       text_heads=2, text_layers=3, text_tune_from=1, act="gelu", tail="pooled_and_patches",
+                       block_order="openclip", mask_ratio=0.7)
+
+
+def test_model_h_tiny(golden):
+    """H/14 structure (video_encoder_ViT_H_14.py + OpenCLIP text blocks, wired by TVTSv2_H_14.forward):
+    state-dict registration order, erf-GELU, ln_post on CLS only, CLS-less patch tokens into the sort head."""
+    f = golden("model_h_tiny")
+    arch = h_tiny_arch()
+    assert [str(s) for s in f["names"]] == list(O.param_shapes(arch).keys())
+    full = [str(s) for s in f["names"]]
+    big = list(O.param_shapes(O.ARCHS["H_14"]).keys())
+    # the full-size table is the same sequence with more layers: block-local order must agree
+    blk = lambda names, pre: [n[len(pre):] for n in names if n.startswith(pre)]  # noqa: E731
+    for pre in ("video_model.transformer.resblocks.1.", "text_model.resblocks.2."):
+        assert blk(full, pre) == blk(big, pre)
+    P = leaves(O.synth_params(arch, seed=int(f["seed"])))
+    b = O.synth_batch(arch, B=int(f["B"]), T=int(f["T"]), seed=int(f["batch_seed"]), caption_len=int(f["caption_len"]))
+    _check_model(f, arch, P, b)
+    for k in f.files:
+        if k.startswith("g_") and k not in ("gn_names", "gn_vals", "grad_norm"):
+            assert relerr(f[k], P[k[2:]].grad) < GTOL, k
+
+
 def test_model_tiny_nt1(golden):
     f = golden("model_tiny_nt1")
     arch = O.tiny_arch()
