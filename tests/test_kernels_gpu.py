@@ -439,3 +439,33 @@ def test_param_store_shadows(K):
         w = st.p(name).reshape(st.shapes[name][0], -1)
         assert torch.equal(st.w(name).float(), w.to(torch.bfloat16).float())
         assert torch.equal(st.wt(name).float(), w.t().to(torch.bfloat16).float())
+
+
+def test_patch_gather_14x14_padded_k(gpu):
+    """H/14 patches: 3*14*14 = 588 columns in conv-weight order, zero-padded to 640 (bit-exact bf16 rounding of the
+    pixels), the padded weight copy, and the padded wgrad folded back into a [W, 588] gradient."""
+    B, T, img, p, n, W = 2, 3, 56, 14, 5, 64
+    g = img // p
+    gen = torch.Generator().manual_seed(44)
+    video = torch.randn(B, T, 3, img, img, generator=gen)
+    keep_ind = torch.stack([torch.randperm(g * g, generator=gen)[:n].sort().values for _ in range(B)])
+    keep = keep_ind.to(torch.int32).to(DEV)
+    Kc, Kp = 3 * p * p, 640
+    cols = torch.full((B * T * n, Kp), 7.0, dtype=torch.bfloat16, device=DEV)
+    K.patch_gather(video.to(DEV), keep, cols, B=B, T=T, n=n, img=img, patch=p)
+    pix = video.reshape(B, T, 3, g, p, g, p).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, T, g * g, Kc)
+    ref_cols = torch.gather(pix, 2, keep_ind[:, None, :, None].expand(B, T, n, Kc)).reshape(-1, Kc)
+    assert torch.equal(cols[:, :Kc].float().cpu(), bf(ref_cols).float())
+    assert float(cols[:, Kc:].float().abs().max()) == 0.0
+    w = bf(rnd(W, Kc, seed=45)).to(DEV)
+    wp = torch.full((W, Kp), 3.0, dtype=torch.bfloat16, device=DEV)
+    K.pad_rows_bf16(w, wp)
+    assert torch.equal(wp[:, :Kc], w) and float(wp[:, Kc:].float().abs().max()) == 0.0
+    pe = torch.empty(B * T * n, W, device=DEV)
+    K.gemm_nt(cols, wp, pe)
+    assert rel(pe, bf(ref_cols).float() @ w.float().cpu().t()) < 1e-5
+    dst = rnd(W, Kc, seed=46).to(DEV)
+    src = rnd(W, Kp, seed=47).to(DEV)
+    want = dst.cpu() + src.cpu()[:, :Kc]
+    K.add_rows_f32(dst, src)
+    assert torch.equal(dst.cpu(), want)

@@ -111,6 +111,41 @@ def test_small_arch_webvid_batch(gpu):
     assert float(store.g("pred_model.head.weight").abs().max()) == 0.0
 
 
+def test_small_h14_forward_backward(gpu):
+    """H/14 structure: head dim 80, 14x14 patches (K 588 -> 640), erf-GELU, pooled = ln_post(CLS) @ proj, the sort head
+    sees the un-normalised patch tokens without CLS (video_encoder_ViT_H_14.py:472-484)."""
+    from tvts_amd import arch as A
+    m, oarch, P = build(arch=A.small_arch_h(), seed=5)
+    batch = O.synth_batch(oarch, B=4, T=3, seed=7, caption_len=11)
+    assert batch["keep_ind"].shape[1] == 4
+    r1, r2, rte, rve, rpred, grads = oracle_step(P, batch, oarch)
+    l1, l2, te, ve, pred, store = engine_step(m, batch)
+    assert min_cos(te, rte) > 0.9995 and rel(te, rte) < 0.02
+    assert min_cos(ve, rve) > 0.9995 and rel(ve, rve) < 0.02, (min_cos(ve, rve), rel(ve, rve))
+    assert rel(pred.view_as(rpred), rpred) < 0.03
+    assert abs(l1 - r1) < 1e-2 and abs(l2 - r2) < 1e-2, (l1, r1, l2, r2)
+    check_grads(store, grads)
+    assert list(dict(m.named_parameters()).keys()) == list(O.param_shapes(oarch).keys())
+    # the pieces the reference exposes: (patch tokens @ proj without CLS, pooled embedding)
+    tok, pooled = m.compute_video(batch["video"], batch["keep_ind"])
+    assert tok.shape == (4, 3 * 4, oarch["embed"]) and rel(pooled, rve) < 0.02
+
+
+def test_small_h14_webvid_batch_16_frames(gpu):
+    """NT = 1 (no sorting loss: the patch-token projection gets no gradient) and a 16-frame clip, which needs the
+    temporal table widened past the reference's 12 rows (BASELINE config 3)."""
+    from tvts_amd import arch as A
+    m, oarch, P = build(arch=A.small_arch_h(num_frames=16), seed=6)
+    batch = O.synth_batch(oarch, B=3, T=16, seed=8, n_trans=1, caption_len=9)
+    r1, r2, rte, rve, rpred, grads = oracle_step(P, batch, oarch)
+    l1, l2, te, ve, pred, store = engine_step(m, batch)
+    assert pred is None and rpred is None
+    assert min_cos(ve, rve) > 0.9995 and abs(l1 - r1) < 1e-2
+    # B = 3 at temperature 0.05: the softmax gradient scales every parameter gradient by the same factor, which moves
+    # ~1.4 % with the bf16 forward perturbation here (per-tensor cosines stay > 0.9997) -> 2 % on the norm
+    check_grads(store, grads, gn_tol=0.02)
+
+
 def test_autograd_surface_matches_engine(gpu):
     """The nn.Module path the kept entrypoint / reference trainer would drive: model(data), sim_matrix,
     NormSoftmaxLoss, CE*2, loss.backward(), p.grad."""

@@ -35,6 +35,15 @@ def small_arch(**over) -> dict:
     return a
 
 
+def small_arch_h(**over) -> dict:
+    """Reduced H/14-style architecture: head dim 80, 14x14 patches (K = 588, padded to 640 for the MFMA GEMM),
+    erf-GELU, OpenCLIP block registration order, ln_post on CLS only, tube mask 0.7."""
+    a = small_arch(name="H_14", image=56, patch=14, width=320, heads=4, act="gelu", tail="pooled_and_patches",
+                   block_order="openclip", mask_ratio=0.7)
+    a.update(over)
+    return a
+
+
 def patches_per_frame(arch) -> int:
     return (arch["image"] // arch["patch"]) ** 2
 

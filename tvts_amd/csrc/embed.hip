@@ -30,11 +30,37 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restri
     }
 }
 
+// any patch size (H/14: p = 14, K = 588): one thread per output column, columns K..ldo-1 are written as zeros so the
+// patch-embedding GEMM can run with its K padded to a multiple of 64.
+__global__ __launch_bounds__(256) void patch_gather_any_kernel(const float* __restrict__ video, const int* __restrict__ keep,
+                                                               int B, int T, int n, int img, int p, bf16* __restrict__ out,
+                                                               int ldo) {
+    const int K = 3 * p * p;
+    const int row = blockIdx.x;
+    const int i = row % n, f = (row / n) % T, b = row / (n * T);
+    const int g = img / p;
+    const int pi = keep[b * n + i];
+    const int gy = pi / g, gx = pi % g;
+    const float* fr = video + ((size_t)(b * T + f) * 3) * img * img;
+    for (int c = threadIdx.x; c < ldo; c += 256) {
+        float v = 0.f;
+        if (c < K) {
+            const int ch = c / (p * p), rem = c % (p * p), py = rem / p, px = rem % p;
+            v = fr[((size_t)ch * img + gy * p + py) * img + gx * p + px];
+        }
+        out[(size_t)row * ldo + c] = (bf16)v;
+    }
+}
+
 extern "C" int tvts_patch_gather(const float* video, const int* keep, int B, int T, int n, int img, int patch, void* out,
                                  int ldo, hipStream_t stream) {
-    if (B <= 0 || T <= 0 || n <= 0 || patch % 8 || img % patch || ldo % 8) return TVTS_EINVAL;
-    hipLaunchKernelGGL(patch_gather_kernel, dim3(B * T * n), dim3(256), 0, stream, video, keep, B, T, n, img, patch,
-                       (bf16*)out, ldo);
+    if (B <= 0 || T <= 0 || n <= 0 || patch <= 0 || img % patch || ldo % 8 || ldo < 3 * patch * patch) return TVTS_EINVAL;
+    if (patch % 8 || ldo != 3 * patch * patch)
+        hipLaunchKernelGGL(patch_gather_any_kernel, dim3(B * T * n), dim3(256), 0, stream, video, keep, B, T, n, img, patch,
+                           (bf16*)out, ldo);
+    else
+        hipLaunchKernelGGL(patch_gather_kernel, dim3(B * T * n), dim3(256), 0, stream, video, keep, B, T, n, img, patch,
+                           (bf16*)out, ldo);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

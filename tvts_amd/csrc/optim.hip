@@ -8,6 +8,7 @@
 //                        applies the data-parallel 1/world gradient scale and refreshes the bf16 weight shadow.
 //   tvts_cast_f32_bf16   shadow refresh when an external optimizer owned the update (drop-in path)
 //   tvts_transpose_bf16_batched   [N,K] -> [K,N] copies of every GEMM weight (dgrad operand), one launch
+//   tvts_pad_rows_bf16 / tvts_add_rows_f32   K-padding of the 14x14 patch-embedding weight and its wgrad (H/14)
 #include "common.h"
 
 struct AdamGroups { float lr[4]; float wd[4]; float step_size[4]; };
@@ -101,6 +102,37 @@ extern "C" int tvts_transpose_bf16_batched(const void* src, void* dst, const voi
     if (ntiles <= 0) return TVTS_EINVAL;
     hipLaunchKernelGGL(transpose_batched_kernel, dim3(ntiles), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst,
                        (const TrTile*)tiles);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// Zero-padded bf16 row copy: dst[r, 0:cols_pad] = src[r, 0:cols] | 0.  The H/14 patch-embedding weight ([W, 588]) gets
+// its K padded to 640 this way so the MFMA GEMM's 64-wide K loop and 16-byte row alignment hold.
+__global__ __launch_bounds__(256) void pad_rows_kernel(const bf16* __restrict__ src, int lds_, bf16* __restrict__ dst, int ldd,
+                                                       int cols, int cols_pad) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < cols_pad; c += 256)
+        dst[(size_t)r * ldd + c] = c < cols ? src[(size_t)r * lds_ + c] : (bf16)0.f;
+}
+extern "C" int tvts_pad_rows_bf16(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, int cols_pad,
+                                  hipStream_t stream) {
+    if (rows <= 0 || cols <= 0 || cols_pad < cols || ld_dst < cols_pad || ld_src < cols) return TVTS_EINVAL;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(rows), dim3(256), 0, stream, (const bf16*)src, ld_src, (bf16*)dst, ld_dst, cols,
+                       cols_pad);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+// dst[r, c] += src[r, c] for c < cols (fp32, independent row strides): folds the padded wgrad scratch back into the
+// [W, 588] gradient of the patch-embedding weight.
+__global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds_,
+                                                       int cols) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += 256) dst[(size_t)r * ldd + c] += src[(size_t)r * lds_ + c];
+}
+extern "C" int tvts_add_rows_f32(float* dst, int ld_dst, const float* src, int ld_src, int rows, int cols,
+                                 hipStream_t stream) {
+    if (rows <= 0 || cols <= 0 || ld_dst < cols || ld_src < cols) return TVTS_EINVAL;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(rows), dim3(256), 0, stream, dst, ld_dst, src, ld_src, cols);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

@@ -66,6 +66,12 @@ class ParamStore:
             rec[i] = t
         self.n_tiles = len(tiles)
         self.tile_table = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+        # patch-embedding GEMM: K = 3*p*p must be a multiple of 64 for the MFMA kernel; H/14 (588) gets a zero-padded copy
+        kc = 3 * arch["patch"] ** 2
+        self.conv_k = kc
+        self.conv_kpad = -(-kc // 64) * 64
+        self.conv_pad = (torch.zeros(arch["width"], self.conv_kpad, dtype=torch.bfloat16, device=device)
+                         if self.conv_kpad != kc else None)
         self.m: Optional[torch.Tensor] = None
         self.v: Optional[torch.Tensor] = None
         self.shadow_version = -1
@@ -110,6 +116,12 @@ class ParamStore:
             K.cast_f32_bf16(self.flat, self.shadow)
         if self.n_tiles:
             K.transpose_batched(self.shadow, self.shadow_t, self.tile_table, self.n_tiles)
+        if self.conv_pad is not None:
+            K.pad_rows_bf16(self.w("video_model.conv1.weight"), self.conv_pad)
+
+    def w_conv(self) -> torch.Tensor:
+        """bf16 patch-embedding weight [W, K padded to 64]."""
+        return self.conv_pad if self.conv_pad is not None else self.w("video_model.conv1.weight")
 
 
 _TEXT_NAMES = dict(ln1="ln_1", qkv_w="attn.in_proj_weight", qkv_b="attn.in_proj_bias", o_w="attn.out_proj.weight",
@@ -125,10 +137,16 @@ class Engine:
         self.P = store
         self.arch = store.arch
         a = self.arch
-        if a["tail"] != "all_tokens":
-            raise NotImplementedError("tail 'pooled_and_patches' (H/14) is not built yet")
-        if a["width"] // a["heads"] != 64 or a["text_width"] // a["text_heads"] != 64 or a["embed"] // a["sort_heads"] != 64:
-            raise NotImplementedError("attention kernels are built for head dim 64")
+        if a["tail"] not in ("all_tokens", "pooled_and_patches"):
+            raise ValueError(f"unknown tail {a['tail']!r}")
+        self.dh = a["width"] // a["heads"]            # ViT head dim: 64 (B/32, B/16) or 80 (H/14)
+        self.dh_text = a["text_width"] // a["text_heads"]
+        self.dh_sort = a["embed"] // a["sort_heads"]
+        for d, w, h in ((self.dh, a["width"], a["heads"]), (self.dh_text, a["text_width"], a["text_heads"]),
+                        (self.dh_sort, a["embed"], a["sort_heads"])):
+            if d not in (64, 80) or d * h != w:
+                raise NotImplementedError(f"attention kernels are built for head dim 64 and 80, not {w}/{h}")
+        self.pooled_tail = a["tail"] == "pooled_and_patches"
         self.dev = store.device
         self.buf: Dict[str, torch.Tensor] = {}
         self.requires_grad = {name: True for name in store.shapes}
@@ -181,13 +199,14 @@ class Engine:
 
     # ------------------------------------------------------------------ generic pre-LN block (text tower, sort head)
     def _block_fwd(self, pre, nm, x_in, x_out, tag, M, Wd, heads, Bn, S, causal, act, eps):
+        hd = Wd // heads
         ln1 = self._b(tag + ".ln1", (M, Wd))
         self._ln(x_in, pre + nm["ln1"], eps, ln1, tag + ".ln1")
         qkv = self._b(tag + ".qkv", (M, 3 * Wd))
         self._lin(ln1, pre + nm["qkv_w"], pre + nm["qkv_b"], qkv, M)
         att = self._b(tag + ".att", (M, Wd))
         lse = self._f(tag + ".lse", (M, heads))
-        K.attn_fwd("full", qkv, att, lse, B=Bn, heads=heads, S=S, causal=causal)
+        K.attn_fwd("full", qkv, att, lse, B=Bn, heads=heads, S=S, causal=causal, head_dim=hd)
         mid = self._f(tag + ".mid", (M, Wd))
         self._lin(att, pre + nm["o_w"], pre + nm["o_b"], mid, M, residual=x_in)
         ln2 = self._b(tag + ".ln2", (M, Wd))
@@ -200,6 +219,7 @@ class Engine:
     def _block_bwd(self, pre, nm, x_in, dx, dxb, dx_in, dxb_in, tag, M, Wd, heads, Bn, S, causal, act, scr):
         """dx/dxb: grad wrt block output (fp32 / bf16).  Writes grad wrt block input to dx_in/dxb_in."""
         B_ = self.buf
+        hd = Wd // heads
         dh = self._b(scr + ".dh", (M, 4 * Wd))
         dln = self._b(scr + ".dln", (M, Wd))
         self._lin_bwd(dxb, B_[tag + ".a"], pre + nm["pj_w"], pre + nm["pj_b"], dh, M, gate_h=B_[tag + ".h"], gate_act=act)
@@ -212,9 +232,9 @@ class Engine:
         dqkv = self._b(scr + ".dqkv", (M, 3 * Wd))
         delta = self._f(scr + ".delta", (M, heads))
         qkv, lse = B_[tag + ".qkv"], B_[tag + ".lse"]
-        K.attn_delta(datt, B_[tag + ".att"], delta, rows=M, heads=heads)
-        K.attn_bwd_dq("full", qkv, datt, lse, delta, dqkv, B=Bn, heads=heads, S=S, causal=causal)
-        K.attn_bwd_dkv("full", qkv, datt, lse, delta, dqkv, B=Bn, heads=heads, S=S, causal=causal)
+        K.attn_delta(datt, B_[tag + ".att"], delta, rows=M, heads=heads, head_dim=hd)
+        K.attn_bwd_dq("full", qkv, datt, lse, delta, dqkv, B=Bn, heads=heads, S=S, causal=causal, head_dim=hd)
+        K.attn_bwd_dkv("full", qkv, datt, lse, delta, dqkv, B=Bn, heads=heads, S=S, causal=causal, head_dim=hd)
         self._lin_bwd(dqkv, B_[tag + ".ln1"], pre + nm["qkv_w"], pre + nm["qkv_b"], dln, M)
         self._ln_bwd(dln, x_in, pre + nm["ln1"], tag + ".ln1", dx_in, dx_bf16=dxb_in, res1=dmid)
 
@@ -260,30 +280,31 @@ class Engine:
     # ------------------------------------------------------------------ video tower
     def _st_attention_fwd(self, qkv, att, lse, mode, B, T, n):
         h, S = self.arch["heads"], 1 + T * n
-        K.attn_fwd(mode, qkv, att, lse, B=B, heads=h, S=S, T=T, n=n)
-        K.attn_fwd("cls", qkv, att, lse, B=B, heads=h, S=S, T=T, n=n)
+        K.attn_fwd(mode, qkv, att, lse, B=B, heads=h, S=S, T=T, n=n, head_dim=self.dh)
+        K.attn_fwd("cls", qkv, att, lse, B=B, heads=h, S=S, T=T, n=n, head_dim=self.dh)
 
     def _st_attention_bwd(self, qkv, att, datt, lse, dqkv, mode, B, T, n, scr):
         h, S = self.arch["heads"], 1 + T * n
         M = B * S
         delta = self._f(scr + ".delta", (M, h))
-        cls_acc = self._f(scr + ".clsacc", (B, h, 2, 64), zero=True)
-        K.attn_delta(datt, att, delta, rows=M, heads=h)
-        K.attn_bwd_dq(mode, qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n)
-        K.attn_bwd_dq("cls", qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n)
-        K.attn_bwd_dkv(mode, qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, cls_acc=cls_acc)
-        K.attn_cls_finalize(cls_acc, dqkv, B=B, heads=h, S=S)
+        hd = self.dh
+        cls_acc = self._f(scr + ".clsacc", (B, h, 2, hd), zero=True)
+        K.attn_delta(datt, att, delta, rows=M, heads=h, head_dim=hd)
+        K.attn_bwd_dq(mode, qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, head_dim=hd)
+        K.attn_bwd_dq("cls", qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, head_dim=hd)
+        K.attn_bwd_dkv(mode, qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, cls_acc=cls_acc, head_dim=hd)
+        K.attn_cls_finalize(cls_acc, dqkv, B=B, heads=h, S=S, head_dim=hd)
 
-    def video_forward(self, video, keep_dev, B, T):
+    def video_forward(self, video, keep_dev, B, T, vid_rows=None):
         a = self.arch
         W, E, p = a["width"], a["embed"], a["patch"]
         n = keep_dev.shape[1]
         S = 1 + T * n
-        M, Mp, Kp = B * S, B * T * n, 3 * p * p
+        M, Mp, Kp = B * S, B * T * n, self.P.conv_kpad
         cols = self._b("vit.im2col", (Mp, Kp))
         K.patch_gather(video, keep_dev, cols, B=B, T=T, n=n, img=a["image"], patch=p)
         pe = self._f("vit.patch", (Mp, W))
-        K.gemm_nt(cols, self.P.w("video_model.conv1.weight"), pe, M=Mp)
+        K.gemm_nt(cols, self.P.w_conv(), pe, M=Mp)
         tok = self._f("vit.tok", (M, W))
         K.vit_assemble(pe, self.P.p("video_model.class_embedding"), self.P.p("video_model.positional_embedding"),
                        self.P.p("video_model.temporal_embedding"), keep_dev, tok, B=B, T=T, n=n)
@@ -314,26 +335,58 @@ class Engine:
             xo = self._f(f"vit.x{l + 1}", (M, W))
             self._lin(act, pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", xo, M, residual=s_res)
             x = xo
-        lnp = self._b("vit.lnpost", (M, W))
-        self._ln(x, "video_model.ln_post", 1e-5, lnp, "vit.lnpost")
         out = self._f("vit.out", (M, E))
-        K.gemm_nt(lnp, self.P.wt("video_model.proj"), out, M=M)  # x @ proj, proj stored [W,E]
-        return out
+        if not self.pooled_tail:  # B models: ln_post on every token, all S projected rows feed the sort head
+            lnp = self._b("vit.lnpost", (M, W))
+            self._ln(x, "video_model.ln_post", 1e-5, lnp, "vit.lnpost")
+            K.gemm_nt(lnp, self.P.wt("video_model.proj"), out, M=M)  # x @ proj, proj stored [W,E]
+            return out, None
+        # H/14 (video_encoder_ViT_H_14.py:472-484): pooled = ln_post(CLS) @ proj in fp32; the patch tokens are projected
+        # WITHOUT ln_post (row 0 of each clip is computed too but never read: sort_assemble takes rows 1..S-1)
+        xb = self._b("vit.xlast_b", (M, W))
+        K.cast_f32_bf16(x, xb)
+        K.gemm_nt(xb, self.P.wt("video_model.proj"), out, M=M)
+        lnc = self._f("vit.lnpost_cls", (B, W))
+        if vid_rows is None:
+            vid_rows = (torch.arange(B, device=self.dev) * S).to(torch.int32)
+        self._ln(x, "video_model.ln_post", 1e-5, lnc, "vit.lnpost", rows=vid_rows)
+        pooled = self._f("vit.pooled", (B, E))
+        K.gemm_small(lnc, self.P.p("video_model.proj"), pooled, M=B, N=E, K=W, sa=(W, 1), sb=(E, 1))
+        return out, pooled
 
-    def video_backward(self, dout_b, keep_dev, B, T):
-        """dout_b: bf16 [B*S, E] grad of the projected tokens (CLS rows carry the embedding grad)."""
+    def video_backward(self, dout_b, keep_dev, B, T, d_pooled=None):
+        """dout_b: bf16 [B*S, E] grad of the projected tokens (B models: CLS rows carry the embedding grad; H/14: None
+        when there is no sorting loss); d_pooled: fp32 [B, E] grad of the pooled embedding (H/14 only)."""
         a, B_ = self.arch, self.buf
         W, E, p = a["width"], a["embed"], a["patch"]
         n = keep_dev.shape[1]
         S = 1 + T * n
         M, Mp = B * S, B * T * n
         rg = self.requires_grad
-        if rg["video_model.proj"]:  # dproj[W,E] += lnpost^T dout
-            K.gemm_tn(B_["vit.lnpost"], dout_b, self.P.g("video_model.proj"), M=M, accumulate=True)
         dln = self._b("vit.s.dln", (M, W))
-        K.gemm_nt(dout_b, self.P.w("video_model.proj"), dln, M=M)
         dx, dxb = self._f("vit.dxA", (M, W)), self._b("vit.dxbA", (M, W))
-        self._ln_bwd(dln, B_[f"vit.x{a['layers']}"], "video_model.ln_post", "vit.lnpost", dx, dx_bf16=dxb)
+        if not self.pooled_tail:
+            if rg["video_model.proj"]:  # dproj[W,E] += lnpost^T dout
+                K.gemm_tn(B_["vit.lnpost"], dout_b, self.P.g("video_model.proj"), M=M, accumulate=True)
+            K.gemm_nt(dout_b, self.P.w("video_model.proj"), dln, M=M)
+            self._ln_bwd(dln, B_[f"vit.x{a['layers']}"], "video_model.ln_post", "vit.lnpost", dx, dx_bf16=dxb)
+        else:
+            # patch-token branch (no LN): dproj += x^T dout, dx = dout proj^T (CLS rows of dout are zero)
+            if dout_b is not None:
+                if rg["video_model.proj"]:
+                    K.gemm_tn(B_["vit.xlast_b"], dout_b, self.P.g("video_model.proj"), M=M, accumulate=True)
+                K.gemm_nt(dout_b, self.P.w("video_model.proj"), dx, M=M)
+            else:
+                dx.zero_()
+            # pooled branch, fp32: dproj += lnc^T d_pooled, d_lnc = d_pooled proj^T, ln_post backward on the CLS rows only
+            lnc = B_["vit.lnpost_cls"]
+            if rg["video_model.proj"]:
+                K.gemm_small(lnc, d_pooled, self.P.g("video_model.proj"), M=W, N=E, K=B, sa=(1, W), sb=(E, 1), accumulate=True)
+            dlnc = self._f("vit.s.dlnc", (B, W))
+            K.gemm_small(d_pooled, self.P.p("video_model.proj"), dlnc, M=B, N=W, K=E, sa=(E, 1), sb=(1, E))
+            self._ln_bwd(dlnc, B_[f"vit.x{a['layers']}"], "video_model.ln_post", "vit.lnpost", dx, res1=dx,
+                         rows=self.ctx["vid_rows"])
+            K.cast_f32_bf16(dx, dxb)
         dh = self._b("vit.s.dh", (M, 4 * W))
         datt = self._b("vit.s.datt", (M, W))
         dqkv = self._b("vit.s.dqkv", (M, 3 * W))
@@ -368,7 +421,12 @@ class Engine:
                            self.P.g("video_model.positional_embedding"), self.P.g("video_model.temporal_embedding"),
                            B=B, T=T, n=n)
         if rg["video_model.conv1.weight"]:
-            K.gemm_tn(dpatch, B_["vit.im2col"], self.P.g2d("video_model.conv1.weight"), M=Mp, accumulate=True)
+            if self.P.conv_pad is None:
+                K.gemm_tn(dpatch, B_["vit.im2col"], self.P.g2d("video_model.conv1.weight"), M=Mp, accumulate=True)
+            else:  # K padded to 64: wgrad into a [W, Kpad] scratch, the 588 real columns are folded into the gradient
+                scr = self._f("vit.s.dconv", (W, self.P.conv_kpad))
+                K.gemm_tn(dpatch, B_["vit.im2col"], scr, M=Mp, accumulate=False)
+                K.add_rows_f32(self.P.g2d("video_model.conv1.weight"), scr)
         self._ready("video_model.class_embedding", "video_model.ln_pre.bias")
         self._ready("video_model.ln_post.weight", "video_model.ln_post.bias")
 
@@ -376,10 +434,12 @@ class Engine:
     def sort_forward(self, out, text_before, B, S, NT):
         a = self.arch
         E, hs = a["embed"], a["sort_heads"]
-        So = S + NT
+        off = 1 if self.pooled_tail else 0  # H/14 hands the sort head the patch tokens without CLS
+        Sv = S - off
+        So = Sv + NT
         Mo = B * So
         xs = self._f("srt.x0", (Mo, E))
-        K.sort_assemble(out, text_before, self.P.p("pred_model.type_embed").view(2, E), xs, B=B, S=S, off=0, Sv=S, NT=NT)
+        K.sort_assemble(out, text_before, self.P.p("pred_model.type_embed").view(2, E), xs, B=B, S=S, off=off, Sv=Sv, NT=NT)
         x = xs
         for l in range(a["sort_depth"]):
             xo = self._f(f"srt.x{l + 1}", (Mo, E))
@@ -398,7 +458,7 @@ class Engine:
         """-> fp32 grad of the sort-head input xs [B*So, E]."""
         a, B_ = self.arch, self.buf
         E, hs, C = a["embed"], a["sort_heads"], a["n_trans"]
-        So = S + NT
+        So = S - (1 if self.pooled_tail else 0) + NT
         Mo, R = B * So, B * NT
         nf = B_["srt.nf"]
         K.gemm_small(dpred, nf, self.P.g("pred_model.head.weight"), M=C, N=E, K=R, sa=(1, C), sb=(E, 1), accumulate=True)
@@ -439,8 +499,9 @@ class Engine:
         keep = data["keep_ind"].to(torch.int32).contiguous().to(self.dev)
         n = keep.shape[1]
         S = 1 + T * n
-        So = S + NT
-        sort_rows = (torch.arange(B)[:, None] * So + S + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev)
+        Sv = S - 1 if self.pooled_tail else S
+        So = Sv + NT
+        sort_rows = (torch.arange(B)[:, None] * So + Sv + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev)
         vid_rows = (torch.arange(B) * S).to(torch.int32).to(self.dev)
         return dict(video=video, ids=ids_dev, eot_rows=eot_rows, keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
                     sort_rows=sort_rows, vid_rows=vid_rows)
@@ -454,9 +515,12 @@ class Engine:
         text_emb = self._f("mdl.text_emb", (B, E))
         text_before = self._f("mdl.text_before", (B, NT, E))
         K.text_mean(t, text_emb, text_before, NT=NT, B=B)
-        out = self.video_forward(pb["video"], pb["keep"], B, T)
-        video_emb = self._f("mdl.video_emb", (B, E))
-        K.rows_gather(out, pb["vid_rows"], video_emb)
+        out, pooled = self.video_forward(pb["video"], pb["keep"], B, T, vid_rows=pb["vid_rows"])
+        if pooled is None:
+            video_emb = self._f("mdl.video_emb", (B, E))
+            K.rows_gather(out, pb["vid_rows"], video_emb)
+        else:
+            video_emb = pooled
         pred = self.sort_forward(out, text_before, B, S, NT) if NT != 1 else None
         return text_emb, video_emb, pred
 
@@ -465,13 +529,18 @@ class Engine:
         a, pb = self.arch, self.ctx
         B, T, N, NT, L, S, E = pb["B"], pb["T"], pb["N"], pb["NT"], pb["L"], pb["S"], a["embed"]
         dout = self._b("mdl.dout", (B * S, E))
+        off = 1 if self.pooled_tail else 0
+        dv_cls = None if self.pooled_tail else d_video  # B models: the embedding IS the CLS row of the projected tokens
         if d_pred is not None:
             dxs = self.sort_backward(d_pred, B, S, NT)
-            K.sort_assemble_bwd(dxs, d_video, dout, self.P.g("pred_model.type_embed").view(2, E), B=B, S=S, off=0, Sv=S, NT=NT)
+            K.sort_assemble_bwd(dxs, dv_cls, dout, self.P.g("pred_model.type_embed").view(2, E), B=B, S=S, off=off,
+                                Sv=S - off, NT=NT)
             self._ready("pred_model.type_embed", "pred_model.head.bias")
+        elif not self.pooled_tail:
+            K.sort_assemble_bwd(None, dv_cls, dout, None, B=B, S=S, off=0, Sv=S, NT=NT)
         else:
-            K.sort_assemble_bwd(None, d_video, dout, None, B=B, S=S, off=0, Sv=S, NT=NT)
-        self.video_backward(dout, pb["keep"], B, T)
+            dout = None
+        self.video_backward(dout, pb["keep"], B, T, d_pooled=d_video if self.pooled_tail else None)
         if d_text is not None:
             dt = self._f("mdl.dt", (N, E))
             K.text_mean_bwd(d_text, dt, NT=NT, B=B)

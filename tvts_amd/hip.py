@@ -269,6 +269,19 @@ def cast_f32_bf16(src, dst):
     _chk(lib.tvts_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "tvts_cast_f32_bf16")
 
 
+def pad_rows_bf16(src, dst):
+    """dst[r, :] = src[r, :] zero-extended to dst's width (bf16, row-major 2-D)."""
+    lib = _lib.load()
+    _chk(lib.tvts_pad_rows_bf16(_p(src), _ld(src), _p(dst), _ld(dst), src.shape[0], src.shape[1], dst.shape[1], _stream()),
+         "tvts_pad_rows_bf16")
+
+
+def add_rows_f32(dst, src):
+    """dst[r, c] += src[r, c] for c < dst.shape[1] (fp32; src may be wider)."""
+    lib = _lib.load()
+    _chk(lib.tvts_add_rows_f32(_p(dst), _ld(dst), _p(src), _ld(src), dst.shape[0], dst.shape[1], _stream()), "tvts_add_rows_f32")
+
+
 def transpose_batched(src, dst, tiles, ntiles):
     lib = _lib.load()
     _chk(lib.tvts_transpose_bf16_batched(_p(src), _p(dst), _p(tiles), ntiles, _stream()), "tvts_transpose_bf16_batched")

@@ -206,8 +206,11 @@ class TVTSv2Base(nn.Module):
         v = video_data.to(self.store.device, torch.float32).contiguous()
         B, T = v.shape[:2]
         keep = keep_ind.to(torch.int32).contiguous().to(self.store.device)
-        out = self.engine.video_forward(v, keep, B, T).view(B, -1, self.arch["embed"]).clone()
-        return out, out[:, 0, :].contiguous()
+        out, pooled = self.engine.video_forward(v, keep, B, T)
+        out = out.view(B, -1, self.arch["embed"]).clone()
+        if pooled is None:  # B models (model_dist_TVTSv2_ViT_B_16.py:113-116): all tokens, CLS row is the embedding
+            return out, out[:, 0, :].contiguous()
+        return out[:, 1:, :].contiguous(), pooled.clone()  # H/14 (model_dist_TVTSv2_ViT_H_14.py:151-153)
 
 
 class _SimFn(torch.autograd.Function):
