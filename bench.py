@@ -116,7 +116,9 @@ def main():
     from tvts_amd.optim import FusedHFAdamW
     from tvts_amd.step import StepRunner
 
-    a = A.ARCHS[args.arch]
+    a = dict(A.ARCHS[args.arch])
+    if args.frames > a["num_frames"]:  # BASELINE config 3: 16-frame clips need a temporal table past the reference's 12 rows
+        a["num_frames"] = args.frames
     margs = types.SimpleNamespace(local_rank=local_rank, rank=rank, world_size=world)
     model = TVTSv2Base(margs, arch=a, init_seed=0)
     groups = [[], [], [], []]

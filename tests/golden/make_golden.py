@@ -372,6 +372,61 @@ def gen_model_h_tiny():
          gn_vals=torch.stack(list(gn.values())), **grads)
 
 
+def gen_model_h14():
+    """The real TVTSv2_H_14 class at full size (ViT-H/14 + 24-layer OpenCLIP text tower, 1.22 G parameters), B=2, T=4.
+    OpenCLIP.create_model (pretrained weights, not in the tree) is replaced by a factory that builds the reference's own
+    OpenCLIP TextTransformer from the reference's ViT-H-14.json; every parameter is then overwritten by synth_params."""
+    import json
+    ns = import_reference_h14()
+    with open(os.path.join(REF, "OpenCLIP/model_configs/ViT-H-14.json")) as f:
+        cfg = json.load(f)
+
+    def create_model(name, pretrained=None, cache_dir=None, **kw):
+        assert name == "ViT-H-14"
+        t = cfg["text_cfg"]
+        text = ns.oc.TextTransformer(context_length=t["context_length"], vocab_size=t["vocab_size"], width=t["width"],
+                                     heads=t["heads"], layers=t["layers"], output_dim=cfg["embed_dim"],
+                                     act_layer=torch.nn.GELU, norm_layer=ns.oc.LayerNorm)
+        visual = types.SimpleNamespace(state_dict=lambda: {})
+        return types.SimpleNamespace(transformer=text.transformer, token_embedding=text.token_embedding,
+                                     positional_embedding=text.positional_embedding, ln_final=text.ln_final,
+                                     text_projection=text.text_projection, attn_mask=text.attn_mask, visual=visual)
+    sys.modules["OpenCLIP"].create_model = create_model
+    arch = O.ARCHS["H_14"]
+    args = types.SimpleNamespace(local_rank=0, rank=0, world_size=1)
+    cwd = os.getcwd()
+    os.chdir(REF)  # the class opens 'OpenCLIP/model_configs/ViT-H-14.json' relative to the v2/ directory
+    try:
+        m = ns.mh.TVTSv2_H_14(args, load_checkpoint="")
+    finally:
+        os.chdir(cwd)
+    P = O.synth_params(arch, seed=0)
+    assert list(m.state_dict().keys()) == list(P.keys()), "state-dict key order differs from param_shapes()"
+    m.load_state_dict(P, strict=True)
+    del P
+    batch = O.synth_batch(arch, B=2, T=4, seed=0)
+    te, ve, pred = m(batch)
+    loss1, loss2 = ref_losses(ns, te, ve, pred, batch["label"])
+    (loss1 + loss2).backward()
+    names, vals = [], []
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            names.append(k); vals.append(v.grad.norm())
+    total = torch.sqrt(sum(v ** 2 for v in vals))
+    pd = dict(m.named_parameters())
+    sel = {"g_video_proj": pd["video_model.proj"].grad[:8, :16],
+           "g_text_proj": pd["text_projection"].grad[:8, :16],
+           "g_head": pd["pred_model.head.weight"].grad[:, :64],
+           "g_conv": pd["video_model.conv1.weight"].grad[:4].reshape(4, -1),
+           "g_lnpost": pd["video_model.ln_post.weight"].grad,
+           "g_cfc31": pd["video_model.transformer.resblocks.31.mlp.c_fc.weight"].grad[:8, :16],
+           "g_tqkv0": pd["video_model.transformer.resblocks.0.timeattn.qkv.weight"].grad[:8, :16],
+           "g_temporal": pd["video_model.temporal_embedding"].grad[:, :16],
+           "g_textqkv20": pd["text_model.resblocks.20.attn.in_proj_weight"].grad[:8, :16]}
+    save("model_h14_cfg3", te=te, ve=ve, pred=pred, loss1=loss1, loss2=loss2, grad_norm=total, seed=0,
+         batch_seed=0, B=2, T=4, gn_names=np.array(names), gn_vals=torch.stack(vals), **sel)
+
+
 def gen_groups():
     """Name -> optimizer group, by executing the reference entrypoint's own grouping statements
     (train_dist_TVTSv2_ViT_B_16.py:66-107) on a module exposing the A13 parameter names."""
@@ -442,7 +497,7 @@ def gen_ddp2():
 
 
 GENS = {"block": gen_block, "vit": gen_vit, "text": gen_text, "sort": gen_sort, "model_tiny": gen_model_tiny,
-        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny}
+        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -250,3 +250,36 @@ def test_b32_config1_against_reference_golden(gpu, golden):
           "g_temporal": ("video_model.temporal_embedding", (slice(None), slice(0, 16)))}
     for k, (name, idx) in sl.items():
         assert rel(store.g(name)[idx], torch.tensor(f[k])) < 0.08, (k, rel(store.g(name)[idx], torch.tensor(f[k])))
+
+
+def test_h14_full_size_against_reference_golden(gpu, golden):
+    """BASELINE config 3 architecture: the real TVTSv2_H_14 class (1.22 G parameters) ran in the build container at
+    B=2, T=4; same synthetic parameters and batch here."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    f = golden("model_h14_cfg3")
+    m, oarch, P = build(arch_name="H_14", seed=0)
+    del P
+    batch = O.synth_batch(oarch, B=2, T=4, seed=0)
+    l1, l2, te, ve, pred, store = engine_step(m, batch)
+    rte, rve, rpred = torch.tensor(f["te"]), torch.tensor(f["ve"]), torch.tensor(f["pred"])
+    assert min_cos(te, rte) > 0.9995 and rel(te, rte) < 0.02, (min_cos(te, rte), rel(te, rte))
+    assert min_cos(ve, rve) > 0.9995 and rel(ve, rve) < 0.02, (min_cos(ve, rve), rel(ve, rve))
+    assert float((pred.view_as(rpred).cpu() - rpred).abs().max()) < 0.05
+    assert abs(l1 - float(f["loss1"])) < 1e-2 and abs(l2 - float(f["loss2"])) < 1e-2, (l1, l2)
+    gn = float(store.grad.double().norm())
+    assert abs(gn - float(f["grad_norm"])) < 0.02 * float(f["grad_norm"]), (gn, float(f["grad_norm"]))
+    ref = dict(zip([str(s) for s in f["gn_names"]], f["gn_vals"]))
+    bad = []
+    for k, v in ref.items():
+        mine = float(store.g(k).double().norm())
+        if float(v) > 1e-3 * float(f["grad_norm"]) and abs(mine - float(v)) > 0.06 * float(v):
+            bad.append((k, mine, float(v)))
+    assert not bad, bad[:10]
+    sl = {"g_video_proj": ("video_model.proj", (slice(0, 8), slice(0, 16))),
+          "g_head": ("pred_model.head.weight", (slice(None), slice(0, 64))),
+          "g_lnpost": ("video_model.ln_post.weight", (slice(None),)),
+          "g_cfc31": ("video_model.transformer.resblocks.31.mlp.c_fc.weight", (slice(0, 8), slice(0, 16))),
+          "g_temporal": ("video_model.temporal_embedding", (slice(None), slice(0, 16)))}
+    for k, (name, idx) in sl.items():
+        assert rel(store.g(name)[idx], torch.tensor(f[k])) < 0.1, (k, rel(store.g(name)[idx], torch.tensor(f[k])))
+    assert rel(store.g("video_model.conv1.weight")[:4].reshape(4, -1), torch.tensor(f["g_conv"])) < 0.1

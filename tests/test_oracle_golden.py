@@ -216,3 +216,23 @@ def test_flops_formula():
     for name, T, step in (("B_32", 4, 167.5), ("B_32", 8, 313.3), ("B_16", 8, 606.1)):
         f, b = O.step_flops_per_pair(O.ARCHS[name], T)
         assert abs((f + b) / 1e9 - step) / step < 0.01, (name, (f + b) / 1e9)
+
+
+def test_model_h14_config3(golden):
+    """BASELINE config 3 architecture: the real TVTSv2_H_14 class at full size (1.22 G parameters), B=2, T=4."""
+    f = golden("model_h14_cfg3")
+    arch = O.ARCHS["H_14"]
+    P = leaves(O.synth_params(arch, seed=0))
+    b = O.synth_batch(arch, B=2, T=4, seed=0)
+    _check_model(f, arch, P, b)
+    sl = {"g_video_proj": ("video_model.proj", (slice(0, 8), slice(0, 16))),
+          "g_text_proj": ("text_projection", (slice(0, 8), slice(0, 16))),
+          "g_head": ("pred_model.head.weight", (slice(None), slice(0, 64))),
+          "g_lnpost": ("video_model.ln_post.weight", (slice(None),)),
+          "g_cfc31": ("video_model.transformer.resblocks.31.mlp.c_fc.weight", (slice(0, 8), slice(0, 16))),
+          "g_tqkv0": ("video_model.transformer.resblocks.0.timeattn.qkv.weight", (slice(0, 8), slice(0, 16))),
+          "g_temporal": ("video_model.temporal_embedding", (slice(None), slice(0, 16))),
+          "g_textqkv20": ("text_model.resblocks.20.attn.in_proj_weight", (slice(0, 8), slice(0, 16)))}
+    for k, (name, idx) in sl.items():
+        assert relerr(f[k], P[name].grad[idx]) < 5e-4, k
+    assert relerr(f["g_conv"], P["video_model.conv1.weight"].grad[:4].reshape(4, -1)) < 5e-4
