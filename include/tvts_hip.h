@@ -59,6 +59,13 @@ int tvts_attn_bwd_dkv(int mode, const void* qkv, int ld, int B, int heads, int S
 int tvts_attn_cls_finalize(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq, hipStream_t stream);
 void tvts_attn_set_transpose_read(int on);
 void tvts_attn_set_shared(int on);
+/* whole backward of one attention site (D = rowsum(dO*O), dQ, dK, dV, CLS query + CLS key/value reduction of the divided
+ * geometries) = the autograd of VarAttention.forward video_encoder_ViT_B_16.py:38-76; delta [rows, heads] and
+ * cls_acc [B, heads, 3, dh] are scratch.  SPACE groups of <= 112 tokens run as ONE fused launch. */
+int tvts_attn_bwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
+              int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float* cls_acc,
+              hipStream_t stream);
+void tvts_attn_set_fused(int on);
 
 /* the same entry points for head dim 80 (ViT-H/14, 1280 / 16 heads); qkv is [rows, 3*heads*80] */
 int tvts_attn80_fwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, void* out, int ldo,
@@ -73,6 +80,13 @@ int tvts_attn80_bwd_dkv(int mode, const void* qkv, int ld, int B, int heads, int
 int tvts_attn80_cls_finalize(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq, hipStream_t stream);
 void tvts_attn80_set_transpose_read(int on);
 void tvts_attn80_set_shared(int on);
+/* whole backward of one attention site (D = rowsum(dO*O), dQ, dK, dV, CLS query + CLS key/value reduction of the divided
+ * geometries) = the autograd of VarAttention.forward video_encoder_ViT_B_16.py:38-76; delta [rows, heads] and
+ * cls_acc [B, heads, 3, dh] are scratch.  SPACE groups of <= 112 tokens run as ONE fused launch. */
+int tvts_attn80_bwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
+              int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float* cls_acc,
+              hipStream_t stream);
+void tvts_attn80_set_fused(int on);
 
 /* ---- token assembly (embed.hip): video_encoder_ViT_B_16.py:176-216; model_dist..B_16.py:69-76,98-100;
  *      sort_transformer.py:124-128 */

@@ -216,7 +216,7 @@ def test_divided_attention(K, mode, B, heads, T, n, tr, dh):
         dOd = dO.reshape(B * S, W).to(DEV)
         delta = torch.empty(B * S, heads, device=DEV)
         dqkv = torch.full((B * S, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
-        acc = torch.zeros(B, heads, 2, dh, device=DEV)
+        acc = torch.zeros(B, heads, 3, dh, device=DEV)
         K.attn_delta(dOd, out, delta, rows=B * S, heads=heads, head_dim=dh)
         K.attn_bwd_dq(mode, qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh)
         K.attn_bwd_dq("cls", qd, dOd, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh)
@@ -230,6 +230,40 @@ def test_divided_attention(K, mode, B, heads, T, n, tr, dh):
             assert rel(got[:, 0, sl], ref_dqkv[:, 0, sl]) < 2e-2, (nm + "_cls", rel(got[:, 0, sl], ref_dqkv[:, 0, sl]))
     finally:
         K.attn_set_transpose_read(True)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("dh", [64, 80])
+@pytest.mark.parametrize("mode,B,heads,T,n", [("space", 2, 2, 3, 21), ("space", 1, 3, 2, 98), ("space", 2, 2, 4, 111),
+                                              ("space", 1, 2, 2, 15), ("space", 1, 2, 2, 16), ("space", 1, 1, 2, 196),
+                                              ("space", 2, 4, 3, 76), ("time", 2, 2, 8, 5), ("time", 1, 2, 16, 7),
+                                              ("time", 2, 3, 12, 4)])
+def test_attention_site_backward(K, mode, B, heads, T, n, dh, fused):
+    """tvts_attn_bwd: the whole backward of one divided-attention site in one call (fused single-launch kernels where
+    the group fits; the split delta / dQ / dK,dV passes otherwise), against autograd of the reference formulation."""
+    K.attn_set_fused(fused)
+    try:
+        S, W = 1 + T * n, heads * dh
+        qkv = bf(rnd(B, S, 3 * W, seed=35))
+        dO = bf(rnd(B, S, W, seed=36))
+        ref_out, ref_dqkv = _ref_divided(qkv.float(), heads, mode, T, n, dO.float())
+        qd = qkv.reshape(B * S, 3 * W).to(DEV)
+        out = torch.full((B * S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B * S, heads, device=DEV)
+        K.attn_fwd(mode, qd, out, lse, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh)
+        K.attn_fwd("cls", qd, out, lse, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh)
+        dOd = dO.reshape(B * S, W).to(DEV)
+        delta = torch.full((B * S, heads), float("nan"), device=DEV)
+        dqkv = torch.full((B * S, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        acc = torch.full((B, heads, 3, dh), float("nan"), device=DEV)
+        K.attn_bwd(mode, qd, dOd, out, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n, cls_acc=acc, head_dim=dh)
+        got = dqkv.float().view(B, S, 3 * W).cpu()
+        assert torch.isfinite(got).all()
+        for nm, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
+            assert rel(got[..., sl], ref_dqkv[..., sl]) < 2e-2, (nm, rel(got[..., sl], ref_dqkv[..., sl]))
+            assert rel(got[:, 0, sl], ref_dqkv[:, 0, sl]) < 2e-2, (nm + "_cls", rel(got[:, 0, sl], ref_dqkv[:, 0, sl]))
+    finally:
+        K.attn_set_fused(True)
 
 
 def _ref_full(qkv, heads, causal, dO):

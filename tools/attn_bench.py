@@ -32,7 +32,7 @@ def run(mode, Bn, heads, S, T=0, n=0, causal=False):
     out = torch.empty(M, W, dtype=torch.bfloat16, device=dev)
     lse, delta = torch.empty(M, heads, device=dev), torch.empty(M, heads, device=dev)
     dqkv = torch.empty(M, 3 * W, dtype=torch.bfloat16, device=dev)
-    acc = torch.zeros(Bn, heads, 2, 64, device=dev)
+    acc = torch.zeros(Bn, heads, 3, 64, device=dev)
     kw = dict(B=Bn, heads=heads, S=S, T=T, n=n)
     if mode == "full":
         kw["causal"] = causal
@@ -43,7 +43,18 @@ def run(mode, Bn, heads, S, T=0, n=0, causal=False):
     if mode != "cls":
         extra = dict(cls_acc=acc) if mode in ("space", "time") else {}
         dkv = timeit(lambda: K.attn_bwd_dkv(mode, qkv, dO, lse, delta, dqkv, **kw, **extra))
+    site = ""
+    if mode != "cls":
+        extra = dict(cls_acc=acc) if mode in ("space", "time") else {}
+        K.attn_fwd(mode, qkv, out, lse, **kw)
+        ts = []
+        for fused in (True, False):
+            K.attn_set_fused(fused)
+            ts.append(timeit(lambda: K.attn_bwd(mode, qkv, dO, out, lse, delta, dqkv, **kw, **extra)))
+        K.attn_set_fused(True)
+        site = f"  site-bwd fused {ts[0]:7.1f} us / split {ts[1]:7.1f} us"
     gb = M * 3 * W * 2 / 1e9
+    print(site, end="")
     print(f"{mode:6s} B={Bn} h={heads} S={S}: fwd {f:7.1f} us  dq {dq:7.1f} us  dkv {dkv:7.1f} us   (qkv {gb * 1e3:.0f} MB)")
 
 

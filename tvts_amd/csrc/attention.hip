@@ -25,6 +25,7 @@
 // query (which attends every token), so each dqkv element is written exactly once; the CLS key/value
 // gradient is the only cross-group sum and goes through fp32 atomics + a tiny finalize kernel.
 #include "common.h"
+#include <stdlib.h>
 
 enum { MODE_FULL = 0, MODE_SPACE = 1, MODE_TIME = 2, MODE_CLS = 3 };
 // Head dimension is a compile-time constant of this translation unit: the file is compiled twice
@@ -54,6 +55,7 @@ struct AttnGeom {
     int W;                  // heads * 64
     float scale2;           // dh^-0.5 * log2(e)
     float scale;            // dh^-0.5
+    int ablate;             // dev knob (TVTS_ATTN_ABLATE): 1 skip phase A, 2 skip phase B, 4 skip global loads
 };
 
 struct Grp { int b, h, sub, nq, nk; };
@@ -304,10 +306,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
 
 // ------------------------------------------------------------------------------------------------ D = rowsum(dO * O)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ dO, int lddo, const bf16* __restrict__ O,
-                                                         int ldo, int rows, int heads, float* __restrict__ delta) {
-    const long rh = (long)blockIdx.x * 256 + threadIdx.x;  // (row, head)
+                                                         int ldo, int rows, int row_step, int heads, float* __restrict__ delta) {
+    long rh = (long)blockIdx.x * 256 + threadIdx.x;  // (row, head)
     if (rh >= (long)rows * heads) return;
-    const int row = (int)(rh / heads), h = (int)(rh % heads);
+    const int row = (int)(rh / heads) * row_step, h = (int)(rh % heads);  // row_step = S: the CLS rows only
+    rh = (long)row * heads + h;
     float s = 0.f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnGeom g, const bf1
     }
     if (kj < r.nk) {
         if (EXT && kj == 0) {  // CLS key/value: summed over all groups of (b,h)
-            float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 2) * DH;
+            float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -898,7 +901,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
     }
     if (active && kj < r.nk) {
         if (EXT && kj == 0) {
-            float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 2) * DH;
+            float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -1032,16 +1035,459 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, cons
     if (threadIdx.x < 2 * DH) {
         const int kv = threadIdx.x / DH, d = threadIdx.x % DH;
         const float v = red[0][kv][d] + red[1][kv][d] + red[2][kv][d] + red[3][kv][d];
-        atomicAdd(cls_acc + ((size_t)(r.b * g.heads + r.h) * 2 + kv) * DH + d, v);
+        atomicAdd(cls_acc + ((size_t)(r.b * g.heads + r.h) * 3 + kv) * DH + d, v);
     }
 }
 
-__global__ void attn_cls_finalize_kernel(const float* __restrict__ cls_acc, int B, int heads, int S, int W,
+// ================================================================================================
+// FUSED SPACE-geometry backward: one block per (b, frame, head) group does dQ, dK and dV in one launch.
+// The group's token set X = {CLS, the n kept patches of the frame} serves as the extended query set AND the key
+// set, so its Q / K / V / dO head slices are staged into LDS exactly once (the split dQ + dK/dV passes read them
+// twice and once more for D = rowsum(dO*O)).  Phase A: each wave owns query tiles, forms S^T and dP^T against every
+// key tile from LDS, gets D_q = sum_k P*dP in registers (exact: all keys of a patch query live in this group), writes
+// dQ and leaves D_q in LDS.  Phase B: each wave owns key tiles and accumulates dK / dV over all (extended) queries
+// with the stats from LDS; the CLS query takes lse / D from global (its softmax spans every frame), the CLS key /
+// value gradient goes through the fp32 cls_acc atomics as before.  Needs n + 1 <= 112 (7 row tiles).
+// ================================================================================================
+#define FUSED_MAX_TILES 7
+#define FUSED_THREADS 512  // 8 waves: one query tile and one key tile each; 2 blocks per CU (LDS) = 4 waves per SIMD
+template <bool TR>
+__device__ __forceinline__ bf16x8 frag_T_lim(const char* tile, int u, int dt, int lane, int lim) {
+    const int gq = lane >> 4, i = lane & 15;
+    bf16x8 out;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row0 = u * 32 + half * 16 + gq * 4;
+        if (u * 32 + half * 16 < lim) {  // wave-uniform: tiles past `lim` rows are not allocated, their P / dS are zero
+            if (TR) {
+                const char* p = tile + (row0 + (i >> 2)) * VSTRIDE + dt * 32 + (i & 3) * 8;
+                const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))p);
+                const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[half * 4 + e] = tb[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[half * 4 + e] = *(const bf16*)(tile + (row0 + e) * VSTRIDE + (dt * 16 + i) * 2);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[half * 4 + e] = (bf16)0.f;
+        }
+    }
+    return out;
+}
+
+template <int MT, bool TR>
+__global__ __launch_bounds__(FUSED_THREADS, 4) void attn_bwd_space_fused_kernel(AttnGeom g, const bf16* __restrict__ qkv,
+                                                                              const bf16* __restrict__ dO, int lddo,
+                                                                              const float* __restrict__ lse2,
+                                                                              const float* __restrict__ delta,
+                                                                              bf16* __restrict__ dqkv, int lddq,
+                                                                              float* __restrict__ cls_acc) {
+    // MT (row tiles of the group) is a template parameter so that every loop below is straight-line code: the LDS
+    // reads of a phase are then issued back to back instead of one dependent round trip per branch.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RA = MT * 16, TB = RA * VSTRIDE, NU = (MT + 1) / 2, NW = FUSED_THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Grp r = decode<MODE_SPACE>(g, blockIdx.x);
+    const int m = g.n + 1;
+    char* Qs = smem;
+    char* Ks = Qs + TB;
+    char* Vs = Ks + TB;
+    char* Ds = Vs + TB;
+    float* st_lse = (float*)(Ds + TB);
+    float* st_dl = st_lse + RA;
+    const int gq = lane >> 4, li = lane & 15;
+    const int hcol = r.h * DH;
+
+    // ---- stage Q | K | V | dO of the group's tokens (rows m..RA-1 zero), all loads in flight before the first store
+    {
+        constexpr int PER = (RA * NCH + FUSED_THREADS - 1) / FUSED_THREADS;
+        bf16x8 stg[4][PER];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16* base = t == 3 ? dO + hcol : qkv + t * g.W + hcol;
+            const int ld = t == 3 ? lddo : g.ld;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = tid + FUSED_THREADS * i, row = c / NCH, ch = c % NCH;
+                stg[t][i] = (row < m && !(g.ablate & 4)) ? ldg8(base + (size_t)k_row<MODE_SPACE>(g, r, row) * ld + ch * 8) : zero8();
+            }
+        }
+        if (tid < RA) {
+            const size_t o = (size_t)k_row<MODE_SPACE>(g, r, tid < m ? tid : 0) * g.heads + r.h;
+            st_lse[tid] = tid < m ? lse2[o] : 0.f;
+            st_dl[tid] = tid == 0 ? delta[o] : 0.f;  // CLS query: D from the delta pass over the CLS rows
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = tid + FUSED_THREADS * i, row = c / NCH, ch = c % NCH;
+                if (row < RA) *(bf16x8*)(smem + t * TB + row * VSTRIDE + ch * 16) = stg[t][i];
+            }
+    }
+    __syncthreads();
+
+    // ---- phase A: dQ of the query tiles this wave owns (+ D_q into LDS)
+    if (!(g.ablate & 1))
+    for (int qt = wave; qt < MT; qt += NW) {
+        const int qj = qt * 16 + li;
+        bf16x8 qf[KS], dof[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { qf[ks] = frag_row(Qs, qj, ks, gq); dof[ks] = frag_row(Ds, qj, ks, gq); }
+        const float lse = st_lse[qj];
+        f32x4 P[2 * NU], dP[2 * NU];
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * NU; ++t) {
+            P[t] = (f32x4){0, 0, 0, 0};
+            dP[t] = (f32x4){0, 0, 0, 0};
+            if (t < MT) {
+                f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, t * 16 + li, ks, gq), qf[ks], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Vs, t * 16 + li, ks, gq), dof[ks], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = t * 16 + gq * 4 + e;
+                    const float pe = __builtin_amdgcn_exp2f(sc[e] * g.scale2 - lse);
+                    float p = key < m ? pe : 0.f;
+                    if (t == 0 && e == 0) p = (gq == 0 && qj == 0 && r.sub != 0) ? 0.f : p;  // CLS x CLS: frame 0 only
+                    P[t][e] = p;
+                    dP[t][e] = dp[e];
+                    part += p * dp[e];
+                }
+            }
+        }
+        float dlt = group_sum(part);
+        if (qj == 0) dlt = st_dl[0];  // CLS query: its softmax spans every frame, D comes from the delta pass
+        f32x4 acc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            bf16x8 dsf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = 2 * u + (j >> 2), e = j & 3;
+                dsf[j] = (bf16)(P[t][e] * (dP[t][e] - dlt) * g.scale);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ks, u, dt, lane, RA), dsf, acc[dt], 0, 0, 0);
+        }
+        if (qj >= 1 && qj < m) {
+            bf16* dq = dqkv + (size_t)k_row<MODE_SPACE>(g, r, qj) * lddq + hcol;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                *(bf16x4*)(dq + dt * 16 + gq * 4) = (bf16x4){(bf16)acc[dt][0], (bf16)acc[dt][1], (bf16)acc[dt][2], (bf16)acc[dt][3]};
+        } else if (qj == 0) {  // this frame's share of the CLS query gradient
+            float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3 + 2) * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(a + dt * 16 + gq * 4 + e, acc[dt][e]);
+        }
+        if (gq == 0 && qj >= 1) st_dl[qj] = dlt;
+    }
+    __syncthreads();
+
+    // ---- phase B: dK / dV of the key tiles this wave owns, over all extended queries
+    if (!(g.ablate & 2))
+    for (int kt = wave; kt < MT; kt += NW) {
+        const int kj = kt * 16 + li;
+        bf16x8 kb[KS], vb[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { kb[ks] = frag_row(Ks, kj, ks, gq); vb[ks] = frag_row(Vs, kj, ks, gq); }
+        f32x4 dv[DT], dk[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
+        const bool cls_dup = kj == 0 && r.sub != 0;  // CLS query x CLS key is counted by frame 0 only
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            bf16x8 pf, dsf;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int tile = 2 * u + t;
+                if (tile < MT) {  // compile-time
+                    f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, tile * 16 + li, ks, gq), kb[ks], sc, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ds, tile * 16 + li, ks, gq), vb[ks], dp, 0, 0, 0);
+                    }
+                    const f32x4 l4 = *(const f32x4*)(st_lse + tile * 16 + gq * 4);
+                    const f32x4 d4 = *(const f32x4*)(st_dl + tile * 16 + gq * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int qi = tile * 16 + gq * 4 + e;
+                        const bool ok = qi < m && kj < m && !(qi == 0 && cls_dup);
+                        const float pe = __builtin_amdgcn_exp2f(sc[e] * g.scale2 - l4[e]);
+                        const float pp = ok ? pe : 0.f;
+                        pf[t * 4 + e] = (bf16)pp;
+                        dsf[t * 4 + e] = (bf16)(pp * (dp[e] - d4[e]) * g.scale);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pf[t * 4 + e] = (bf16)0.f; dsf[t * 4 + e] = (bf16)0.f; }
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ds, u, dt, lane, RA), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Qs, u, dt, lane, RA), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+        if (kj < m) {
+            if (kj == 0) {  // CLS key/value: summed over the frames of (b,h)
+                float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        atomicAdd(a + dt * 16 + gq * 4 + e, dk[dt][e]);
+                        atomicAdd(a + DH + dt * 16 + gq * 4 + e, dv[dt][e]);
+                    }
+            } else {
+                const size_t row = (size_t)k_row<MODE_SPACE>(g, r, kj) * lddq;
+                bf16* dkp = dqkv + row + g.W + hcol;
+                bf16* dvp = dqkv + row + 2 * g.W + hcol;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    *(bf16x4*)(dkp + dt * 16 + gq * 4) = (bf16x4){(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
+                    *(bf16x4*)(dvp + dt * 16 + gq * 4) = (bf16x4){(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
+                }
+            }
+        }
+    }
+}
+
+// FUSED TIME-geometry backward.  The groups (b, patch slot, head) are tiny (T + 1 tokens) and very many, so a WAVE owns
+// a group: its Q / K / V / dO rows live in wave-private LDS tiles (the next group's rows are already in flight in
+// registers while the current one is computed), phase A and phase B run back to back in the same wave, and the three
+// CLS-token sums (dK, dV, dQ) stay in registers over the block's chunk of patch slots -> one set of atomics per block.
+template <int MT, bool TR>
+__global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kernel(AttnGeom g, const bf16* __restrict__ qkv,
+                                                                  const bf16* __restrict__ dO, int lddo,
+                                                                  const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                                  bf16* __restrict__ dqkv, int lddq, float* __restrict__ cls_acc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RA = MT * 16, TB = RA * VSTRIDE, NU = (MT + 1) / 2;
+    constexpr int WB = 4 * TB + 2 * RA * 4 + 3 * DH * 4;  // bytes of one wave's region: tiles, stats, CLS sums
+    constexpr int PT = (RA * NCH + 63) / 64;         // 16-byte chunks per lane per tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* base = smem + wave * WB;
+    char* Qs = base;
+    char* Ks = Qs + TB;
+    char* Vs = Ks + TB;
+    char* Ds = Vs + TB;
+    float* st_lse = (float*)(Ds + TB);
+    float* st_dl = st_lse + RA;
+    float* csum = st_dl + RA;                        // [dK | dV | dQ][DH] of the CLS token, summed over this wave's groups
+    const int chunks = (g.n + TIME_CHUNK - 1) / TIME_CHUNK;
+    Grp r;  // block order (b, chunk, h): the heads of one token range run next to each other
+    r.h = blockIdx.x % g.heads;
+    const int c = (blockIdx.x / g.heads) % chunks;
+    r.b = blockIdx.x / (g.heads * chunks); r.nq = g.T; r.nk = g.T + 1;
+    const int p_end = (c + 1) * TIME_CHUNK < g.n ? (c + 1) * TIME_CHUNK : g.n;
+    const int gq = lane >> 4, li = lane & 15;
+    const int hcol = r.h * DH;
+    const int m = g.T + 1;
+    const size_t ocls = (size_t)(r.b * g.S) * g.heads + r.h;
+    const float lse_c = lse2[ocls], dl_c = delta[ocls];
+    for (int i = lane; i < 3 * DH; i += 64) csum[i] = 0.f;
+
+    bf16x8 stg[4][PT];
+    float lse_pf = 0.f;
+    auto issue = [&](int p) {
+        r.sub = p;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16* src = t == 3 ? dO + hcol : qkv + t * g.W + hcol;
+            const int ld = t == 3 ? lddo : g.ld;
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int cc = lane + 64 * i, row = cc / NCH, ch = cc % NCH;
+                stg[t][i] = row < m ? ldg8(src + (size_t)k_row<MODE_TIME>(g, r, row) * ld + ch * 8) : zero8();
+            }
+        }
+        if (lane >= 1 && lane < m) lse_pf = lse2[(size_t)k_row<MODE_TIME>(g, r, lane) * g.heads + r.h];
+    };
+    int p = c * TIME_CHUNK + wave;
+    if (p < p_end) issue(p);
+    for (; p < p_end; p += 4) {
+        // registers -> this wave's LDS tiles (rows m..RA-1 arrive as zeros), stats of the extended query rows
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int cc = lane + 64 * i, row = cc / NCH, ch = cc % NCH;
+                if (row < RA) *(bf16x8*)(base + t * TB + row * VSTRIDE + ch * 16) = stg[t][i];
+            }
+        if (lane < RA) {
+            st_lse[lane] = lane == 0 ? lse_c : (lane < m ? lse_pf : 0.f);
+            st_dl[lane] = lane == 0 ? dl_c : 0.f;
+        }
+        const bool first = p == 0;  // the CLS query x CLS key term is counted by patch slot 0 only
+        if (p + 4 < p_end) issue(p + 4);
+        r.sub = p;
+
+        // ---- phase A: dQ (+ D_q)
+#pragma unroll
+        for (int qt = 0; qt < MT; ++qt) {
+            const int qj = qt * 16 + li;
+            bf16x8 qf[KS], dof[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { qf[ks] = frag_row(Qs, qj, ks, gq); dof[ks] = frag_row(Ds, qj, ks, gq); }
+            const float lse = st_lse[qj];
+            f32x4 P[2 * NU], dP[2 * NU];
+            float part = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2 * NU; ++t) {
+                P[t] = (f32x4){0, 0, 0, 0};
+                dP[t] = (f32x4){0, 0, 0, 0};
+                if (t < MT) {
+                    f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, t * 16 + li, ks, gq), qf[ks], sc, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Vs, t * 16 + li, ks, gq), dof[ks], dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = t * 16 + gq * 4 + e;
+                        const float pe = __builtin_amdgcn_exp2f(sc[e] * g.scale2 - lse);
+                        float pp = key < m ? pe : 0.f;
+                        if (t == 0 && e == 0) pp = (gq == 0 && qj == 0 && !first) ? 0.f : pp;
+                        P[t][e] = pp;
+                        dP[t][e] = dp[e];
+                        part += pp * dp[e];
+                    }
+                }
+            }
+            float dlt = group_sum(part);
+            if (qj == 0) dlt = dl_c;
+            f32x4 acc[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                bf16x8 dsf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = 2 * u + (j >> 2), e = j & 3;
+                    dsf[j] = (bf16)(P[t][e] * (dP[t][e] - dlt) * g.scale);
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ks, u, dt, lane, RA), dsf, acc[dt], 0, 0, 0);
+            }
+            if (qj >= 1 && qj < m) {
+                bf16* dq = dqkv + (size_t)k_row<MODE_TIME>(g, r, qj) * lddq + hcol;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    *(bf16x4*)(dq + dt * 16 + gq * 4) = (bf16x4){(bf16)acc[dt][0], (bf16)acc[dt][1], (bf16)acc[dt][2], (bf16)acc[dt][3]};
+            }
+            if (qt == 0 && li == 0) {  // column 0 = the CLS query: this group's share of its gradient
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    f32x4* a = (f32x4*)(csum + 2 * DH + dt * 16 + gq * 4);
+                    *a += acc[dt];
+                }
+            }
+            if (gq == 0 && qj >= 1) st_dl[qj] = dlt;
+        }
+
+        // ---- phase B: dK / dV
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+            const int kj = kt * 16 + li;
+            bf16x8 kb[KS], vb[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { kb[ks] = frag_row(Ks, kj, ks, gq); vb[ks] = frag_row(Vs, kj, ks, gq); }
+            f32x4 dv[DT], dk[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
+            const bool cls_dup = kj == 0 && !first;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                bf16x8 pf, dsf;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int tile = 2 * u + t;
+                    if (tile < MT) {
+                        f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, tile * 16 + li, ks, gq), kb[ks], sc, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ds, tile * 16 + li, ks, gq), vb[ks], dp, 0, 0, 0);
+                        }
+                        const f32x4 l4 = *(const f32x4*)(st_lse + tile * 16 + gq * 4);
+                        const f32x4 d4 = *(const f32x4*)(st_dl + tile * 16 + gq * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int qi = tile * 16 + gq * 4 + e;
+                            const bool ok = qi < m && kj < m && !(qi == 0 && cls_dup);
+                            const float pe = __builtin_amdgcn_exp2f(sc[e] * g.scale2 - l4[e]);
+                            const float pp = ok ? pe : 0.f;
+                            pf[t * 4 + e] = (bf16)pp;
+                            dsf[t * 4 + e] = (bf16)(pp * (dp[e] - d4[e]) * g.scale);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { pf[t * 4 + e] = (bf16)0.f; dsf[t * 4 + e] = (bf16)0.f; }
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ds, u, dt, lane, RA), pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Qs, u, dt, lane, RA), dsf, dk[dt], 0, 0, 0);
+                }
+            }
+            if (kt == 0 && li == 0) {  // column 0 = the CLS key / value
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    f32x4* a = (f32x4*)(csum + dt * 16 + gq * 4);
+                    *a += dk[dt];
+                    f32x4* c2 = (f32x4*)(csum + DH + dt * 16 + gq * 4);
+                    *c2 += dv[dt];
+                }
+            }
+            if (kj >= 1 && kj < m) {
+                const size_t row = (size_t)k_row<MODE_TIME>(g, r, kj) * lddq;
+                bf16* dkp = dqkv + row + g.W + hcol;
+                bf16* dvp = dqkv + row + 2 * g.W + hcol;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    *(bf16x4*)(dkp + dt * 16 + gq * 4) = (bf16x4){(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
+                    *(bf16x4*)(dvp + dt * 16 + gq * 4) = (bf16x4){(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
+                }
+            }
+        }
+    }
+    // combine the four waves' CLS sums: one set of atomics per block
+    __syncthreads();
+    if (threadIdx.x < 3 * DH) {
+        const int i = threadIdx.x;
+        const float v = *(const float*)(smem + 0 * WB + 4 * TB + 2 * RA * 4 + i * 4) + *(const float*)(smem + 1 * WB + 4 * TB + 2 * RA * 4 + i * 4) +
+                        *(const float*)(smem + 2 * WB + 4 * TB + 2 * RA * 4 + i * 4) + *(const float*)(smem + 3 * WB + 4 * TB + 2 * RA * 4 + i * 4);
+        atomicAdd(cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH + i, v);
+    }
+}
+
+// cls_acc [B, heads, 3, DH] = fp32 sums of (dK, dV, dQ) of the CLS token -> bf16 into the CLS row of dqkv; the dQ slot is
+// only used by the fused kernels (the split path writes the CLS dQ from its own CLS-query pass).
+__global__ void attn_cls_finalize_kernel(const float* __restrict__ cls_acc, int B, int heads, int S, int W, int with_q,
                                          bf16* __restrict__ dqkv, int lddq) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b, h, kv, d)
-    if (idx >= B * heads * 2 * DH) return;
-    const int d = idx % DH, kv = (idx / DH) % 2, h = (idx / (2 * DH)) % heads, b = idx / (2 * DH * heads);
-    dqkv[(size_t)(b * S) * lddq + (1 + kv) * W + h * DH + d] = (bf16)cls_acc[idx];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b, h, slot, d)
+    if (idx >= B * heads * 3 * DH) return;
+    const int d = idx % DH, slot = (idx / DH) % 3, h = (idx / (3 * DH)) % heads, b = idx / (3 * DH * heads);
+    if (slot == 2 && !with_q) return;
+    const int third = slot == 2 ? 0 : 1 + slot;
+    dqkv[(size_t)(b * S) * lddq + third * W + h * DH + d] = (bf16)cls_acc[idx];
 }
 
 }  // namespace NS_DH
@@ -1060,6 +1506,9 @@ static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int 
     g.B = B; g.heads = heads; g.S = S; g.T = T; g.n = n; g.causal = causal; g.ld = ld; g.W = heads * DH;
     g.scale = 1.0f / sqrtf((float)DH);
     g.scale2 = g.scale * 1.4426950408889634f;
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("TVTS_ATTN_ABLATE"); abl = e ? atoi(e) : 0; }
+    g.ablate = abl;
     return TVTS_OK;
 }
 static int items_q(const AttnGeom& g, int mode) {
@@ -1123,7 +1572,7 @@ extern "C" int ABI(delta)(const void* dO, int lddo, const void* O, int ldo, int 
     if (rows <= 0 || heads <= 0 || lddo % 8 || ldo % 8) return TVTS_EINVAL;
     const long total = (long)rows * heads * 8;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16*)dO, lddo,
-                       (const bf16*)O, ldo, rows, heads, delta);
+                       (const bf16*)O, ldo, rows, 1, heads, delta);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
@@ -1154,7 +1603,7 @@ extern "C" int ABI(bwd_dq)(int mode, const void* qkv, int ld, int B, int heads, 
     return TVTS_OK;
 }
 
-// cls_acc: fp32 [B, heads, 2, 64], zeroed by the caller before the SPACE/TIME pass, consumed by
+// cls_acc: fp32 [B, heads, 3, dh] (dK | dV | dQ of the CLS token), zeroed by the caller before the SPACE/TIME pass, consumed by
 // tvts_attn_cls_finalize afterwards (unused for FULL).
 extern "C" int ABI(bwd_dkv)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
                                  const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
@@ -1193,9 +1642,83 @@ extern "C" int ABI(bwd_dkv)(int mode, const void* qkv, int ld, int B, int heads,
 
 extern "C" int ABI(cls_finalize)(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq,
                                       hipStream_t stream) {
-    const int total = B * heads * 2 * DH;
+    const int total = B * heads * 3 * DH;
     hipLaunchKernelGGL(attn_cls_finalize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, cls_acc, B, heads, S,
-                       heads * DH, (bf16*)dqkv, lddq);
+                       heads * DH, 0, (bf16*)dqkv, lddq);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
+}
+
+// Whole backward of one attention site: D = rowsum(dO*O), dQ, dK, dV (and, for the divided space / time geometries,
+// the CLS query and the CLS key/value reduction).  SPACE groups that fit 112 rows take the fused single-launch kernel.
+static int g_fused = 1;
+extern "C" void ABI(set_fused)(int on) { g_fused = on ? 1 : 0; }
+extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+                        const void* dO, int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv,
+                        int lddq, float* cls_acc, hipStream_t stream) {
+    if (mode == MODE_CLS) return TVTS_EINVAL;
+    AttnGeom g;
+    int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
+    if (rc) return rc;
+    if (lddo % 8 || ldo % 8 || lddq % 4) return TVTS_EINVAL;
+    const bool divided = mode == MODE_SPACE || mode == MODE_TIME;
+    if (divided) {
+        if (!cls_acc) return TVTS_EINVAL;
+        if (hipMemsetAsync(cls_acc, 0, (size_t)B * heads * 3 * DH * sizeof(float), stream) != hipSuccess) return TVTS_EINVAL;
+    }
+    const bool fused_space = g_fused && g_use_tr && mode == MODE_SPACE && n + 1 <= FUSED_MAX_TILES * 16;
+    const bool fused_time = g_fused && g_use_tr && mode == MODE_TIME && T + 1 <= 32;
+    typedef void (*FusedKern)(AttnGeom, const bf16*, const bf16*, int, const float*, const float*, bf16*, int, float*);
+    if (fused_space || fused_time) {
+        // D for the CLS rows only (the patch rows get theirs inside the fused kernels)
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((long)B * heads + 255) / 256)), dim3(256), 0, stream,
+                           (const bf16*)dO, lddo, (const bf16*)O, ldo, B, S, heads, delta);
+        FusedKern kern = nullptr;
+        int lds_bytes = 0, blocks = 0, threads = 0, slot = 0;
+        if (fused_space) {
+            const int MT = (n + 1 + 15) / 16, RA = MT * 16;
+            lds_bytes = 4 * RA * VSTRIDE + 2 * RA * (int)sizeof(float);
+            switch (MT) {
+                case 1: kern = attn_bwd_space_fused_kernel<1, true>; break;
+                case 2: kern = attn_bwd_space_fused_kernel<2, true>; break;
+                case 3: kern = attn_bwd_space_fused_kernel<3, true>; break;
+                case 4: kern = attn_bwd_space_fused_kernel<4, true>; break;
+                case 5: kern = attn_bwd_space_fused_kernel<5, true>; break;
+                case 6: kern = attn_bwd_space_fused_kernel<6, true>; break;
+                default: kern = attn_bwd_space_fused_kernel<7, true>; break;
+            }
+            blocks = B * heads * T; threads = FUSED_THREADS; slot = MT;
+        } else {
+            const int MT = (T + 1 + 15) / 16, RA = MT * 16;
+            lds_bytes = 4 * (4 * RA * VSTRIDE + 2 * RA * 4 + 3 * DH * 4);
+            kern = MT == 1 ? attn_bwd_time_fused_kernel<1, true> : attn_bwd_time_fused_kernel<2, true>;
+            blocks = B * heads * ceil_div(n, TIME_CHUNK); threads = 256; slot = FUSED_MAX_TILES + MT;
+        }
+        static bool attr_set[FUSED_MAX_TILES + 3] = {};
+        if (!attr_set[slot]) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+                return TVTS_EINVAL;
+            attr_set[slot] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo,
+                           lse2, delta, (bf16*)dqkv, lddq, cls_acc);
+        TVTS_LAUNCH_CHECK();
+        const int total = B * heads * 3 * DH;  // CLS row of dqkv: dK, dV and dQ all come from the accumulators
+        hipLaunchKernelGGL(attn_cls_finalize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, cls_acc, B, heads, S,
+                           heads * DH, 1, (bf16*)dqkv, lddq);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
+    rc = ABI(delta)(dO, lddo, O, ldo, B * S, heads, delta, stream);
+    if (rc) return rc;
+    rc = ABI(bwd_dq)(mode, qkv, ld, B, heads, S, T, n, causal, dO, lddo, lse2, delta, dqkv, lddq, stream);
+    if (rc) return rc;
+    rc = ABI(bwd_dkv)(mode, qkv, ld, B, heads, S, T, n, causal, dO, lddo, lse2, delta, dqkv, lddq, cls_acc, stream);
+    if (rc) return rc;
+    if (divided) {
+        rc = ABI(bwd_dq)(MODE_CLS, qkv, ld, B, heads, S, T, n, 0, dO, lddo, lse2, delta, dqkv, lddq, stream);
+        if (rc) return rc;
+        rc = ABI(cls_finalize)(cls_acc, B, heads, S, dqkv, lddq, stream);
+    }
+    return rc;
 }

@@ -232,9 +232,7 @@ class Engine:
         dqkv = self._b(scr + ".dqkv", (M, 3 * Wd))
         delta = self._f(scr + ".delta", (M, heads))
         qkv, lse = B_[tag + ".qkv"], B_[tag + ".lse"]
-        K.attn_delta(datt, B_[tag + ".att"], delta, rows=M, heads=heads, head_dim=hd)
-        K.attn_bwd_dq("full", qkv, datt, lse, delta, dqkv, B=Bn, heads=heads, S=S, causal=causal, head_dim=hd)
-        K.attn_bwd_dkv("full", qkv, datt, lse, delta, dqkv, B=Bn, heads=heads, S=S, causal=causal, head_dim=hd)
+        K.attn_bwd("full", qkv, datt, B_[tag + ".att"], lse, delta, dqkv, B=Bn, heads=heads, S=S, causal=causal, head_dim=hd)
         self._lin_bwd(dqkv, B_[tag + ".ln1"], pre + nm["qkv_w"], pre + nm["qkv_b"], dln, M)
         self._ln_bwd(dln, x_in, pre + nm["ln1"], tag + ".ln1", dx_in, dx_bf16=dxb_in, res1=dmid)
 
@@ -288,12 +286,8 @@ class Engine:
         M = B * S
         delta = self._f(scr + ".delta", (M, h))
         hd = self.dh
-        cls_acc = self._f(scr + ".clsacc", (B, h, 2, hd), zero=True)
-        K.attn_delta(datt, att, delta, rows=M, heads=h, head_dim=hd)
-        K.attn_bwd_dq(mode, qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, head_dim=hd)
-        K.attn_bwd_dq("cls", qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, head_dim=hd)
-        K.attn_bwd_dkv(mode, qkv, datt, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, cls_acc=cls_acc, head_dim=hd)
-        K.attn_cls_finalize(cls_acc, dqkv, B=B, heads=h, S=S, head_dim=hd)
+        cls_acc = self._f(scr + ".clsacc", (B, h, 3, hd))
+        K.attn_bwd(mode, qkv, datt, att, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, cls_acc=cls_acc, head_dim=hd)
 
     def video_forward(self, video, keep_dev, B, T, vid_rows=None):
         a = self.arch

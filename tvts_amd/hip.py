@@ -161,6 +161,19 @@ def attn_bwd_dkv(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, cau
     _chk(rc, "tvts_attn_bwd_dkv")
 
 
+def attn_bwd(mode, qkv, dO, O, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None, head_dim=64):
+    """Whole backward of one attention site into dqkv (delta / cls_acc are scratch)."""
+    lib = _lib.load()
+    rc = _attn_fn(lib, "bwd", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO), _p(O),
+                                        _ld(O), _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc), _stream())
+    _chk(rc, "tvts_attn_bwd")
+
+
+def attn_set_fused(on: bool):
+    _lib.load().tvts_attn_set_fused(int(on))
+    _lib.load().tvts_attn80_set_fused(int(on))
+
+
 def attn_cls_finalize(cls_acc, dqkv, *, B, heads, S, head_dim=64):
     lib = _lib.load()
     _chk(_attn_fn(lib, "cls_finalize", head_dim)(_p(cls_acc), B, heads, S, _p(dqkv), _ld(dqkv), _stream()), "tvts_attn_cls_finalize")
