@@ -66,6 +66,10 @@ int tvts_attn_bwd(int mode, const void* qkv, int ld, int B, int heads, int S, in
               int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float* cls_acc,
               hipStream_t stream);
 void tvts_attn_set_fused(int on);
+/* forward of one divided-attention site including the CLS row (VarAttention.forward video_encoder_ViT_B_16.py:38-76);
+ * cls_ws: fp32 scratch of >= B * heads * max(T, ceil(n / 28)) * (dh + 2) elements (partial softmax states of the CLS query) */
+int tvts_attn_fwd_divided(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
+                      float* lse2, float* cls_ws, long cls_ws_elems, hipStream_t stream);
 
 /* the same entry points for head dim 80 (ViT-H/14, 1280 / 16 heads); qkv is [rows, 3*heads*80] */
 int tvts_attn80_fwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, void* out, int ldo,
@@ -87,6 +91,10 @@ int tvts_attn80_bwd(int mode, const void* qkv, int ld, int B, int heads, int S, 
               int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float* cls_acc,
               hipStream_t stream);
 void tvts_attn80_set_fused(int on);
+/* forward of one divided-attention site including the CLS row (VarAttention.forward video_encoder_ViT_B_16.py:38-76);
+ * cls_ws: fp32 scratch of >= B * heads * max(T, ceil(n / 28)) * (dh + 2) elements (partial softmax states of the CLS query) */
+int tvts_attn80_fwd_divided(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
+                      float* lse2, float* cls_ws, long cls_ws_elems, hipStream_t stream);
 
 /* ---- token assembly (embed.hip): video_encoder_ViT_B_16.py:176-216; model_dist..B_16.py:69-76,98-100;
  *      sort_transformer.py:124-128 */

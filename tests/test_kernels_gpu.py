@@ -266,6 +266,38 @@ def test_attention_site_backward(K, mode, B, heads, T, n, dh, fused):
         K.attn_set_fused(True)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("dh", [64, 80])
+@pytest.mark.parametrize("mode,B,heads,T,n", [("space", 2, 2, 3, 21), ("space", 1, 3, 2, 98), ("space", 2, 2, 4, 111),
+                                              ("space", 1, 2, 2, 15), ("space", 1, 1, 2, 196), ("space", 2, 4, 3, 76),
+                                              ("time", 2, 2, 8, 5), ("time", 1, 2, 16, 7), ("time", 2, 3, 12, 30),
+                                              ("time", 1, 2, 8, 98)])
+def test_attention_site_forward(K, mode, B, heads, T, n, dh, fused):
+    """tvts_attn_fwd_divided: patch rows and the CLS row (merged from per-group partial softmax states) in one call."""
+    K.attn_set_fused(fused)
+    try:
+        S, W = 1 + T * n, heads * dh
+        qkv = bf(rnd(B, S, 3 * W, seed=37))
+        ref_out = O.divided_attention_core(qkv.float(), heads, mode, T, n)
+        qd = qkv.reshape(B * S, 3 * W).to(DEV)
+        out = torch.full((B * S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lse = torch.full((B * S, heads), float("nan"), device=DEV)
+        ws = torch.full((B * heads * max(T, -(-n // 28)) * (dh + 2),), float("nan"), device=DEV)
+        K.attn_fwd_divided(mode, qd, out, lse, ws, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh)
+        got = out.float().view(B, S, W).cpu()
+        assert torch.isfinite(got).all() and torch.isfinite(lse).all()
+        assert rel(got, ref_out) < 8e-3, rel(got, ref_out)
+        assert rel(got[:, 0], ref_out[:, 0]) < 8e-3, rel(got[:, 0], ref_out[:, 0])
+        # lse (log2 domain) against the streaming kernels
+        K.attn_set_fused(False)
+        out2 = torch.empty_like(out)
+        lse2 = torch.empty_like(lse)
+        K.attn_fwd_divided(mode, qd, out2, lse2, ws, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh)
+        assert float((lse - lse2).abs().max()) < 2e-3
+    finally:
+        K.attn_set_fused(True)
+
+
 def _ref_full(qkv, heads, causal, dO):
     B, S, W3 = qkv.shape
     W = W3 // 3

@@ -44,6 +44,14 @@ def run(mode, Bn, heads, S, T=0, n=0, causal=False):
         extra = dict(cls_acc=acc) if mode in ("space", "time") else {}
         dkv = timeit(lambda: K.attn_bwd_dkv(mode, qkv, dO, lse, delta, dqkv, **kw, **extra))
     site = ""
+    if mode in ("space", "time"):
+        ws = torch.empty(Bn * heads * max(T, -(-n // 28)) * 66, device=dev)
+        tf = []
+        for fused in (True, False):
+            K.attn_set_fused(fused)
+            tf.append(timeit(lambda: K.attn_fwd_divided(mode, qkv, out, lse, ws, B=Bn, heads=heads, S=S, T=T, n=n)))
+        K.attn_set_fused(True)
+        site = f"  site-fwd fused {tf[0]:7.1f} us / split {tf[1]:7.1f} us\n"
     if mode != "cls":
         extra = dict(cls_acc=acc) if mode in ("space", "time") else {}
         K.attn_fwd(mode, qkv, out, lse, **kw)
@@ -52,7 +60,7 @@ def run(mode, Bn, heads, S, T=0, n=0, causal=False):
             K.attn_set_fused(fused)
             ts.append(timeit(lambda: K.attn_bwd(mode, qkv, dO, out, lse, delta, dqkv, **kw, **extra)))
         K.attn_set_fused(True)
-        site = f"  site-bwd fused {ts[0]:7.1f} us / split {ts[1]:7.1f} us"
+        site += f"  site-bwd fused {ts[0]:7.1f} us / split {ts[1]:7.1f} us\n"
     gb = M * 3 * W * 2 / 1e9
     print(site, end="")
     print(f"{mode:6s} B={Bn} h={heads} S={S}: fwd {f:7.1f} us  dq {dq:7.1f} us  dkv {dkv:7.1f} us   (qkv {gb * 1e3:.0f} MB)")

@@ -1478,6 +1478,289 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
     }
 }
 
+// ================================================================================================
+// FUSED divided-attention FORWARD.  Same ownership as the fused backward: a block per SPACE group, a wave per TIME
+// group.  Every key of a patch query lives in its group, so the softmax is a single pass over register-resident score
+// tiles (no online rescaling).  The CLS query attends every token of the clip: each group contributes a partial
+// softmax state (max, sum, unnormalised O) over ITS keys -- the CLS key itself only in group 0 -- which a tiny merge
+// kernel combines into the CLS output row and its log-sum-exp.  cls_part: [B, heads, G, DH + 2] fp32 with G = T (SPACE)
+// or ceil(n / TIME_CHUNK) (TIME: partials are merged per wave in registers and per block through LDS first).
+// ================================================================================================
+template <int MT, bool TR>
+__global__ __launch_bounds__(256, 4) void attn_fwd_space_fused_kernel(AttnGeom g, const bf16* __restrict__ qkv,
+                                                                   bf16* __restrict__ out, int ldo, float* __restrict__ lse2,
+                                                                   float* __restrict__ cls_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // K | V tiles of the group
+    constexpr int RA = MT * 16, TB = RA * VSTRIDE, NU = (MT + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Grp r = decode<MODE_SPACE>(g, blockIdx.x);
+    const int m = g.n + 1;
+    char* Ks = smem;
+    char* Vs = Ks + TB;
+    const int gq = lane >> 4, li = lane & 15;
+    const int hcol = r.h * DH;
+    {
+        constexpr int PER = (RA * NCH + 255) / 256;
+        bf16x8 stg[2][PER];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
+                stg[t][i] = row < m ? ldg8(qkv + (size_t)k_row<MODE_SPACE>(g, r, row) * g.ld + (1 + t) * g.W + hcol + ch * 8) : zero8();
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
+                if (row < RA) *(bf16x8*)(smem + t * TB + row * VSTRIDE + ch * 16) = stg[t][i];
+            }
+    }
+    // the first query tile's fragments come straight from global memory while the staging settles
+    bf16x8 qf[KS];
+    {
+        const int qj = wave * 16 + li;
+        ld_frags(qkv + (size_t)k_row<MODE_SPACE>(g, r, qj < m ? qj : m - 1) * g.ld + hcol, gq, qf);
+    }
+    __syncthreads();
+    for (int qt = wave; qt < MT; qt += 4) {
+        const int qj = qt * 16 + li;
+        f32x4 st[2 * NU];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * NU; ++t) {
+            st[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (t < MT) {
+                f32x4 sc = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, t * 16 + li, ks, gq), qf[ks], sc, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = t * 16 + gq * 4 + e;
+                    const bool ok = key < m && !(key == 0 && qj == 0 && r.sub != 0);  // CLS x CLS: frame 0 only
+                    const float v = ok ? sc[e] * g.scale2 : -INFINITY;
+                    st[t][e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        }
+        mx = group_max(mx);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * NU; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pp = __builtin_amdgcn_exp2f(st[t][e] - mx);
+                st[t][e] = pp;
+                rs += pp;
+            }
+        const float l = group_sum(rs);
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Vs, u, dt, lane, RA), pf, o[dt], 0, 0, 0);
+        }
+        if (qj >= 1 && qj < m) {
+            const float inv = 1.0f / l;
+            const int row = k_row<MODE_SPACE>(g, r, qj);
+            bf16* op = out + (size_t)row * ldo + hcol;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                *(bf16x4*)(op + dt * 16 + gq * 4) = (bf16x4){(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
+            if (gq == 0) lse2[(size_t)row * g.heads + r.h] = mx + log2f(l);
+        } else if (qj == 0) {  // this frame's partial softmax state of the CLS query
+            float* cp = cls_part + ((size_t)(r.b * g.heads + r.h) * g.T + r.sub) * (DH + 2);
+            if (gq == 0) { cp[0] = mx; cp[1] = l; }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cp[2 + dt * 16 + gq * 4 + e] = o[dt][e];
+        }
+        if (qt + 4 < MT) {
+            const int qn = (qt + 4) * 16 + li;
+            ld_frags(qkv + (size_t)k_row<MODE_SPACE>(g, r, qn < m ? qn : m - 1) * g.ld + hcol, gq, qf);
+        }
+    }
+}
+
+template <int MT, bool TR>
+__global__ __launch_bounds__(256) void attn_fwd_time_fused_kernel(AttnGeom g, const bf16* __restrict__ qkv,
+                                                                  bf16* __restrict__ out, int ldo, float* __restrict__ lse2,
+                                                                  float* __restrict__ cls_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // per wave: V tile | CLS state [DH + 2]
+    constexpr int RA = MT * 16, TB = RA * VSTRIDE, NU = (MT + 1) / 2;
+    constexpr int WB = TB + (DH + 2 + 2) * 4;
+    constexpr int PT = (RA * NCH + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* Vs = smem + wave * WB;
+    const int chunks = (g.n + TIME_CHUNK - 1) / TIME_CHUNK;
+    Grp r;
+    r.h = blockIdx.x % g.heads;
+    const int c = (blockIdx.x / g.heads) % chunks;
+    r.b = blockIdx.x / (g.heads * chunks); r.nq = g.T; r.nk = g.T + 1;
+    const int p_end = (c + 1) * TIME_CHUNK < g.n ? (c + 1) * TIME_CHUNK : g.n;
+    const int gq = lane >> 4, li = lane & 15;
+    const int hcol = r.h * DH;
+    const int m = g.T + 1;
+    float Mr = -1e30f, Lr = 0.f;  // running softmax state of the CLS query over this wave's groups (column 0 lanes)
+    f32x4 Or[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) Or[dt] = (f32x4){0, 0, 0, 0};
+
+    bf16x8 qf[MT][KS], kf[MT][KS], vst[PT];
+    auto issue = [&](int p) {
+        r.sub = p;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int j = t * 16 + li;
+            const bf16* rowp = qkv + (size_t)k_row<MODE_TIME>(g, r, j < m ? j : m - 1) * g.ld + hcol;
+            ld_frags(rowp, gq, qf[t]);
+            ld_frags(rowp + g.W, gq, kf[t]);
+        }
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int cc = lane + 64 * i, row = cc / NCH, ch = cc % NCH;
+            vst[i] = row < m ? ldg8(qkv + (size_t)k_row<MODE_TIME>(g, r, row) * g.ld + 2 * g.W + hcol + ch * 8) : zero8();
+        }
+    };
+    int p = c * TIME_CHUNK + wave;
+    if (p < p_end) issue(p);
+    for (; p < p_end; p += 4) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int cc = lane + 64 * i, row = cc / NCH, ch = cc % NCH;
+            if (row < RA) *(bf16x8*)(Vs + row * VSTRIDE + ch * 16) = vst[i];
+        }
+        bf16x8 qc[MT][KS], kc[MT][KS];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { qc[t][ks] = qf[t][ks]; kc[t][ks] = kf[t][ks]; }
+        const bool first = p == 0;
+        if (p + 4 < p_end) issue(p + 4);
+        r.sub = p;
+#pragma unroll
+        for (int qt = 0; qt < MT; ++qt) {
+            const int qj = qt * 16 + li;
+            f32x4 st[2 * NU];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2 * NU; ++t) {
+                st[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                if (t < MT) {
+                    f32x4 sc = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[t][ks], qc[qt][ks], sc, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = t * 16 + gq * 4 + e;
+                        const bool ok = key < m && !(key == 0 && qj == 0 && !first);
+                        const float v = ok ? sc[e] * g.scale2 : -INFINITY;
+                        st[t][e] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                }
+            }
+            mx = group_max(mx);
+            float rs = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2 * NU; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pp = __builtin_amdgcn_exp2f(st[t][e] - mx);
+                    st[t][e] = pp;
+                    rs += pp;
+                }
+            const float l = group_sum(rs);
+            f32x4 o[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Vs, u, dt, lane, RA), pf, o[dt], 0, 0, 0);
+            }
+            if (qj >= 1 && qj < m) {
+                const float inv = 1.0f / l;
+                const int row = k_row<MODE_TIME>(g, r, qj);
+                bf16* op = out + (size_t)row * ldo + hcol;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    *(bf16x4*)(op + dt * 16 + gq * 4) = (bf16x4){(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
+                if (gq == 0) lse2[(size_t)row * g.heads + r.h] = mx + log2f(l);
+            }
+            if (qt == 0) {  // column 0 = the CLS query: fold this group's state into the running one
+                const float Mn = fmaxf(Mr, mx);
+                const float a = __builtin_amdgcn_exp2f(Mr - Mn), b = __builtin_amdgcn_exp2f(mx - Mn);
+                Lr = Lr * a + l * b;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) Or[dt] = Or[dt] * a + o[dt] * b;
+                Mr = Mn;
+            }
+        }
+    }
+    // the four waves' CLS states -> one partial per block
+    float* cst = (float*)(smem + wave * WB + TB);
+    if (li == 0) {
+        if (gq == 0) { cst[0] = Mr; cst[1] = Lr; }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cst[2 + dt * 16 + gq * 4 + e] = Or[dt][e];
+    }
+    __syncthreads();
+    if (threadIdx.x < DH) {
+        const int d = threadIdx.x;
+        float M = -1e30f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, *(const float*)(smem + w * WB + TB));
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* cw = (const float*)(smem + w * WB + TB);
+            const float sc = __builtin_amdgcn_exp2f(cw[0] - M);
+            L += cw[1] * sc;
+            O += cw[2 + d] * sc;
+        }
+        float* cp = cls_part + ((size_t)(r.b * g.heads + r.h) * chunks + c) * (DH + 2);
+        if (d == 0) { cp[0] = M; cp[1] = L; }
+        cp[2 + d] = O;
+    }
+}
+
+// CLS output row = merge of the G partial softmax states of (b, h)
+__global__ void attn_cls_merge_kernel(const float* __restrict__ cls_part, int G, int heads, int S, bf16* __restrict__ out,
+                                      int ldo, float* __restrict__ lse2) {
+    const int bh = blockIdx.x, d = threadIdx.x;
+    if (d >= DH) return;
+    const float* cp = cls_part + (size_t)bh * G * (DH + 2);
+    float M = -1e30f;
+    for (int i = 0; i < G; ++i) M = fmaxf(M, cp[(size_t)i * (DH + 2)]);
+    float L = 0.f, O = 0.f;
+    for (int i = 0; i < G; ++i) {
+        const float sc = __builtin_amdgcn_exp2f(cp[(size_t)i * (DH + 2)] - M);
+        L += cp[(size_t)i * (DH + 2) + 1] * sc;
+        O += cp[(size_t)i * (DH + 2) + 2 + d] * sc;
+    }
+    const int b = bh / heads, h = bh % heads;
+    const size_t row = (size_t)b * S;
+    out[row * ldo + h * DH + d] = (bf16)(O / L);
+    if (d == 0) lse2[row * heads + h] = M + log2f(L);
+}
+
 // cls_acc [B, heads, 3, DH] = fp32 sums of (dK, dV, dQ) of the CLS token -> bf16 into the CLS row of dqkv; the dQ slot is
 // only used by the fused kernels (the split path writes the CLS dQ from its own CLS-query pass).
 __global__ void attn_cls_finalize_kernel(const float* __restrict__ cls_acc, int B, int heads, int S, int W, int with_q,
@@ -1721,4 +2004,52 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
         rc = ABI(cls_finalize)(cls_acc, B, heads, S, dqkv, lddq, stream);
     }
     return rc;
+}
+
+// Forward of one divided-attention site, patch rows AND the CLS row: fused single-pass kernels + the CLS merge where the
+// groups fit (SPACE n + 1 <= 112, TIME T + 1 <= 32), the streaming kernels + the CLS-query kernel otherwise.
+// cls_ws: fp32 scratch, at least B * heads * max(T, ceil(n / 28)) * (dh + 2) elements.
+extern "C" int ABI(fwd_divided)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
+                                float* lse2, float* cls_ws, long cls_ws_elems, hipStream_t stream) {
+    if (mode != MODE_SPACE && mode != MODE_TIME) return TVTS_EINVAL;
+    AttnGeom g;
+    int rc = make_geom(g, mode, B, heads, S, T, n, 0, ld);
+    if (rc) return rc;
+    if (ldo % 4) return TVTS_EINVAL;
+    const bool fs = g_fused && g_use_tr && mode == MODE_SPACE && n + 1 <= FUSED_MAX_TILES * 16;
+    const bool ft = g_fused && g_use_tr && mode == MODE_TIME && T + 1 <= 32;
+    const int G = mode == MODE_SPACE ? T : ceil_div(n, TIME_CHUNK);
+    if ((fs || ft) && cls_ws && cls_ws_elems >= (long)B * heads * G * (DH + 2)) {
+        typedef void (*Kern)(AttnGeom, const bf16*, bf16*, int, float*, float*);
+        Kern kern = nullptr;
+        int lds_bytes, blocks;
+        if (fs) {
+            const int MT = (n + 1 + 15) / 16;
+            switch (MT) {
+                case 1: kern = attn_fwd_space_fused_kernel<1, true>; break;
+                case 2: kern = attn_fwd_space_fused_kernel<2, true>; break;
+                case 3: kern = attn_fwd_space_fused_kernel<3, true>; break;
+                case 4: kern = attn_fwd_space_fused_kernel<4, true>; break;
+                case 5: kern = attn_fwd_space_fused_kernel<5, true>; break;
+                case 6: kern = attn_fwd_space_fused_kernel<6, true>; break;
+                default: kern = attn_fwd_space_fused_kernel<7, true>; break;
+            }
+            lds_bytes = 2 * MT * 16 * VSTRIDE;
+            blocks = B * heads * T;
+        } else {
+            const int MT = (T + 1 + 15) / 16;
+            kern = MT == 1 ? attn_fwd_time_fused_kernel<1, true> : attn_fwd_time_fused_kernel<2, true>;
+            lds_bytes = 4 * (MT * 16 * VSTRIDE + (DH + 4) * 4);
+            blocks = B * heads * G;
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2, cls_ws);
+        TVTS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(attn_cls_merge_kernel, dim3(B * heads), dim3(DH <= 64 ? 64 : 128), 0, stream, cls_ws, G, heads, S,
+                           (bf16*)out, ldo, lse2);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
+    rc = ABI(fwd)(mode, qkv, ld, B, heads, S, T, n, 0, out, ldo, lse2, stream);
+    if (rc) return rc;
+    return ABI(fwd)(MODE_CLS, qkv, ld, B, heads, S, T, n, 0, out, ldo, lse2, stream);
 }

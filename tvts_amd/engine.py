@@ -278,8 +278,8 @@ class Engine:
     # ------------------------------------------------------------------ video tower
     def _st_attention_fwd(self, qkv, att, lse, mode, B, T, n):
         h, S = self.arch["heads"], 1 + T * n
-        K.attn_fwd(mode, qkv, att, lse, B=B, heads=h, S=S, T=T, n=n, head_dim=self.dh)
-        K.attn_fwd("cls", qkv, att, lse, B=B, heads=h, S=S, T=T, n=n, head_dim=self.dh)
+        ws = self._f("vit.clsws", (B * h * max(T, -(-n // 28)) * (self.dh + 2),))
+        K.attn_fwd_divided(mode, qkv, att, lse, ws, B=B, heads=h, S=S, T=T, n=n, head_dim=self.dh)
 
     def _st_attention_bwd(self, qkv, att, datt, lse, dqkv, mode, B, T, n, scr):
         h, S = self.arch["heads"], 1 + T * n

@@ -161,6 +161,14 @@ def attn_bwd_dkv(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, cau
     _chk(rc, "tvts_attn_bwd_dkv")
 
 
+def attn_fwd_divided(mode, qkv, out, lse2, cls_ws, *, B, heads, S, T, n, head_dim=64):
+    """Forward of one divided-attention site (patch rows + CLS row); cls_ws is fp32 scratch."""
+    lib = _lib.load()
+    rc = _attn_fn(lib, "fwd_divided", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, _p(out), _ld(out), _p(lse2),
+                                                _p(cls_ws), cls_ws.numel(), _stream())
+    _chk(rc, "tvts_attn_fwd_divided")
+
+
 def attn_bwd(mode, qkv, dO, O, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None, head_dim=64):
     """Whole backward of one attention site into dqkv (delta / cls_acc are scratch)."""
     lib = _lib.load()
