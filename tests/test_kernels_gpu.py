@@ -507,7 +507,7 @@ def test_param_store_shadows(K):
         assert torch.equal(st.wt(name).float(), w.t().to(torch.bfloat16).float())
 
 
-def test_patch_gather_14x14_padded_k(gpu):
+def test_patch_gather_14x14_padded_k(K):
     """H/14 patches: 3*14*14 = 588 columns in conv-weight order, zero-padded to 640 (bit-exact bf16 rounding of the
     pixels), the padded weight copy, and the padded wgrad folded back into a [W, 588] gradient."""
     B, T, img, p, n, W = 2, 3, 56, 14, 5, 64
