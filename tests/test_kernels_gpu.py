@@ -160,11 +160,17 @@ def test_layernorm(K, W, eps):
     assert rel(y32, y) < 1e-5
     dx, dxb = torch.empty(M, W, device=DEV), torch.empty(M, W, dtype=torch.bfloat16, device=DEV)
     dg, db = torch.zeros(W, device=DEV), torch.zeros(W, device=DEV)
-    K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), dx, dx_bf16=dxb, res1=res.to(DEV), res2=res.to(DEV),
+    res2 = bf(rnd(M, W, seed=21))  # the side-branch residual term is a bf16 tensor
+    K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), dx, dx_bf16=dxb, res1=res.to(DEV), res2=res2.to(DEV),
                     dgamma=dg, dbeta=db)
-    assert rel(dx, xr.grad + 2 * res) < 1e-5
-    assert rel(dxb.float(), xr.grad + 2 * res) < 4e-3
+    want = xr.grad + res + res2.float()
+    assert rel(dx, want) < 1e-5
+    assert rel(dxb.float(), want) < 4e-3
     assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+    # bf16-only output (no fp32 gradient tensor)
+    dxb2 = torch.empty_like(dxb)
+    K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), None, dx_bf16=dxb2)
+    assert rel(dxb2.float(), xr.grad) < 4e-3
 
 
 def test_layernorm_rows(K):

@@ -3,7 +3,8 @@
 // forward : y = (x - mean) * rstd * gamma + beta, x fp32 (optionally gathered rows), y bf16 or fp32;
 //           mean / rstd are saved for the backward pass.
 // backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ res1 + res2],  g = dy * gamma
-//           dx fp32 (+ optional bf16 copy that feeds the next MFMA GEMM), dgamma / dbeta accumulated
+//           res1 fp32 (the residual-stream gradient), res2 bf16 (a side-branch gradient that only exists as a GEMM
+//           operand anyway); dx fp32 and / or a bf16 copy that feeds the next MFMA GEMM; dgamma / dbeta accumulated
 //           with per-block partial sums and one fp32 atomic per column per block.
 // Reference: nn.LayerNorm as used at v2/model/video_encoder_ViT_B_16.py:79-85 (eps 1e-5, fp32) and
 // v2/model/sort_transformer.py:99 (eps 1e-6).
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      int ldx, const int* __restrict__ rows,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ res1,
-                                                     const float* __restrict__ res2, int ldr, int M, int W,
+                                                     const bf16* __restrict__ res2, int ldr2, int ldr, int M, int W,
                                                      float* __restrict__ dx, int lddx, bf16* __restrict__ dx_bf16,
                                                      int lddxb, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ float red[2][4][256 * LN_MAX_IT / 64 * 64];  // [gamma|beta][wave][column slot]
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[it][e] - c1 - xh[it][e] * c2);
                 if (res1) o += load4<float>(res1 + (size_t)xr * ldr + c);
-                if (res2) o += load4<float>(res2 + (size_t)xr * ldr + c);
-                store4(dx + (size_t)xr * lddx + c, o);
+                if (res2) o += load4<bf16>(res2 + (size_t)xr * ldr2 + c);
+                if (dx) store4(dx + (size_t)xr * lddx + c, o);
                 if (dx_bf16) store4(dx_bf16 + (size_t)xr * lddxb + c, o);
             }
         }
@@ -171,19 +172,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 
 extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const float* x, int ldx, const int* rows,
                                   const float* mean, const float* rstd, const float* gamma, const float* res1,
-                                  const float* res2, int ldr, int M, int W, float* dx, int lddx, void* dx_bf16,
-                                  int lddxb, float* dgamma, float* dbeta, hipStream_t stream) {
-    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || lddy % 4 || lddx % 4) return TVTS_EINVAL;
-    if ((res1 || res2) && ldr % 4) return TVTS_EINVAL;
+                                  int ldr, const void* res2_bf16, int ldr2, int M, int W, float* dx, int lddx,
+                                  void* dx_bf16, int lddxb, float* dgamma, float* dbeta, hipStream_t stream) {
+    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || lddy % 4) return TVTS_EINVAL;
+    if ((!dx && !dx_bf16) || (dx && lddx % 4)) return TVTS_EINVAL;
+    if ((res1 && ldr % 4) || (res2_bf16 && ldr2 % 4)) return TVTS_EINVAL;
+    const bf16* res2 = (const bf16*)res2_bf16;
     if (dx_bf16 && lddxb % 4) return TVTS_EINVAL;
     int blocks = ceil_div(M, 4);
     if (blocks > 512) blocks = 512;
     if (dy_f32)
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, lddy, x, ldx, rows,
-                           mean, rstd, gamma, res1, res2, ldr, M, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta);
+                           mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)dy, lddy, x, ldx, rows,
-                           mean, rstd, gamma, res1, res2, ldr, M, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta);
+                           mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

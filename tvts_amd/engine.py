@@ -385,7 +385,7 @@ class Engine:
         datt = self._b("vit.s.datt", (M, W))
         dqkv = self._b("vit.s.dqkv", (M, 3 * W))
         dsr, dsrb = self._f("vit.s.dsres", (M, W)), self._b("vit.s.dsresb", (M, W))
-        dtr, dtrb = self._f("vit.s.dtres", (M, W)), self._b("vit.s.dtresb", (M, W))
+        dtrb = self._b("vit.s.dtresb", (M, W))
         for l in reversed(range(a["layers"])):
             pre, tg = f"video_model.transformer.resblocks.{l}.", f"vit{l}"
             x_in = B_[f"vit.x{l}"]
@@ -397,7 +397,9 @@ class Engine:
             self._lin_bwd(dsrb, B_[tg + ".att_s"], pre + "attn.proj.weight", pre + "attn.proj.bias", datt, M)
             self._st_attention_bwd(B_[tg + ".qkv_s"], B_[tg + ".att_s"], datt, B_[tg + ".lse_s"], dqkv, "space", B, T, n, "vit.s")
             self._lin_bwd(dqkv, B_[tg + ".ln1"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", dln, M)
-            self._ln_bwd(dln, B_[tg + ".t_res"], pre + "ln_1", tg + ".ln1", dtr, dx_bf16=dtrb)
+            # the time-residual gradient is a side branch (t_res only feeds ln_1): it lives in bf16 only -- as the operand of
+            # the timeattn.proj GEMMs and as the bf16 residual term of the ln_3 backward
+            self._ln_bwd(dln, B_[tg + ".t_res"], pre + "ln_1", tg + ".ln1", None, dx_bf16=dtrb)
             # temporal attention branch
             self._lin_bwd(dtrb, B_[tg + ".att_t"], pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", datt, M)
             self._st_attention_bwd(B_[tg + ".qkv_t"], B_[tg + ".att_t"], datt, B_[tg + ".lse_t"], dqkv, "time", B, T, n, "vit.s")
@@ -405,7 +407,7 @@ class Engine:
             nx = "B" if (a["layers"] - l) % 2 == 1 else "A"
             dxi, dxbi = self._f("vit.dx" + nx, (M, W)), self._b("vit.dxb" + nx, (M, W))
             # x feeds ln_3, the time residual and the space residual
-            self._ln_bwd(dln, x_in, pre + "ln_3", tg + ".ln3", dxi, dx_bf16=dxbi, res1=dsr, res2=dtr)
+            self._ln_bwd(dln, x_in, pre + "ln_3", tg + ".ln3", dxi, dx_bf16=dxbi, res1=dsr, res2=dtrb)
             dx, dxb = dxi, dxbi
             self._ready(pre + "attn.qkv.weight", pre + "ln_2.bias")
         dtok = self._f("vit.dtok", (M, W))

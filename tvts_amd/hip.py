@@ -117,13 +117,15 @@ def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=Non
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2=None, dgamma=None, dbeta=None,
                   rows=None, M=None):
+    """dx (fp32, may be None when only the bf16 copy is wanted) = LN backward [+ res1 (fp32) + res2 (bf16)]."""
     lib = _lib.load()
     M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
-    ldr = _ld(res1) if res1 is not None else (_ld(res2) if res2 is not None else 0)
+    assert res2 is None or res2.dtype == torch.bfloat16
     rc = lib.tvts_layernorm_bwd(_p(dy), _ld(dy), 1 if dy.dtype == torch.float32 else 0, _p(x), _ld(x), _p(rows),
-                                _p(mean), _p(rstd), _p(gamma), _p(res1), _p(res2), ldr, M, x.shape[1], _p(dx), _ld(dx),
-                                _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0, _p(dgamma), _p(dbeta),
-                                _stream())
+                                _p(mean), _p(rstd), _p(gamma), _p(res1), _ld(res1) if res1 is not None else 0, _p(res2),
+                                _ld(res2) if res2 is not None else 0, M, x.shape[1], _p(dx),
+                                _ld(dx) if dx is not None else 0, _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0,
+                                _p(dgamma), _p(dbeta), _stream())
     _chk(rc, "tvts_layernorm_bwd")
 
 
