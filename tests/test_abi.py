@@ -101,3 +101,29 @@ def test_bench_flop_model_matches_baseline_table():
     for name, T, step in (("B_32", 4, 167.5), ("B_32", 8, 313.3), ("B_16", 8, 606.1)):
         f, b = bench.step_flops_per_pair(A.ARCHS[name], T)
         assert abs((f + b) / 1e9 - step) / step < 0.01
+
+
+def test_gradient_sync_ranges_cover_every_parameter_once():
+    """The backward hands flat gradient ranges to the all-reduce as it finishes them (Engine._ready): for every
+    architecture (B-style and OpenCLIP-style registration order) the ranges must tile the flat buffer exactly once."""
+    import numpy as np
+    from tvts_amd import arch as A
+    CH = 1024
+    for a in list(A.ARCHS.values()) + [A.small_arch(), A.small_arch_h()]:
+        shapes = A.param_shapes(a)
+        off, o = {}, 0
+        for n, s in shapes.items():
+            off[n] = o
+            o += -(-int(np.prod(s)) // CH) * CH
+        cover = np.zeros(o // CH, dtype=int)
+        groups = [("text_",), ("video_model.class_embedding", "video_model.positional_embedding", "video_model.proj",
+                               "video_model.temporal_embedding", "video_model.conv1.", "video_model.ln_pre."),
+                  ("video_model.ln_post.",), ("pred_model.",)]
+        groups += [(f"video_model.transformer.resblocks.{l}.",) for l in range(a["layers"])]
+        for g in groups:
+            names = [n for n in shapes if n.startswith(g)]
+            lo = min(off[n] for n in names)
+            hi = max(off[n] + -(-int(np.prod(shapes[n])) // CH) * CH for n in names)
+            assert [n for n in shapes if lo <= off[n] < hi] == names, (a["name"], g)
+            cover[lo // CH:hi // CH] += 1
+        assert (cover == 1).all(), a["name"]

@@ -152,11 +152,24 @@ class Engine:
         self.requires_grad = {name: True for name in store.shapes}
         self.ctx: dict = {}
         self.grad_ready = None  # optional callback(start, end): flat grad range is final (GradSync.reduce_range)
+        self._ranges: dict = {}
 
-    def _ready(self, first: str, last: str):
-        if self.grad_ready is not None:
-            P = self.P
-            self.grad_ready(P.off[first], P.off[last] + -(-P._n(last) // CH) * CH)
+    def _ready(self, *prefixes: str):
+        """The gradients of every parameter whose name starts with one of `prefixes` are final: hand their flat range
+        (contiguous in state-dict order, whichever registration order the architecture uses) to the gradient sync."""
+        if self.grad_ready is None:
+            return
+        P = self.P
+        key = prefixes
+        rng = self._ranges.get(key)
+        if rng is None:
+            names = [n for n in P.shapes if n.startswith(prefixes)]
+            lo = min(P.off[n] for n in names)
+            hi = max(P.off[n] + -(-P._n(n) // CH) * CH for n in names)
+            inside = [n for n in P.shapes if lo <= P.off[n] < hi]
+            assert inside == names, f"parameters {prefixes} are not contiguous in the flat buffer"
+            rng = self._ranges[key] = (lo, hi)
+        self.grad_ready(*rng)
 
     # ------------------------------------------------------------------ workspace
     def _b(self, name, shape, dtype=torch.bfloat16, zero=False):
@@ -409,7 +422,7 @@ class Engine:
             # x feeds ln_3, the time residual and the space residual
             self._ln_bwd(dln, x_in, pre + "ln_3", tg + ".ln3", dxi, dx_bf16=dxbi, res1=dsr, res2=dtrb)
             dx, dxb = dxi, dxbi
-            self._ready(pre + "attn.qkv.weight", pre + "ln_2.bias")
+            self._ready(pre)
         dtok = self._f("vit.dtok", (M, W))
         self._ln_bwd(dx, B_["vit.tok"], "video_model.ln_pre", "vit.lnpre", dtok)
         dpatch = self._b("vit.dpatch", (Mp, W))
@@ -423,8 +436,9 @@ class Engine:
                 scr = self._f("vit.s.dconv", (W, self.P.conv_kpad))
                 K.gemm_tn(dpatch, B_["vit.im2col"], scr, M=Mp, accumulate=False)
                 K.add_rows_f32(self.P.g2d("video_model.conv1.weight"), scr)
-        self._ready("video_model.class_embedding", "video_model.ln_pre.bias")
-        self._ready("video_model.ln_post.weight", "video_model.ln_post.bias")
+        self._ready("video_model.class_embedding", "video_model.positional_embedding", "video_model.proj",
+                    "video_model.temporal_embedding", "video_model.conv1.", "video_model.ln_pre.")
+        self._ready("video_model.ln_post.")
 
     # ------------------------------------------------------------------ sort head
     def sort_forward(self, out, text_before, B, S, NT):
@@ -531,7 +545,7 @@ class Engine:
             dxs = self.sort_backward(d_pred, B, S, NT)
             K.sort_assemble_bwd(dxs, dv_cls, dout, self.P.g("pred_model.type_embed").view(2, E), B=B, S=S, off=off,
                                 Sv=S - off, NT=NT)
-            self._ready("pred_model.type_embed", "pred_model.head.bias")
+            self._ready("pred_model.")
         elif not self.pooled_tail:
             K.sort_assemble_bwd(None, dv_cls, dout, None, B=B, S=S, off=0, Sv=S, NT=NT)
         else:
@@ -541,7 +555,7 @@ class Engine:
             dt = self._f("mdl.dt", (N, E))
             K.text_mean_bwd(d_text, dt, NT=NT, B=B)
             self.text_backward(dt, pb["ids"], pb["eot_rows"], N, L)
-            self._ready("text_positional_embedding", "text_ln_final.bias")
+            self._ready("text_")
 
 
 class LossHead:
