@@ -1430,6 +1430,11 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
             if (eff >= 0.93) { splits = sp; break; }
         }
     }
+    // the partials must fit the caller's workspace: fewer, longer ranges beat the atomic fallback
+    if (workspace != nullptr && splits > 1 && (long)splits * Na * Nb > workspace_elems) {
+        const int fit = (int)(workspace_elems / ((long)Na * Nb));
+        if (fit >= 2) splits = fit;
+    }
     g.m_per_split = ceil_div(ceil_div(M, splits), 64) * 64;
     splits = ceil_div(M, g.m_per_split);
     // split partials: plain stores into the caller's workspace + one reduce pass (an fp32 atomic epilogue costs

@@ -65,13 +65,13 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
         GEMM_PROFILE.append(("gemm_nt", 2.0 * M * N * K, ev0, ev1, (M, N, K, "f32" if out.dtype == torch.float32 else "bf16", "res" if residual is not None else "", str(act or ""), "gate" if gate_h is not None else "")))
 
 
-TN_WORKSPACE = None  # fp32 scratch tensor for the split partials of gemm_tn (allocated lazily, 96 MiB)
+TN_WORKSPACE = None  # fp32 scratch tensor for the split partials of gemm_tn (allocated lazily, 256 MiB: 8 partials of the largest weight, H/14 mlp 1280 x 5120)
 
 
 def _tn_workspace(dev):
     global TN_WORKSPACE
     if TN_WORKSPACE is None or TN_WORKSPACE.device != dev:
-        TN_WORKSPACE = torch.empty(24 * 1024 * 1024, dtype=torch.float32, device=dev)
+        TN_WORKSPACE = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev)
     return TN_WORKSPACE
 
 
