@@ -26,105 +26,157 @@ __device__ __forceinline__ void store4(bf16* p, f32x4 v) {
     *(bf16x4*)p = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 }
 
-template <typename TO>
+// Both kernels are templated on IT = ceil(W / 256) (register arrays sized to the row, no dead iterations) and walk
+// their rows in a grid-stride loop with the NEXT row's loads issued before the current row's reductions: a wave always
+// has two rows of traffic in flight instead of one load -> reduce -> store round trip at a time.
+template <typename TO, int IT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ rows,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, int M, int W, TO* __restrict__ y, int ldy,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int stride = gridDim.x * 4;
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
-    const int xr = rows ? rows[r] : r;
-    const float* xp = x + (size_t)xr * ldx;
-    f32x4 v[LN_MAX_IT];
-    float s = 0.f;
+    f32x4 gm[IT], bt[IT];
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
+    for (int it = 0; it < IT; ++it) {
         const int c = lane * 4 + it * 256;
-        if (c < W) {
-            v[it] = load4<float>(xp + c);
-            s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
-        }
+        gm[it] = c < W ? load4<float>(gamma + c) : (f32x4){0, 0, 0, 0};
+        bt[it] = c < W ? load4<float>(beta + c) : (f32x4){0, 0, 0, 0};
     }
-    const float mean = wave_sum(s) / (float)W;
-    float q = 0.f;
+    const float invW = 1.0f / (float)W;
+    f32x4 v[IT], nx[IT];
+    auto load_row = [&](int rr, f32x4 (&d)[IT]) {
+        const float* xp = x + (size_t)(rows ? rows[rr] : rr) * ldx;
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
-        const int c = lane * 4 + it * 256;
-        if (c < W) {
+        for (int it = 0; it < IT; ++it) {
+            const int c = lane * 4 + it * 256;
+            d[it] = c < W ? load4<float>(xp + c) : (f32x4){0, 0, 0, 0};
+        }
+    };
+    load_row(r, v);
+    for (; r < M; r += stride) {
+        const bool more = r + stride < M;
+        if (more) load_row(r + stride, nx);
+        float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[it][e] - mean;
-                q += d * d;
+        for (int it = 0; it < IT; ++it) s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
+        const float mean = wave_sum(s) * invW;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = lane * 4 + it * 256;
+            if (c < W) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[it][e] - mean;
+                    q += d * d;
+                }
             }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+        const float rstd = rsqrtf(wave_sum(q) * invW + eps);
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
-        const int c = lane * 4 + it * 256;
-        if (c < W) {
-            const f32x4 g = load4<float>(gamma + c), b = load4<float>(beta + c);
-            f32x4 o;
+        for (int it = 0; it < IT; ++it) {
+            const int c = lane * 4 + it * 256;
+            if (c < W) {
+                f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd * g[e] + b[e];
-            store4(y + (size_t)r * ldy + c, o);
+                for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd * gm[it][e] + bt[it][e];
+                store4(y + (size_t)r * ldy + c, o);
+            }
+        }
+        if (lane == 0) {
+            if (mean_out) mean_out[r] = mean;
+            if (rstd_out) rstd_out[r] = rstd;
+        }
+        if (more) {
+#pragma unroll
+            for (int it = 0; it < IT; ++it) v[it] = nx[it];
         }
     }
-    if (lane == 0) {
-        if (mean_out) mean_out[r] = mean;
-        if (rstd_out) rstd_out[r] = rstd;
-    }
+}
+
+template <typename TO>
+static void launch_ln_fwd(int it, dim3 grid, hipStream_t stream, const float* x, int ldx, const int* rows, const float* gamma,
+                          const float* beta, float eps, int M, int W, TO* y, int ldy, float* mean, float* rstd) {
+#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<TO, N>), grid, dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd); break;
+    switch (it) { LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) default: LN_FWD_CASE(5) }
+#undef LN_FWD_CASE
 }
 
 extern "C" int tvts_layernorm_fwd(const float* x, int ldx, const int* rows, const float* gamma, const float* beta,
                                   float eps, int M, int W, void* y, int ldy, int y_f32, float* mean, float* rstd,
                                   hipStream_t stream) {
     if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || ldy % 4) return TVTS_EINVAL;
-    const dim3 grid(ceil_div(M, 4)), block(256);
-    if (y_f32)
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, stream, x, ldx, rows, gamma, beta, eps, M, W, (float*)y,
-                           ldy, mean, rstd);
-    else
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, block, 0, stream, x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y,
-                           ldy, mean, rstd);
+    int blocks = ceil_div(M, 4);
+    if (blocks > 2048) blocks = 2048;  // 8 blocks x 4 waves per CU, two rows in flight per wave
+    const int it = ceil_div(W, 256);
+    if (y_f32) launch_ln_fwd<float>(it, dim3(blocks), stream, x, ldx, rows, gamma, beta, eps, M, W, (float*)y, ldy, mean, rstd);
+    else launch_ln_fwd<bf16>(it, dim3(blocks), stream, x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
 
-template <typename TDY>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const float* __restrict__ x,
-                                                     int ldx, const int* __restrict__ rows,
-                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ gamma, const float* __restrict__ res1,
-                                                     const bf16* __restrict__ res2, int ldr2, int ldr, int M, int W,
-                                                     float* __restrict__ dx, int lddx, bf16* __restrict__ dx_bf16,
-                                                     int lddxb, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float red[2][4][256 * LN_MAX_IT / 64 * 64];  // [gamma|beta][wave][column slot]
+template <typename TDY> struct RawDy;
+template <> struct RawDy<float> { typedef f32x4 T; };
+template <> struct RawDy<bf16> { typedef bf16x4 T; };
+__device__ __forceinline__ f32x4 widen(f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 widen(bf16x4 v) { return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+
+template <typename TDY, int IT>
+__global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const float* __restrict__ x,
+                                                        int ldx, const int* __restrict__ rows,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ res1,
+                                                        const bf16* __restrict__ res2, int ldr2, int ldr, int M, int W,
+                                                        float* __restrict__ dx, int lddx, bf16* __restrict__ dx_bf16,
+                                                        int lddxb, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    typedef typename RawDy<TDY>::T DyV;
+    __shared__ float red[2][4][IT * 256];  // [gamma|beta][wave][column slot]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 ag[LN_MAX_IT], ab[LN_MAX_IT], gm[LN_MAX_IT];
+    f32x4 ag[IT], ab[IT], gm[IT];
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
+    for (int it = 0; it < IT; ++it) {
         ag[it] = (f32x4){0, 0, 0, 0};
         ab[it] = (f32x4){0, 0, 0, 0};
         const int c = lane * 4 + it * 256;
         gm[it] = c < W ? load4<float>(gamma + c) : (f32x4){0, 0, 0, 0};
     }
     const float invW = 1.0f / (float)W;
-    for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
-        const int xr = rows ? rows[r] : r;
-        const float mu = mean[r], rs = rstd[r];
-        f32x4 xh[LN_MAX_IT], g[LN_MAX_IT];
-        float s1 = 0.f, s2 = 0.f;
+    const int stride = gridDim.x * 4;
+    struct Row { f32x4 x[IT]; DyV d[IT]; f32x4 r1[IT]; bf16x4 r2[IT]; float mu, rs; int xr; };
+    auto load_row = [&](int rr, Row& w) {
+        w.xr = rows ? rows[rr] : rr;
+        w.mu = mean[rr];
+        w.rs = rstd[rr];
 #pragma unroll
-        for (int it = 0; it < LN_MAX_IT; ++it) {
+        for (int it = 0; it < IT; ++it) {
             const int c = lane * 4 + it * 256;
             if (c < W) {
-                const f32x4 xv = load4<float>(x + (size_t)xr * ldx + c);
-                const f32x4 d = load4<TDY>(dy + (size_t)r * lddy + c);
+                w.x[it] = load4<float>(x + (size_t)w.xr * ldx + c);
+                w.d[it] = *(const DyV*)(dy + (size_t)rr * lddy + c);
+                if (res1) w.r1[it] = load4<float>(res1 + (size_t)w.xr * ldr + c);
+                if (res2) w.r2[it] = *(const bf16x4*)(res2 + (size_t)w.xr * ldr2 + c);
+            }
+        }
+    };
+    int r = blockIdx.x * 4 + wave;
+    Row cur, nxt;
+    if (r < M) load_row(r, cur);
+    for (; r < M; r += stride) {
+        const bool more = r + stride < M;
+        if (more) load_row(r + stride, nxt);
+        f32x4 xh[IT], g[IT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = lane * 4 + it * 256;
+            if (c < W) {
+                const f32x4 d = widen(cur.d[it]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    xh[it][e] = (xv[e] - mu) * rs;
+                    xh[it][e] = (cur.x[it][e] - cur.mu) * cur.rs;
                     g[it][e] = d[e] * gm[it][e];
                     s1 += g[it][e];
                     s2 += g[it][e] * xh[it][e];
@@ -135,30 +187,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         }
         const float c1 = wave_sum(s1) * invW, c2 = wave_sum(s2) * invW;
 #pragma unroll
-        for (int it = 0; it < LN_MAX_IT; ++it) {
+        for (int it = 0; it < IT; ++it) {
             const int c = lane * 4 + it * 256;
             if (c < W) {
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rs * (g[it][e] - c1 - xh[it][e] * c2);
-                if (res1) o += load4<float>(res1 + (size_t)xr * ldr + c);
-                if (res2) o += load4<bf16>(res2 + (size_t)xr * ldr2 + c);
-                if (dx) store4(dx + (size_t)xr * lddx + c, o);
-                if (dx_bf16) store4(dx_bf16 + (size_t)xr * lddxb + c, o);
+                for (int e = 0; e < 4; ++e) o[e] = cur.rs * (g[it][e] - c1 - xh[it][e] * c2);
+                if (res1) o += cur.r1[it];
+                if (res2) o += widen(cur.r2[it]);
+                if (dx) store4(dx + (size_t)cur.xr * lddx + c, o);
+                if (dx_bf16) store4(dx_bf16 + (size_t)cur.xr * lddxb + c, o);
             }
         }
+        if (more) cur = nxt;
     }
     if (!dgamma) return;
     // block reduce the per-wave partials, then one atomic per column per block
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it)
+    for (int it = 0; it < IT; ++it)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             red[0][wave][(it * 4 + e) * 64 + lane] = ag[it][e];
             red[1][wave][(it * 4 + e) * 64 + lane] = ab[it][e];
         }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < LN_MAX_IT * 4 * 64; idx += 256) {
+    for (int idx = threadIdx.x; idx < IT * 4 * 64; idx += 256) {
         const int l = idx & 63, ie = idx >> 6;
         const int c = l * 4 + (ie >> 2) * 256 + (ie & 3);
         if (c < W) {
@@ -168,6 +221,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
             atomicAdd(dbeta + c, sb);
         }
     }
+}
+
+template <typename TDY>
+static void launch_ln_bwd(int it, dim3 grid, hipStream_t stream, const TDY* dy, int lddy, const float* x, int ldx, const int* rows,
+                          const float* mean, const float* rstd, const float* gamma, const float* res1, const bf16* res2,
+                          int ldr2, int ldr, int M, int W, float* dx, int lddx, bf16* dxb, int lddxb, float* dgamma,
+                          float* dbeta) {
+#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta); break;
+    switch (it) { LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) default: LN_BWD_CASE(5) }
+#undef LN_BWD_CASE
 }
 
 extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const float* x, int ldx, const int* rows,
@@ -180,13 +243,14 @@ extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const fl
     const bf16* res2 = (const bf16*)res2_bf16;
     if (dx_bf16 && lddxb % 4) return TVTS_EINVAL;
     int blocks = ceil_div(M, 4);
-    if (blocks > 512) blocks = 512;
+    if (blocks > 512) blocks = 512;  // 2 blocks per CU (register-limited), two rows in flight per wave
+    const int it = ceil_div(W, 256);
     if (dy_f32)
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, lddy, x, ldx, rows,
-                           mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta);
+        launch_ln_bwd<float>(it, dim3(blocks), stream, (const float*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2,
+                             ldr, M, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)dy, lddy, x, ldx, rows,
-                           mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta);
+        launch_ln_bwd<bf16>(it, dim3(blocks), stream, (const bf16*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2,
+                            ldr, M, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
