@@ -43,7 +43,7 @@ int tvts_layernorm_fwd(const float* x, int ldx, const int* rows, const float* ga
 int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const float* x, int ldx, const int* rows, const float* mean,
                        const float* rstd, const float* gamma, const float* res1, int ldr, const void* res2_bf16, int ldr2,
                        int M, int W, float* dx, int lddx, void* dx_bf16, int lddxb, float* dgamma, float* dbeta,
-                       hipStream_t stream);
+                       float* workspace, long workspace_elems, hipStream_t stream);
 
 /* ---- attention (attention.hip), head dim 64, packed qkv [rows, 3*heads*64]:
  *      divided space-time attention video_encoder_ViT_B_16.py:11-15,38-76; causal text attention

@@ -167,6 +167,10 @@ def test_layernorm(K, W, eps):
     assert rel(dx, want) < 1e-5
     assert rel(dxb.float(), want) < 4e-3
     assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+    # the atomic fallback of the dgamma / dbeta reduction (no workspace) gives the same sums
+    dg2, db2 = torch.zeros(W, device=DEV), torch.zeros(W, device=DEV)
+    K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), dx, dgamma=dg2, dbeta=db2, workspace=False)
+    assert rel(dg2, gr.grad) < 1e-4 and rel(db2, br.grad) < 1e-4
     # bf16-only output (no fp32 gradient tensor)
     dxb2 = torch.empty_like(dxb)
     K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), None, dx_bf16=dxb2)

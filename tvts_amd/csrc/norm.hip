@@ -5,7 +5,8 @@
 // backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ res1 + res2],  g = dy * gamma
 //           res1 fp32 (the residual-stream gradient), res2 bf16 (a side-branch gradient that only exists as a GEMM
 //           operand anyway); dx fp32 and / or a bf16 copy that feeds the next MFMA GEMM; dgamma / dbeta accumulated
-//           with per-block partial sums and one fp32 atomic per column per block.
+//           from per-block partial sums: written to a workspace and combined by a second tiny kernel (or, without
+//           a workspace, one fp32 atomic per column per block).
 // Reference: nn.LayerNorm as used at v2/model/video_encoder_ViT_B_16.py:79-85 (eps 1e-5, fp32) and
 // v2/model/sort_transformer.py:99 (eps 1e-6).
 #include "common.h"
@@ -124,14 +125,15 @@ template <> struct RawDy<bf16> { typedef bf16x4 T; };
 __device__ __forceinline__ f32x4 widen(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 widen(bf16x4 v) { return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 
-template <typename TDY, int IT>
-__global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const float* __restrict__ x,
+template <typename TDY, int IT, bool R1, bool R2>
+__global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : 2) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                         int ldx, const int* __restrict__ rows,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ res1,
                                                         const bf16* __restrict__ res2, int ldr2, int ldr, int M, int W,
                                                         float* __restrict__ dx, int lddx, bf16* __restrict__ dx_bf16,
-                                                        int lddxb, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                        int lddxb, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        float* __restrict__ partial) {
     typedef typename RawDy<TDY>::T DyV;
     __shared__ float red[2][4][IT * 256];  // [gamma|beta][wave][column slot]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const TDY* __restrict__ 
     }
     const float invW = 1.0f / (float)W;
     const int stride = gridDim.x * 4;
-    struct Row { f32x4 x[IT]; DyV d[IT]; f32x4 r1[IT]; bf16x4 r2[IT]; float mu, rs; int xr; };
+    struct Row { f32x4 x[IT]; DyV d[IT]; f32x4 r1[R1 ? IT : 1]; bf16x4 r2[R2 ? IT : 1]; float mu, rs; int xr; };
     auto load_row = [&](int rr, Row& w) {
         w.xr = rows ? rows[rr] : rr;
         w.mu = mean[rr];
@@ -156,8 +158,8 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const TDY* __restrict__ 
             if (c < W) {
                 w.x[it] = load4<float>(x + (size_t)w.xr * ldx + c);
                 w.d[it] = *(const DyV*)(dy + (size_t)rr * lddy + c);
-                if (res1) w.r1[it] = load4<float>(res1 + (size_t)w.xr * ldr + c);
-                if (res2) w.r2[it] = *(const bf16x4*)(res2 + (size_t)w.xr * ldr2 + c);
+                if (R1) w.r1[it] = load4<float>(res1 + (size_t)w.xr * ldr + c);
+                if (R2) w.r2[it] = *(const bf16x4*)(res2 + (size_t)w.xr * ldr2 + c);
             }
         }
     };
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const TDY* __restrict__ 
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = cur.rs * (g[it][e] - c1 - xh[it][e] * c2);
-                if (res1) o += cur.r1[it];
-                if (res2) o += widen(cur.r2[it]);
+                if (R1) o += cur.r1[it];
+                if (R2) o += widen(cur.r2[it]);
                 if (dx) store4(dx + (size_t)cur.xr * lddx + c, o);
                 if (dx_bf16) store4(dx_bf16 + (size_t)cur.xr * lddxb + c, o);
             }
@@ -217,40 +219,91 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const TDY* __restrict__ 
         if (c < W) {
             const float sg = red[0][0][idx] + red[0][1][idx] + red[0][2][idx] + red[0][3][idx];
             const float sb = red[1][0][idx] + red[1][1][idx] + red[1][2][idx] + red[1][3][idx];
-            atomicAdd(dgamma + c, sg);
-            atomicAdd(dbeta + c, sb);
+            if (partial) {  // per-block partial sums, combined by ln_dgamma_reduce_kernel (plain stores, deterministic)
+                partial[((size_t)blockIdx.x * 2 + 0) * W + c] = sg;
+                partial[((size_t)blockIdx.x * 2 + 1) * W + c] = sb;
+            } else {        // no workspace: one atomic per column per block
+                atomicAdd(dgamma + c, sg);
+                atomicAdd(dbeta + c, sb);
+            }
         }
     }
 }
 
-template <typename TDY>
-static void launch_ln_bwd(int it, dim3 grid, hipStream_t stream, const TDY* dy, int lddy, const float* x, int ldx, const int* rows,
+// dgamma[c] += sum_b partial[b][0][c], dbeta[c] += sum_b partial[b][1][c]
+__global__ __launch_bounds__(1024) void ln_dgamma_reduce_kernel(const float* __restrict__ partial, int nblocks, int W,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    // 64 columns x 16 row-groups per block: each thread sums nblocks / 16 partials with 8 independent loads in flight
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int k = blockIdx.y;
+    __shared__ float acc[16][64];
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < W) {
+        int b = part;
+        for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += partial[((size_t)(b + u * 16) * 2 + k) * W + c];
+        }
+        for (; b < nblocks; b += 16) s[0] += partial[((size_t)b * 2 + k) * W + c];
+    }
+    acc[part][threadIdx.x & 63] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (part == 0 && c < W) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += acc[p][threadIdx.x];
+        float* dst = k == 0 ? dgamma : dbeta;
+        dst[c] += t;
+    }
+}
+
+template <typename TDY, bool R1, bool R2>
+static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int lddy, const float* x, int ldx, const int* rows,
                           const float* mean, const float* rstd, const float* gamma, const float* res1, const bf16* res2,
-                          int ldr2, int ldr, int M, int W, float* dx, int lddx, bf16* dxb, int lddxb, float* dgamma,
-                          float* dbeta) {
-#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta); break;
+                          int ldr2, int ldr, int W, float* dx, int lddx, bf16* dxb, int lddxb, float* dgamma, float* dbeta,
+                          float* ws, long ws_elems) {
+    // persistent grid: as many blocks per CU as the variant's registers allow (see __launch_bounds__ above)
+    const int per_cu = it <= 3 ? ((R1 || R2) ? 3 : 4) : 2;
+    int blocks = ceil_div(M, 4);
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    const dim3 grid(blocks);
+    float* partial = (dgamma && ws && ws_elems >= (long)blocks * 2 * W) ? ws : nullptr;
+#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N, R1, R2>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta, partial); break;
     switch (it) { LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) default: LN_BWD_CASE(5) }
 #undef LN_BWD_CASE
+    if (partial)
+        hipLaunchKernelGGL(ln_dgamma_reduce_kernel, dim3(ceil_div(W, 64), 2), dim3(1024), 0, stream, partial, blocks, W, dgamma, dbeta);
+}
+template <typename TDY>
+static void launch_ln_bwd_res(int it, int M, hipStream_t stream, const TDY* dy, int lddy, const float* x, int ldx,
+                              const int* rows, const float* mean, const float* rstd, const float* gamma, const float* res1,
+                              const bf16* res2, int ldr2, int ldr, int W, float* dx, int lddx, bf16* dxb, int lddxb,
+                              float* dgamma, float* dbeta, float* ws, long ws_elems) {
+#define LN_ARGS it, M, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, W, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_elems
+    if (res1 && res2) launch_ln_bwd<TDY, true, true>(LN_ARGS);
+    else if (res1) launch_ln_bwd<TDY, true, false>(LN_ARGS);
+    else if (res2) launch_ln_bwd<TDY, false, true>(LN_ARGS);
+    else launch_ln_bwd<TDY, false, false>(LN_ARGS);
+#undef LN_ARGS
 }
 
 extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const float* x, int ldx, const int* rows,
                                   const float* mean, const float* rstd, const float* gamma, const float* res1,
                                   int ldr, const void* res2_bf16, int ldr2, int M, int W, float* dx, int lddx,
-                                  void* dx_bf16, int lddxb, float* dgamma, float* dbeta, hipStream_t stream) {
+                                  void* dx_bf16, int lddxb, float* dgamma, float* dbeta, float* workspace,
+                                  long workspace_elems, hipStream_t stream) {
     if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || lddy % 4) return TVTS_EINVAL;
     if ((!dx && !dx_bf16) || (dx && lddx % 4)) return TVTS_EINVAL;
     if ((res1 && ldr % 4) || (res2_bf16 && ldr2 % 4)) return TVTS_EINVAL;
     const bf16* res2 = (const bf16*)res2_bf16;
     if (dx_bf16 && lddxb % 4) return TVTS_EINVAL;
-    int blocks = ceil_div(M, 4);
-    if (blocks > 512) blocks = 512;  // 2 blocks per CU (register-limited), two rows in flight per wave
     const int it = ceil_div(W, 256);
     if (dy_f32)
-        launch_ln_bwd<float>(it, dim3(blocks), stream, (const float*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2,
-                             ldr, M, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta);
+        launch_ln_bwd_res<float>(it, M, stream, (const float*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, W,
+                                 dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems);
     else
-        launch_ln_bwd<bf16>(it, dim3(blocks), stream, (const bf16*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2,
-                            ldr, M, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta);
+        launch_ln_bwd_res<bf16>(it, M, stream, (const bf16*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, W,
+                                dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

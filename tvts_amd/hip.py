@@ -115,17 +115,29 @@ def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=Non
     _chk(rc, "tvts_layernorm_fwd")
 
 
+LN_WORKSPACE = None  # fp32 scratch for the per-block dgamma/dbeta partials of layernorm_bwd (1024 blocks x 2 x 1280)
+
+
+def _ln_workspace(dev):
+    global LN_WORKSPACE
+    if LN_WORKSPACE is None or LN_WORKSPACE.device != dev:
+        LN_WORKSPACE = torch.empty(1024 * 2 * 1280, dtype=torch.float32, device=dev)
+    return LN_WORKSPACE
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2=None, dgamma=None, dbeta=None,
-                  rows=None, M=None):
-    """dx (fp32, may be None when only the bf16 copy is wanted) = LN backward [+ res1 (fp32) + res2 (bf16)]."""
+                  rows=None, M=None, workspace=True):
+    """dx (fp32, may be None when only the bf16 copy is wanted) = LN backward [+ res1 (fp32) + res2 (bf16)];
+    dgamma / dbeta are ACCUMULATED (+=) from per-block partials in a shared scratch buffer."""
     lib = _lib.load()
+    ws = _ln_workspace(x.device) if (workspace and dgamma is not None) else None
     M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
     assert res2 is None or res2.dtype == torch.bfloat16
     rc = lib.tvts_layernorm_bwd(_p(dy), _ld(dy), 1 if dy.dtype == torch.float32 else 0, _p(x), _ld(x), _p(rows),
                                 _p(mean), _p(rstd), _p(gamma), _p(res1), _ld(res1) if res1 is not None else 0, _p(res2),
                                 _ld(res2) if res2 is not None else 0, M, x.shape[1], _p(dx),
                                 _ld(dx) if dx is not None else 0, _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0,
-                                _p(dgamma), _p(dbeta), _stream())
+                                _p(dgamma), _p(dbeta), _p(ws), ws.numel() if ws is not None else 0, _stream())
     _chk(rc, "tvts_layernorm_bwd")
 
 
