@@ -3,7 +3,7 @@
 out=$1; ctrs=$2; shift 3
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf $out
-timeout 240 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o p -- "$@" > $out.log 2>&1
+timeout 90 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o p -- "$@" > $out.log 2>&1
 f=$(find $out -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
