@@ -126,7 +126,7 @@ __device__ __forceinline__ f32x4 widen(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 widen(bf16x4 v) { return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 
 template <typename TDY, int IT, bool R1, bool R2>
-__global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : 2) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const float* __restrict__ x,
+__global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 && R2) ? 2 : 3)) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                         int ldx, const int* __restrict__ rows,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ res1,
@@ -163,12 +163,14 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : 2) void ln_bw
             }
         }
     };
+    constexpr bool PF = IT <= 3;  // wider rows (1024, 1280 columns) do not have the registers for a second row in flight
     int r = blockIdx.x * 4 + wave;
     Row cur, nxt;
-    if (r < M) load_row(r, cur);
+    if (PF && r < M) load_row(r, cur);
     for (; r < M; r += stride) {
-        const bool more = r + stride < M;
-        if (more) load_row(r + stride, nxt);
+        const bool more = PF && r + stride < M;
+        if (PF) { if (more) load_row(r + stride, nxt); }
+        else load_row(r, cur);
         f32x4 xh[IT], g[IT];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -263,7 +265,7 @@ static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int 
                           int ldr2, int ldr, int W, float* dx, int lddx, bf16* dxb, int lddxb, float* dgamma, float* dbeta,
                           float* ws, long ws_elems) {
     // persistent grid: as many blocks per CU as the variant's registers allow (see __launch_bounds__ above)
-    const int per_cu = it <= 3 ? ((R1 || R2) ? 3 : 4) : 2;
+    const int per_cu = it <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 && R2) ? 2 : 3);
     int blocks = ceil_div(M, 4);
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     const dim3 grid(blocks);
