@@ -1039,6 +1039,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, cons
     }
 }
 
+// Coalesced store of one 16-row x DH output tile held in the MFMA C layout (lane (li = row, gq) holds columns
+// dt*16 + gq*4 .. +3 of its row): written straight from registers that is one 8-byte piece per lane and instruction,
+// 32 bytes per row -- measured at half the fused TIME backward's run time.  Two dt-columns (a 64-byte row segment) at a
+// time go through a 1 KiB wave-private LDS patch (16-byte chunks XOR-swizzled by row) so that every lane stores 16
+// contiguous bytes and four neighbouring lanes complete the segment.  rowfn(row) -> destination of that row's first
+// head column, or nullptr for a masked row.
+template <typename RowFn>
+__device__ __forceinline__ void store_tile_rows(char* patch, const f32x4 (&v)[DT], int lane, RowFn rowfn) {
+    const int li = lane & 15, gq = lane >> 4;
+    const int rrow = lane >> 2, rc = lane & 3;
+    bf16* dst = rowfn(rrow);
+#pragma unroll
+    for (int d2 = 0; d2 < (DT + 1) / 2; ++d2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int dt = 2 * d2 + h;
+            if (dt < DT) {
+                const int pidx = h * 4 + gq;  // 8-byte piece of the 64-byte row segment
+                *(bf16x4*)(patch + li * 64 + (((pidx >> 1) ^ (li & 3)) << 4) + (pidx & 1) * 8) =
+                    (bf16x4){(bf16)v[dt][0], (bf16)v[dt][1], (bf16)v[dt][2], (bf16)v[dt][3]};
+            }
+        }
+        // the 8-byte writes and the 16-byte read below use different vector types: keep the compiler from reordering them
+        // on type-based alias grounds (the LDS itself executes a wave's accesses in order)
+        asm volatile("" ::: "memory");
+        const bf16x8 w = *(const bf16x8*)(patch + rrow * 64 + ((rc ^ (rrow & 3)) << 4));
+        asm volatile("" ::: "memory");
+        if (dst && 2 * d2 + (rc >> 1) < DT) *(bf16x8*)(dst + d2 * 32 + rc * 8) = w;
+    }
+}
+
 // ================================================================================================
 // FUSED SPACE-geometry backward: one block per (b, frame, head) group does dQ, dK and dV in one launch.
 // The group's token set X = {CLS, the n kept patches of the frame} serves as the extended query set AND the key
@@ -1097,6 +1128,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void attn_bwd_space_fused_kernel(
     char* Ds = Vs + TB;
     float* st_lse = (float*)(Ds + TB);
     float* st_dl = st_lse + RA;
+    char* opatch = (char*)(st_dl + RA) + wave * 1024;  // this wave's output-staging patch
     const int gq = lane >> 4, li = lane & 15;
     const int hcol = r.h * DH;
 
@@ -1179,12 +1211,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void attn_bwd_space_fused_kernel(
             for (int dt = 0; dt < DT; ++dt)
                 acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ks, u, dt, lane, RA), dsf, acc[dt], 0, 0, 0);
         }
-        if (qj >= 1 && qj < m) {
-            bf16* dq = dqkv + (size_t)k_row<MODE_SPACE>(g, r, qj) * lddq + hcol;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                *(bf16x4*)(dq + dt * 16 + gq * 4) = (bf16x4){(bf16)acc[dt][0], (bf16)acc[dt][1], (bf16)acc[dt][2], (bf16)acc[dt][3]};
-        } else if (qj == 0) {  // this frame's share of the CLS query gradient
+        store_tile_rows(opatch, acc, lane, [&](int rr) -> bf16* {
+            const int j = qt * 16 + rr;
+            return (j >= 1 && j < m) ? dqkv + (size_t)k_row<MODE_SPACE>(g, r, j) * lddq + hcol : nullptr; });
+        if (qj == 0) {  // this frame's share of the CLS query gradient
             float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3 + 2) * DH;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
@@ -1241,27 +1271,23 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void attn_bwd_space_fused_kernel(
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Qs, u, dt, lane, RA), dsf, dk[dt], 0, 0, 0);
             }
         }
-        if (kj < m) {
-            if (kj == 0) {  // CLS key/value: summed over the frames of (b,h)
-                float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH;
+        if (kj == 0) {  // CLS key/value: summed over the frames of (b,h)
+            float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH;
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        atomicAdd(a + dt * 16 + gq * 4 + e, dk[dt][e]);
-                        atomicAdd(a + DH + dt * 16 + gq * 4 + e, dv[dt][e]);
-                    }
-            } else {
-                const size_t row = (size_t)k_row<MODE_SPACE>(g, r, kj) * lddq;
-                bf16* dkp = dqkv + row + g.W + hcol;
-                bf16* dvp = dqkv + row + 2 * g.W + hcol;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    *(bf16x4*)(dkp + dt * 16 + gq * 4) = (bf16x4){(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
-                    *(bf16x4*)(dvp + dt * 16 + gq * 4) = (bf16x4){(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(a + dt * 16 + gq * 4 + e, dk[dt][e]);
+                    atomicAdd(a + DH + dt * 16 + gq * 4 + e, dv[dt][e]);
                 }
-            }
         }
+        auto krowp = [&](int third) {
+            return [&, third](int rr) -> bf16* {
+                const int j = kt * 16 + rr;
+                return (j >= 1 && j < m) ? dqkv + (size_t)k_row<MODE_SPACE>(g, r, j) * lddq + third * g.W + hcol : nullptr; };
+        };
+        store_tile_rows(opatch, dk, lane, krowp(1));
+        store_tile_rows(opatch, dv, lane, krowp(2));
     }
 }
 
@@ -1276,7 +1302,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
                                                                   bf16* __restrict__ dqkv, int lddq, float* __restrict__ cls_acc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RA = MT * 16, TB = RA * VSTRIDE, NU = (MT + 1) / 2;
-    constexpr int WB = 4 * TB + 2 * RA * 4 + 3 * DH * 4;  // bytes of one wave's region: tiles, stats, CLS sums
+    constexpr int WB = 4 * TB + 2 * RA * 4 + 3 * DH * 4 + 1024;  // bytes of one wave's region: tiles, stats, CLS sums, output patch
     constexpr int PT = (RA * NCH + 63) / 64;         // 16-byte chunks per lane per tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char* base = smem + wave * WB;
@@ -1287,6 +1313,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
     float* st_lse = (float*)(Ds + TB);
     float* st_dl = st_lse + RA;
     float* csum = st_dl + RA;                        // [dK | dV | dQ][DH] of the CLS token, summed over this wave's groups
+    char* opatch = (char*)(csum + 3 * DH);           // output-staging patch
     const int chunks = (g.n + TIME_CHUNK - 1) / TIME_CHUNK;
     Grp r;  // block order (b, chunk, h): the heads of one token range run next to each other
     r.h = blockIdx.x % g.heads;
@@ -1385,12 +1412,9 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
                 for (int dt = 0; dt < DT; ++dt)
                     acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ks, u, dt, lane, RA), dsf, acc[dt], 0, 0, 0);
             }
-            if (qj >= 1 && qj < m) {
-                bf16* dq = dqkv + (size_t)k_row<MODE_TIME>(g, r, qj) * lddq + hcol;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    *(bf16x4*)(dq + dt * 16 + gq * 4) = (bf16x4){(bf16)acc[dt][0], (bf16)acc[dt][1], (bf16)acc[dt][2], (bf16)acc[dt][3]};
-            }
+            store_tile_rows(opatch, acc, lane, [&](int rr) -> bf16* {
+                const int j = qt * 16 + rr;
+                return (j >= 1 && j < m) ? dqkv + (size_t)k_row<MODE_TIME>(g, r, j) * lddq + hcol : nullptr; });
             if (qt == 0 && li == 0) {  // column 0 = the CLS query: this group's share of its gradient
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
@@ -1456,16 +1480,13 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
                     *c2 += dv[dt];
                 }
             }
-            if (kj >= 1 && kj < m) {
-                const size_t row = (size_t)k_row<MODE_TIME>(g, r, kj) * lddq;
-                bf16* dkp = dqkv + row + g.W + hcol;
-                bf16* dvp = dqkv + row + 2 * g.W + hcol;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    *(bf16x4*)(dkp + dt * 16 + gq * 4) = (bf16x4){(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
-                    *(bf16x4*)(dvp + dt * 16 + gq * 4) = (bf16x4){(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
-                }
-            }
+            auto krowp = [&](int third) {
+                return [&, third](int rr) -> bf16* {
+                    const int j = kt * 16 + rr;
+                    return (j >= 1 && j < m) ? dqkv + (size_t)k_row<MODE_TIME>(g, r, j) * lddq + third * g.W + hcol : nullptr; };
+            };
+            store_tile_rows(opatch, dk, lane, krowp(1));
+            store_tile_rows(opatch, dv, lane, krowp(2));
         }
     }
     // combine the four waves' CLS sums: one set of atomics per block
@@ -1497,6 +1518,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_space_fused_kernel(AttnGeom g
     const int m = g.n + 1;
     char* Ks = smem;
     char* Vs = Ks + TB;
+    char* opatch = Vs + TB + wave * 1024;  // this wave's output-staging patch
     const int gq = lane >> 4, li = lane & 15;
     const int hcol = r.h * DH;
     {
@@ -1569,14 +1591,17 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_space_fused_kernel(AttnGeom g
             for (int dt = 0; dt < DT; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Vs, u, dt, lane, RA), pf, o[dt], 0, 0, 0);
         }
-        if (qj >= 1 && qj < m) {
+        {
             const float inv = 1.0f / l;
-            const int row = k_row<MODE_SPACE>(g, r, qj);
-            bf16* op = out + (size_t)row * ldo + hcol;
+            f32x4 on[DT];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                *(bf16x4*)(op + dt * 16 + gq * 4) = (bf16x4){(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
-            if (gq == 0) lse2[(size_t)row * g.heads + r.h] = mx + log2f(l);
+            for (int dt = 0; dt < DT; ++dt) on[dt] = o[dt] * inv;
+            store_tile_rows(opatch, on, lane, [&](int rr) -> bf16* {
+                const int j = qt * 16 + rr;
+                return (j >= 1 && j < m) ? out + (size_t)k_row<MODE_SPACE>(g, r, j) * ldo + hcol : nullptr; });
+        }
+        if (qj >= 1 && qj < m) {
+            if (gq == 0) lse2[(size_t)k_row<MODE_SPACE>(g, r, qj) * g.heads + r.h] = mx + log2f(l);
         } else if (qj == 0) {  // this frame's partial softmax state of the CLS query
             float* cp = cls_part + ((size_t)(r.b * g.heads + r.h) * g.T + r.sub) * (DH + 2);
             if (gq == 0) { cp[0] = mx; cp[1] = l; }
@@ -1598,10 +1623,11 @@ __global__ __launch_bounds__(256) void attn_fwd_time_fused_kernel(AttnGeom g, co
                                                                   float* __restrict__ cls_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // per wave: V tile | CLS state [DH + 2]
     constexpr int RA = MT * 16, TB = RA * VSTRIDE, NU = (MT + 1) / 2;
-    constexpr int WB = TB + (DH + 2 + 2) * 4;
+    constexpr int WB = TB + (DH + 2 + 2) * 4 + 1024;
     constexpr int PT = (RA * NCH + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char* Vs = smem + wave * WB;
+    char* opatch = Vs + TB + (DH + 4) * 4;  // output-staging patch (behind the V tile and the CLS state)
     const int chunks = (g.n + TIME_CHUNK - 1) / TIME_CHUNK;
     Grp r;
     r.h = blockIdx.x % g.heads;
@@ -1693,15 +1719,16 @@ __global__ __launch_bounds__(256) void attn_fwd_time_fused_kernel(AttnGeom g, co
                 for (int dt = 0; dt < DT; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Vs, u, dt, lane, RA), pf, o[dt], 0, 0, 0);
             }
-            if (qj >= 1 && qj < m) {
+            {
                 const float inv = 1.0f / l;
-                const int row = k_row<MODE_TIME>(g, r, qj);
-                bf16* op = out + (size_t)row * ldo + hcol;
+                f32x4 on[DT];
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    *(bf16x4*)(op + dt * 16 + gq * 4) = (bf16x4){(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
-                if (gq == 0) lse2[(size_t)row * g.heads + r.h] = mx + log2f(l);
+                for (int dt = 0; dt < DT; ++dt) on[dt] = o[dt] * inv;
+                store_tile_rows(opatch, on, lane, [&](int rr) -> bf16* {
+                    const int j = qt * 16 + rr;
+                    return (j >= 1 && j < m) ? out + (size_t)k_row<MODE_TIME>(g, r, j) * ldo + hcol : nullptr; });
             }
+            if (qj >= 1 && qj < m && gq == 0) lse2[(size_t)k_row<MODE_TIME>(g, r, qj) * g.heads + r.h] = mx + log2f(l);
             if (qt == 0) {  // column 0 = the CLS query: fold this group's state into the running one
                 const float Mn = fmaxf(Mr, mx);
                 const float a = __builtin_amdgcn_exp2f(Mr - Mn), b = __builtin_amdgcn_exp2f(mx - Mn);
@@ -1960,7 +1987,7 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
         int lds_bytes = 0, blocks = 0, threads = 0, slot = 0;
         if (fused_space) {
             const int MT = (n + 1 + 15) / 16, RA = MT * 16;
-            lds_bytes = 4 * RA * VSTRIDE + 2 * RA * (int)sizeof(float);
+            lds_bytes = 4 * RA * VSTRIDE + 2 * RA * (int)sizeof(float) + (FUSED_THREADS / 64) * 1024;
             switch (MT) {
                 case 1: kern = attn_bwd_space_fused_kernel<1, true>; break;
                 case 2: kern = attn_bwd_space_fused_kernel<2, true>; break;
@@ -1973,7 +2000,7 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
             blocks = B * heads * T; threads = FUSED_THREADS; slot = MT;
         } else {
             const int MT = (T + 1 + 15) / 16, RA = MT * 16;
-            lds_bytes = 4 * (4 * RA * VSTRIDE + 2 * RA * 4 + 3 * DH * 4);
+            lds_bytes = 4 * (4 * RA * VSTRIDE + 2 * RA * 4 + 3 * DH * 4 + 1024);
             kern = MT == 1 ? attn_bwd_time_fused_kernel<1, true> : attn_bwd_time_fused_kernel<2, true>;
             blocks = B * heads * ceil_div(n, TIME_CHUNK); threads = 256; slot = FUSED_MAX_TILES + MT;
         }
@@ -2034,12 +2061,12 @@ extern "C" int ABI(fwd_divided)(int mode, const void* qkv, int ld, int B, int he
                 case 6: kern = attn_fwd_space_fused_kernel<6, true>; break;
                 default: kern = attn_fwd_space_fused_kernel<7, true>; break;
             }
-            lds_bytes = 2 * MT * 16 * VSTRIDE;
+            lds_bytes = 2 * MT * 16 * VSTRIDE + 4 * 1024;
             blocks = B * heads * T;
         } else {
             const int MT = (T + 1 + 15) / 16;
             kern = MT == 1 ? attn_fwd_time_fused_kernel<1, true> : attn_fwd_time_fused_kernel<2, true>;
-            lds_bytes = 4 * (MT * 16 * VSTRIDE + (DH + 4) * 4);
+            lds_bytes = 4 * (MT * 16 * VSTRIDE + (DH + 4) * 4 + 1024);
             blocks = B * heads * G;
         }
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2, cls_ws);
