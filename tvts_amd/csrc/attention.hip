@@ -172,6 +172,37 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// Coalesced store of one 16-row x DH output tile held in the MFMA C layout (lane (li = row, gq) holds columns
+// dt*16 + gq*4 .. +3 of its row): written straight from registers that is one 8-byte piece per lane and instruction,
+// 32 bytes per row -- measured at half the fused TIME backward's run time.  Two dt-columns (a 64-byte row segment) at a
+// time go through a 1 KiB wave-private LDS patch (16-byte chunks XOR-swizzled by row) so that every lane stores 16
+// contiguous bytes and four neighbouring lanes complete the segment.  rowfn(row) -> destination of that row's first
+// head column, or nullptr for a masked row.
+template <typename RowFn>
+__device__ __forceinline__ void store_tile_rows(char* patch, const f32x4 (&v)[DT], int lane, RowFn rowfn) {
+    const int li = lane & 15, gq = lane >> 4;
+    const int rrow = lane >> 2, rc = lane & 3;
+    bf16* dst = rowfn(rrow);
+#pragma unroll
+    for (int d2 = 0; d2 < (DT + 1) / 2; ++d2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int dt = 2 * d2 + h;
+            if (dt < DT) {
+                const int pidx = h * 4 + gq;  // 8-byte piece of the 64-byte row segment
+                *(bf16x4*)(patch + li * 64 + (((pidx >> 1) ^ (li & 3)) << 4) + (pidx & 1) * 8) =
+                    (bf16x4){(bf16)v[dt][0], (bf16)v[dt][1], (bf16)v[dt][2], (bf16)v[dt][3]};
+            }
+        }
+        // the 8-byte writes and the 16-byte read below use different vector types: keep the compiler from reordering them
+        // on type-based alias grounds (the LDS itself executes a wave's accesses in order)
+        asm volatile("" ::: "memory");
+        const bf16x8 w = *(const bf16x8*)(patch + rrow * 64 + ((rc ^ (rrow & 3)) << 4));
+        asm volatile("" ::: "memory");
+        if (dst && 2 * d2 + (rc >> 1) < DT) *(bf16x8*)(dst + d2 * 32 + rc * 8) = w;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int MODE, bool TR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* __restrict__ qkv, bf16* __restrict__ out,
@@ -678,17 +709,17 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const 
             stage_store64(sv, nb + TILE_B, tid);
         }
     }
-    if (active && qi < r.nq) {
+    __syncthreads();  // every wave is done with the K/V tiles: their LDS now serves as the output-staging patches
+    {
         const float inv = 1.0f / l_run;
-        const int row = q_row<MODE>(g, r, qi);
-        bf16* op = out + (size_t)row * ldo + hcol;
+        f32x4 on[DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const bf16x4 v = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
-            *(bf16x4*)(op + dt * 16 + gq * 4) = v;
-        }
-        if (gq == 0) lse2[(size_t)row * g.heads + r.h] = m_run + log2f(l_run);
+        for (int dt = 0; dt < DT; ++dt) on[dt] = o[dt] * inv;
+        store_tile_rows(smem + wave * 1024, on, lane, [&](int rr) -> bf16* {
+            const int j = q0 + rr;
+            return (active && j < r.nq) ? out + (size_t)q_row<MODE>(g, r, j) * ldo + hcol : nullptr; });
     }
+    if (active && qi < r.nq && gq == 0) lse2[(size_t)q_row<MODE>(g, r, qi) * g.heads + r.h] = m_run + log2f(l_run);
 }
 
 template <int MODE, bool TR>
@@ -786,12 +817,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_shared_kernel(AttnGeom g, con
             stage_store64(sv, nb + TILE_B, tid);
         }
     }
-    if (active && qi < r.nq) {
-        bf16* dq = dqkv + (size_t)qrow * lddq + hcol;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            *(bf16x4*)(dq + dt * 16 + gq * 4) = (bf16x4){(bf16)acc[dt][0], (bf16)acc[dt][1], (bf16)acc[dt][2], (bf16)acc[dt][3]};
-    }
+    __syncthreads();  // the K/V tiles are dead: reuse their LDS as output-staging patches
+    store_tile_rows(smem + wave * 1024, acc, lane, [&](int rr) -> bf16* {
+        const int j = q0 + rr;
+        return (active && j < r.nq) ? dqkv + (size_t)q_row<MODE>(g, r, j) * lddq + hcol : nullptr; });
 }
 
 template <int MODE, bool TR>
@@ -899,26 +928,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
             if (tid < 64) stat[buf ^ 1][tid >> 5][tid & 31] = sstat;
         }
     }
-    if (active && kj < r.nk) {
-        if (EXT && kj == 0) {
-            float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH;
+    if (active && kj < r.nk && EXT && kj == 0) {
+        float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    atomicAdd(a + dt * 16 + gq * 4 + e, dk[dt][e]);
-                    atomicAdd(a + DH + dt * 16 + gq * 4 + e, dv[dt][e]);
-                }
-        } else {
-            bf16* dkp = dqkv + (size_t)krow_ * lddq + g.W + hcol;
-            bf16* dvp = dqkv + (size_t)krow_ * lddq + 2 * g.W + hcol;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                *(bf16x4*)(dkp + dt * 16 + gq * 4) = (bf16x4){(bf16)dk[dt][0], (bf16)dk[dt][1], (bf16)dk[dt][2], (bf16)dk[dt][3]};
-                *(bf16x4*)(dvp + dt * 16 + gq * 4) = (bf16x4){(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(a + dt * 16 + gq * 4 + e, dk[dt][e]);
+                atomicAdd(a + DH + dt * 16 + gq * 4 + e, dv[dt][e]);
             }
-        }
     }
+    __syncthreads();  // the Q/dO tiles are dead: reuse their LDS as output-staging patches
+    auto krowp = [&](int third) {
+        return [&, third](int rr) -> bf16* {
+            const int j = k0 + rr;
+            return (active && j < r.nk && !(EXT && j == 0)) ? dqkv + (size_t)k_row<MODE>(g, r, j) * lddq + third * g.W + hcol : nullptr; };
+    };
+    store_tile_rows(smem + wave * 1024, dk, lane, krowp(1));
+    store_tile_rows(smem + wave * 1024, dv, lane, krowp(2));
 }
 
 // TIME geometry dK/dV: the groups are tiny (T queries x T+1 keys) and very many (B*h*n).  A block takes one
@@ -1036,37 +1063,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, cons
         const int kv = threadIdx.x / DH, d = threadIdx.x % DH;
         const float v = red[0][kv][d] + red[1][kv][d] + red[2][kv][d] + red[3][kv][d];
         atomicAdd(cls_acc + ((size_t)(r.b * g.heads + r.h) * 3 + kv) * DH + d, v);
-    }
-}
-
-// Coalesced store of one 16-row x DH output tile held in the MFMA C layout (lane (li = row, gq) holds columns
-// dt*16 + gq*4 .. +3 of its row): written straight from registers that is one 8-byte piece per lane and instruction,
-// 32 bytes per row -- measured at half the fused TIME backward's run time.  Two dt-columns (a 64-byte row segment) at a
-// time go through a 1 KiB wave-private LDS patch (16-byte chunks XOR-swizzled by row) so that every lane stores 16
-// contiguous bytes and four neighbouring lanes complete the segment.  rowfn(row) -> destination of that row's first
-// head column, or nullptr for a masked row.
-template <typename RowFn>
-__device__ __forceinline__ void store_tile_rows(char* patch, const f32x4 (&v)[DT], int lane, RowFn rowfn) {
-    const int li = lane & 15, gq = lane >> 4;
-    const int rrow = lane >> 2, rc = lane & 3;
-    bf16* dst = rowfn(rrow);
-#pragma unroll
-    for (int d2 = 0; d2 < (DT + 1) / 2; ++d2) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int dt = 2 * d2 + h;
-            if (dt < DT) {
-                const int pidx = h * 4 + gq;  // 8-byte piece of the 64-byte row segment
-                *(bf16x4*)(patch + li * 64 + (((pidx >> 1) ^ (li & 3)) << 4) + (pidx & 1) * 8) =
-                    (bf16x4){(bf16)v[dt][0], (bf16)v[dt][1], (bf16)v[dt][2], (bf16)v[dt][3]};
-            }
-        }
-        // the 8-byte writes and the 16-byte read below use different vector types: keep the compiler from reordering them
-        // on type-based alias grounds (the LDS itself executes a wave's accesses in order)
-        asm volatile("" ::: "memory");
-        const bf16x8 w = *(const bf16x8*)(patch + rrow * 64 + ((rc ^ (rrow & 3)) << 4));
-        asm volatile("" ::: "memory");
-        if (dst && 2 * d2 + (rc >> 1) < DT) *(bf16x8*)(dst + d2 * 32 + rc * 8) = w;
     }
 }
 
