@@ -583,6 +583,58 @@ def train_step(P: Params, batch: dict, arch, opt_state: dict, truncate_text: boo
     return float(loss1), float(loss2), grads
 
 
+# --------------------------------------------------------------------------------------
+# validation metrics (v2/model/metric.py:16-126,129-187,285-296; trainer.py:527-635) -- SURVEY.md 8f N1
+# --------------------------------------------------------------------------------------
+
+def t2v_ranks(sims):
+    """metric.py:28-66: rank of each text query's own video in sims [n_text, n_vid], ties broken optimistically
+    (the first position of the ground-truth distance in the sorted row)."""
+    import numpy as np
+    sims = np.asarray(sims, dtype=np.float32)
+    nq, nv = sims.shape
+    q = nq // nv
+    dists = -sims
+    sorted_d = np.sort(dists, axis=1)
+    cols = np.empty(nq, dtype=np.float64)
+    for i in range(nq):
+        cols[i] = np.where(sorted_d[i] - dists[i, i // q] == 0)[0][0]
+    return cols
+
+
+def v2t_ranks(sims):
+    """metric.py:143-187: for each video the best rank among its own captions in sims.T, ties averaged."""
+    import numpy as np
+    d = -np.asarray(sims, dtype=np.float32).T  # [n_vid, n_caps]
+    nv, nc = d.shape
+    q = nc // nv
+    out = np.empty(nv, dtype=np.float64)
+    for i in range(nv):
+        sd = np.sort(d[i])
+        out[i] = min(np.where(sd - d[i, j] == 0)[0].mean() for j in range(i * q, (i + 1) * q))
+    return out
+
+
+def cols2metrics(cols, num_queries=None):
+    """metric.py:285-296."""
+    import numpy as np
+    cols = np.asarray(cols, dtype=np.float64)
+    n = len(cols) if num_queries is None else num_queries
+    m = {"R1": 100 * float(np.sum(cols == 0)) / n, "R5": 100 * float(np.sum(cols < 5)) / n,
+         "R10": 100 * float(np.sum(cols < 10)) / n, "R50": 100 * float(np.sum(cols < 50)) / n,
+         "MedR": float(np.median(cols) + 1), "MeanR": float(np.mean(cols) + 1)}
+    stats = [m["R1"], m["R5"], m["R10"]]
+    m["geometric_mean_R1-R5-R10"] = float(np.exp(np.mean(np.log(stats)))) if min(stats) > 0 else 0.0
+    return m
+
+
+def sorting_accuracy(pred_argmax, labels):
+    """trainer.py:575-583: a sample counts when ALL of its NT predicted positions are right -> (hits, samples)."""
+    import numpy as np
+    pred_argmax, labels = np.asarray(pred_argmax), np.asarray(labels)
+    return int(np.all(pred_argmax == labels, axis=1).sum()), int(pred_argmax.shape[0])
+
+
 def step_flops_per_pair(arch, T: int, caption_len: int = 32, NT: int = 4) -> Tuple[float, float]:
     """Algorithmic matmul FLOPs per video-text pair (fwd, bwd) -- SURVEY.md 8d formula."""
     p, W, E, Wt = arch["patch"], arch["width"], arch["embed"], arch["text_width"]

@@ -427,6 +427,27 @@ def gen_model_h14():
          batch_seed=0, B=2, T=4, gn_names=np.array(names), gn_vals=torch.stack(vals), **sel)
 
 
+def gen_metrics():
+    """v2/model/metric.py t2v_metrics / v2t_metrics on similarity matrices with and without ties, 1 and 2 captions
+    per video (the functions are executed as they are; ipdb is the only import that needs a stub)."""
+    _stub("ipdb")
+    mm = _load("ref_metric", os.path.join(REF, "model/metric.py"))
+    rng = np.random.RandomState(5)
+    out = {}
+    cases = {"rand_square": rng.randn(37, 37).astype(np.float32),
+             "ties_square": np.round(rng.randn(29, 29) * 1.5).astype(np.float32) / 2,   # many exact ties
+             "two_caps": rng.randn(40, 20).astype(np.float32),
+             "two_caps_ties": np.round(rng.randn(24, 12) * 2).astype(np.float32)}
+    cases["rand_square"][np.arange(37), np.arange(37)] += 1.5  # a model that has learnt something
+    keys = ["R1", "R5", "R10", "R50", "MedR", "MeanR", "geometric_mean_R1-R5-R10"]
+    for name, sims in cases.items():
+        out["sims_" + name] = sims
+        for fn in ("t2v_metrics", "v2t_metrics"):
+            res = getattr(mm, fn)(sims.copy())
+            out[f"{fn}_{name}"] = np.array([float(res[k]) for k in keys], dtype=np.float64)
+    save("metrics", keys=np.array(keys), **out)
+
+
 def gen_groups():
     """Name -> optimizer group, by executing the reference entrypoint's own grouping statements
     (train_dist_TVTSv2_ViT_B_16.py:66-107) on a module exposing the A13 parameter names."""
@@ -497,7 +518,7 @@ def gen_ddp2():
 
 
 GENS = {"block": gen_block, "vit": gen_vit, "text": gen_text, "sort": gen_sort, "model_tiny": gen_model_tiny,
-        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14}
+        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

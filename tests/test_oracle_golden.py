@@ -236,3 +236,16 @@ def test_model_h14_config3(golden):
     for k, (name, idx) in sl.items():
         assert relerr(f[k], P[name].grad[idx]) < 5e-4, k
     assert relerr(f["g_conv"], P["video_model.conv1.weight"].grad[:4].reshape(4, -1)) < 5e-4
+
+
+def test_retrieval_metrics(golden):
+    """v2/model/metric.py t2v_metrics / v2t_metrics (executed in the build container) on matrices with and without ties."""
+    f = golden("metrics")
+    keys = [str(k) for k in f["keys"]]
+    for name in ("rand_square", "ties_square", "two_caps", "two_caps_ties"):
+        sims = f["sims_" + name]
+        for fn, ranks in (("t2v_metrics", O.t2v_ranks), ("v2t_metrics", O.v2t_ranks)):
+            got = O.cols2metrics(ranks(sims))
+            want = dict(zip(keys, f[f"{fn}_{name}"]))
+            for k in keys:
+                assert abs(got[k] - want[k]) < 1e-9 * max(1.0, abs(want[k])), (name, fn, k, got[k], want[k])

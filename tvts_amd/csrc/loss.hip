@@ -109,3 +109,52 @@ extern "C" int tvts_cross_entropy(const float* logits, const int* labels, int R,
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- validation metrics
+// Rank of the ground truth in a text x video similarity matrix (x[i, j] = <text_i, video_j>, n_text = q * n_vid, the
+// captions of video j are rows j*q .. j*q + q - 1), exactly as v2/model/metric.py ranks with its "sort, then find the
+// positions equal to the ground-truth distance" formulation:
+//   mode 0 (t2v_metrics :16-126, ties broken optimistically): ranks[i] = #{ j : x[i, j] > x[i, i / q] }
+//   mode 1 (v2t_metrics :129-187, ties averaged, closest own caption): for video j,
+//          ranks[j] = min over its captions c of  #{ k : x[k, j] > x[c, j] } + (#{ k : x[k, j] == x[c, j] } - 1) / 2
+// One block per query; comparisons are exact fp32 like the reference's numpy.
+__global__ __launch_bounds__(256) void retrieval_rank_kernel(const float* __restrict__ x, long ld, int n_text, int n_vid, int q,
+                                                             int mode, float* __restrict__ ranks) {
+    __shared__ int red[2][4];
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = mode == 0 ? n_vid : n_text;               // candidates of this query
+    const long cs = mode == 0 ? 1 : ld;                      // stride between candidates
+    const float* base = mode == 0 ? x + (long)i * ld : x + i;
+    const int ngt = mode == 0 ? 1 : q;
+    float best = 3.0e38f;
+    for (int c = 0; c < ngt; ++c) {
+        const int gt_idx = mode == 0 ? i / q : i * q + c;
+        const float gt = base[(long)gt_idx * cs];
+        int greater = 0, equal = 0;
+        for (int k = threadIdx.x; k < n; k += 256) {
+            const float v = base[(long)k * cs];
+            greater += v > gt;
+            equal += v == gt;
+        }
+        greater = (int)wave_sum((float)greater);  // counts < 2^24: exact in fp32
+        equal = (int)wave_sum((float)equal);
+        __syncthreads();
+        if (lane == 0) { red[0][wave] = greater; red[1][wave] = equal; }
+        __syncthreads();
+        const int g_all = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const int e_all = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const float rank = mode == 0 ? (float)g_all : (float)g_all + 0.5f * (float)(e_all - 1);
+        best = rank < best ? rank : best;
+    }
+    if (threadIdx.x == 0) ranks[i] = best;
+}
+extern "C" int tvts_retrieval_ranks(const float* sims, long ld, int n_text, int n_vid, int mode, float* ranks,
+                                    hipStream_t stream) {
+    if (n_text <= 0 || n_vid <= 0 || n_text % n_vid || (mode != 0 && mode != 1) || n_text >= (1 << 24)) return TVTS_EINVAL;
+    const int q = n_text / n_vid;
+    hipLaunchKernelGGL(retrieval_rank_kernel, dim3(mode == 0 ? n_text : n_vid), dim3(256), 0, stream, sims, ld, n_text, n_vid, q,
+                       mode, ranks);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}

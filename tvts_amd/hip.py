@@ -289,6 +289,17 @@ def cross_entropy(logits, labels, scale, dlogits, loss):
                                 _stream()), "tvts_cross_entropy")
 
 
+def retrieval_ranks(sims, mode):
+    """ranks of the ground truth per query of a text x video similarity matrix; mode 't2v' | 'v2t'."""
+    lib = _lib.load()
+    assert sims.dtype == torch.float32 and sims.dim() == 2 and sims.stride(1) == 1
+    nt, nv = sims.shape
+    ranks = torch.empty(nt if mode == "t2v" else nv, dtype=torch.float32, device=sims.device)
+    _chk(lib.tvts_retrieval_ranks(_p(sims), sims.stride(0), nt, nv, 0 if mode == "t2v" else 1, _p(ranks), _stream()),
+         "tvts_retrieval_ranks")
+    return ranks
+
+
 def adamw_hf(p, g, m, v, shadow, chunk_group, lr4, wd4, step, beta1=0.9, beta2=0.999, eps=1e-6, grad_scale=1.0,
              step_dev=None):
     lib = _lib.load()

@@ -146,24 +146,71 @@ class _TrainerBase(Multi_BaseTrainer_dist):
 
     @torch.no_grad()
     def _valid_epoch(self, epoch):
-        """Sorting accuracy + contrastive loss on the validation loaders (a reduced form of trainer.py:527-635;
-        the numpy retrieval metrics of model/metric.py stay out of scope)."""
-        res = {}
+        """Validation after an epoch (v2/trainer/trainer.py:527-635): eval forward on the HIP engine, embeddings /
+        labels / predicted orders gathered over the ranks, sorting accuracy (a sample counts when all of its NT
+        positions are right, :575-583), and the configured retrieval metrics on the text x video similarity matrix
+        of everything seen -- similarity and ranks computed on the device (tvts_amd.model.metric)."""
+        from ..model._common import sim_matrix
+        self.model.eval()
+        world = self.args.world_size if dist.is_available() and dist.is_initialized() else 1
+
+        def gather(t):
+            if world == 1:
+                return t
+            parts = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(parts, t.contiguous())
+            return torch.cat(parts, dim=0)
+
+        res_dict, nested = {}, {}
         for dl_idx, dl in enumerate(self.valid_data_loader):
-            correct, count = 0, 0
+            hits, count = 0, 0
+            text_arr, vid_arr = [], []
             for data in dl:
                 data = self._tokenize(data)
                 te, ve, pred = self.model(data, return_embeds=True)
-                if pred is not None and "label" in data:
-                    lab = data["label"].to(pred.device)
-                    correct += int((pred.argmax(-1) == lab).sum())
-                    count += lab.numel()
-            if count:
-                t = torch.tensor([correct, count], dtype=torch.float64, device=self.device)
-                if self.args.world_size > 1:
-                    dist.all_reduce(t)
-                res[f"val_loss_{dl_idx}"] = float(t[0] / t[1])  # (sic) the reference logs accuracy under this key (:585-588,630)
-        return res
+                text_arr.append(gather(te.detach().float()))
+                vid_arr.append(gather(ve.detach().float()))
+                if pred is not None:
+                    labels_all = gather(data["label"].to(pred.device))
+                    preds_all = gather(pred.argmax(dim=-1))
+                    hits += int((preds_all == labels_all).all(dim=1).sum())
+                    count += preds_all.shape[0]
+                else:  # the reference reports 1 / 1 for loaders without transcripts (:590-592)
+                    hits, count = 1, 1
+            sims = sim_matrix(torch.cat(text_arr), torch.cat(vid_arr))
+            name = getattr(dl, "dataset_name", f"val{dl_idx}")
+            nested[dl_idx] = {}
+            for metric in self.metrics:
+                res = metric(sims)
+                nested[dl_idx][metric.__name__] = res
+                if self.args.rank == 0:
+                    verbose(epoch=epoch, metrics=res, name=name, mode=metric.__name__)
+                    if self.writer is not None:
+                        for key, val in format_nested_metrics_for_writer(res, mode=metric.__name__, name=name).items():
+                            self.writer.log_scalar(key, val)
+            if self.writer is not None and self.args.rank == 0:
+                self.writer.log_scalar(f"loss_val_{dl_idx}", hits / max(len(dl), 1))
+            if self.args.rank == 0:
+                res_dict[f"val_loss_{dl_idx}"] = hits / count  # (sic) the reference logs the accuracy under this key (:630)
+        if self.args.rank == 0 and "val_loss_0" in res_dict:
+            print("Top-1 Accuracy for Frame Prediction:", res_dict["val_loss_0"])
+        self.last_val_metrics = nested
+        self.model.train()
+        return res_dict
+
+
+def verbose(epoch, metrics, mode, name="TEST"):
+    """v2/trainer/trainer.py:942-947."""
+    r1, r5, r10, r50 = metrics["R1"], metrics["R5"], metrics["R10"], metrics["R50"]
+    msg = f"[{mode}]{name:s} epoch {epoch}, R@1: {r1:.1f}"
+    msg += f", R@5: {r5:.1f}, R@10: {r10:.1f}, R@50: {r50:.1f}"
+    msg += f", MedR: {metrics['MedR']:g}, MeanR: {metrics['MeanR']:.1f}"
+    print(msg)
+
+
+def format_nested_metrics_for_writer(metrics, mode, name="TEST"):
+    """v2/trainer/trainer.py:950-955."""
+    return {f"[{mode}]{name}_{key}": val for key, val in metrics.items()}
 
 
 class Trainer_TVTSv2_B_32(_TrainerBase):
