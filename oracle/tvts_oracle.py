@@ -135,25 +135,26 @@ def param_shapes(arch) -> "Dict[str, Tuple[int, ...]]":
             out[pre + k] = blk[k]
     out["video_model.ln_post.weight"] = (W,)
     out["video_model.ln_post.bias"] = (W,)
-    out["pred_model.type_embed"] = (1, 2, E)
-    for i in range(arch["sort_depth"]):
-        pre = f"pred_model.blocks.{i}."
-        out[pre + "norm1.weight"] = (E,)
-        out[pre + "norm1.bias"] = (E,)
-        out[pre + "attn.qkv.weight"] = (3 * E, E)
-        out[pre + "attn.qkv.bias"] = (3 * E,)
-        out[pre + "attn.proj.weight"] = (E, E)
-        out[pre + "attn.proj.bias"] = (E,)
-        out[pre + "norm2.weight"] = (E,)
-        out[pre + "norm2.bias"] = (E,)
-        out[pre + "mlp.fc1.weight"] = (4 * E, E)
-        out[pre + "mlp.fc1.bias"] = (4 * E,)
-        out[pre + "mlp.fc2.weight"] = (E, 4 * E)
-        out[pre + "mlp.fc2.bias"] = (E,)
-    out["pred_model.norm.weight"] = (E,)
-    out["pred_model.norm.bias"] = (E,)
-    out["pred_model.head.weight"] = (arch["n_trans"], E)
-    out["pred_model.head.bias"] = (arch["n_trans"],)
+    if arch.get("sort_head", True):  # the downstream inference models carry no transcript-sorting head
+        out["pred_model.type_embed"] = (1, 2, E)
+        for i in range(arch["sort_depth"]):
+            pre = f"pred_model.blocks.{i}."
+            out[pre + "norm1.weight"] = (E,)
+            out[pre + "norm1.bias"] = (E,)
+            out[pre + "attn.qkv.weight"] = (3 * E, E)
+            out[pre + "attn.qkv.bias"] = (3 * E,)
+            out[pre + "attn.proj.weight"] = (E, E)
+            out[pre + "attn.proj.bias"] = (E,)
+            out[pre + "norm2.weight"] = (E,)
+            out[pre + "norm2.bias"] = (E,)
+            out[pre + "mlp.fc1.weight"] = (4 * E, E)
+            out[pre + "mlp.fc1.bias"] = (4 * E,)
+            out[pre + "mlp.fc2.weight"] = (E, 4 * E)
+            out[pre + "mlp.fc2.bias"] = (E,)
+        out["pred_model.norm.weight"] = (E,)
+        out["pred_model.norm.bias"] = (E,)
+        out["pred_model.head.weight"] = (arch["n_trans"], E)
+        out["pred_model.head.bias"] = (arch["n_trans"],)
     return out
 
 
@@ -357,6 +358,8 @@ def video_tower(P: Params, video: Tensor, keep_ind: Tensor, arch,
         video = video.unsqueeze(1)
     T = video.shape[1]
     n = keep_ind.shape[1]
+    if keep_ind.shape[0] == 1 and video.shape[0] > 1:  # one tube mask broadcast over the batch (downstream scripts)
+        keep_ind = keep_ind.expand(video.shape[0], -1)
     x = video_embed_tokens(P, video, keep_ind, arch)
     if taps is not None:
         taps["vit_in"] = x
@@ -457,7 +460,7 @@ def model_forward(P: Params, batch: dict, arch, truncate_text: bool = True,
     text_before = t.detach().permute(1, 0, 2)
     text_emb = t.mean(0)
     video_emb, tokens = video_tower(P, video, batch["keep_ind"], arch, taps)
-    pred = sort_head(P, text_before, tokens, arch) if NT != 1 else None
+    pred = sort_head(P, text_before, tokens, arch) if (NT != 1 and arch.get("sort_head", True)) else None
     return text_emb, video_emb, pred
 
 

@@ -448,6 +448,35 @@ def gen_metrics():
     save("metrics", keys=np.array(keys), **out)
 
 
+def downstream_arch(name):
+    return dict(O.ARCHS[name], mask_ratio=0.0, sort_head=False)
+
+
+def gen_downstream():
+    """The reference's inference-only TVTSv2_B_16 (v2/downstream/model_TVTSv2_ViT_B_16.py): no tube masking (196 patches,
+    keep_ind broadcast over the batch), no sort head; a retrieval-style batch (B=2, T=4, one caption each) and the
+    zero-shot scripts' text pass beside dummy single frames."""
+    ns = import_reference()
+    _stub("downstream")
+    dm = _load("downstream.model_TVTSv2_ViT_B_16", os.path.join(REF, "downstream/model_TVTSv2_ViT_B_16.py"))
+    arch = downstream_arch("B_16")
+    m = dm.TVTSv2_B_16(load_checkpoint="")
+    P = O.synth_params(arch, seed=0)
+    assert list(m.state_dict().keys()) == list(P.keys()), "downstream state-dict keys differ from param_shapes(sort_head=False)"
+    m.load_state_dict(P, strict=True)
+    m.eval()
+    b = O.synth_batch(O.ARCHS["B_16"], B=2, T=4, seed=3, n_trans=1)
+    keep = torch.arange(196).unsqueeze(0)
+    with torch.no_grad():
+        keep_b = keep.expand(2, -1)  # the datasets deliver one index row per sample
+        te, ve = m({"text": b["text"], "video": b["video"], "keep_ind": keep_b}, return_embeds=True)
+        sims = m({"text": b["text"], "video": b["video"], "keep_ind": keep_b}, return_embeds=False)
+        g = torch.Generator().manual_seed(4)
+        prompts = O.synth_batch(O.ARCHS["B_16"], B=3, T=1, seed=5, n_trans=1, caption_len=12)["text"]
+        cls_emb, _ = m({"text": prompts, "video": torch.zeros(3, 3, 224, 224), "keep_ind": keep}, return_embeds=True)
+    save("downstream_b16", te=te, ve=ve, sims=sims, prompts=prompts, cls_emb=cls_emb, seed=0, batch_seed=3)
+
+
 def gen_groups():
     """Name -> optimizer group, by executing the reference entrypoint's own grouping statements
     (train_dist_TVTSv2_ViT_B_16.py:66-107) on a module exposing the A13 parameter names."""
@@ -518,7 +547,7 @@ def gen_ddp2():
 
 
 GENS = {"block": gen_block, "vit": gen_vit, "text": gen_text, "sort": gen_sort, "model_tiny": gen_model_tiny,
-        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics}
+        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

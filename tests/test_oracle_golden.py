@@ -249,3 +249,20 @@ def test_retrieval_metrics(golden):
             want = dict(zip(keys, f[f"{fn}_{name}"]))
             for k in keys:
                 assert abs(got[k] - want[k]) < 1e-9 * max(1.0, abs(want[k])), (name, fn, k, got[k], want[k])
+
+
+def test_downstream_b16(golden):
+    """The reference's inference-only model copy (v2/downstream/model_TVTSv2_ViT_B_16.py): mask 0, no sort head."""
+    f = golden("downstream_b16")
+    arch = dict(O.ARCHS["B_16"], mask_ratio=0.0, sort_head=False)
+    assert not any(k.startswith("pred_model") for k in O.param_shapes(arch))
+    P = O.synth_params(arch, seed=int(f["seed"]))
+    b = O.synth_batch(O.ARCHS["B_16"], B=2, T=4, seed=int(f["batch_seed"]), n_trans=1)
+    keep = torch.arange(196).unsqueeze(0)
+    with torch.no_grad():
+        te, ve, pred = O.model_forward(P, {"text": b["text"], "video": b["video"], "keep_ind": keep.expand(2, -1)}, arch)
+        assert pred is None
+        assert relerr(f["te"], te) < RTOL and relerr(f["ve"], ve) < RTOL
+        assert relerr(f["sims"], O.sim_matrix(te, ve)) < RTOL
+        cls = O.text_tower(P, torch.tensor(f["prompts"]), arch)
+        assert relerr(f["cls_emb"], cls) < RTOL

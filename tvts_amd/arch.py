@@ -106,25 +106,26 @@ def param_shapes(arch) -> "OrderedDict[str, Tuple[int, ...]]":
             o[pre + k] = blk[k]
     o["video_model.ln_post.weight"] = (W,)
     o["video_model.ln_post.bias"] = (W,)
-    o["pred_model.type_embed"] = (1, 2, E)
-    for i in range(arch["sort_depth"]):
-        pre = f"pred_model.blocks.{i}."
-        o[pre + "norm1.weight"] = (E,)
-        o[pre + "norm1.bias"] = (E,)
-        o[pre + "attn.qkv.weight"] = (3 * E, E)
-        o[pre + "attn.qkv.bias"] = (3 * E,)
-        o[pre + "attn.proj.weight"] = (E, E)
-        o[pre + "attn.proj.bias"] = (E,)
-        o[pre + "norm2.weight"] = (E,)
-        o[pre + "norm2.bias"] = (E,)
-        o[pre + "mlp.fc1.weight"] = (4 * E, E)
-        o[pre + "mlp.fc1.bias"] = (4 * E,)
-        o[pre + "mlp.fc2.weight"] = (E, 4 * E)
-        o[pre + "mlp.fc2.bias"] = (E,)
-    o["pred_model.norm.weight"] = (E,)
-    o["pred_model.norm.bias"] = (E,)
-    o["pred_model.head.weight"] = (arch["n_trans"], E)
-    o["pred_model.head.bias"] = (arch["n_trans"],)
+    if arch.get("sort_head", True):  # the downstream inference models carry no transcript-sorting head
+        o["pred_model.type_embed"] = (1, 2, E)
+        for i in range(arch["sort_depth"]):
+            pre = f"pred_model.blocks.{i}."
+            o[pre + "norm1.weight"] = (E,)
+            o[pre + "norm1.bias"] = (E,)
+            o[pre + "attn.qkv.weight"] = (3 * E, E)
+            o[pre + "attn.qkv.bias"] = (3 * E,)
+            o[pre + "attn.proj.weight"] = (E, E)
+            o[pre + "attn.proj.bias"] = (E,)
+            o[pre + "norm2.weight"] = (E,)
+            o[pre + "norm2.bias"] = (E,)
+            o[pre + "mlp.fc1.weight"] = (4 * E, E)
+            o[pre + "mlp.fc1.bias"] = (4 * E,)
+            o[pre + "mlp.fc2.weight"] = (E, 4 * E)
+            o[pre + "mlp.fc2.bias"] = (E,)
+        o["pred_model.norm.weight"] = (E,)
+        o["pred_model.norm.bias"] = (E,)
+        o["pred_model.head.weight"] = (arch["n_trans"], E)
+        o["pred_model.head.bias"] = (arch["n_trans"],)
     return o
 
 

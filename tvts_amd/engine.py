@@ -147,6 +147,7 @@ class Engine:
             if d not in (64, 80) or d * h != w:
                 raise NotImplementedError(f"attention kernels are built for head dim 64 and 80, not {w}/{h}")
         self.pooled_tail = a["tail"] == "pooled_and_patches"
+        self.has_sort_head = bool(a.get("sort_head", True))
         self.dev = store.device
         self.buf: Dict[str, torch.Tensor] = {}
         self.requires_grad = {name: True for name in store.shapes}
@@ -506,7 +507,10 @@ class Engine:
         NT = N // B
         eot_rows = (torch.arange(N) * L + eot).to(torch.int32).to(self.dev)
         ids_dev = ids_cpu[:, :L].to(torch.int32).contiguous().to(self.dev)
-        keep = data["keep_ind"].to(torch.int32).contiguous().to(self.dev)
+        keep = data["keep_ind"].to(torch.int32)
+        if keep.shape[0] == 1 and B > 1:  # one tube mask for the whole batch (the downstream scripts pass arange(n)[None])
+            keep = keep.expand(B, -1)
+        keep = keep.contiguous().to(self.dev)
         n = keep.shape[1]
         S = 1 + T * n
         Sv = S - 1 if self.pooled_tail else S
@@ -531,7 +535,7 @@ class Engine:
             K.rows_gather(out, pb["vid_rows"], video_emb)
         else:
             video_emb = pooled
-        pred = self.sort_forward(out, text_before, B, S, NT) if NT != 1 else None
+        pred = self.sort_forward(out, text_before, B, S, NT) if (NT != 1 and self.has_sort_head) else None
         return text_emb, video_emb, pred
 
     def backward(self, d_text, d_video, d_pred):
