@@ -101,6 +101,11 @@ int tvts_attn80_fwd_divided(int mode, const void* qkv, int ld, int B, int heads,
  *      sort_transformer.py:124-128 */
 int tvts_patch_gather(const float* video, const int* keep, int B, int T, int n, int img, int patch, void* out, int ldo,
                       hipStream_t stream);
+/* uint8 H x W x 3 frames (resized on the host): crop + ClipToTensor + Normalize (video_transforms/video_transform.py:24-75,
+ * functional.py:81-97; base_dataset.py:125-127) fused into the tube-mask gather; mean3 / std3 are HOST arrays, crop is a
+ * device [B,2] (top, left) or NULL for the centre crop */
+int tvts_patch_gather_u8(const unsigned char* frames, int H0, int W0, const int* crop, const int* keep, int B, int T, int n,
+                         int img, int patch, const float* mean3, const float* std3, void* out, int ldo, hipStream_t stream);
 int tvts_vit_assemble(const float* patch, int ldp, const float* cls, const float* pos, const float* temporal,
                       const int* keep, int B, int T, int n, int W, float* tok, int ldt, hipStream_t stream);
 int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int B, int T, int n, int W, void* dpatch, int ldp,

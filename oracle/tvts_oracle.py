@@ -325,6 +325,24 @@ def st_block(x: Tensor, P: Params, pre: str, arch, T: int, n: int) -> Tensor:
     return s_res + linear(hid, P[pre + "mlp.c_proj.weight"], P[pre + "mlp.c_proj.bias"])
 
 
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)  # v2/video_transforms/videoaug.py:17,26
+
+
+def frames_to_video(frames_u8: Tensor, image: int, crop: Optional[Tensor] = None) -> Tensor:
+    """uint8 frames [B, T, H0, W0, 3] (decoded + resized) -> the fp32 [B, T, 3, image, image] clip the model is fed:
+    CenterCrop / RandomCrop offset, ClipToTensor (float32, / 255) and Normalize ((v - mean) / std in fp32), in the
+    reference's operation order (video_transforms/video_transform.py:24-75, functional.py:81-97, base_dataset.py:125-127)."""
+    B, T, H0, W0, _ = frames_u8.shape
+    out = torch.empty(B, T, 3, image, image, dtype=torch.float32)
+    mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32)[:, None, None]
+    std = torch.tensor(IMAGENET_STD, dtype=torch.float32)[:, None, None]
+    for b in range(B):
+        y0, x0 = ((H0 - image) // 2, (W0 - image) // 2) if crop is None else (int(crop[b, 0]), int(crop[b, 1]))
+        clip = frames_u8[b, :, y0:y0 + image, x0:x0 + image, :].permute(0, 3, 1, 2).float().div(255)
+        out[b] = clip.sub(mean).div(std)
+    return out
+
+
 def video_embed_tokens(P: Params, video: Tensor, keep_ind: Tensor, arch) -> Tensor:
     """Patch embed + CLS + space/time position + tube-mask gather + ln_pre
     (v2/model/video_encoder_ViT_B_16.py:176-218).  Gather-then-embed, which is

@@ -477,6 +477,25 @@ def gen_downstream():
     save("downstream_b16", te=te, ve=ve, sims=sims, prompts=prompts, cls_emb=cls_emb, seed=0, batch_seed=3)
 
 
+def gen_transform():
+    """The reference's eval transform tail on uint8 frames (video_transforms/videoaug.py:20-27 after the cv2 resize):
+    CenterCrop -> ClipToTensor -> Normalize, executed from video_transform.py / functional.py (cv2, skimage and
+    torchvision are import-time dependencies of those files only; stubbed)."""
+    _stub("cv2"); _stub("skimage"); _stub("skimage.transform"); _stub("torchvision")
+    _stub("torchvision.transforms")
+    vt_pkg = _stub("video_transforms")
+    vt_pkg.functional = _load("video_transforms.functional", os.path.join(REF, "video_transforms/functional.py"))
+    vt = _load("video_transforms.video_transform", os.path.join(REF, "video_transforms/video_transform.py"))
+    rng = np.random.RandomState(11)
+    frames = rng.randint(0, 256, size=(3, 40, 44, 3)).astype(np.uint8)  # T x H0 x W0 x 3, as TensorToNumpy + Resize hand over
+    clip = [frames[t] for t in range(frames.shape[0])]
+    clip = vt.CenterCrop(32)(clip)
+    ten = vt.ClipToTensor(channel_nb=3)(clip)                       # C x T x H x W
+    ten = vt.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])(ten)
+    out = ten.permute(1, 0, 2, 3)                                   # base_dataset.py:126 -> T x C x H x W
+    save("transform", frames=frames, out=out, image=32)
+
+
 def gen_groups():
     """Name -> optimizer group, by executing the reference entrypoint's own grouping statements
     (train_dist_TVTSv2_ViT_B_16.py:66-107) on a module exposing the A13 parameter names."""
@@ -547,7 +566,7 @@ def gen_ddp2():
 
 
 GENS = {"block": gen_block, "vit": gen_vit, "text": gen_text, "sort": gen_sort, "model_tiny": gen_model_tiny,
-        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream}
+        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream, "transform": gen_transform}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

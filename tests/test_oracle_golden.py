@@ -266,3 +266,11 @@ def test_downstream_b16(golden):
         assert relerr(f["sims"], O.sim_matrix(te, ve)) < RTOL
         cls = O.text_tower(P, torch.tensor(f["prompts"]), arch)
         assert relerr(f["cls_emb"], cls) < RTOL
+
+
+def test_uint8_transform_tail(golden):
+    """CenterCrop -> ClipToTensor -> Normalize of the reference's video_transform.py on uint8 frames: bit-exact."""
+    f = golden("transform")
+    frames = torch.tensor(f["frames"]).unsqueeze(0)  # [1, T, H0, W0, 3]
+    out = O.frames_to_video(frames, int(f["image"]))
+    assert torch.equal(out[0], torch.tensor(f["out"]))

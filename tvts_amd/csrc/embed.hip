@@ -65,6 +65,46 @@ extern "C" int tvts_patch_gather(const float* video, const int* keep, int B, int
     return TVTS_OK;
 }
 
+// uint8 wire format: the frames arrive as the decoder leaves them -- uint8, H x W x 3 interleaved, already
+// resized on the host -- and the rest of the reference's transform chain runs here, fused into the tube-mask gather:
+// crop (video_transform.CenterCrop / RandomCrop = an offset per sample), ClipToTensor (float32 / 255) and Normalize
+// ((v - mean) / std, fp32, same operation order -> bit-identical to v2/video_transforms/video_transform.py:24-75,
+// functional.py:81-97), then the bf16 rounding of the im2col row.  4x less PCIe / HBM traffic than fp32 frames.
+__global__ __launch_bounds__(256) void patch_gather_u8_kernel(const unsigned char* __restrict__ frames, int H0, int W0,
+                                                              const int* __restrict__ crop, const int* __restrict__ keep,
+                                                              int B, int T, int n, int img, int p, float m0, float m1,
+                                                              float m2, float s0, float s1, float s2,
+                                                              bf16* __restrict__ out, int ldo) {
+    const int K = 3 * p * p;
+    const int row = blockIdx.x;  // (b, f, i)
+    const int i = row % n, f = (row / n) % T, b = row / (n * T);
+    const int g = img / p;
+    const int pi = keep[b * n + i];
+    const int gy = pi / g, gx = pi % g;
+    const int y0 = crop ? crop[2 * b] : (H0 - img) / 2, x0 = crop ? crop[2 * b + 1] : (W0 - img) / 2;
+    const unsigned char* fr = frames + (size_t)(b * T + f) * H0 * W0 * 3;
+    for (int c = threadIdx.x; c < ldo; c += 256) {
+        float v = 0.f;
+        if (c < K) {
+            const int ch = c / (p * p), rem = c % (p * p), py = rem / p, px = rem % p;
+            const float u = (float)fr[((size_t)(y0 + gy * p + py) * W0 + (x0 + gx * p + px)) * 3 + ch];
+            const float mean = ch == 0 ? m0 : ch == 1 ? m1 : m2, sd = ch == 0 ? s0 : ch == 1 ? s1 : s2;
+            v = (u / 255.0f - mean) / sd;
+        }
+        out[(size_t)row * ldo + c] = (bf16)v;
+    }
+}
+extern "C" int tvts_patch_gather_u8(const unsigned char* frames, int H0, int W0, const int* crop, const int* keep, int B,
+                                    int T, int n, int img, int patch, const float* mean3, const float* std3, void* out,
+                                    int ldo, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || n <= 0 || patch <= 0 || img % patch || H0 < img || W0 < img || ldo % 8 || ldo < 3 * patch * patch)
+        return TVTS_EINVAL;
+    hipLaunchKernelGGL(patch_gather_u8_kernel, dim3(B * T * n), dim3(256), 0, stream, frames, H0, W0, crop, keep, B, T, n, img,
+                       patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (bf16*)out, ldo);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- ViT token assemble
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch, int ldp,
                                                            const float* __restrict__ cls, const float* __restrict__ pos,

@@ -310,7 +310,10 @@ class Engine:
         S = 1 + T * n
         M, Mp, Kp = B * S, B * T * n, self.P.conv_kpad
         cols = self._b("vit.im2col", (Mp, Kp))
-        K.patch_gather(video, keep_dev, cols, B=B, T=T, n=n, img=a["image"], patch=p)
+        if video.dtype == torch.uint8:
+            K.patch_gather_u8(video, keep_dev, cols, B=B, T=T, n=n, img=a["image"], patch=p, crop=self.ctx.get("crop"))
+        else:
+            K.patch_gather(video, keep_dev, cols, B=B, T=T, n=n, img=a["image"], patch=p)
         pe = self._f("vit.patch", (Mp, W))
         K.gemm_nt(cols, self.P.w_conv(), pe, M=Mp)
         tok = self._f("vit.tok", (M, W))
@@ -495,9 +498,20 @@ class Engine:
         """Host-side (plumbing): dtype/device normalisation of the reference batch dict."""
         a = self.arch
         video = data["video"]
-        if video.dim() == 4:
-            video = video.unsqueeze(1)
-        video = video.to(self.dev, torch.float32).contiguous()
+        crop = None
+        if video.dtype == torch.uint8:
+            # uint8 wire format (SURVEY.md 8f N3): [B, T, H0, W0, 3] frames as decoded + resized; crop / 255 / normalise
+            # happen inside the patch gather.  data["crop"]: [B, 2] (top, left) of a random crop, absent = centre crop.
+            if video.dim() == 4:
+                video = video.unsqueeze(1)
+            assert video.dim() == 5 and video.shape[-1] == 3, "uint8 video must be [B, T, H, W, 3]"
+            video = video.to(self.dev).contiguous()
+            if data.get("crop") is not None:
+                crop = data["crop"].to(torch.int32).contiguous().to(self.dev)
+        else:
+            if video.dim() == 4:
+                video = video.unsqueeze(1)
+            video = video.to(self.dev, torch.float32).contiguous()
         B, T = video.shape[:2]
         ids = data["text"]
         ids_cpu = ids.detach().to("cpu", torch.int64)
@@ -517,7 +531,7 @@ class Engine:
         So = Sv + NT
         sort_rows = (torch.arange(B)[:, None] * So + Sv + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev)
         vid_rows = (torch.arange(B) * S).to(torch.int32).to(self.dev)
-        return dict(video=video, ids=ids_dev, eot_rows=eot_rows, keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
+        return dict(video=video, crop=crop, ids=ids_dev, eot_rows=eot_rows, keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
                     sort_rows=sort_rows, vid_rows=vid_rows)
 
     def forward(self, pb: dict):

@@ -212,6 +212,19 @@ def patch_gather(video, keep, out, *, B, T, n, img, patch):
     _chk(lib.tvts_patch_gather(_p(video), _p(keep), B, T, n, img, patch, _p(out), _ld(out), _stream()), "tvts_patch_gather")
 
 
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)  # video_transforms/videoaug.py:17,26
+
+
+def patch_gather_u8(frames, keep, out, *, B, T, n, img, patch, crop=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """frames: uint8 [B, T, H0, W0, 3] on the device; crop: int32 [B, 2] (top, left) or None (centre crop)."""
+    import ctypes
+    lib = _lib.load()
+    assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.shape[-1] == 3 and keep.dtype == torch.int32
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    _chk(lib.tvts_patch_gather_u8(_p(frames), frames.shape[2], frames.shape[3], _p(crop), _p(keep), B, T, n, img, patch, m3, s3,
+                                  _p(out), _ld(out), _stream()), "tvts_patch_gather_u8")
+
+
 def vit_assemble(patch, cls, pos, temporal, keep, tok, *, B, T, n):
     lib = _lib.load()
     _chk(lib.tvts_vit_assemble(_p(patch), _ld(patch), _p(cls), _p(pos), _p(temporal), _p(keep), B, T, n, tok.shape[1],

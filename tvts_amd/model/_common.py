@@ -203,7 +203,9 @@ class TVTSv2Base(nn.Module):
         self._fresh_shadows()
         if video_data.dim() == 4:
             video_data = video_data.unsqueeze(1)
-        v = video_data.to(self.store.device, torch.float32).contiguous()
+        v = video_data.to(self.store.device).contiguous() if video_data.dtype == torch.uint8 else \
+            video_data.to(self.store.device, torch.float32).contiguous()
+        self.engine.ctx = dict(self.engine.ctx, crop=None)
         B, T = v.shape[:2]
         keep = keep_ind.to(torch.int32).contiguous().to(self.store.device)
         out, pooled = self.engine.video_forward(v, keep, B, T)
