@@ -104,10 +104,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # test hooks for the single-GPU box (tests/test_bench_dist_gpu.py): every rank on device 0 with the gloo backend --
+    # the collectives' call pattern is what is being checked there; the real run is one rank per GPU over RCCL
+    if os.environ.get("TVTS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("TVTS_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from tvts_amd import arch as A
     from tvts_amd import hip as K
@@ -198,12 +206,17 @@ def main():
         "step_mfma_frac": pairs_per_s * (fwd + bwd) / (world * PEAK_BF16_TFLOPS * 1e12),
     }
 
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
         # dominant kernel family = the bf16 MFMA GEMMs (gemm_nt_kernel / gemm_tn_kernel): one instrumented eager
-        # step with a HIP event pair around every GEMM launch on the launch stream.
-        K.GEMM_PROFILE = []
+        # step with a HIP event pair around every GEMM launch on the launch stream.  EVERY rank runs the step (it
+        # contains the all-gather / all-reduce of the data-parallel path); rank 0 records.
+        if rank == 0:
+            K.GEMM_PROFILE = []
         one_step(0, device_step=False)
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    if rank == 0 and not args.no_roofline:
         recs, K.GEMM_PROFILE = K.GEMM_PROFILE, None
         tot_ms = sum(r[2].elapsed_ms(r[3]) for r in recs)
         tot_fl = sum(r[1] for r in recs)
