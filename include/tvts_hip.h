@@ -131,8 +131,9 @@ int tvts_cross_entropy(const float* logits, const int* labels, int R, int C, flo
                        hipStream_t stream);
 /* validation: rank of the ground truth per query in sims[n_text, n_vid] (text x video);
  * mode 0 = model/metric.py:16-126 t2v_metrics (ranks[n_text], optimistic ties), mode 1 = :129-187 v2t_metrics
- * (ranks[n_vid], averaged ties, closest own caption) */
-int tvts_retrieval_ranks(const float* sims, long ld, int n_text, int n_vid, int mode, float* ranks, hipStream_t stream);
+ * (ranks[n_vid], averaged ties, closest own caption); valid: optional n_text bytes, 0 = caption missing (query_masks) */
+int tvts_retrieval_ranks(const float* sims, long ld, int n_text, int n_vid, int mode, const unsigned char* valid,
+                         float* ranks, hipStream_t stream);
 
 /* ---- optimizer (optim.hip): transformers.AdamW as built at train_dist_TVTSv2_ViT_B_16.py:118-125 */
 int tvts_adamw_hf(float* p, const float* g, float* m, float* v, void* shadow_bf16, const unsigned char* chunk_group,

@@ -608,9 +608,9 @@ def train_step(P: Params, batch: dict, arch, opt_state: dict, truncate_text: boo
 # validation metrics (v2/model/metric.py:16-126,129-187,285-296; trainer.py:527-635) -- SURVEY.md 8f N1
 # --------------------------------------------------------------------------------------
 
-def t2v_ranks(sims):
-    """metric.py:28-66: rank of each text query's own video in sims [n_text, n_vid], ties broken optimistically
-    (the first position of the ground-truth distance in the sorted row)."""
+def t2v_ranks(sims, query_masks=None):
+    """metric.py:28-66,104-111: rank of each text query's own video in sims [n_text, n_vid], ties broken optimistically
+    (the first position of the ground-truth distance in the sorted row); masked queries are dropped."""
     import numpy as np
     sims = np.asarray(sims, dtype=np.float32)
     nq, nv = sims.shape
@@ -620,19 +620,26 @@ def t2v_ranks(sims):
     cols = np.empty(nq, dtype=np.float64)
     for i in range(nq):
         cols[i] = np.where(sorted_d[i] - dists[i, i // q] == 0)[0][0]
+    if query_masks is not None:
+        cols = cols[np.asarray(query_masks).reshape(-1).astype(bool)]
     return cols
 
 
-def v2t_ranks(sims):
-    """metric.py:143-187: for each video the best rank among its own captions in sims.T, ties averaged."""
+def v2t_ranks(sims, query_masks=None):
+    """metric.py:143-187: for each video the best rank among its own captions in sims.T, ties averaged; a missing caption
+    gets the distance 1e8 (:160-166) and is skipped as a target (:175-177)."""
     import numpy as np
     d = -np.asarray(sims, dtype=np.float32).T  # [n_vid, n_caps]
     nv, nc = d.shape
     q = nc // nv
+    if query_masks is not None:
+        d = d.copy()
+        d[:, np.logical_not(np.asarray(query_masks).reshape(-1).astype(bool))] = 1e8
     out = np.empty(nv, dtype=np.float64)
     for i in range(nv):
         sd = np.sort(d[i])
-        out[i] = min(np.where(sd - d[i, j] == 0)[0].mean() for j in range(i * q, (i + 1) * q))
+        out[i] = min((np.where(sd - d[i, j] == 0)[0].mean() for j in range(i * q, (i + 1) * q) if d[i, j] != 1e8),
+                     default=np.inf)
     return out
 
 

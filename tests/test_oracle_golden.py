@@ -249,6 +249,14 @@ def test_retrieval_metrics(golden):
             want = dict(zip(keys, f[f"{fn}_{name}"]))
             for k in keys:
                 assert abs(got[k] - want[k]) < 1e-9 * max(1.0, abs(want[k])), (name, fn, k, got[k], want[k])
+    # MSRVTT-style missing captions (query_masks)
+    sims, mask = f["sims_two_caps"], f["query_mask_two_caps"]
+    for fn, ranks in (("t2v_metrics", O.t2v_ranks), ("v2t_metrics", O.v2t_ranks)):
+        cols = ranks(sims, mask)
+        got = O.cols2metrics(cols, int(mask.sum()) if fn == "t2v_metrics" else None)
+        want = dict(zip(keys, f[f"{fn}_two_caps_masked"]))
+        for k in keys:
+            assert abs(got[k] - want[k]) < 1e-6 * max(1.0, abs(want[k])), ("masked", fn, k, got[k], want[k])  # the reference divides by a float32 mask sum
 
 
 def test_downstream_b16(golden):

@@ -38,6 +38,19 @@ def test_rank_kernel_and_metrics_against_reference_golden(gpu, golden):
                 assert abs(float(got[k]) - want[k]) < 1e-6 * max(1.0, abs(want[k])), (name, fn, k, got[k], want[k])
 
 
+def test_metrics_with_query_masks(gpu, golden):
+    """zero_ret_*.py hands the metrics MSRVTT's caption mask (metric.py:104-111,160-177)."""
+    from tvts_amd.model import metric as M
+    f = golden("metrics")
+    keys = [str(k) for k in f["keys"]]
+    sims, mask = torch.tensor(f["sims_two_caps"], device=DEV), f["query_mask_two_caps"]
+    for fn in ("t2v_metrics", "v2t_metrics"):
+        got = getattr(M, fn)(sims, query_masks=mask)
+        want = dict(zip(keys, f[f"{fn}_two_caps_masked"]))
+        for k in keys:
+            assert abs(float(got[k]) - want[k]) < 1e-6 * max(1.0, abs(want[k])), (fn, k, got[k], want[k])
+
+
 def test_rank_kernel_large_with_ties(gpu):
     from tvts_amd import hip as K
     g = torch.Generator().manual_seed(3)

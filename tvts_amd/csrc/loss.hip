@@ -118,8 +118,11 @@ extern "C" int tvts_cross_entropy(const float* logits, const int* labels, int R,
 //   mode 1 (v2t_metrics :129-187, ties averaged, closest own caption): for video j,
 //          ranks[j] = min over its captions c of  #{ k : x[k, j] > x[c, j] } + (#{ k : x[k, j] == x[c, j] } - 1) / 2
 // One block per query; comparisons are exact fp32 like the reference's numpy.
+// valid (optional, n_text bytes): captions that exist (MSRVTT videos with fewer captions, metric.py:104-111,160-176):
+// a missing caption is no candidate and no ground truth in mode 1; mode 0 ranks every row, the caller drops the masked ones.
 __global__ __launch_bounds__(256) void retrieval_rank_kernel(const float* __restrict__ x, long ld, int n_text, int n_vid, int q,
-                                                             int mode, float* __restrict__ ranks) {
+                                                             int mode, const unsigned char* __restrict__ valid,
+                                                             float* __restrict__ ranks) {
     __shared__ int red[2][4];
     const int i = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -130,12 +133,14 @@ __global__ __launch_bounds__(256) void retrieval_rank_kernel(const float* __rest
     float best = 3.0e38f;
     for (int c = 0; c < ngt; ++c) {
         const int gt_idx = mode == 0 ? i / q : i * q + c;
+        if (mode == 1 && valid && !valid[gt_idx]) continue;  // block-uniform
         const float gt = base[(long)gt_idx * cs];
         int greater = 0, equal = 0;
         for (int k = threadIdx.x; k < n; k += 256) {
             const float v = base[(long)k * cs];
-            greater += v > gt;
-            equal += v == gt;
+            const bool ok = !(mode == 1 && valid && !valid[k]);
+            greater += ok && v > gt;
+            equal += ok && v == gt;
         }
         greater = (int)wave_sum((float)greater);  // counts < 2^24: exact in fp32
         equal = (int)wave_sum((float)equal);
@@ -149,12 +154,12 @@ __global__ __launch_bounds__(256) void retrieval_rank_kernel(const float* __rest
     }
     if (threadIdx.x == 0) ranks[i] = best;
 }
-extern "C" int tvts_retrieval_ranks(const float* sims, long ld, int n_text, int n_vid, int mode, float* ranks,
-                                    hipStream_t stream) {
+extern "C" int tvts_retrieval_ranks(const float* sims, long ld, int n_text, int n_vid, int mode,
+                                    const unsigned char* valid, float* ranks, hipStream_t stream) {
     if (n_text <= 0 || n_vid <= 0 || n_text % n_vid || (mode != 0 && mode != 1) || n_text >= (1 << 24)) return TVTS_EINVAL;
     const int q = n_text / n_vid;
     hipLaunchKernelGGL(retrieval_rank_kernel, dim3(mode == 0 ? n_text : n_vid), dim3(256), 0, stream, sims, ld, n_text, n_vid, q,
-                       mode, ranks);
+                       mode, valid, ranks);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

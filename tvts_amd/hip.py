@@ -302,13 +302,15 @@ def cross_entropy(logits, labels, scale, dlogits, loss):
                                 _stream()), "tvts_cross_entropy")
 
 
-def retrieval_ranks(sims, mode):
-    """ranks of the ground truth per query of a text x video similarity matrix; mode 't2v' | 'v2t'."""
+def retrieval_ranks(sims, mode, valid=None):
+    """ranks of the ground truth per query of a text x video similarity matrix; mode 't2v' | 'v2t';
+    valid: optional uint8 [n_text], 0 where a caption is missing (the reference's query_masks)."""
     lib = _lib.load()
     assert sims.dtype == torch.float32 and sims.dim() == 2 and sims.stride(1) == 1
     nt, nv = sims.shape
     ranks = torch.empty(nt if mode == "t2v" else nv, dtype=torch.float32, device=sims.device)
-    _chk(lib.tvts_retrieval_ranks(_p(sims), sims.stride(0), nt, nv, 0 if mode == "t2v" else 1, _p(ranks), _stream()),
+    assert valid is None or (valid.dtype == torch.uint8 and valid.numel() == nt and valid.is_contiguous())
+    _chk(lib.tvts_retrieval_ranks(_p(sims), sims.stride(0), nt, nv, 0 if mode == "t2v" else 1, _p(valid), _p(ranks), _stream()),
          "tvts_retrieval_ranks")
     return ranks
 

@@ -30,17 +30,27 @@ def cols2metrics(cols, num_queries):
     return m
 
 
+def _valid_bytes(query_masks, n_text, device):
+    if query_masks is None:
+        return None
+    qm = query_masks.detach().cpu().numpy() if isinstance(query_masks, torch.Tensor) else np.asarray(query_masks)
+    assert qm.size == n_text, "invalid query mask shape"
+    return torch.as_tensor(qm.reshape(-1) != 0).to(torch.uint8).to(device).contiguous()
+
+
 def t2v_metrics(sims, query_masks=None):
-    """sims[i, j] = <text_i, video_j>; ties broken optimistically (metric.py:16-126)."""
-    if query_masks is not None:
-        raise NotImplementedError("query_masks (MSRVTT's missing captions) are not part of the pretraining validation")
+    """sims[i, j] = <text_i, video_j>; ties broken optimistically; query_masks ([n_vid, captions_per_video], 0 = caption
+    missing) drops those queries (metric.py:16-126)."""
     sims = _device_sims(sims)
-    return cols2metrics(K.retrieval_ranks(sims, "t2v"), sims.shape[0])
+    ranks = K.retrieval_ranks(sims, "t2v")
+    valid = _valid_bytes(query_masks, sims.shape[0], sims.device)
+    if valid is not None:
+        ranks = ranks[valid.bool()]
+    return cols2metrics(ranks, int(ranks.numel()))
 
 
 def v2t_metrics(sims, query_masks=None):
-    """closest own caption per video, ties averaged (metric.py:129-187)."""
-    if query_masks is not None:
-        raise NotImplementedError("query_masks (MSRVTT's missing captions) are not part of the pretraining validation")
+    """closest own caption per video, ties averaged; missing captions are neither candidates nor targets (metric.py:129-187)."""
     sims = _device_sims(sims)
-    return cols2metrics(K.retrieval_ranks(sims, "v2t"), sims.shape[1])
+    ranks = K.retrieval_ranks(sims, "v2t", valid=_valid_bytes(query_masks, sims.shape[0], sims.device))
+    return cols2metrics(ranks, sims.shape[1])
