@@ -545,3 +545,49 @@ def test_patch_gather_14x14_padded_k(K):
     want = dst.cpu() + src.cpu()[:, :Kc]
     K.add_rows_f32(dst, src)
     assert torch.equal(dst.cpu(), want)
+
+
+def _e4m3(x):
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_fp8_quantisation(K, dtype):
+    """per-tensor e4m3 (OCP) quantisation: bit patterns of torch.float8_e4m3fn on x * 448 / amax."""
+    x = (rnd(300, 256, seed=51) * 3).to(dtype)
+    x[5, 7] = -17.0
+    q, scale = K.quantize_fp8(x.to(DEV))
+    s = float(x.float().abs().max()) / 448.0
+    assert abs(float(scale) - s) < 1e-7 * s
+    want = _e4m3(x.float() * (1.0 / torch.tensor(s, dtype=torch.float32)))
+    got = q.cpu().view(torch.float8_e4m3fn)
+    diff = (got.float() - want.float()).abs()
+    # identical except where x / scale sits within rounding of a tie (the kernel multiplies by 1 / scale in fp32)
+    assert float((diff > 0).float().mean()) < 2e-3 and float((diff / want.float().abs().clamp_min(1e-3)).max()) <= 0.13
+    # a strided view (columns of a wider matrix)
+    wide = torch.zeros(300, 512, dtype=dtype, device=DEV)
+    wide[:, 128:384] = x.to(DEV)
+    q2, s2 = K.quantize_fp8(wide[:, 128:384])
+    assert torch.equal(q2, q) and torch.equal(s2, scale)
+
+
+@pytest.mark.parametrize("M,N,K_", [(256, 256, 128), (1000, 768, 768), (777, 1280, 1280), (9420, 3072, 768)])
+def test_gemm_nt_fp8(K, M, N, K_):
+    """out = sa*sb * (A8 B8^T) + bias: exact products of the e4m3 values, fp32 accumulation."""
+    a, b = rnd(M, K_, seed=52), rnd(N, K_, seed=53) * K_ ** -0.5
+    a8, sa = K.quantize_fp8(a.to(DEV))
+    b8, sb = K.quantize_fp8(b.to(DEV))
+    bias = rnd(N, seed=54).to(DEV)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    K.gemm_nt_fp8(a8, sa, b8, sb, out, bias=bias)
+    ad, bd = a8.cpu().view(torch.float8_e4m3fn).float(), b8.cpu().view(torch.float8_e4m3fn).float()
+    ref = (ad.double() @ bd.double().t()) * (float(sa) * float(sb)) + bias.cpu().double()
+    assert rel(out, ref) < 5e-5, rel(out, ref)  # fp32 accumulation inside the matrix pipe
+    # against the unquantised product: the quantisation error of two e4m3 tensors
+    assert rel(out, a.double() @ b.double().t() + bias.cpu().double()) < 0.06
+    outb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    res = rnd(M, N, seed=55).to(DEV)
+    K.gemm_nt_fp8(a8, sa, b8, sb, outb)
+    assert rel(outb.float(), ref - bias.cpu().double()) < 4e-3
+    K.gemm_nt_fp8(a8, sa, b8, sb, out, bias=bias, residual=res)
+    assert rel(out, ref + res.cpu().double()) < 5e-5

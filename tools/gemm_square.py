@@ -41,3 +41,15 @@ for (na, nb) in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
     ms2 = timeit(lambda: torch.matmul(p.t(), q, out=outb))
     fl = 2.0 * M * na * nb
     print(f"TN {M}x{na}x{nb}: ours {ms*1e3:7.1f} us {fl/ms/1e9:7.1f} TF | hipBLASLt {ms2*1e3:7.1f} us {fl/ms2/1e9:7.1f} TF")
+
+print("fp8 (e4m3, per-tensor scales) on the same pipelined kernel")
+for (m, n, k) in ((4096, 4096, 4096), (8192, 8192, 8192), (M, 2304, 768), (M, 3072, 768), (M, 768, 3072), (38944, 3840, 1280), (38944, 5120, 1280), (38944, 1280, 5120)):
+    a = (torch.rand(m, k, device="cuda") * 2 - 1)
+    b = (torch.rand(n, k, device="cuda") * 2 - 1)
+    a8, sa = K.quantize_fp8(a.bfloat16()); b8, sb = K.quantize_fp8(b.bfloat16())
+    out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    ms = timeit(lambda: K.gemm_nt_fp8(a8, sa, b8, sb, out))
+    ab, bb = a.bfloat16(), b.bfloat16()
+    ms2 = timeit(lambda: K.gemm_nt(ab, bb, out))
+    fl = 2.0 * m * n * k
+    print(f"NT {m}x{n}x{k}: fp8 {ms*1e3:7.1f} us {fl/ms/1e9:7.1f} TF | bf16 {ms2*1e3:7.1f} us {fl/ms2/1e9:7.1f} TF")

@@ -36,6 +36,7 @@ struct GemmNT {
     int tiles_m, tiles_n;
     int ablate;  // experiment knob TVTS_NT_ABLATE: 1 skip MFMA, 2 skip DMA in the K loop, 4 skip fragment reads, 8 skip epilogue
     int swz;  // XOR mask of the LDS chunk swizzle (7; 0 = linear image, experiment knob TVTS_NT_SWZ)
+    const float* sa; const float* sb;  // fp8 operands: per-tensor scales (device scalars), out = sa*sb * (A B^T) + ...
 };
 
 // --- one [128 rows][64 k] bf16 tile: 16 KiB, rows of 128 B, 16-B chunk c of row r stored at chunk c^(r&7)
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256s_kernel(GemmNT g) {
 // ------------------------------------------------------------------------------------------------
 template <int ACT, int GATE>
 __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn,
-                                                  int lane, char* patch) {
+                                                  int lane, char* patch, float scale = 1.0f) {
     // patch: 16 rows x 256 B (64 fp32), 16-B chunk c of row r stored at chunk c ^ r
     const int nb = n0 + wn * 64;
     const int li = lane & 15, gq = lane >> 4;
@@ -571,7 +572,7 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i] + bias4[j];
+            *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i] * scale + bias4[j];
             acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         if (g.out_f32) {
@@ -639,7 +640,7 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
         asm volatile("" ::: "memory");        \
     } while (0)
 
-template <int ACT, int GATE>
+template <int ACT, int GATE, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 32K | B 32K] + 8 x 4K patches
     const int tid = threadIdx.x;
@@ -703,10 +704,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i) dst[i] = frag_rows128(buf, arow + ((h) * 4 + i) * 16, (ks) * 4 + gq)
 #define LOAD_B(dst, buf, ks)                                                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) dst[j] = frag_rows128((buf) + 32768, brow + j * 16, (ks) * 4 + gq)
+    // FP8: the operands are e4m3 matrices addressed as bf16 matrices of half the width (the staging and the LDS image are
+    // byte-identical); a 16-byte fragment then holds 16 k-values of its row and feeds two 16x16x32 fp8 MFMAs (its low and
+    // its high 8 bytes -- A and B use the same split, so every k meets its partner).
+    typedef __attribute__((ext_vector_type(2))) long i64x2;
 #define MFMA16(av, bv, h)                                                                              \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
-            acc[j][(h) * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[j], av[i], acc[j][(h) * 4 + i], 0, 0, 0)
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+            if (FP8) {                                                                                 \
+                const i64x2 a8 = __builtin_bit_cast(i64x2, av[i]), b8 = __builtin_bit_cast(i64x2, bv[j]); \
+                acc[j][(h) * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b8[0], a8[0], acc[j][(h) * 4 + i], 0, 0, 0); \
+                acc[j][(h) * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b8[1], a8[1], acc[j][(h) * 4 + i], 0, 0, 0); \
+            } else {                                                                                   \
+                acc[j][(h) * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[j], av[i], acc[j][(h) * 4 + i], 0, 0, 0); \
+            }                                                                                          \
+        }
     LOAD_B(bF[0], smem, 0);
     LOAD_A(aF[0], smem, 0, 0);
 
@@ -729,7 +741,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         }
         MFMA16(aF[1], bF[1], 1);
         if (++kt == nk) {
-            epilogue256_patch<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, patch);
+            epilogue256_patch<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, patch, FP8 ? g.sa[0] * g.sb[0] : 1.0f);
             kt = 0; ++tl;
             const int tile = range_lo + slot + tl * per_xcd;
             m0 = (tile / g.tiles_n) * 256; n0 = (tile % g.tiles_n) * 256;
@@ -875,7 +887,7 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     g.A = (const bf16*)A; g.lda = lda; g.B = (const bf16*)B; g.ldb = ldb;
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
-    g.out = out; g.ldc = ldc; g.out_f32 = out_f32;
+    g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.sa = nullptr; g.sb = nullptr;
     { static const char* e = getenv("TVTS_NT_SWZ"); g.swz = e ? atoi(e) : 7; }
     { static const char* e = getenv("TVTS_NT_ABLATE"); g.ablate = e ? atoi(e) : 0; }
     const bool pipe = g_nt_tile == 768 || (g_nt_tile == 0);
@@ -936,6 +948,31 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), 65536, stream, g);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// fp8 (OCP e4m3) operands, fp32 accumulate: out[M,N] = scale_a * scale_b * (A[M,K] B[N,K]^T) + bias [+ residual], A / B row-major
+// bytes with per-tensor scales held in device memory (BASELINE config 4's weight/activation path; the building block, the
+// step engine does not use it yet).  Same pipelined 256x256 kernel: K % 128 == 0, lda / ldb % 16 == 0.
+extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
+                                const float* scale_b, const float* bias, const float* residual, int ldr, void* out, int ldc,
+                                int out_f32, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b) return TVTS_EINVAL;
+    if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || (residual && ldr % 4)) return TVTS_EINVAL;
+    GemmNT g;
+    g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;  // byte-identical bf16 view, half as wide
+    g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = ACT_NONE;
+    g.preact = nullptr; g.ldp = 0; g.gate_h = nullptr; g.ldh = 0; g.gate_act = ACT_NONE;
+    g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.swz = 7; g.ablate = 0; g.sa = scale_a; g.sb = scale_b;
+    g.tiles_n = ceil_div(N, 256);
+    g.tiles_m = ceil_div(M, 256);
+    const int total_tiles = g.tiles_m * g.tiles_n;
+    const int grid = total_tiles < 256 ? ((total_tiles + 7) / 8) * 8 : 256;
+    void (*kern)(GemmNT) = gemm_nt256p_kernel<0, 0, true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 163840, stream, g);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

@@ -137,6 +137,56 @@ extern "C" int tvts_add_rows_f32(float* dst, int ld_dst, const float* src, int l
     return TVTS_OK;
 }
 
+// ---- fp8 (OCP e4m3) quantisation with one scale per tensor: scale = amax / 448, q = rne(x / scale), |q| <= 448
+//      (the weight / activation format of tvts_gemm_nt_fp8; torch.float8_e4m3fn bit patterns)
+template <typename T>
+__global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ x, long ld, int rows, int cols, float* __restrict__ amax) {
+    float m = 0.f;
+    for (long r = blockIdx.x; r < rows; r += gridDim.x)
+        for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf((float)x[r * ld + c]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)amax, __float_as_uint(m));  // non-negative floats order like their bits
+}
+template <typename T>
+__global__ __launch_bounds__(256) void quant_fp8_kernel(const T* __restrict__ x, long ld, int rows, int cols,
+                                                        const float* __restrict__ amax, unsigned char* __restrict__ out, long ldo,
+                                                        float* __restrict__ scale_out) {
+    const float am = amax[0];
+    const float scale = am > 0.f ? am / 448.0f : 1.0f;
+    const float inv = 1.0f / scale;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && scale_out) scale_out[0] = scale;
+    for (long r = blockIdx.x; r < rows; r += gridDim.x)
+        for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf((float)x[r * ld + c + e] * inv, -448.0f), 448.0f);
+            int pk = 0;
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], pk, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+            *(int*)(out + r * ldo + c) = pk;
+        }
+}
+extern "C" int tvts_amax(const void* x, int is_f32, long ld, int rows, int cols, float* amax, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return TVTS_EINVAL;
+    if (hipMemsetAsync(amax, 0, sizeof(float), stream) != hipSuccess) return TVTS_EINVAL;
+    const int blocks = rows < 2048 ? rows : 2048;
+    if (is_f32) hipLaunchKernelGGL(amax_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, ld, rows, cols, amax);
+    else hipLaunchKernelGGL(amax_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, ld, rows, cols, amax);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+extern "C" int tvts_quant_fp8(const void* x, int is_f32, long ld, int rows, int cols, const float* amax, void* out, long ldo,
+                              float* scale_out, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0 || cols % 4 || ldo % 4 || ld % 4) return TVTS_EINVAL;
+    const int blocks = rows < 2048 ? rows : 2048;
+    if (is_f32) hipLaunchKernelGGL(quant_fp8_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, ld, rows, cols, amax,
+                                   (unsigned char*)out, ldo, scale_out);
+    else hipLaunchKernelGGL(quant_fp8_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, ld, rows, cols, amax,
+                            (unsigned char*)out, ldo, scale_out);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
 // probe used by tests: what does ds_read_b64_tr_b16 return?  in: 16 x 64 bf16 row-major tile (row stride 160 B in LDS)
 __global__ void probe_tr16_kernel(const bf16* __restrict__ in, bf16* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char tile[16 * 160];
