@@ -35,6 +35,33 @@ def allgather_embeds(video_emb: torch.Tensor, text_emb: torch.Tensor, scratch=No
     return out[:, :E].contiguous(), out[:, E:].contiguous()
 
 
+class EmbedGather:
+    """The same exchange started early: `start` is called by the engine as soon as both embeddings exist (before the
+    sort head's forward), the collective runs asynchronously on RCCL's stream, `result` waits for it where the loss needs
+    the gathered rows (trainer.py:479-483)."""
+
+    def __init__(self):
+        self.W, _ = world()
+        self.pending = None
+
+    def start(self, text_emb: torch.Tensor, video_emb: torch.Tensor):
+        if self.W == 1:
+            self.pending = (None, video_emb, text_emb)
+            return
+        B, E = video_emb.shape
+        packed = torch.cat([video_emb, text_emb], dim=1).contiguous()
+        out = torch.empty(self.W * B, 2 * E, dtype=packed.dtype, device=packed.device)
+        self.pending = (dist.all_gather_into_tensor(out, packed, async_op=True), out, E)
+
+    def result(self):
+        h, a, b = self.pending
+        self.pending = None
+        if h is None:
+            return a, b
+        h.wait()
+        return a[:, :b].contiguous(), a[:, b:].contiguous()
+
+
 def local_rows(grad_all: torch.Tensor, B: int) -> torch.Tensor:
     """AllGather_multi.backward: this rank's rows of the gradient wrt the gathered tensor."""
     _, r = world()

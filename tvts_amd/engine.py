@@ -153,6 +153,7 @@ class Engine:
         self.requires_grad = {name: True for name in store.shapes}
         self.ctx: dict = {}
         self.grad_ready = None  # optional callback(start, end): flat grad range is final (GradSync.reduce_range)
+        self.embeds_ready = None  # optional callback(text_emb, video_emb): both embeddings exist, the sort head has not run yet
         self._ranges: dict = {}
 
     def _ready(self, *prefixes: str):
@@ -549,6 +550,8 @@ class Engine:
             K.rows_gather(out, pb["vid_rows"], video_emb)
         else:
             video_emb = pooled
+        if self.embeds_ready is not None:  # the embedding all-gather starts here and travels under the sort head's forward
+            self.embeds_ready(text_emb, video_emb)
         pred = self.sort_forward(out, text_before, B, S, NT) if (NT != 1 and self.has_sort_head) else None
         return text_emb, video_emb, pred
 

@@ -21,10 +21,11 @@ class StepRunner:
         self.sync = D.GradSync(self.store.grad)
         self.fused = hasattr(optimizer, "chunk_group")
         self.eng.grad_ready = self.sync.reduce_range if self.sync.W > 1 else None
+        self.gather = D.EmbedGather()
 
     def losses_and_grads(self, pb, te, ve, pred, labels):
         B = pb["B"]
-        vg, tg = D.allgather_embeds(ve, te)
+        vg, tg = self.gather.result()  # started by the engine before the sort head ran
         loss1, dv_all, dt_all = self.head.contrastive(vg, tg)
         if pred is not None:
             loss2, dpred = self.head.sorting(pred, labels)
@@ -44,7 +45,11 @@ class StepRunner:
     def run(self, pb, labels, device_step=False):
         """The device-side part of the step (capturable in a hipGraph when world == 1)."""
         self.store.grad.zero_()
-        te, ve, pred = self.eng.forward(pb)
+        self.eng.embeds_ready = self.gather.start  # only the training step gathers; eval / autograd forwards do not
+        try:
+            te, ve, pred = self.eng.forward(pb)
+        finally:
+            self.eng.embeds_ready = None
         loss1, loss2, d_te, d_ve, dpred = self.losses_and_grads(pb, te, ve, pred, labels)
         self.eng.backward(d_te, d_ve, dpred)
         scale = self.sync.finish()
