@@ -559,6 +559,14 @@ class Engine:
         """Accumulates parameter gradients into the flat grad buffer (+=).  d_* are fp32 GPU tensors (or None)."""
         a, pb = self.arch, self.ctx
         B, T, N, NT, L, S, E = pb["B"], pb["T"], pb["N"], pb["NT"], pb["L"], pb["S"], a["embed"]
+        # the text tower first: it shares nothing with the video / sort-head backward (the sort head sees DETACHED caption
+        # embeddings, model_dist..B_16.py:69), and its gradient range (token embedding included) is the largest single
+        # all-reduce of the step -- issued here it travels under the whole video backward instead of after it
+        if d_text is not None:
+            dt = self._f("mdl.dt", (N, E))
+            K.text_mean_bwd(d_text, dt, NT=NT, B=B)
+            self.text_backward(dt, pb["ids"], pb["eot_rows"], N, L)
+            self._ready("text_")
         dout = self._b("mdl.dout", (B * S, E))
         off = 1 if self.pooled_tail else 0
         dv_cls = None if self.pooled_tail else d_video  # B models: the embedding IS the CLS row of the projected tokens
@@ -572,11 +580,6 @@ class Engine:
         else:
             dout = None
         self.video_backward(dout, pb["keep"], B, T, d_pooled=d_video if self.pooled_tail else None)
-        if d_text is not None:
-            dt = self._f("mdl.dt", (N, E))
-            K.text_mean_bwd(d_text, dt, NT=NT, B=B)
-            self.text_backward(dt, pb["ids"], pb["eot_rows"], N, L)
-            self._ready("text_")
 
 
 class LossHead:
