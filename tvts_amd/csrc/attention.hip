@@ -264,13 +264,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
             }
         mx = group_max(mx);
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float rs = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float p = exp2f(st[t][e] - m_new);
+                const float p = __builtin_amdgcn_exp2f(st[t][e] - m_new);
                 st[t][e] = p;
                 rs += p;
             }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnGeom g, const bf16* _
         for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float sc = exp2f(red[(w * (2 + DT * 4) + 0) * 64 + lane] - mm);
+            const float sc = __builtin_amdgcn_exp2f(red[(w * (2 + DT * 4) + 0) * 64 + lane] - mm);
             ll += red[(w * (2 + DT * 4) + 1) * 64 + lane] * sc;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnGeom g, const bf16
                 for (int e = 0; e < 4; ++e) {
                     const int key = kt0 + t * 16 + gq * 4 + e;
                     const bool ok = key < r.nk && !(MODE == MODE_FULL && g.causal && key > qi);
-                    const float p = ok ? exp2f(s[e] * g.scale2 - lse) : 0.f;
+                    const float p = ok ? __builtin_amdgcn_exp2f(s[e] * g.scale2 - lse) : 0.f;
                     ds[t][e] = p * (dp[e] - dlt) * g.scale;
                 }
             }
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnGeom g, const bf1
                     const int qrow = qx_row<MODE>(g, r, qi);
                     const float lse = lse2[(size_t)qrow * g.heads + r.h];
                     const float dlt = delta[(size_t)qrow * g.heads + r.h];
-                    p = exp2f(s[e] * g.scale2 - lse);
+                    p = __builtin_amdgcn_exp2f(s[e] * g.scale2 - lse);
                     d = p * (dp[e] - dlt) * g.scale;
                 }
                 pf[t * 4 + e] = (bf16)p;
@@ -676,13 +676,13 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const 
                 }
             mx = group_max(mx);
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f(m_run - m_new);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             float rs = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float p = exp2f(st[t][e] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(st[t][e] - m_new);
                     st[t][e] = p;
                     rs += p;
                 }
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_shared_kernel(AttnGeom g, con
                     for (int e = 0; e < 4; ++e) {
                         const int key = kt0 + t * 16 + gq * 4 + e;
                         const bool ok = key < r.nk && !(causal && key > qi);
-                        const float p = ok ? exp2f(s[e] * g.scale2 - lse) : 0.f;
+                        const float p = ok ? __builtin_amdgcn_exp2f(s[e] * g.scale2 - lse) : 0.f;
                         ds[t][e] = p * (dp[e] - dlt) * g.scale;
                     }
                 }
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
                     float p = 0.f, d = 0.f;
                     if (ok) {
                         const int ql = t * 16 + gq * 4 + e;
-                        p = exp2f(s[e] * g.scale2 - stat[buf][0][ql]);
+                        p = __builtin_amdgcn_exp2f(s[e] * g.scale2 - stat[buf][0][ql]);
                         d = p * (dp[e] - stat[buf][1][ql]) * g.scale;
                     }
                     pf[t * 4 + e] = (bf16)p;
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, cons
                         const bool ok = qi < nqx && kj < r.nk && !(qi == 0 && kj == 0 && p != 0);  // CLS x CLS once
                         float pp = 0.f, d = 0.f;
                         if (ok) {
-                            pp = exp2f(s[e] * g.scale2 - stat[wave][0][ql]);
+                            pp = __builtin_amdgcn_exp2f(s[e] * g.scale2 - stat[wave][0][ql]);
                             d = pp * (dp[e] - stat[wave][1][ql]) * g.scale;
                         }
                         pf[t * 4 + e] = (bf16)pp;
