@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--batch", type=int, default=192, help="pairs per GPU (the reference config uses 12 on V100)")
     ap.add_argument("--caption-len", type=int, default=32)
+    ap.add_argument("--fp8", action="store_true", help="BASELINE config 4: e4m3 forward GEMMs in the ViT blocks")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -127,6 +128,8 @@ def main():
     a = dict(A.ARCHS[args.arch])
     if args.frames > a["num_frames"]:  # BASELINE config 3: 16-frame clips need a temporal table past the reference's 12 rows
         a["num_frames"] = args.frames
+    if args.fp8:
+        a["fp8"] = True
     margs = types.SimpleNamespace(local_rank=local_rank, rank=rank, world_size=world)
     model = TVTSv2Base(margs, arch=a, init_seed=0)
     groups = [[], [], [], []]
@@ -197,7 +200,8 @@ def main():
     line = {
         "metric": "video-text pairs/sec/node, TVTSv2 pretrain step", "value": pairs_per_s, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp8 e4m3 forward GEMMs (ViT blocks) + bf16" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"TVTSv2 ViT-{args.arch.replace('_', '/')} {T}-frame 224^2, mask {a['mask_ratio']}, "
                                f"{args.caption_len}-token captions x4, full pretrain step (fwd+losses+bwd+HF-AdamW)",
                    "pairs_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",

@@ -33,8 +33,8 @@ int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int
 /* fp8 (OCP e4m3) operands with per-tensor scales in device memory, fp32 accumulate: the GEMM of BASELINE config 4's
  * weight / activation path (nn.Linear sites of video_encoder_ViT_H_14.py); K % 128 == 0, lda / ldb % 16 == 0 (bytes) */
 int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
-                     const float* scale_b, const float* bias, const float* residual, int ldr, void* out, int ldc, int out_f32,
-                     hipStream_t stream);
+                     const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact, int ldp,
+                     void* out, int ldc, int out_f32, hipStream_t stream);
 /* per-tensor fp8 quantisation: amax[0] = max |x| ; q = rne(x * 448 / amax) as e4m3, scale_out[0] = amax / 448 */
 int tvts_amax(const void* x, int is_f32, long ld, int rows, int cols, float* amax, hipStream_t stream);
 int tvts_quant_fp8(const void* x, int is_f32, long ld, int rows, int cols, const float* amax, void* out, long ldo,

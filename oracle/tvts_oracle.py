@@ -255,6 +255,22 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
     return y if b is None else y + b
 
 
+def fake_quant_e4m3(t: Tensor) -> Tensor:
+    """per-tensor OCP e4m3 quantise -> dequantise (scale = amax / 448, round to nearest even, gradient passed straight
+    through): what the fp8 weight / activation GEMMs of BASELINE config 4 see."""
+    amax = t.detach().abs().max()
+    scale = amax / 448.0 if float(amax) > 0 else torch.ones(())
+    q = (t.detach() / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * scale
+    return t + (q - t).detach()
+
+
+def linear_fp8(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    """nn.Linear whose FORWARD product runs on e4m3 copies of the activation and the weight (the backward of the build
+    keeps bf16 operands, i.e. straight-through here)."""
+    y = fake_quant_e4m3(x) @ fake_quant_e4m3(w).t()
+    return y if b is None else y + b
+
+
 def _softmax_attend(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor] = None) -> Tensor:
     """softmax(q k^T) v over the last two dims (v2/model/video_encoder_ViT_B_16.py:11-15)."""
     s = q @ k.transpose(-1, -2)
@@ -268,15 +284,16 @@ def _softmax_attend(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor] = No
 # --------------------------------------------------------------------------------------
 
 def divided_attention(x: Tensor, wqkv: Tensor, bqkv: Tensor, wo: Tensor, bo: Tensor,
-                      heads: int, mode: str, T: int, n: int) -> Tensor:
+                      heads: int, mode: str, T: int, n: int, lin=None) -> Tensor:
     """VarAttention.forward restated with explicit token tables.
 
     x: [B, 1+T*n, W].  mode 'time': token (f, i) attends {CLS} + {(f', i)}; mode 'space':
     token (f, i) attends {CLS} + {(f, i')}.  The CLS query attends all tokens.  q is scaled by
     dh^-0.5 before the CLS split (:45-51); CLS k/v are key 0 of every group (:56-60).
     """
-    out = divided_attention_core(linear(x, wqkv, bqkv), heads, mode, T, n)
-    return linear(out, wo, bo)
+    lin = linear if lin is None else lin
+    out = divided_attention_core(lin(x, wqkv, bqkv), heads, mode, T, n)
+    return lin(out, wo, bo)
 
 
 def divided_attention_core(qkv_packed: Tensor, heads: int, mode: str, T: int, n: int) -> Tensor:
@@ -312,17 +329,18 @@ def st_block(x: Tensor, P: Params, pre: str, arch, T: int, n: int) -> Tensor:
     NB the space residual starts from the block input x, not from the time residual (:121).
     """
     h = arch["heads"]
+    lin = linear_fp8 if arch.get("fp8") else linear
     t_out = divided_attention(layer_norm(x, P[pre + "ln_3.weight"], P[pre + "ln_3.bias"], 1e-5),
                               P[pre + "timeattn.qkv.weight"], P[pre + "timeattn.qkv.bias"],
-                              P[pre + "timeattn.proj.weight"], P[pre + "timeattn.proj.bias"], h, "time", T, n)
+                              P[pre + "timeattn.proj.weight"], P[pre + "timeattn.proj.bias"], h, "time", T, n, lin)
     t_res = x + t_out
     s_out = divided_attention(layer_norm(t_res, P[pre + "ln_1.weight"], P[pre + "ln_1.bias"], 1e-5),
                               P[pre + "attn.qkv.weight"], P[pre + "attn.qkv.bias"],
-                              P[pre + "attn.proj.weight"], P[pre + "attn.proj.bias"], h, "space", T, n)
+                              P[pre + "attn.proj.weight"], P[pre + "attn.proj.bias"], h, "space", T, n, lin)
     s_res = x + s_out
-    hid = _act(arch)(linear(layer_norm(s_res, P[pre + "ln_2.weight"], P[pre + "ln_2.bias"], 1e-5),
-                            P[pre + "mlp.c_fc.weight"], P[pre + "mlp.c_fc.bias"]))
-    return s_res + linear(hid, P[pre + "mlp.c_proj.weight"], P[pre + "mlp.c_proj.bias"])
+    hid = _act(arch)(lin(layer_norm(s_res, P[pre + "ln_2.weight"], P[pre + "ln_2.bias"], 1e-5),
+                         P[pre + "mlp.c_fc.weight"], P[pre + "mlp.c_fc.bias"]))
+    return s_res + lin(hid, P[pre + "mlp.c_proj.weight"], P[pre + "mlp.c_proj.bias"])
 
 
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)  # v2/video_transforms/videoaug.py:17,26

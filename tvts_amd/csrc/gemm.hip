@@ -956,20 +956,22 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
 // bytes with per-tensor scales held in device memory (BASELINE config 4's weight/activation path; the building block, the
 // step engine does not use it yet).  Same pipelined 256x256 kernel: K % 128 == 0, lda / ldb % 16 == 0.
 extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
-                                const float* scale_b, const float* bias, const float* residual, int ldr, void* out, int ldc,
-                                int out_f32, hipStream_t stream) {
+                                const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact,
+                                int ldp, void* out, int ldc, int out_f32, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b) return TVTS_EINVAL;
-    if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || (residual && ldr % 4)) return TVTS_EINVAL;
+    if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || (residual && ldr % 4) || (preact && ldp % 8)) return TVTS_EINVAL;
     GemmNT g;
     g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;  // byte-identical bf16 view, half as wide
-    g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = ACT_NONE;
-    g.preact = nullptr; g.ldp = 0; g.gate_h = nullptr; g.ldh = 0; g.gate_act = ACT_NONE;
+    g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
+    g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = nullptr; g.ldh = 0; g.gate_act = ACT_NONE;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.swz = 7; g.ablate = 0; g.sa = scale_a; g.sb = scale_b;
     g.tiles_n = ceil_div(N, 256);
     g.tiles_m = ceil_div(M, 256);
     const int total_tiles = g.tiles_m * g.tiles_n;
     const int grid = total_tiles < 256 ? ((total_tiles + 7) / 8) * 8 : 256;
-    void (*kern)(GemmNT) = gemm_nt256p_kernel<0, 0, true>;
+    void (*kern)(GemmNT) = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, true> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, true>
+                         : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, true> : nullptr;
+    if (!kern) return TVTS_EINVAL;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 163840, stream, g);

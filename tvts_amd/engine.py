@@ -72,6 +72,9 @@ class ParamStore:
         self.conv_kpad = -(-kc // 64) * 64
         self.conv_pad = (torch.zeros(arch["width"], self.conv_kpad, dtype=torch.bfloat16, device=device)
                          if self.conv_kpad != kc else None)
+        self.w8: Dict[str, tuple] = {}
+        self.fp8_names = [n for n in self.shapes if n.startswith("video_model.transformer.resblocks.") and
+                          n.endswith(("qkv.weight", "proj.weight", "c_fc.weight", "c_proj.weight"))]
         self.m: Optional[torch.Tensor] = None
         self.v: Optional[torch.Tensor] = None
         self.shadow_version = -1
@@ -118,6 +121,15 @@ class ParamStore:
             K.transpose_batched(self.shadow, self.shadow_t, self.tile_table, self.n_tiles)
         if self.conv_pad is not None:
             K.pad_rows_bf16(self.w("video_model.conv1.weight"), self.conv_pad)
+        if self.arch.get("fp8"):  # BASELINE config 4: e4m3 copies (+ per-tensor scales) of the ViT blocks' linear weights
+            for name in self.fp8_names:
+                if name not in self.w8:
+                    s0 = self.shapes[name]
+                    self.w8[name] = (torch.empty(s0[0], int(np.prod(s0[1:])), dtype=torch.uint8, device=self.device),
+                                     torch.empty(1, dtype=torch.float32, device=self.device),
+                                     torch.empty(1, dtype=torch.float32, device=self.device))
+                q, sc, am = self.w8[name]
+                K.quantize_fp8(self.p(name).view(q.shape), q=q, scale=sc, amax=am)
 
     def w_conv(self) -> torch.Tensor:
         """bf16 patch-embedding weight [W, K padded to 64]."""
@@ -189,6 +201,14 @@ class Engine:
 
     # ------------------------------------------------------------------ linear helpers
     def _lin(self, a, wname, bname, out, M, **epi):
+        if wname in self.P.w8:  # fp8 weight/activation path (BASELINE config 4): forward GEMMs of the ViT blocks
+            w8, ws, _ = self.P.w8[wname]
+            a2 = a[:M]
+            q = self._b("fp8.q%d" % a2.shape[1], a2.shape, torch.uint8)
+            sc, am = self._f("fp8.scale", (1,)), self._f("fp8.amax", (1,))
+            K.quantize_fp8(a2, q=q, scale=sc, amax=am)
+            K.gemm_nt_fp8(q, sc, w8, ws, out[:M], bias=self.P.p(bname) if bname else None, **epi)
+            return
         K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
 
     def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, **epi):

@@ -65,13 +65,14 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
         GEMM_PROFILE.append(("gemm_nt", 2.0 * M * N * K, ev0, ev1, (M, N, K, "f32" if out.dtype == torch.float32 else "bf16", "res" if residual is not None else "", str(act or ""), "gate" if gate_h is not None else "")))
 
 
-def quantize_fp8(x):
-    """per-tensor e4m3 quantisation of a bf16 / fp32 matrix -> (q uint8 [rows, cols], scale float32[1]); x ~ q * scale."""
+def quantize_fp8(x, q=None, scale=None, amax=None):
+    """per-tensor e4m3 quantisation of a bf16 / fp32 matrix -> (q uint8 [rows, cols], scale float32[1]); x ~ q * scale.
+    q / scale / amax may be preallocated (the engine's workspace)."""
     lib = _lib.load()
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.bfloat16, torch.float32)
-    amax = torch.empty(1, dtype=torch.float32, device=x.device)
-    scale = torch.empty(1, dtype=torch.float32, device=x.device)
-    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    amax = torch.empty(1, dtype=torch.float32, device=x.device) if amax is None else amax
+    scale = torch.empty(1, dtype=torch.float32, device=x.device) if scale is None else scale
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if q is None else q
     f32 = 1 if x.dtype == torch.float32 else 0
     _chk(lib.tvts_amax(_p(x), f32, x.stride(0), x.shape[0], x.shape[1], _p(amax), _stream()), "tvts_amax")
     _chk(lib.tvts_quant_fp8(_p(x), f32, x.stride(0), x.shape[0], x.shape[1], _p(amax), _p(q), q.stride(0), _p(scale), _stream()),
@@ -79,16 +80,24 @@ def quantize_fp8(x):
     return q, scale
 
 
-def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None):
-    """out[M,N] = sa*sb * (a8[M,K] @ b8[N,K]^T) + bias [+ residual]; a8 / b8 uint8 e4m3 bit patterns, sa / sb float32[1]."""
+def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, preact=None):
+    """out[M,N] = act(sa*sb * (a8[M,K] @ b8[N,K]^T) + bias) [+ residual]; a8 / b8 uint8 e4m3 bit patterns, sa / sb float32[1];
+    preact receives the bf16 pre-activation like gemm_nt."""
     lib = _lib.load()
     M, Kd = a8.shape
     N = b8.shape[0]
     assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and b8.shape[1] == Kd
+    if GEMM_PROFILE is not None:
+        ev0, ev1 = Event(), Event()
+        ev0.record()
     rc = lib.tvts_gemm_nt_fp8(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), _p(sb), _p(bias), _p(residual),
-                              _ld(residual) if residual is not None else 0, _p(out), _ld(out),
+                              _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
+                              _ld(preact) if preact is not None else 0, _p(out), _ld(out),
                               1 if out.dtype == torch.float32 else 0, _stream())
     _chk(rc, "tvts_gemm_nt_fp8")
+    if GEMM_PROFILE is not None:
+        ev1.record()
+        GEMM_PROFILE.append(("gemm_nt_fp8", 2.0 * M * N * Kd, ev0, ev1, (M, N, Kd, "fp8", "res" if residual is not None else "", str(act or ""), "")))
 
 
 TN_WORKSPACE = None  # fp32 scratch tensor for the split partials of gemm_tn (allocated lazily, 256 MiB: 8 partials of the largest weight, H/14 mlp 1280 x 5120)
