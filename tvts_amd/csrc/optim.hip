@@ -139,11 +139,22 @@ extern "C" int tvts_add_rows_f32(float* dst, int ld_dst, const float* src, int l
 
 // ---- fp8 (OCP e4m3) quantisation with one scale per tensor: scale = amax / 448, q = rne(x / scale), |q| <= 448
 //      (the weight / activation format of tvts_gemm_nt_fp8; torch.float8_e4m3fn bit patterns)
+// 16 bytes per lane and access: 8 bf16 or 4 fp32 (cols % 8 == 0 resp. % 4, rows 16-byte aligned)
+template <typename T> struct Vec16;
+template <> struct Vec16<bf16> { typedef bf16x8 V; static constexpr int N = 8; };
+template <> struct Vec16<float> { typedef f32x4 V; static constexpr int N = 4; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ x, long ld, int rows, int cols, float* __restrict__ amax) {
+    typedef typename Vec16<T>::V V;
+    constexpr int N = Vec16<T>::N;
     float m = 0.f;
     for (long r = blockIdx.x; r < rows; r += gridDim.x)
-        for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf((float)x[r * ld + c]));
+        for (int c = threadIdx.x * N; c < cols; c += 256 * N) {
+            const V v = *(const V*)(x + r * ld + c);
+#pragma unroll
+            for (int e = 0; e < N; ++e) m = fmaxf(m, fabsf((float)v[e]));
+        }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)amax, __float_as_uint(m));  // non-negative floats order like their bits
 }
@@ -151,23 +162,32 @@ template <typename T>
 __global__ __launch_bounds__(256) void quant_fp8_kernel(const T* __restrict__ x, long ld, int rows, int cols,
                                                         const float* __restrict__ amax, unsigned char* __restrict__ out, long ldo,
                                                         float* __restrict__ scale_out) {
+    typedef typename Vec16<T>::V V;
+    constexpr int N = Vec16<T>::N;
     const float am = amax[0];
     const float scale = am > 0.f ? am / 448.0f : 1.0f;
     const float inv = 1.0f / scale;
     if (blockIdx.x == 0 && threadIdx.x == 0 && scale_out) scale_out[0] = scale;
     for (long r = blockIdx.x; r < rows; r += gridDim.x)
-        for (int c = threadIdx.x * 4; c < cols; c += 1024) {
-            float v[4];
+        for (int c = threadIdx.x * N; c < cols; c += 256 * N) {
+            const V v = *(const V*)(x + r * ld + c);
+            int pk[N / 4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf((float)x[r * ld + c + e] * inv, -448.0f), 448.0f);
-            int pk = 0;
-            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], pk, false);
-            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
-            *(int*)(out + r * ldo + c) = pk;
+            for (int h = 0; h < N / 4; ++h) {
+                float f[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = fminf(fmaxf((float)v[h * 4 + e] * inv, -448.0f), 448.0f);
+                int p = 0;
+                p = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], p, false);
+                p = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], p, true);
+                pk[h] = p;
+            }
+            if (N == 8) *(long*)(out + r * ldo + c) = ((long)(unsigned)pk[N / 4 - 1] << 32) | (unsigned)pk[0];
+            else *(int*)(out + r * ldo + c) = pk[0];
         }
 }
 extern "C" int tvts_amax(const void* x, int is_f32, long ld, int rows, int cols, float* amax, hipStream_t stream) {
-    if (rows <= 0 || cols <= 0) return TVTS_EINVAL;
+    if (rows <= 0 || cols <= 0 || cols % (is_f32 ? 4 : 8) || ld % (is_f32 ? 4 : 8)) return TVTS_EINVAL;
     if (hipMemsetAsync(amax, 0, sizeof(float), stream) != hipSuccess) return TVTS_EINVAL;
     const int blocks = rows < 2048 ? rows : 2048;
     if (is_f32) hipLaunchKernelGGL(amax_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, ld, rows, cols, amax);
@@ -177,7 +197,7 @@ extern "C" int tvts_amax(const void* x, int is_f32, long ld, int rows, int cols,
 }
 extern "C" int tvts_quant_fp8(const void* x, int is_f32, long ld, int rows, int cols, const float* amax, void* out, long ldo,
                               float* scale_out, hipStream_t stream) {
-    if (rows <= 0 || cols <= 0 || cols % 4 || ldo % 4 || ld % 4) return TVTS_EINVAL;
+    if (rows <= 0 || cols <= 0 || cols % (is_f32 ? 4 : 8) || ldo % 8 || ld % (is_f32 ? 4 : 8)) return TVTS_EINVAL;
     const int blocks = rows < 2048 ? rows : 2048;
     if (is_f32) hipLaunchKernelGGL(quant_fp8_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, ld, rows, cols, amax,
                                    (unsigned char*)out, ldo, scale_out);
