@@ -156,7 +156,11 @@ __global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ x, long
             for (int e = 0; e < N; ++e) m = fmaxf(m, fabsf((float)v[e]));
         }
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)amax, __float_as_uint(m));  // non-negative floats order like their bits
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)  // one atomic per block (every wave hammering the single address serialises the whole kernel)
+        atomicMax((unsigned*)amax, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));  // non-negative floats order like their bits
 }
 template <typename T>
 __global__ __launch_bounds__(256) void quant_fp8_kernel(const T* __restrict__ x, long ld, int rows, int cols,
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void quant_fp8_kernel(const T* __restrict__ x,
 extern "C" int tvts_amax(const void* x, int is_f32, long ld, int rows, int cols, float* amax, hipStream_t stream) {
     if (rows <= 0 || cols <= 0 || cols % (is_f32 ? 4 : 8) || ld % (is_f32 ? 4 : 8)) return TVTS_EINVAL;
     if (hipMemsetAsync(amax, 0, sizeof(float), stream) != hipSuccess) return TVTS_EINVAL;
-    const int blocks = rows < 2048 ? rows : 2048;
+    const int blocks = rows < 1024 ? rows : 1024;
     if (is_f32) hipLaunchKernelGGL(amax_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, ld, rows, cols, amax);
     else hipLaunchKernelGGL(amax_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, ld, rows, cols, amax);
     TVTS_LAUNCH_CHECK();
