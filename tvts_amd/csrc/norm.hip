@@ -126,7 +126,7 @@ __device__ __forceinline__ f32x4 widen(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 widen(bf16x4 v) { return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 
 template <typename TDY, int IT, bool R1, bool R2>
-__global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 && R2) ? 2 : 3)) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const float* __restrict__ x,
+__global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3)) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                         int ldx, const int* __restrict__ rows,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ res1,
@@ -265,7 +265,7 @@ static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int 
                           int ldr2, int ldr, int W, float* dx, int lddx, bf16* dxb, int lddxb, float* dgamma, float* dbeta,
                           float* ws, long ws_elems) {
     // persistent grid: as many blocks per CU as the variant's registers allow (see __launch_bounds__ above)
-    const int per_cu = it <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 && R2) ? 2 : 3);
+    const int per_cu = it <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3);
     int blocks = ceil_div(M, 4);
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     const dim3 grid(blocks);
