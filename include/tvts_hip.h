@@ -47,9 +47,9 @@ int tvts_gemm_small_f32(const float* A, long sai, long sak, const float* B, long
 int tvts_colsum_bf16(const void* X, int ld, int M, int N, float* out, hipStream_t stream);
 
 /* ---- LayerNorm (norm.hip): video_encoder_ViT_B_16.py:79-85 (eps 1e-5), sort_transformer.py:99 (eps 1e-6) */
-int tvts_layernorm_fwd(const float* x, int ldx, const int* rows, const float* gamma, const float* beta, float eps, int M,
+int tvts_layernorm_fwd(const void* x, int ldx, int x_bf16, const int* rows, const float* gamma, const float* beta, float eps, int M,
                        int W, void* y, int ldy, int y_f32, float* mean, float* rstd, hipStream_t stream);
-int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const float* x, int ldx, const int* rows, const float* mean,
+int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const void* x, int ldx, int x_bf16, const int* rows, const float* mean,
                        const float* rstd, const float* gamma, const float* res1, int ldr, const void* res2_bf16, int ldr2,
                        int M, int W, float* dx, int lddx, void* dx_bf16, int lddxb, float* dgamma, float* dbeta,
                        float* workspace, long workspace_elems, hipStream_t stream);

@@ -171,6 +171,21 @@ def test_layernorm(K, W, eps):
     dg2, db2 = torch.zeros(W, device=DEV), torch.zeros(W, device=DEV)
     K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), dx, dgamma=dg2, dbeta=db2, workspace=False)
     assert rel(dg2, gr.grad) < 1e-4 and rel(db2, br.grad) < 1e-4
+    # a bf16 input (side-branch value that only this LayerNorm consumes): forward and the residual-free backward
+    xb = bf(x)
+    xbr = xb.float().clone().requires_grad_(True)
+    g2, b2 = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yb_ref = O.layer_norm(xbr, g2, b2, eps)
+    yb_ref.backward(dy.float())
+    yb = torch.empty(M, W, dtype=torch.bfloat16, device=DEV)
+    mean_b, rstd_b = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    K.layernorm_fwd(xb.to(DEV), g.to(DEV), b.to(DEV), eps, yb, mean_b, rstd_b)
+    assert rel(yb.float(), yb_ref) < 4e-3
+    dxb3 = torch.empty(M, W, dtype=torch.bfloat16, device=DEV)
+    dg3, db3 = torch.zeros(W, device=DEV), torch.zeros(W, device=DEV)
+    K.layernorm_bwd(dy.to(DEV), xb.to(DEV), mean_b, rstd_b, g.to(DEV), None, dx_bf16=dxb3, dgamma=dg3, dbeta=db3)
+    assert rel(dxb3.float(), xbr.grad) < 4e-3
+    assert rel(dg3, g2.grad) < 1e-4 and rel(db3, b2.grad) < 1e-4
     # bf16-only output (no fp32 gradient tensor)
     dxb2 = torch.empty_like(dxb)
     K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), None, dx_bf16=dxb2)

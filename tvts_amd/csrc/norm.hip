@@ -30,8 +30,8 @@ __device__ __forceinline__ void store4(bf16* p, f32x4 v) {
 // Both kernels are templated on IT = ceil(W / 256) (register arrays sized to the row, no dead iterations) and walk
 // their rows in a grid-stride loop with the NEXT row's loads issued before the current row's reductions: a wave always
 // has two rows of traffic in flight instead of one load -> reduce -> store round trip at a time.
-template <typename TO, int IT>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ rows,
+template <typename TO, int IT, typename TX = float>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, int ldx, const int* __restrict__ rows,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, int M, int W, TO* __restrict__ y, int ldy,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
@@ -49,11 +49,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float invW = 1.0f / (float)W;
     f32x4 v[IT], nx[IT];
     auto load_row = [&](int rr, f32x4 (&d)[IT]) {
-        const float* xp = x + (size_t)(rows ? rows[rr] : rr) * ldx;
+        const TX* xp = x + (size_t)(rows ? rows[rr] : rr) * ldx;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int c = lane * 4 + it * 256;
-            d[it] = c < W ? load4<float>(xp + c) : (f32x4){0, 0, 0, 0};
+            d[it] = c < W ? load4<TX>(xp + c) : (f32x4){0, 0, 0, 0};
         }
     };
     load_row(r, v);
@@ -98,23 +98,26 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-template <typename TO>
-static void launch_ln_fwd(int it, dim3 grid, hipStream_t stream, const float* x, int ldx, const int* rows, const float* gamma,
+template <typename TO, typename TX>
+static void launch_ln_fwd(int it, dim3 grid, hipStream_t stream, const TX* x, int ldx, const int* rows, const float* gamma,
                           const float* beta, float eps, int M, int W, TO* y, int ldy, float* mean, float* rstd) {
-#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<TO, N>), grid, dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd); break;
+#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<TO, N, TX>), grid, dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd); break;
     switch (it) { LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) default: LN_FWD_CASE(5) }
 #undef LN_FWD_CASE
 }
 
-extern "C" int tvts_layernorm_fwd(const float* x, int ldx, const int* rows, const float* gamma, const float* beta,
+// x: the fp32 residual stream, or (x_bf16) a side-branch value that only this LayerNorm consumes and that is therefore
+// kept in bf16 (the time residual of the space-time block: the space branch restarts from the block input).
+extern "C" int tvts_layernorm_fwd(const void* x, int ldx, int x_bf16, const int* rows, const float* gamma, const float* beta,
                                   float eps, int M, int W, void* y, int ldy, int y_f32, float* mean, float* rstd,
                                   hipStream_t stream) {
-    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || ldy % 4) return TVTS_EINVAL;
+    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || ldy % 4 || (x_bf16 && y_f32)) return TVTS_EINVAL;
     int blocks = ceil_div(M, 4);
     if (blocks > 2048) blocks = 2048;  // 8 blocks x 4 waves per CU, two rows in flight per wave
     const int it = ceil_div(W, 256);
-    if (y_f32) launch_ln_fwd<float>(it, dim3(blocks), stream, x, ldx, rows, gamma, beta, eps, M, W, (float*)y, ldy, mean, rstd);
-    else launch_ln_fwd<bf16>(it, dim3(blocks), stream, x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd);
+    if (x_bf16) launch_ln_fwd<bf16, bf16>(it, dim3(blocks), stream, (const bf16*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd);
+    else if (y_f32) launch_ln_fwd<float, float>(it, dim3(blocks), stream, (const float*)x, ldx, rows, gamma, beta, eps, M, W, (float*)y, ldy, mean, rstd);
+    else launch_ln_fwd<bf16, float>(it, dim3(blocks), stream, (const float*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
@@ -125,8 +128,8 @@ template <> struct RawDy<bf16> { typedef bf16x4 T; };
 __device__ __forceinline__ f32x4 widen(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 widen(bf16x4 v) { return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 
-template <typename TDY, int IT, bool R1, bool R2>
-__global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3)) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const float* __restrict__ x,
+template <typename TDY, int IT, bool R1, bool R2, typename TX = float>
+__global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3)) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const TX* __restrict__ x,
                                                         int ldx, const int* __restrict__ rows,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ res1,
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
         for (int it = 0; it < IT; ++it) {
             const int c = lane * 4 + it * 256;
             if (c < W) {
-                w.x[it] = load4<float>(x + (size_t)w.xr * ldx + c);
+                w.x[it] = load4<TX>(x + (size_t)w.xr * ldx + c);
                 w.d[it] = *(const DyV*)(dy + (size_t)rr * lddy + c);
                 if (R1) w.r1[it] = load4<float>(res1 + (size_t)w.xr * ldr + c);
                 if (R2) w.r2[it] = *(const bf16x4*)(res2 + (size_t)w.xr * ldr2 + c);
@@ -259,8 +262,8 @@ __global__ __launch_bounds__(1024) void ln_dgamma_reduce_kernel(const float* __r
     }
 }
 
-template <typename TDY, bool R1, bool R2>
-static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int lddy, const float* x, int ldx, const int* rows,
+template <typename TDY, bool R1, bool R2, typename TX = float>
+static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int lddy, const TX* x, int ldx, const int* rows,
                           const float* mean, const float* rstd, const float* gamma, const float* res1, const bf16* res2,
                           int ldr2, int ldr, int W, float* dx, int lddx, bf16* dxb, int lddxb, float* dgamma, float* dbeta,
                           float* ws, long ws_elems) {
@@ -270,7 +273,7 @@ static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int 
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     const dim3 grid(blocks);
     float* partial = (dgamma && ws && ws_elems >= (long)blocks * 2 * W) ? ws : nullptr;
-#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N, R1, R2>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta, partial); break;
+#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N, R1, R2, TX>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta, partial); break;
     switch (it) { LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) default: LN_BWD_CASE(5) }
 #undef LN_BWD_CASE
     if (partial)
@@ -289,7 +292,7 @@ static void launch_ln_bwd_res(int it, int M, hipStream_t stream, const TDY* dy, 
 #undef LN_ARGS
 }
 
-extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const float* x, int ldx, const int* rows,
+extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const void* x_, int ldx, int x_bf16, const int* rows,
                                   const float* mean, const float* rstd, const float* gamma, const float* res1,
                                   int ldr, const void* res2_bf16, int ldr2, int M, int W, float* dx, int lddx,
                                   void* dx_bf16, int lddxb, float* dgamma, float* dbeta, float* workspace,
@@ -299,6 +302,15 @@ extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const fl
     if ((res1 && ldr % 4) || (res2_bf16 && ldr2 % 4)) return TVTS_EINVAL;
     const bf16* res2 = (const bf16*)res2_bf16;
     if (dx_bf16 && lddxb % 4) return TVTS_EINVAL;
+    if (x_bf16) {  // side-branch input kept in bf16: only the residual-free bf16-dy form exists (ln_1 of the space-time block)
+        if (dy_f32 || res1 || res2) return TVTS_EINVAL;
+        launch_ln_bwd<bf16, false, false, bf16>(ceil_div(W, 256), M, stream, (const bf16*)dy, lddy, (const bf16*)x_, ldx, rows, mean, rstd,
+                                                gamma, res1, res2, ldr2, ldr, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta,
+                                                workspace, workspace_elems);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
+    const float* x = (const float*)x_;
     const int it = ceil_div(W, 256);
     if (dy_f32)
         launch_ln_bwd_res<float>(it, M, stream, (const float*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, W,

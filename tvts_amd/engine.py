@@ -350,7 +350,8 @@ class Engine:
             self._lin(ln3, pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", qkv_t, M)
             att_t, lse_t = self._b(tg + ".att_t", (M, W)), self._f(tg + ".lse_t", (M, a["heads"]))
             self._st_attention_fwd(qkv_t, att_t, lse_t, "time", B, T, n)
-            t_res = self._f(tg + ".t_res", (M, W))
+            # the time residual only feeds ln_1 (the space branch restarts from x, video_encoder_ViT_B_16.py:121): bf16
+            t_res = self._b(tg + ".t_res", (M, W))
             self._lin(att_t, pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", t_res, M, residual=x)
             ln1 = self._b(tg + ".ln1", (M, W))
             self._ln(t_res, pre + "ln_1", 1e-5, ln1, tg + ".ln1")

@@ -145,7 +145,7 @@ def colsum(x, out, *, M=None):
 def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=None):
     lib = _lib.load()
     M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
-    rc = lib.tvts_layernorm_fwd(_p(x), _ld(x), _p(rows), _p(gamma), _p(beta), eps, M, x.shape[1], _p(y), _ld(y),
+    rc = lib.tvts_layernorm_fwd(_p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(rows), _p(gamma), _p(beta), eps, M, x.shape[1], _p(y), _ld(y),
                                 1 if y.dtype == torch.float32 else 0, _p(mean), _p(rstd), _stream())
     _chk(rc, "tvts_layernorm_fwd")
 
@@ -168,7 +168,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2
     ws = _ln_workspace(x.device) if (workspace and dgamma is not None) else None
     M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
     assert res2 is None or res2.dtype == torch.bfloat16
-    rc = lib.tvts_layernorm_bwd(_p(dy), _ld(dy), 1 if dy.dtype == torch.float32 else 0, _p(x), _ld(x), _p(rows),
+    rc = lib.tvts_layernorm_bwd(_p(dy), _ld(dy), 1 if dy.dtype == torch.float32 else 0, _p(x), _ld(x),
+                                1 if x.dtype == torch.bfloat16 else 0, _p(rows),
                                 _p(mean), _p(rstd), _p(gamma), _p(res1), _ld(res1) if res1 is not None else 0, _p(res2),
                                 _ld(res2) if res2 is not None else 0, M, x.shape[1], _p(dx),
                                 _ld(dx) if dx is not None else 0, _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0,
