@@ -505,6 +505,56 @@ def gen_transform():
     save("transform", frames=frames, out=out, image=32)
 
 
+def gen_downstream_more():
+    """The other two downstream copies: TVTSv2_B_32 (49 unmasked patches: the fused SPACE kernels' range) and the full-size
+    TVTSv2_H_14 (256 unmasked patches, head dim 80, pooled tail; OpenCLIP.create_model replaced as in gen_model_h14)."""
+    import json
+    ns = import_reference_h14()
+    if "downstream" not in sys.modules:
+        _stub("downstream")
+    d32 = _load("downstream.model_TVTSv2_ViT_B_32", os.path.join(REF, "downstream/model_TVTSv2_ViT_B_32.py"))
+    arch = downstream_arch("B_32")
+    m = d32.TVTSv2_B_32(load_checkpoint="")
+    P = O.synth_params(arch, seed=0)
+    assert list(m.state_dict().keys()) == list(P.keys())
+    m.load_state_dict(P, strict=True); m.eval()
+    b = O.synth_batch(O.ARCHS["B_32"], B=2, T=5, seed=6, n_trans=1)
+    keep = torch.arange(49).unsqueeze(0).expand(2, -1)
+    with torch.no_grad():
+        te, ve = m({"text": b["text"], "video": b["video"], "keep_ind": keep}, return_embeds=True)
+    save("downstream_b32", te=te, ve=ve, seed=0, batch_seed=6)
+    del m, P
+    with open(os.path.join(REF, "OpenCLIP/model_configs/ViT-H-14.json")) as f:
+        cfg = json.load(f)
+
+    def create_model(name, pretrained=None, cache_dir=None, **kw):
+        t = cfg["text_cfg"]
+        text = ns.oc.TextTransformer(context_length=t["context_length"], vocab_size=t["vocab_size"], width=t["width"],
+                                     heads=t["heads"], layers=t["layers"], output_dim=cfg["embed_dim"],
+                                     act_layer=torch.nn.GELU, norm_layer=ns.oc.LayerNorm)
+        return types.SimpleNamespace(transformer=text.transformer, token_embedding=text.token_embedding,
+                                     positional_embedding=text.positional_embedding, ln_final=text.ln_final,
+                                     text_projection=text.text_projection, attn_mask=text.attn_mask,
+                                     visual=types.SimpleNamespace(state_dict=lambda: {}))
+    sys.modules["OpenCLIP"].create_model = create_model
+    dh = _load("downstream.model_TVTSv2_ViT_H_14", os.path.join(REF, "downstream/model_TVTSv2_ViT_H_14.py"))
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        m = dh.TVTSv2_H_14(load_checkpoint="")
+    finally:
+        os.chdir(cwd)
+    arch = downstream_arch("H_14")
+    P = O.synth_params(arch, seed=0)
+    assert list(m.state_dict().keys()) == list(P.keys())
+    m.load_state_dict(P, strict=True); m.eval()
+    del P
+    b = O.synth_batch(O.ARCHS["H_14"], B=1, T=2, seed=7, n_trans=1)
+    with torch.no_grad():
+        te, ve = m({"text": b["text"], "video": b["video"], "keep_ind": torch.arange(256).unsqueeze(0)}, return_embeds=True)
+    save("downstream_h14", te=te, ve=ve, seed=0, batch_seed=7)
+
+
 def gen_groups():
     """Name -> optimizer group, by executing the reference entrypoint's own grouping statements
     (train_dist_TVTSv2_ViT_B_16.py:66-107) on a module exposing the A13 parameter names."""
@@ -575,7 +625,7 @@ def gen_ddp2():
 
 
 GENS = {"block": gen_block, "vit": gen_vit, "text": gen_text, "sort": gen_sort, "model_tiny": gen_model_tiny,
-        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream, "transform": gen_transform}
+        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream, "transform": gen_transform, "downstream_more": gen_downstream_more}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -65,3 +65,24 @@ def test_zero_shot_text_pass_and_logits(model, golden):
     target = want.argmax(1)
     assert Z.accuracy(logits, target, topk=(1, 5)) == [7.0, 7.0]
     assert Z.accuracy(logits, want.argmin(1), topk=(1, 11)) == [0.0, 7.0]
+
+
+@pytest.mark.parametrize("name,B,T,n", [("B_32", 2, 5, 49), ("H_14", 1, 2, 256)])
+def test_downstream_other_archs_against_reference_golden(name, B, T, n, golden):
+    """TVTSv2_B_32 (49 unmasked patches: fused SPACE kernels) and the full-size TVTSv2_H_14 (256 patches, head dim 80, pooled
+    tail) of v2/downstream, against the reference's own outputs."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import importlib
+    mod = importlib.import_module(f"tvts_amd.downstream.model_TVTSv2_ViT_{name}")
+    m = getattr(mod, f"TVTSv2_{name}")(load_checkpoint=None)
+    arch = dict(O.ARCHS[name], mask_ratio=0.0, sort_head=False)
+    m.load_state_dict(O.synth_params(arch, seed=0), strict=True)
+    f = golden("downstream_" + name.lower().replace("_", ""))
+    b = O.synth_batch(O.ARCHS[name], B=B, T=T, seed=int(f["batch_seed"]), n_trans=1)
+    te, ve = m({"text": b["text"], "video": b["video"], "keep_ind": torch.arange(n).unsqueeze(0).expand(B, -1)})
+    assert rel(te, f["te"]) < 0.02 and rel(ve, f["ve"]) < 0.02, (rel(te, f["te"]), rel(ve, f["ve"]))
+    cos = torch.nn.functional.cosine_similarity(ve.cpu().double(), torch.tensor(f["ve"]).double(), dim=1)
+    assert float(cos.min()) > 0.9995
+    del m
+    torch.cuda.empty_cache()

@@ -282,3 +282,15 @@ def test_uint8_transform_tail(golden):
     frames = torch.tensor(f["frames"]).unsqueeze(0)  # [1, T, H0, W0, 3]
     out = O.frames_to_video(frames, int(f["image"]))
     assert torch.equal(out[0], torch.tensor(f["out"]))
+
+
+def test_downstream_b32(golden):
+    """v2/downstream/model_TVTSv2_ViT_B_32.py: 49 unmasked patches per frame."""
+    f = golden("downstream_b32")
+    arch = dict(O.ARCHS["B_32"], mask_ratio=0.0, sort_head=False)
+    P = O.synth_params(arch, seed=int(f["seed"]))
+    b = O.synth_batch(O.ARCHS["B_32"], B=2, T=5, seed=int(f["batch_seed"]), n_trans=1)
+    with torch.no_grad():
+        te, ve, _ = O.model_forward(P, {"text": b["text"], "video": b["video"],
+                                        "keep_ind": torch.arange(49).unsqueeze(0).expand(2, -1)}, arch)
+    assert relerr(f["te"], te) < RTOL and relerr(f["ve"], ve) < RTOL
