@@ -555,6 +555,36 @@ def gen_downstream_more():
     save("downstream_h14", te=te, ve=ve, seed=0, batch_seed=7)
 
 
+def gen_model_b16():
+    """The real TVTSv2_B_16 class (the headline architecture: 196 patches, tube mask 0.5 -> 98 kept) at B=2, T=4."""
+    ns = import_reference()
+    arch = O.ARCHS["B_16"]
+    P = O.synth_params(arch, seed=0)
+    args = types.SimpleNamespace(local_rank=0, rank=0, world_size=1)
+    m = ns.m16.TVTSv2_B_16(args, load_checkpoint="")
+    m.load_state_dict(P, strict=True)
+    assert list(m.state_dict().keys()) == list(P.keys())
+    batch = O.synth_batch(arch, B=2, T=4, seed=1)
+    te, ve, pred = m(batch)
+    loss1, loss2 = ref_losses(ns, te, ve, pred, batch["label"])
+    (loss1 + loss2).backward()
+    names, vals = [], []
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            names.append(k); vals.append(v.grad.norm())
+    total = torch.sqrt(sum(v ** 2 for v in vals))
+    pd = dict(m.named_parameters())
+    sel = {"g_video_proj": pd["video_model.proj"].grad[:8, :16],
+           "g_head": pd["pred_model.head.weight"].grad,
+           "g_conv": pd["video_model.conv1.weight"].grad[:4].reshape(4, -1),
+           "g_cfc11": pd["video_model.transformer.resblocks.11.mlp.c_fc.weight"].grad[:8, :16],
+           "g_tqkv0": pd["video_model.transformer.resblocks.0.timeattn.qkv.weight"].grad[:8, :16],
+           "g_pos": pd["video_model.positional_embedding"].grad[:, :16],
+           "g_textqkv10": pd["text_model.resblocks.10.attn.in_proj_weight"].grad[:8, :16]}
+    save("model_b16_cfg2", te=te, ve=ve, pred=pred, loss1=loss1, loss2=loss2, grad_norm=total, seed=0,
+         batch_seed=1, B=2, T=4, gn_names=np.array(names), gn_vals=torch.stack(vals), **sel)
+
+
 def gen_groups():
     """Name -> optimizer group, by executing the reference entrypoint's own grouping statements
     (train_dist_TVTSv2_ViT_B_16.py:66-107) on a module exposing the A13 parameter names."""
@@ -625,7 +655,7 @@ def gen_ddp2():
 
 
 GENS = {"block": gen_block, "vit": gen_vit, "text": gen_text, "sort": gen_sort, "model_tiny": gen_model_tiny,
-        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream, "transform": gen_transform, "downstream_more": gen_downstream_more}
+        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream, "transform": gen_transform, "downstream_more": gen_downstream_more, "model_b16": gen_model_b16}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -307,3 +307,31 @@ def test_fp8_forward_path(gpu):
     oa32 = dict(oarch, fp8=False)
     f1, f2, fte, fve, fpred, fgrads = oracle_step(P, batch, oa32)
     assert min_cos(ve, fve) > 0.995 and abs(l1 - f1) < 5e-2 and abs(l2 - f2) < 5e-2, (min_cos(ve, fve), l1, f1, l2, f2)
+
+
+def test_b16_config2_against_reference_golden(gpu, golden):
+    """The headline architecture (BASELINE config 2's model): the real TVTSv2_B_16 class ran in the build container at
+    B=2, T=4 with tube mask 0.5 (98 of 196 patches kept: the fused SPACE / TIME attention kernels' shapes)."""
+    f = golden("model_b16_cfg2")
+    m, oarch, P = build(arch_name="B_16", seed=0)
+    del P
+    batch = O.synth_batch(oarch, B=2, T=4, seed=int(f["batch_seed"]))
+    l1, l2, te, ve, pred, store = engine_step(m, batch)
+    rte, rve, rpred = torch.tensor(f["te"]), torch.tensor(f["ve"]), torch.tensor(f["pred"])
+    assert min_cos(te, rte) > 0.9995 and rel(te, rte) < 0.02, (min_cos(te, rte), rel(te, rte))
+    assert min_cos(ve, rve) > 0.9995 and rel(ve, rve) < 0.02, (min_cos(ve, rve), rel(ve, rve))
+    assert float((pred.view_as(rpred).cpu() - rpred).abs().max()) < 0.05
+    assert abs(l1 - float(f["loss1"])) < 1e-2 and abs(l2 - float(f["loss2"])) < 1e-2, (l1, l2)
+    gn = float(store.grad.double().norm())
+    assert abs(gn - float(f["grad_norm"])) < 0.01 * float(f["grad_norm"]), (gn, float(f["grad_norm"]))
+    ref = dict(zip([str(s) for s in f["gn_names"]], f["gn_vals"]))
+    bad = []
+    for k, v in ref.items():
+        mine = float(store.g(k).double().norm())
+        if float(v) > 1e-3 * float(f["grad_norm"]) and abs(mine - float(v)) > 0.05 * float(v):
+            bad.append((k, mine, float(v)))
+    assert not bad, bad[:10]
+    for k, (name, idx) in {"g_video_proj": ("video_model.proj", (slice(0, 8), slice(0, 16))),
+                           "g_head": ("pred_model.head.weight", (slice(None), slice(None))),
+                           "g_pos": ("video_model.positional_embedding", (slice(None), slice(0, 16)))}.items():
+        assert rel(store.g(name)[idx], torch.tensor(f[k])) < 0.08, (k, rel(store.g(name)[idx], torch.tensor(f[k])))

@@ -294,3 +294,21 @@ def test_downstream_b32(golden):
         te, ve, _ = O.model_forward(P, {"text": b["text"], "video": b["video"],
                                         "keep_ind": torch.arange(49).unsqueeze(0).expand(2, -1)}, arch)
     assert relerr(f["te"], te) < RTOL and relerr(f["ve"], ve) < RTOL
+
+
+def test_model_b16_config2(golden):
+    """The headline architecture: the real TVTSv2_B_16 class (tube mask 0.5), B=2, T=4."""
+    f = golden("model_b16_cfg2")
+    arch = O.ARCHS["B_16"]
+    P = leaves(O.synth_params(arch, seed=0))
+    b = O.synth_batch(arch, B=2, T=4, seed=int(f["batch_seed"]))
+    _check_model(f, arch, P, b)
+    sl = {"g_video_proj": ("video_model.proj", (slice(0, 8), slice(0, 16))),
+          "g_head": ("pred_model.head.weight", (slice(None), slice(None))),
+          "g_cfc11": ("video_model.transformer.resblocks.11.mlp.c_fc.weight", (slice(0, 8), slice(0, 16))),
+          "g_tqkv0": ("video_model.transformer.resblocks.0.timeattn.qkv.weight", (slice(0, 8), slice(0, 16))),
+          "g_pos": ("video_model.positional_embedding", (slice(None), slice(0, 16))),
+          "g_textqkv10": ("text_model.resblocks.10.attn.in_proj_weight", (slice(0, 8), slice(0, 16)))}
+    for k, (name, idx) in sl.items():
+        assert relerr(f[k], P[name].grad[idx]) < 2e-4, k
+    assert relerr(f["g_conv"], P["video_model.conv1.weight"].grad[:4].reshape(4, -1)) < 2e-4
