@@ -77,6 +77,40 @@ def cpu_baseline(arch_name, T, caption_len, pairs, max_seconds):
                 "sample": f"CPU oracle step did not finish within {4 * max_seconds + 60:.0f} s ({type(e).__name__})"}
 
 
+def gemm_bytes(kind, shp):
+    """operand + result bytes of one GEMM launch if every matrix crossed HBM exactly once (the floor `traffic` is read
+    against)."""
+    if kind == "gemm_tn":
+        M, Na, Nb = shp[:3]
+        return 2.0 * M * (Na + Nb) + 4.0 * Na * Nb
+    M, N, K, odt, res, act, gate = shp
+    eb = 1.0 if odt == "fp8" else 2.0
+    b = eb * K * (M + N) + M * N * (4.0 if odt == "f32" else 2.0)
+    if res:
+        b += 4.0 * M * N
+    if act:      # pre-activation side output kept for the backward
+        b += 2.0 * M * N
+    if gate:     # activation-gradient gate reads the saved pre-activation
+        b += 2.0 * M * N
+    return b
+
+
+def pmc_traffic(args):
+    """HBM bytes of the step's GEMM launches from a committed PMC pass of this exact workload (counters cannot be read
+    live: they need rocprofv3's own passes, tools/pmc_traffic.sh).  None when no such measurement is committed."""
+    import glob
+    if args.fp8:
+        return None
+    pat = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                       f"*pmc_step_traffic_{args.arch}_t{args.frames}_b{args.batch}.json")
+    hits = sorted(glob.glob(pat))
+    if not hits:
+        return None
+    d = json.load(open(hits[-1]))
+    d["source"] = "profiles/" + os.path.basename(hits[-1])
+    return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,9 +266,18 @@ def main():
         if os.environ.get('TVTS_BENCH_SHAPES'):
             for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][2])[:24]:
                 print(f'[shape] {v[2]:7.2f} ms n={v[0]:3d} {v[1] / (v[2] * 1e-3) / 1e12:7.1f} TF  {k}', file=sys.stderr)
+        if os.environ.get('TVTS_BENCH_ORDER'):   # dev: launch-ordered GEMM list (joined with PMC rows by tools/pmc_join.py)
+            json.dump([[kind, list(shp), s.elapsed_ms(e), gemm_bytes(kind, shp)] for kind, f, s, e, shp in recs],
+                      open(os.environ['TVTS_BENCH_ORDER'], 'w'))
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        traffic = pmc_traffic(args)
         line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                            "frac": ach / PEAK_BF16_TFLOPS,
+                            "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
+                            "traffic_unit": "HBM bytes per step over the same launches (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                            "WRITE_SIZE, tools/pmc_traffic.sh)" if traffic else None,
+                            "traffic_source": traffic["source"] if traffic else None,
+                            "algorithmic_bytes": sum(gemm_bytes(r[0], r[4]) for r in recs),
                             "kernel": "gemm_nt_kernel + gemm_tn_kernel (all MFMA GEMM launches of one step)",
                             "launches": len(recs), "gemm_ms_per_step": tot_ms,
                             "by_kernel": {k: {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]}

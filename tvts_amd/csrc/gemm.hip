@@ -34,6 +34,7 @@ struct GemmNT {
     const bf16* gate_h; int ldh; int gate_act;
     void* out; int ldc; int out_f32;
     int tiles_m, tiles_n;
+    int gc;      // 256x256 pipelined kernel: tile columns per column group (0 = plain row-major tile order)
     int ablate;  // experiment knob TVTS_NT_ABLATE: 1 skip MFMA, 2 skip DMA in the K loop, 4 skip fragment reads, 8 skip epilogue
     int swz;  // XOR mask of the LDS chunk swizzle (7; 0 = linear image, experiment knob TVTS_NT_SWZ)
     const float* sa; const float* sb;  // fp8 operands: per-tensor scales (device scalars), out = sa*sb * (A B^T) + ...
@@ -286,12 +287,23 @@ __device__ __forceinline__ const char* uniform_ptr(const void* p) {  // make wav
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (const char*)(((unsigned long long)hi << 32) | lo);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void stage_issue256(const StageOff256& o, const bf16* ubase_, char* lds_tile, int wave) {
     const char* ubase = uniform_ptr(ubase_);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
         __builtin_amdgcn_global_load_lds((const GLB_PTR(void))((const char*)ubase + o.off[t]),
-                                         (LDS_PTR(void))(lds_tile + (t * 8 + wave) * 1024), 16, 0, 0);
+                                         (LDS_PTR(void))(lds_tile + (t * 8 + wave) * 1024), 16, 0, AUX);
+}
+// tile index -> tile origin.  gc == 0: row-major over (m, n).  gc > 0: column groups of gc tile columns, row-major
+// inside a group, so the tiles an XCD works on at one time span gc weight panels instead of all of them.
+__device__ __forceinline__ void tile_origin256(const GemmNT& g, int t, int gc, int& m0, int& n0) {
+    if (gc <= 0) { m0 = (t / g.tiles_n) * 256; n0 = (t % g.tiles_n) * 256; return; }
+    const int per_group = g.tiles_m * gc;
+    const int grp = t / per_group, r = t - grp * per_group;
+    const int c0 = grp * gc;
+    const int w = (g.tiles_n - c0) < gc ? (g.tiles_n - c0) : gc;
+    m0 = (r / w) * 256; n0 = (c0 + r % w) * 256;
 }
 
 template <int ACT, int GATE>
@@ -658,25 +670,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     if (slot >= range_n) return;
     const int ntl = (range_n - slot + per_xcd - 1) / per_xcd;
     const int total_st = ntl * nk;
+    const int gc = g.gc;
 
     // DMA cursor
     int i_st = 0, i_kt = 0, i_tl = 0, i_m0, i_n0;
     StageOff256 oa, ob;
     {
-        const int tile = range_lo + slot;
-        i_m0 = (tile / g.tiles_n) * 256; i_n0 = (tile % g.tiles_n) * 256;
+        tile_origin256(g, range_lo + slot, gc, i_m0, i_n0);
         stage_offsets256(oa, g.lda, i_m0, g.M - 1, wave, lane);
         stage_offsets256(ob, g.ldb, i_n0, g.N - 1, wave, lane);
     }
     auto issue = [&]() {
         char* dst = smem + (i_st & 1) * 65536;
-        stage_issue256(oa, g.A + (size_t)i_m0 * g.lda + i_kt * BK, dst, wave);
-        stage_issue256(ob, g.B + (size_t)i_n0 * g.ldb + i_kt * BK, dst + 32768, wave);
+        if (g.ablate & 16) stage_issue256<2>(oa, g.A + (size_t)i_m0 * g.lda + i_kt * BK, dst, wave);
+        else stage_issue256<0>(oa, g.A + (size_t)i_m0 * g.lda + i_kt * BK, dst, wave);
+        if (g.ablate & 32) stage_issue256<2>(ob, g.B + (size_t)i_n0 * g.ldb + i_kt * BK, dst + 32768, wave);
+        else stage_issue256<0>(ob, g.B + (size_t)i_n0 * g.ldb + i_kt * BK, dst + 32768, wave);
         ++i_st;
         if (++i_kt == nk) {
             i_kt = 0; ++i_tl;
-            const int tile = range_lo + slot + i_tl * per_xcd;
-            i_m0 = (tile / g.tiles_n) * 256; i_n0 = (tile % g.tiles_n) * 256;
+            tile_origin256(g, range_lo + slot + i_tl * per_xcd, gc, i_m0, i_n0);
             stage_offsets256(oa, g.lda, i_m0, g.M - 1, wave, lane);
             stage_offsets256(ob, g.ldb, i_n0, g.N - 1, wave, lane);
         }
@@ -692,10 +705,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int kt = 0, tl = 0, m0, n0;
-    {
-        const int tile = range_lo + slot;
-        m0 = (tile / g.tiles_n) * 256; n0 = (tile % g.tiles_n) * 256;
-    }
+    tile_origin256(g, range_lo + slot, gc, m0, n0);
     const int arow = wm * 128 + (lane & 15), brow = wn * 64 + (lane & 15), gq = lane >> 4;
     // fragment registers: two A half-sets (4 MFMA row-tiles each) and two B sets, refilled while the matrix pipe
     // works on the other one
@@ -743,8 +753,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         if (++kt == nk) {
             epilogue256_patch<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, patch, FP8 ? g.sa[0] * g.sb[0] : 1.0f);
             kt = 0; ++tl;
-            const int tile = range_lo + slot + tl * per_xcd;
-            m0 = (tile / g.tiles_n) * 256; n0 = (tile % g.tiles_n) * 256;
+            tile_origin256(g, range_lo + slot + tl * per_xcd, gc, m0, n0);
         }
     }
 #undef LOAD_A
@@ -889,7 +898,17 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.sa = nullptr; g.sb = nullptr;
     { static const char* e = getenv("TVTS_NT_SWZ"); g.swz = e ? atoi(e) : 7; }
-    { static const char* e = getenv("TVTS_NT_ABLATE"); g.ablate = e ? atoi(e) : 0; }
+    { const char* e = getenv("TVTS_NT_ABLATE"); g.ablate = e ? atoi(e) : 0; }
+    // Wide outputs (>= 10 tile columns: the MLP's 4x expansion): walk the tiles in column groups of 6 or 5.  An XCD's 32
+    // co-resident tiles then span 5-6 weight panels x 5-6 row panels instead of all 12-20 weight panels x 2-3 row panels
+    // -- FETCH_SIZE (L2 misses) of the fc1 / fc2-dgrad GEMMs falls by 40 % (tools/gemm_l2.py, tools/l2run.sh), time by 3-5 %.
+    g.gc = 0;
+    {
+        const int tn = ceil_div(N, 256);
+        if (tn >= 10) g.gc = tn % 6 == 0 ? 6 : tn % 5 == 0 ? 5 : 0;
+        if (g.ablate >> 8) g.gc = (g.ablate >> 8) & 15;   // dev override (15 = force 0)
+        if (g.gc == 15) g.gc = 0;
+    }
     const bool pipe = g_nt_tile == 768 || (g_nt_tile == 0);
     const bool stag = g_nt_tile == 512;
     const int ring = g_nt_tile == 1024 ? 4 : g_nt_tile == 1280 ? 5 : 0;
@@ -964,7 +983,7 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
     g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;  // byte-identical bf16 view, half as wide
     g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = nullptr; g.ldh = 0; g.gate_act = ACT_NONE;
-    g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.swz = 7; g.ablate = 0; g.sa = scale_a; g.sb = scale_b;
+    g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.swz = 7; g.ablate = 0; g.gc = 0; g.sa = scale_a; g.sb = scale_b;
     g.tiles_n = ceil_div(N, 256);
     g.tiles_m = ceil_div(M, 256);
     const int total_tiles = g.tiles_m * g.tiles_n;
@@ -992,6 +1011,7 @@ struct GemmTN {
     int M, Na, Nb;
     float* out; int ldo;
     int tiles_b, tiles_ab, m_per_split, n_items;
+    int tiles_a, a_fast;  // 128-tile kernel: walk the tiles of an m-range with the SHORTER tile dimension fastest
     int atomic;
     float* ws;      // split partials [splits][Na][Nb] (plain stores, reduced by tn_reduce_kernel) or nullptr -> fp32 atomics
     float* colsum;  // optional: colsum[a] += sum_m P[m,a]  (bias gradient fused into the weight gradient)
@@ -1046,13 +1066,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
     if (item >= g.n_items) return;
     const int split = item / g.tiles_ab;
     const int t = item % g.tiles_ab;
-    const int a0 = (t / g.tiles_b) * 128, b0 = (t % g.tiles_b) * 128;
+    // the co-resident tiles of an XCD (64) then form a patch as square as the output allows: the panels of the wide operand
+    // are shared by blocks running side by side, those of the narrow one are the ones re-read round after round
+    const int ta = g.a_fast ? t % g.tiles_a : t / g.tiles_b, tb = g.a_fast ? t / g.tiles_a : t % g.tiles_b;
+    const int a0 = ta * 128, b0 = tb * 128;
     const int m_begin = split * g.m_per_split;
     int m_end = m_begin + g.m_per_split;
     m_end = m_end < g.M ? m_end : g.M;
     if (m_begin >= m_end) return;
     const int nk = (m_end - m_begin + 63) / 64;
-    const bool do_cs = g.colsum != nullptr && (t % g.tiles_b) == 0 && wb == 0;  // wave-uniform
+    const bool do_cs = g.colsum != nullptr && tb == 0 && wb == 0;  // wave-uniform
     f32x4 cs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1456,6 +1479,8 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     const int tiles_a = ceil_div(Na, 128);
     g.tiles_b = ceil_div(Nb, 128);
     g.tiles_ab = tiles_a * g.tiles_b;
+    g.tiles_a = tiles_a;
+    { const char* e = getenv("TVTS_TN_AFAST"); g.a_fast = e ? atoi(e) : (tiles_a < g.tiles_b ? 1 : 0); }
     // split the contraction over M into S ranges (range s lives on XCD s % 8, see the kernel).  S is chosen for
     // whole rounds of 2 blocks x 256 CUs: the smallest S reaching >= 93 % round efficiency, else the best one.
     int splits = 1;
