@@ -115,6 +115,11 @@ int tvts_patch_gather(const float* video, const int* keep, int B, int T, int n, 
  * device [B,2] (top, left) or NULL for the centre crop */
 int tvts_patch_gather_u8(const unsigned char* frames, int H0, int W0, const int* crop, const int* keep, int B, int T, int n,
                          int img, int patch, const float* mean3, const float* std3, void* out, int ldo, hipStream_t stream);
+/* tube mask drawn on the device (replaces the per-sample np.random.shuffle(arange(ppf))[:n_keep] of the dataset worker,
+ * v2/data_loader/YTTemporal_dataset.py:207-213): keep[b, :] = the n_keep patch indices with the smallest counter-based
+ * random keys of sample number first_sample + b -- an unsorted prefix of a uniformly random permutation, shared by all
+ * frames of the clip; ppf <= 1024; seed / first_sample are taken as unsigned 64-bit values */
+int tvts_tube_mask(long seed, long first_sample, int B, int ppf, int n_keep, int* keep, hipStream_t stream);
 int tvts_vit_assemble(const float* patch, int ldp, const float* cls, const float* pos, const float* temporal,
                       const int* keep, int B, int T, int n, int W, float* tok, int ldt, hipStream_t stream);
 int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int B, int T, int n, int W, void* dpatch, int ldp,

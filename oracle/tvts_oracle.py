@@ -696,3 +696,32 @@ def step_flops_per_pair(arch, T: int, caption_len: int = 32, NT: int = 4) -> Tup
     frozen = arch["text_tune_from"]
     bwd = 2 * fwd - patch - (frozen / Lt) * text_gemm
     return float(fwd), float(bwd)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tube mask (N3, input pipeline): the reference draws np.random.shuffle(arange(ppf))[:n_keep] per sample in the dataset
+# worker (v2/data_loader/YTTemporal_dataset.py:207-213).  A worker's Mersenne-Twister stream is not part of any contract,
+# so the device generator is pinned on (a) this exact integer restatement of ITS counter-based draw and (b) the
+# reference's distributional contract: an unsorted n_keep-prefix of a uniformly random permutation of range(ppf).
+# ---------------------------------------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def tube_mask(seed, first_sample, B, ppf, n_keep):
+    """int32 [B, n_keep]: patch indices of sample first_sample + b ordered by their 54-bit random keys (ties cannot occur:
+    the patch index is the low 10 bits of the sorted word)."""
+    import numpy as _np
+    out = _np.zeros((B, n_keep), dtype=_np.int32)
+    for b in range(B):
+        base = _splitmix64(((seed & _M64) + _splitmix64(((first_sample & _M64) + b) & _M64)) & _M64)
+        words = sorted(((_splitmix64((base + i) & _M64) & ~0x3FF) | i) for i in range(ppf))
+        out[b] = [w & 0x3FF for w in words[:n_keep]]
+    return out

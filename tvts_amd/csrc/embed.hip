@@ -312,3 +312,50 @@ extern "C" int tvts_rows_gather(const float* src, int ld_src, const int* rows, i
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- tube mask on the device
+// The reference draws the tube mask per sample in the dataset worker: a shuffled arange(ppf) cut to its first n_keep
+// entries, shared by every frame of the clip (v2/data_loader/YTTemporal_dataset.py:207-213).  Here one block per sample
+// gives every patch index a counter-based 54-bit random key (splitmix64 of seed, global sample number, patch index), sorts
+// the (key, index) words in LDS and keeps the indices of the n_keep smallest: a uniformly random, unsorted permutation
+// prefix, reproducible for (seed, sample number) whatever the batch split or the rank layout.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void tube_mask_kernel(unsigned long long seed, unsigned long long first_sample, int ppf,
+                                                        int n_keep, int p2, int* __restrict__ keep) {
+    __shared__ unsigned long long w[1024];
+    const unsigned long long base = splitmix64(seed + splitmix64(first_sample + blockIdx.x));
+    for (int i = threadIdx.x; i < p2; i += 256)
+        w[i] = i < ppf ? ((splitmix64(base + (unsigned long long)i) & ~0x3FFull) | (unsigned long long)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= p2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < p2; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = w[i], b = w[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { w[i] = b; w[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n_keep; i += 256) keep[(size_t)blockIdx.x * n_keep + i] = (int)(w[i] & 0x3FFull);
+}
+
+extern "C" int tvts_tube_mask(long seed_, long first_sample_, int B, int ppf, int n_keep, int* keep, hipStream_t stream) {
+    const unsigned long long seed = (unsigned long long)seed_, first_sample = (unsigned long long)first_sample_;
+    if (B < 0 || ppf <= 0 || ppf > 1024 || n_keep < 0 || n_keep > ppf || (B > 0 && n_keep > 0 && keep == nullptr)) return TVTS_EINVAL;
+    if (B == 0 || n_keep == 0) return TVTS_OK;
+    int p2 = 2;
+    while (p2 < ppf) p2 <<= 1;
+    hipLaunchKernelGGL(tube_mask_kernel, dim3(B), dim3(256), 0, stream, seed, first_sample, ppf, n_keep, p2, keep);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}

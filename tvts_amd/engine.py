@@ -543,7 +543,16 @@ class Engine:
         NT = N // B
         eot_rows = (torch.arange(N) * L + eot).to(torch.int32).to(self.dev)
         ids_dev = ids_cpu[:, :L].to(torch.int32).contiguous().to(self.dev)
-        keep = data["keep_ind"].to(torch.int32)
+        if "keep_ind" not in data:
+            # device-drawn tube mask: data["mask_seed"] + the global number of the batch's first sample
+            # reproduce the draw whatever the batch split; the reference draws it in the dataset worker
+            # (YTTemporal_dataset.py:207-213) and ships it with the batch
+            if "mask_seed" not in data:
+                raise KeyError("batch dict needs 'keep_ind' or 'mask_seed' (+ optional 'sample_offset')")
+            keep = K.tube_mask(int(data["mask_seed"]), int(data.get("sample_offset", 0)), B, patches_per_frame(a),
+                               n_keep(a), device=self.dev)
+        else:
+            keep = data["keep_ind"].to(torch.int32)
         if keep.shape[0] == 1 and B > 1:  # one tube mask for the whole batch (the downstream scripts pass arange(n)[None])
             keep = keep.expand(B, -1)
         keep = keep.contiguous().to(self.dev)

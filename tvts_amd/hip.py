@@ -261,6 +261,18 @@ def patch_gather_u8(frames, keep, out, *, B, T, n, img, patch, crop=None, mean=I
                                   _p(out), _ld(out), _stream()), "tvts_patch_gather_u8")
 
 
+def tube_mask(seed, first_sample, B, ppf, n_keep, out=None, device=None):
+    """keep_ind int32 [B, n_keep] drawn on the device: sample number first_sample + b gets the n_keep patch indices with the
+    smallest counter-based random keys (an unsorted prefix of a random permutation, YTTemporal_dataset.py:207-213)."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(B, n_keep, dtype=torch.int32, device=device if device is not None else "cuda")
+    assert out.dtype == torch.int32 and out.is_contiguous() and tuple(out.shape) == (B, n_keep)
+    s64 = lambda v: (int(v) & (2 ** 64 - 1)) - (2 ** 64 if int(v) & (1 << 63) else 0)  # unsigned 64-bit through a C long
+    _chk(lib.tvts_tube_mask(s64(seed), s64(first_sample), B, ppf, n_keep, _p(out), _stream()), "tvts_tube_mask")
+    return out
+
+
 def vit_assemble(patch, cls, pos, temporal, keep, tok, *, B, T, n):
     lib = _lib.load()
     _chk(lib.tvts_vit_assemble(_p(patch), _ld(patch), _p(cls), _p(pos), _p(temporal), _p(keep), B, T, n, tok.shape[1],
