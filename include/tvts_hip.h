@@ -30,15 +30,20 @@ void tvts_gemm_set_nt_tile(int t);
  * partials and a reduce pass combines them (deterministic), without it the partials meet through fp32 atomics. */
 int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb, float* out, int ldo,
                       int accumulate, float* colsum, float* workspace, long workspace_elems, hipStream_t stream);
-/* fp8 (OCP e4m3) operands with per-tensor scales in device memory, fp32 accumulate: the GEMM of BASELINE config 4's
- * weight / activation path (nn.Linear sites of video_encoder_ViT_H_14.py); K % 128 == 0, lda / ldb % 16 == 0 (bytes) */
+/* fp8 (OCP e4m3) operands with scales in device memory, fp32 accumulate: the GEMM of BASELINE config 4's weight / activation
+ * path (nn.Linear sites of video_encoder_ViT_H_14.py); K % 128 == 0, lda / ldb % 16 == 0 (bytes).  scale_b: one scale for the
+ * weight; scale_a: one scale for the tensor, or (scale_a_rows != 0) M per-row scales as written by tvts_quant_fp8_rows */
 int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
-                     const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact, int ldp,
+                     int scale_a_rows, const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact, int ldp,
                      void* out, int ldc, int out_f32, hipStream_t stream);
 /* per-tensor fp8 quantisation: amax[0] = max |x| ; q = rne(x * 448 / amax) as e4m3, scale_out[0] = amax / 448 */
 int tvts_amax(const void* x, int is_f32, long ld, int rows, int cols, float* amax, hipStream_t stream);
 int tvts_quant_fp8(const void* x, int is_f32, long ld, int rows, int cols, const float* amax, void* out, long ldo,
                    float* scale_out, hipStream_t stream);
+/* per-row (per-token) quantisation of a bf16 activation in one pass: row_scale[r] = amax(x[r,:]) / 448 (1 for an all-zero
+ * row), out[r,:] = e4m3(x[r,:] / row_scale[r]); cols % 8 == 0 */
+int tvts_quant_fp8_rows(const void* x, long ld, int rows, int cols, void* out, long ldo, float* row_scale,
+                        hipStream_t stream);
 /* strided fp32 matmul for the tiny products (text_projection model_dist..B_16.py:108, head sort_transformer.py:113,
  * sim_matrix model_dist..B_16.py:126): C[i,j] (+)= alpha * sum_k A[i*sai+k*sak] * B[k*sbk+j*sbj] + bias[j] */
 int tvts_gemm_small_f32(const float* A, long sai, long sak, const float* B, long sbk, long sbj, int M, int N, int K,

@@ -255,19 +255,25 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
     return y if b is None else y + b
 
 
-def fake_quant_e4m3(t: Tensor) -> Tensor:
-    """per-tensor OCP e4m3 quantise -> dequantise (scale = amax / 448, round to nearest even, gradient passed straight
-    through): what the fp8 weight / activation GEMMs of BASELINE config 4 see."""
-    amax = t.detach().abs().max()
-    scale = amax / 448.0 if float(amax) > 0 else torch.ones(())
-    q = (t.detach() / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * scale
+def fake_quant_e4m3(t: Tensor, rowwise: bool = False) -> Tensor:
+    """OCP e4m3 quantise -> dequantise (scale = amax / 448, round to nearest even, gradient passed straight through): what
+    the fp8 weight / activation GEMMs of BASELINE config 4 see.  One scale for the tensor (weights), or with `rowwise` one per
+    row of the last dimension (activations: a scale per token)."""
+    d = t.detach()
+    if rowwise:
+        amax = d.abs().amax(dim=-1, keepdim=True)
+        scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    else:
+        amax = d.abs().max()
+        scale = amax / 448.0 if float(amax) > 0 else torch.ones(())
+    q = (d / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * scale
     return t + (q - t).detach()
 
 
 def linear_fp8(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
     """nn.Linear whose FORWARD product runs on e4m3 copies of the activation and the weight (the backward of the build
     keeps bf16 operands, i.e. straight-through here)."""
-    y = fake_quant_e4m3(x) @ fake_quant_e4m3(w).t()
+    y = fake_quant_e4m3(x, rowwise=True) @ fake_quant_e4m3(w).t()
     return y if b is None else y + b
 
 

@@ -606,3 +606,59 @@ def test_gemm_nt_fp8(K, M, N, K_):
     assert rel(outb.float(), ref - bias.cpu().double()) < 4e-3
     K.gemm_nt_fp8(a8, sa, b8, sb, out, bias=bias, residual=res)
     assert rel(out, ref + res.cpu().double()) < 5e-5
+
+
+@pytest.mark.parametrize("rows,cols", [(300, 256), (1233, 1280), (77, 5120), (9, 5128), (5, 8)])
+def test_fp8_row_quantisation(K, rows, cols):
+    """per-row (token) e4m3 quantisation in one pass: row_scale = amax(row) / 448, bit patterns of torch.float8_e4m3fn on
+    x * (1 / row_scale); an all-zero row gets scale 1 and zero bytes."""
+    x = (rnd(rows, cols, seed=56) * torch.linspace(0.01, 30.0, rows)[:, None]).bfloat16()
+    x[0] = 0
+    x[min(3, rows - 1), cols - 1] = -57.0
+    q, rs = K.quantize_fp8_rows(x.to(DEV))
+    s = x.float().abs().amax(dim=1) / 448.0
+    s[0] = 1.0
+    assert torch.allclose(rs.cpu(), s, rtol=1e-6, atol=0)
+    want = _e4m3(x.float() * (1.0 / rs.cpu())[:, None])
+    got = q.cpu().view(torch.float8_e4m3fn)
+    assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))
+    assert int(q[0].max()) == 0
+    # strided input / output views (columns of wider matrices), preallocated outputs
+    wide = torch.zeros(rows, cols + 64, dtype=torch.bfloat16, device=DEV)
+    wide[:, 32:32 + cols] = x.to(DEV)
+    if cols % 8 == 0 and 32 % 8 == 0:
+        qw = torch.full((rows, cols + 16), 7, dtype=torch.uint8, device=DEV)
+        q2, rs2 = K.quantize_fp8_rows(wide[:, 32:32 + cols], q=qw[:, 8:8 + cols], row_scale=torch.empty(rows + 3, device=DEV))
+        assert torch.equal(q2, q) and torch.equal(rs2[:rows], rs)
+        assert int(qw[:, :8].min()) == 7 and int(qw[:, 8 + cols:].min()) == 7
+
+
+@pytest.mark.parametrize("M,N,K_", [(256, 256, 128), (777, 1280, 1280), (9420, 3072, 768)])
+def test_gemm_nt_fp8_row_scales(K, M, N, K_):
+    """out = row_scale[m] * sb * (A8 B8^T) + bias with the per-token scales of quantize_fp8_rows."""
+    a = rnd(M, K_, seed=57) * torch.logspace(-5, 1.5, M)[:, None]     # rows of very different magnitude (the small ones underflow a tensor-wide scale)
+    b = rnd(N, K_, seed=58) * K_ ** -0.5
+    a8, rs = K.quantize_fp8_rows(a.bfloat16().to(DEV))
+    b8, sb = K.quantize_fp8(b.to(DEV))
+    bias = rnd(N, seed=59).to(DEV)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    K.gemm_nt_fp8(a8, rs, b8, sb, out, bias=bias)
+    ad, bd = a8.cpu().view(torch.float8_e4m3fn).float(), b8.cpu().view(torch.float8_e4m3fn).float()
+    ref = (ad.double() @ bd.double().t()) * rs.cpu().double()[:, None] * float(sb) + bias.cpu().double()
+    err = ((out.cpu().double() - ref).abs() / (ref.abs().amax(dim=1, keepdim=True) + 1e-30)).max()
+    assert float(err) < 5e-5, float(err)
+    # per-token scales keep the small rows accurate: row-relative error against the unquantised product
+    exact = a.bfloat16().double() @ b.double().t()
+    rowrel = ((out.cpu().double() - bias.cpu().double() - exact).norm(dim=1) / exact.norm(dim=1))
+    assert float(rowrel.max()) < 0.08, float(rowrel.max())
+    # one per-tensor scale loses them (what the per-row scales are for)
+    a8t, sat = K.quantize_fp8(a.bfloat16().to(DEV))
+    out_t = torch.empty_like(out)
+    K.gemm_nt_fp8(a8t, sat, b8, sb, out_t)
+    rowrel_t = ((out_t.cpu().double() - exact).norm(dim=1) / exact.norm(dim=1))
+    assert float(rowrel_t.max()) > 3 * float(rowrel.max())
+    act_out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt_fp8(a8, rs, b8, sb, act_out, bias=bias, act="gelu", preact=pre)
+    assert rel(pre.float(), ref) < 4e-3
+    assert rel(act_out.float(), torch.nn.functional.gelu(ref.float()).double()) < 6e-3

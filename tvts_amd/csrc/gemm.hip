@@ -34,6 +34,7 @@ struct GemmNT {
     const bf16* gate_h; int ldh; int gate_act;
     void* out; int ldc; int out_f32;
     int tiles_m, tiles_n;
+    int sa_rows; // fp8: scale_a holds one scale per row of A (per-token activation scales) instead of one for the tensor
     int gc;      // 256x256 pipelined kernel: tile columns per column group (0 = plain row-major tile order)
     int ablate;  // experiment knob TVTS_NT_ABLATE: 1 skip MFMA, 2 skip DMA in the K loop, 4 skip fragment reads, 8 skip epilogue
     int swz;  // XOR mask of the LDS chunk swizzle (7; 0 = linear image, experiment knob TVTS_NT_SWZ)
@@ -570,7 +571,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256s_kernel(GemmNT g) {
 // ------------------------------------------------------------------------------------------------
 template <int ACT, int GATE>
 __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn,
-                                                  int lane, char* patch, float scale = 1.0f) {
+                                                  int lane, char* patch, float scale = 1.0f,
+                                                  const float* row_scale = nullptr) {
     // patch: 16 rows x 256 B (64 fp32), 16-B chunk c of row r stored at chunk c ^ r
     const int nb = n0 + wn * 64;
     const int li = lane & 15, gq = lane >> 4;
@@ -582,9 +584,14 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+        float sc = scale;
+        if (row_scale) {  // per-row (token) scale of the fp8 A operand; `scale` then holds the weight's tensor scale
+            const int m = m0 + wm * 128 + i * 16 + li;
+            sc *= row_scale[m < g.M ? m : g.M - 1];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i] * scale + bias4[j];
+            *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i] * sc + bias4[j];
             acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         if (g.out_f32) {
@@ -751,7 +758,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         }
         MFMA16(aF[1], bF[1], 1);
         if (++kt == nk) {
-            epilogue256_patch<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, patch, FP8 ? g.sa[0] * g.sb[0] : 1.0f);
+            if (FP8 && g.sa_rows) epilogue256_patch<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, patch, g.sb[0], g.sa);
+            else epilogue256_patch<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, patch, FP8 ? g.sa[0] * g.sb[0] : 1.0f);
             kt = 0; ++tl;
             tile_origin256(g, range_lo + slot + tl * per_xcd, gc, m0, n0);
         }
@@ -896,7 +904,7 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     g.A = (const bf16*)A; g.lda = lda; g.B = (const bf16*)B; g.ldb = ldb;
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
-    g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.sa = nullptr; g.sb = nullptr;
+    g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.sa = nullptr; g.sb = nullptr; g.sa_rows = 0;
     { static const char* e = getenv("TVTS_NT_SWZ"); g.swz = e ? atoi(e) : 7; }
     { const char* e = getenv("TVTS_NT_ABLATE"); g.ablate = e ? atoi(e) : 0; }
     // Wide outputs (>= 10 tile columns: the MLP's 4x expansion): walk the tiles in column groups of 6 or 5.  An XCD's 32
@@ -972,10 +980,10 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
 }
 
 // fp8 (OCP e4m3) operands, fp32 accumulate: out[M,N] = scale_a * scale_b * (A[M,K] B[N,K]^T) + bias [+ residual], A / B row-major
-// bytes with per-tensor scales held in device memory (BASELINE config 4's weight/activation path; the building block, the
-// step engine does not use it yet).  Same pipelined 256x256 kernel: K % 128 == 0, lda / ldb % 16 == 0.
+// bytes, scales in device memory: one per tensor, or (scale_a_rows != 0) one per ROW of A -- the per-token activation scales
+// of tvts_quant_fp8_rows (BASELINE config 4's weight/activation path).  Same pipelined 256x256 kernel: K % 128 == 0, lda / ldb % 16 == 0.
 extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
-                                const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact,
+                                int scale_a_rows, const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact,
                                 int ldp, void* out, int ldc, int out_f32, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b) return TVTS_EINVAL;
     if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || (residual && ldr % 4) || (preact && ldp % 8)) return TVTS_EINVAL;
@@ -983,7 +991,7 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
     g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;  // byte-identical bf16 view, half as wide
     g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = nullptr; g.ldh = 0; g.gate_act = ACT_NONE;
-    g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.swz = 7; g.ablate = 0; g.gc = 0; g.sa = scale_a; g.sb = scale_b;
+    g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.swz = 7; g.ablate = 0; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
     g.tiles_n = ceil_div(N, 256);
     g.tiles_m = ceil_div(M, 256);
     const int total_tiles = g.tiles_m * g.tiles_n;

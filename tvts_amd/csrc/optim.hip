@@ -211,6 +211,78 @@ extern "C" int tvts_quant_fp8(const void* x, int is_f32, long ld, int rows, int 
     return TVTS_OK;
 }
 
+// ---- activations: ONE scale per row (token), amax and conversion in a single pass.  A wave owns a row: it is read once into
+//      registers (rows up to 5120 columns; wider rows are read a second time, from cache), reduced to its amax with wave
+//      shuffles, scaled by 448 / amax and written as e4m3 bytes + the row's scale.  3 bytes of traffic per element instead of
+//      the 5 of tvts_amax + tvts_quant_fp8, and a tighter scale than one amax for the whole tensor.
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16* __restrict__ x, long ld, int rows, int cols,
+                                                             unsigned char* __restrict__ out, long ldo, float* __restrict__ row_scale) {
+    constexpr int MAXV = 10;  // 10 x 64 lanes x 8 bf16 = 5120 columns held in registers
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const bool in_regs = cols <= MAXV * 512;
+    for (long r = wave0; r < rows; r += nwaves) {
+        const bf16* xr = x + r * ld;
+        bf16x8 v[MAXV];
+        float m = 0.f;
+        if (in_regs) {
+#pragma unroll
+            for (int t = 0; t < MAXV; ++t) {
+                const int c = (t * 64 + lane) * 8;
+                if (c < cols) {
+                    v[t] = *(const bf16x8*)(xr + c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[t][e]));
+                }
+            }
+        } else {
+            for (int c = lane * 8; c < cols; c += 512) {
+                const bf16x8 u = *(const bf16x8*)(xr + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)u[e]));
+            }
+        }
+        m = wave_max(m);
+        const float scale = m > 0.f ? m / 448.0f : 1.0f;
+        const float inv = 1.0f / scale;
+        if (lane == 0) row_scale[r] = scale;
+        unsigned char* orow = out + r * ldo;
+        auto emit = [&](const bf16x8& u, int c) {
+            int pk[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float f[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = fminf(fmaxf((float)u[h * 4 + e] * inv, -448.0f), 448.0f);
+                int q = 0;
+                q = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], q, false);
+                q = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], q, true);
+                pk[h] = q;
+            }
+            *(long*)(orow + c) = ((long)(unsigned)pk[1] << 32) | (unsigned)pk[0];
+        };
+        if (in_regs) {
+#pragma unroll
+            for (int t = 0; t < MAXV; ++t) {
+                const int c = (t * 64 + lane) * 8;
+                if (c < cols) emit(v[t], c);
+            }
+        } else {
+            for (int c = lane * 8; c < cols; c += 512) emit(*(const bf16x8*)(xr + c), c);
+        }
+    }
+}
+extern "C" int tvts_quant_fp8_rows(const void* x, long ld, int rows, int cols, void* out, long ldo, float* row_scale,
+                                   hipStream_t stream) {
+    if (rows <= 0 || cols <= 0 || cols % 8 || ld % 8 || ldo % 8 || !x || !out || !row_scale) return TVTS_EINVAL;
+    const long want = ((long)rows + 3) / 4;
+    const int blocks = (int)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, ld, rows, cols,
+                       (unsigned char*)out, ldo, row_scale);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
 // probe used by tests: what does ds_read_b64_tr_b16 return?  in: 16 x 64 bf16 row-major tile (row stride 160 B in LDS)
 __global__ void probe_tr16_kernel(const bf16* __restrict__ in, bf16* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char tile[16 * 160];

@@ -205,9 +205,9 @@ class Engine:
             w8, ws, _ = self.P.w8[wname]
             a2 = a[:M]
             q = self._b("fp8.q%d" % a2.shape[1], a2.shape, torch.uint8)
-            sc, am = self._f("fp8.scale", (1,)), self._f("fp8.amax", (1,))
-            K.quantize_fp8(a2, q=q, scale=sc, amax=am)
-            K.gemm_nt_fp8(q, sc, w8, ws, out[:M], bias=self.P.p(bname) if bname else None, **epi)
+            rs = self._f("fp8.row_scale", (max(M, 2),))  # one scale per token (never a 1-element tensor: that means per-tensor)
+            K.quantize_fp8_rows(a2, q=q, row_scale=rs)
+            K.gemm_nt_fp8(q, rs, w8, ws, out[:M], bias=self.P.p(bname) if bname else None, **epi)
             return
         K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
 

@@ -80,17 +80,33 @@ def quantize_fp8(x, q=None, scale=None, amax=None):
     return q, scale
 
 
+def quantize_fp8_rows(x, q=None, row_scale=None):
+    """per-row (per-token) e4m3 quantisation of a bf16 matrix in one pass -> (q uint8 [rows, cols], row_scale float32[rows]);
+    x[r] ~ q[r] * row_scale[r]."""
+    lib = _lib.load()
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.bfloat16
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if q is None else q
+    row_scale = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if row_scale is None else row_scale
+    assert row_scale.numel() >= x.shape[0] and row_scale.dtype == torch.float32
+    _chk(lib.tvts_quant_fp8_rows(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(q), q.stride(0), _p(row_scale), _stream()),
+         "tvts_quant_fp8_rows")
+    return q, row_scale
+
+
 def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, preact=None):
-    """out[M,N] = act(sa*sb * (a8[M,K] @ b8[N,K]^T) + bias) [+ residual]; a8 / b8 uint8 e4m3 bit patterns, sa / sb float32[1];
-    preact receives the bf16 pre-activation like gemm_nt."""
+    """out[M,N] = act(sa*sb * (a8[M,K] @ b8[N,K]^T) + bias) [+ residual]; a8 / b8 uint8 e4m3 bit patterns; sb float32[1]; sa
+    float32[1] (one scale for the tensor) or float32[>= M] (one per row, quantize_fp8_rows); preact receives the bf16
+    pre-activation like gemm_nt."""
     lib = _lib.load()
     M, Kd = a8.shape
     N = b8.shape[0]
     assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and b8.shape[1] == Kd
+    sa_rows = 0 if sa.numel() == 1 else 1
+    assert sa_rows == 0 or sa.numel() >= M
     if GEMM_PROFILE is not None:
         ev0, ev1 = Event(), Event()
         ev0.record()
-    rc = lib.tvts_gemm_nt_fp8(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), _p(sb), _p(bias), _p(residual),
+    rc = lib.tvts_gemm_nt_fp8(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(bias), _p(residual),
                               _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
                               _ld(preact) if preact is not None else 0, _p(out), _ld(out),
                               1 if out.dtype == torch.float32 else 0, _stream())
