@@ -54,6 +54,12 @@ int tvts_colsum_bf16(const void* X, int ld, int M, int N, float* out, hipStream_
 /* ---- LayerNorm (norm.hip): video_encoder_ViT_B_16.py:79-85 (eps 1e-5), sort_transformer.py:99 (eps 1e-6) */
 int tvts_layernorm_fwd(const void* x, int ldx, int x_bf16, const int* rows, const float* gamma, const float* beta, float eps, int M,
                        int W, void* y, int ldy, int y_f32, float* mean, float* rstd, hipStream_t stream);
+/* the same, additionally writing the bf16 output as OCP e4m3 bytes q8[M, W] (ldq bytes per row) with one scale per row
+ * (row_scale[M] = amax(row) / 448): the fp8 operand of the GEMM that follows (BASELINE config 4), identical to
+ * tvts_quant_fp8_rows run on y */
+int tvts_layernorm_fwd_fp8(const void* x, int ldx, int x_bf16, const int* rows, const float* gamma, const float* beta, float eps,
+                           int M, int W, void* y, int ldy, void* q8, int ldq, float* row_scale, float* mean, float* rstd,
+                           hipStream_t stream);
 int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const void* x, int ldx, int x_bf16, const int* rows, const float* mean,
                        const float* rstd, const float* gamma, const float* res1, int ldr, const void* res2_bf16, int ldr2,
                        int M, int W, float* dx, int lddx, void* dx_bf16, int lddxb, float* dgamma, float* dbeta,

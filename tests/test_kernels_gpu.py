@@ -662,3 +662,27 @@ def test_gemm_nt_fp8_row_scales(K, M, N, K_):
     K.gemm_nt_fp8(a8, rs, b8, sb, act_out, bias=bias, act="gelu", preact=pre)
     assert rel(pre.float(), ref) < 4e-3
     assert rel(act_out.float(), torch.nn.functional.gelu(ref.float()).double()) < 6e-3
+
+
+@pytest.mark.parametrize("W,xdt", [(768, torch.float32), (1280, torch.float32), (1280, torch.bfloat16), (320, torch.float32), (1024, torch.bfloat16)])
+def test_layernorm_fwd_fp8_output(K, W, xdt):
+    """LayerNorm forward with the fused e4m3 copy: y / mean / rstd identical to the plain kernel, the fp8 bytes and per-row
+    scales identical to quantize_fp8_rows(y)."""
+    M = 517
+    x = (rnd(M, W, seed=60) * 2 + 0.3).to(xdt).to(DEV)
+    g, b = (1 + 0.1 * rnd(W, seed=61)).to(DEV), (0.1 * rnd(W, seed=62)).to(DEV)
+    y0, y1 = (torch.empty(M, W, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    m0, r0, m1, r1 = (torch.empty(M, device=DEV) for _ in range(4))
+    K.layernorm_fwd(x, g, b, 1e-5, y0, m0, r0)
+    q = torch.full((M, W), 3, dtype=torch.uint8, device=DEV)
+    rs = torch.empty(M, device=DEV)
+    K.layernorm_fwd(x, g, b, 1e-5, y1, m1, r1, q8=q, row_scale=rs)
+    assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    q_ref, rs_ref = K.quantize_fp8_rows(y0)
+    assert torch.equal(q, q_ref) and torch.equal(rs, rs_ref)
+    # gathered rows (the pooled tail's CLS rows)
+    rows = torch.tensor([5, 0, 333, 516], dtype=torch.int32, device=DEV)
+    y2 = torch.empty(4, W, dtype=torch.bfloat16, device=DEV)
+    q2, rs2 = torch.empty(4, W, dtype=torch.uint8, device=DEV), torch.empty(4, device=DEV)
+    K.layernorm_fwd(x, g, b, 1e-5, y2, torch.empty(4, device=DEV), torch.empty(4, device=DEV), rows=rows, q8=q2, row_scale=rs2)
+    assert torch.equal(y2, y0[rows.long()]) and torch.equal(q2, q_ref[rows.long()]) and torch.equal(rs2, rs_ref[rows.long()])

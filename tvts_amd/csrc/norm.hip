@@ -30,11 +30,16 @@ __device__ __forceinline__ void store4(bf16* p, f32x4 v) {
 // Both kernels are templated on IT = ceil(W / 256) (register arrays sized to the row, no dead iterations) and walk
 // their rows in a grid-stride loop with the NEXT row's loads issued before the current row's reductions: a wave always
 // has two rows of traffic in flight instead of one load -> reduce -> store round trip at a time.
-template <typename TO, int IT, typename TX = float>
+// Q8: additionally write the row as OCP e4m3 bytes with ONE scale per row (amax of the bf16-rounded outputs / 448): the fp8
+// operand of the next GEMM (BASELINE config 4) leaves the LayerNorm that produced it, bit-identical to tvts_quant_fp8_rows
+// run on y, without another pass over the activation.
+template <typename TO, int IT, typename TX = float, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, int ldx, const int* __restrict__ rows,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, int M, int W, TO* __restrict__ y, int ldy,
-                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     unsigned char* __restrict__ q8 = nullptr, int ldq = 0,
+                                                     float* __restrict__ row_scale = nullptr) {
     const int lane = threadIdx.x & 63;
     const int stride = gridDim.x * 4;
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -77,6 +82,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
             }
         }
         const float rstd = rsqrtf(wave_sum(q) * invW + eps);
+        f32x4 ob[Q8 ? IT : 1];
+        float am = 0.f;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int c = lane * 4 + it * 256;
@@ -85,7 +92,33 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd * gm[it][e] + bt[it][e];
                 store4(y + (size_t)r * ldy + c, o);
+                if (Q8) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ob[it][e] = (float)(bf16)o[e];  // the value the bf16 consumer sees
+                        am = fmaxf(am, fabsf(ob[it][e]));
+                    }
+                }
             }
+        }
+        if (Q8) {
+            am = wave_max(am);
+            const float scale = am > 0.f ? am / 448.0f : 1.0f;
+            const float inv = 1.0f / scale;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = lane * 4 + it * 256;
+                if (c < W) {
+                    float f[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = fminf(fmaxf(ob[it][e] * inv, -448.0f), 448.0f);
+                    int pk = 0;
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+                    *(int*)(q8 + (size_t)r * ldq + c) = pk;
+                }
+            }
+            if (lane == 0) row_scale[r] = scale;
         }
         if (lane == 0) {
             if (mean_out) mean_out[r] = mean;
@@ -104,6 +137,29 @@ static void launch_ln_fwd(int it, dim3 grid, hipStream_t stream, const TX* x, in
 #define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<TO, N, TX>), grid, dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd); break;
     switch (it) { LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) default: LN_FWD_CASE(5) }
 #undef LN_FWD_CASE
+}
+
+template <typename TX>
+static void launch_ln_fwd_q8(int it, dim3 grid, hipStream_t stream, const TX* x, int ldx, const int* rows, const float* gamma,
+                             const float* beta, float eps, int M, int W, bf16* y, int ldy, float* mean, float* rstd,
+                             unsigned char* q8, int ldq, float* row_scale) {
+#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<bf16, N, TX, true>), grid, dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd, q8, ldq, row_scale); break;
+    switch (it) { LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) default: LN_FWD_CASE(5) }
+#undef LN_FWD_CASE
+}
+
+// LayerNorm forward that also emits the e4m3 copy of its bf16 output with per-row scales (see Q8 above)
+extern "C" int tvts_layernorm_fwd_fp8(const void* x, int ldx, int x_bf16, const int* rows, const float* gamma, const float* beta,
+                                      float eps, int M, int W, void* y, int ldy, void* q8, int ldq, float* row_scale,
+                                      float* mean, float* rstd, hipStream_t stream) {
+    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || ldy % 4 || ldq % 4 || !q8 || !row_scale) return TVTS_EINVAL;
+    int blocks = ceil_div(M, 4);
+    if (blocks > 2048) blocks = 2048;
+    const int it = ceil_div(W, 256);
+    if (x_bf16) launch_ln_fwd_q8<bf16>(it, dim3(blocks), stream, (const bf16*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd, (unsigned char*)q8, ldq, row_scale);
+    else launch_ln_fwd_q8<float>(it, dim3(blocks), stream, (const float*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd, (unsigned char*)q8, ldq, row_scale);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
 }
 
 // x: the fp32 residual stream, or (x_bf16) a side-branch value that only this LayerNorm consumes and that is therefore

@@ -200,14 +200,13 @@ class Engine:
         return self._b(name, shape, torch.float32, zero)
 
     # ------------------------------------------------------------------ linear helpers
-    def _lin(self, a, wname, bname, out, M, **epi):
+    def _lin(self, a, wname, bname, out, M, a8=None, **epi):
         if wname in self.P.w8:  # fp8 weight/activation path (BASELINE config 4): forward GEMMs of the ViT blocks
             w8, ws, _ = self.P.w8[wname]
-            a2 = a[:M]
-            q = self._b("fp8.q%d" % a2.shape[1], a2.shape, torch.uint8)
-            rs = self._f("fp8.row_scale", (max(M, 2),))  # one scale per token (never a 1-element tensor: that means per-tensor)
-            K.quantize_fp8_rows(a2, q=q, row_scale=rs)
-            K.gemm_nt_fp8(q, rs, w8, ws, out[:M], bias=self.P.p(bname) if bname else None, **epi)
+            if a8 is None:  # activations that do not come out of a LayerNorm: one pass, one scale per token
+                a8 = self._fp8_bufs(M, a.shape[1])
+                K.quantize_fp8_rows(a[:M], q=a8[0], row_scale=a8[1])
+            K.gemm_nt_fp8(a8[0], a8[1], w8, ws, out[:M], bias=self.P.p(bname) if bname else None, **epi)
             return
         K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
 
@@ -221,10 +220,20 @@ class Engine:
         if d_in is not None:
             K.gemm_nt(dy, self.P.wt(wname), d_in, M=M, **epi)
 
-    def _ln(self, x, name, eps, y, tag, rows=None, M=None):
+    def _fp8_bufs(self, M, W):
+        # (e4m3 bytes [M, W], per-token scales) -- shared scratch: an activation's fp8 copy only lives until its GEMM is launched
+        return (self._b("fp8.q%d" % W, (M, W), torch.uint8),
+                self._f("fp8.row_scale", (max(M, 2),)))  # never a 1-element tensor: that means "one scale for the tensor"
+
+    def _ln(self, x, name, eps, y, tag, rows=None, M=None, fp8_for=None):
+        """fp8_for: name of the weight the output feeds; when that GEMM runs in fp8 the LayerNorm also emits the e4m3 copy
+        (returned, to be handed to _lin as a8)."""
         M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
         mean, rstd = self._f(tag + ".mean", (M,)), self._f(tag + ".rstd", (M,))
-        K.layernorm_fwd(x, self.P.p(name + ".weight"), self.P.p(name + ".bias"), eps, y, mean, rstd, rows=rows, M=M)
+        a8 = self._fp8_bufs(M, y.shape[1]) if (fp8_for is not None and fp8_for in self.P.w8) else None
+        K.layernorm_fwd(x, self.P.p(name + ".weight"), self.P.p(name + ".bias"), eps, y, mean, rstd, rows=rows, M=M,
+                        q8=a8[0] if a8 else None, row_scale=a8[1] if a8 else None)
+        return a8
 
     def _ln_bwd(self, dy, x, name, tag, dx, dx_bf16=None, res1=None, res2=None, rows=None, M=None):
         tr = self.requires_grad[name + ".weight"]
@@ -345,26 +354,26 @@ class Engine:
         for l in range(a["layers"]):
             pre, tg = f"video_model.transformer.resblocks.{l}.", f"vit{l}"
             ln3 = self._b(tg + ".ln3", (M, W))
-            self._ln(x, pre + "ln_3", 1e-5, ln3, tg + ".ln3")
+            a8 = self._ln(x, pre + "ln_3", 1e-5, ln3, tg + ".ln3", fp8_for=pre + "timeattn.qkv.weight")
             qkv_t = self._b(tg + ".qkv_t", (M, 3 * W))
-            self._lin(ln3, pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", qkv_t, M)
+            self._lin(ln3, pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", qkv_t, M, a8=a8)
             att_t, lse_t = self._b(tg + ".att_t", (M, W)), self._f(tg + ".lse_t", (M, a["heads"]))
             self._st_attention_fwd(qkv_t, att_t, lse_t, "time", B, T, n)
             # the time residual only feeds ln_1 (the space branch restarts from x, video_encoder_ViT_B_16.py:121): bf16
             t_res = self._b(tg + ".t_res", (M, W))
             self._lin(att_t, pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", t_res, M, residual=x)
             ln1 = self._b(tg + ".ln1", (M, W))
-            self._ln(t_res, pre + "ln_1", 1e-5, ln1, tg + ".ln1")
+            a8 = self._ln(t_res, pre + "ln_1", 1e-5, ln1, tg + ".ln1", fp8_for=pre + "attn.qkv.weight")
             qkv_s = self._b(tg + ".qkv_s", (M, 3 * W))
-            self._lin(ln1, pre + "attn.qkv.weight", pre + "attn.qkv.bias", qkv_s, M)
+            self._lin(ln1, pre + "attn.qkv.weight", pre + "attn.qkv.bias", qkv_s, M, a8=a8)
             att_s, lse_s = self._b(tg + ".att_s", (M, W)), self._f(tg + ".lse_s", (M, a["heads"]))
             self._st_attention_fwd(qkv_s, att_s, lse_s, "space", B, T, n)
             s_res = self._f(tg + ".s_res", (M, W))  # residual from the block INPUT x (video_encoder_ViT_B_16.py:121)
             self._lin(att_s, pre + "attn.proj.weight", pre + "attn.proj.bias", s_res, M, residual=x)
             ln2 = self._b(tg + ".ln2", (M, W))
-            self._ln(s_res, pre + "ln_2", 1e-5, ln2, tg + ".ln2")
+            a8 = self._ln(s_res, pre + "ln_2", 1e-5, ln2, tg + ".ln2", fp8_for=pre + "mlp.c_fc.weight")
             h, act = self._b(tg + ".h", (M, 4 * W)), self._b(tg + ".a", (M, 4 * W))
-            self._lin(ln2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", act, M, act=a["act"], preact=h)
+            self._lin(ln2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", act, M, act=a["act"], preact=h, a8=a8)
             xo = self._f(f"vit.x{l + 1}", (M, W))
             self._lin(act, pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", xo, M, residual=s_res)
             x = xo

@@ -158,9 +158,16 @@ def colsum(x, out, *, M=None):
     _chk(lib.tvts_colsum_bf16(_p(x), _ld(x), M, x.shape[1], _p(out), _stream()), "tvts_colsum_bf16")
 
 
-def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=None):
+def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=None, q8=None, row_scale=None):
+    """q8 (uint8 [M, W]) + row_scale (float32 [>= M]): also write the bf16 output as e4m3 bytes with one scale per row."""
     lib = _lib.load()
     M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
+    if q8 is not None:
+        assert y.dtype == torch.bfloat16 and q8.dtype == torch.uint8 and row_scale.dtype == torch.float32 and row_scale.numel() >= M
+        rc = lib.tvts_layernorm_fwd_fp8(_p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(rows), _p(gamma), _p(beta), eps, M,
+                                        x.shape[1], _p(y), _ld(y), _p(q8), q8.stride(0), _p(row_scale), _p(mean), _p(rstd), _stream())
+        _chk(rc, "tvts_layernorm_fwd_fp8")
+        return
     rc = lib.tvts_layernorm_fwd(_p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(rows), _p(gamma), _p(beta), eps, M, x.shape[1], _p(y), _ld(y),
                                 1 if y.dtype == torch.float32 else 0, _p(mean), _p(rstd), _stream())
     _chk(rc, "tvts_layernorm_fwd")
