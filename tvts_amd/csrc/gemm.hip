@@ -992,6 +992,14 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
     g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = nullptr; g.ldh = 0; g.gate_act = ACT_NONE;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.swz = 7; g.ablate = 0; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
+    {   // same column-group walk as the bf16 dispatch (N = 3840: 415 -> 398 us)
+        const char* e = getenv("TVTS_NT_ABLATE");
+        const int ab = e ? atoi(e) : 0;
+        const int tn = ceil_div(N, 256);
+        if (tn >= 10) g.gc = tn % 6 == 0 ? 6 : tn % 5 == 0 ? 5 : 0;
+        if (ab >> 8) g.gc = (ab >> 8) & 15;   // dev override (15 = force 0)
+        if (g.gc == 15) g.gc = 0;
+    }
     g.tiles_n = ceil_div(N, 256);
     g.tiles_m = ceil_div(M, 256);
     const int total_tiles = g.tiles_m * g.tiles_n;
