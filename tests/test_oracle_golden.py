@@ -211,6 +211,35 @@ def test_hf_adamw_restated():
     assert torch.allclose(p, exp, rtol=1e-6, atol=1e-8)
 
 
+def test_hf_adamw_against_torch_adamw():
+    """Independent cross-check of the restated optimizer (transformers.AdamW itself is absent from this image).  HF's update
+    lr * sqrt(bc2)/bc1 * m / (sqrt(v) + eps) equals torch.optim.AdamW's lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps') with
+    eps' = eps / sqrt(bc2), so torch's implementation pins the moment updates and both bias corrections step by step; the two
+    things it cannot pin -- eps outside the bias correction, decay applied to the UPDATED weight -- are the published
+    differences of transformers==4.10.2 and enter through that mapping and the (p - u)(1 - lr wd) identity below."""
+    torch.manual_seed(0)
+    lr, b1, b2, eps = 3e-4, 0.9, 0.999, 1e-6
+    p_ref = torch.nn.Parameter(torch.randn(257, dtype=torch.float64))
+    opt = torch.optim.AdamW([p_ref], lr=lr, betas=(b1, b2), eps=eps, weight_decay=0.0)
+    p = p_ref.detach().clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 8):
+        g = torch.randn(257, dtype=torch.float64) * (10.0 ** torch.randint(-4, 2, (257,)).double())
+        opt.param_groups[0]["eps"] = eps / (1.0 - b2 ** step) ** 0.5
+        p_ref.grad = g.clone()
+        opt.step()
+        O.hf_adamw_step(p, g, m, v, step, lr=lr, wd=0.0, beta1=b1, beta2=b2, eps=eps)
+        st = opt.state[p_ref]
+        assert torch.allclose(m, st["exp_avg"], rtol=1e-12, atol=0) and torch.allclose(v, st["exp_avg_sq"], rtol=1e-12, atol=0)
+        assert torch.allclose(p, p_ref.detach(), rtol=1e-10, atol=1e-14), step
+    # decoupled decay: one more step from the same state with and without it -> p_wd = (p - u) * (1 - lr * wd)
+    g = torch.randn(257, dtype=torch.float64)
+    pa, pb = p.clone(), p.clone()
+    O.hf_adamw_step(pa, g, m.clone(), v.clone(), 8, lr=lr, wd=0.0, beta1=b1, beta2=b2, eps=eps)
+    O.hf_adamw_step(pb, g, m.clone(), v.clone(), 8, lr=lr, wd=0.2, beta1=b1, beta2=b2, eps=eps)
+    assert torch.allclose(pb, pa * (1.0 - lr * 0.2), rtol=1e-14, atol=0)
+
+
 def test_flops_formula():
     # BASELINE.md section 3 table
     for name, T, step in (("B_32", 4, 167.5), ("B_32", 8, 313.3), ("B_16", 8, 606.1)):
