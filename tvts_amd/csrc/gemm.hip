@@ -1027,6 +1027,7 @@ struct GemmTN {
     int M, Na, Nb;
     float* out; int ldo;
     int tiles_b, tiles_ab, m_per_split, n_items;
+    int early_dma;  // 128-tile kernel: issue the next stage's LDS-DMA (inline asm) before the current stage's fragment reads
     int tiles_a, a_fast;  // 128-tile kernel: walk the tiles of an m-range with the SHORTER tile dimension fastest
     int atomic;
     float* ws;      // split partials [splits][Na][Nb] (plain stores, reduced by tn_reduce_kernel) or nullptr -> fp32 atomics
@@ -1048,6 +1049,32 @@ __device__ __forceinline__ void stage_cols128(const bf16* __restrict__ base, int
         col = col < c_max ? col : c_max;
         const bf16* src = base + (size_t)gm * ld + col;
         __builtin_amdgcn_global_load_lds((const GLB_PTR(void))src, (LDS_PTR(void))(lds_tile + r0 * 256), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void glds16_asm(unsigned voff, const char* sbase, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+// the same 64-row stage issued from inline asm: hipcc parks an s_waitcnt vmcnt(0) in front of every transposing LDS read
+// that follows the LDS-DMA builtin (it cannot tell the buffers apart), which forces "reads first, then the next stage's
+// DMA"; issued this way the DMA can start BEFORE the reads of the current stage and flies under them as well.  Offsets are
+// 32-bit from a wave-uniform base (the dispatcher checks the operand fits 4 GiB).
+__device__ __forceinline__ void stage_cols128_asm(const bf16* __restrict__ base, int ld, int m0, int m_max, int c0, int c_max,
+                                                  unsigned lds_tile, int wave, int lane) {
+    const char* ub = uniform_ptr(base);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r0 = (t * 4 + wave) * 4;
+        const int row = r0 + (lane >> 4);
+        const int s16 = lane & 15;
+        const int chunk32 = (s16 >> 1) ^ (row & 7);
+        int gm = m0 + row;
+        gm = gm < m_max ? gm : m_max;
+        int col = c0 + chunk32 * 16 + (s16 & 1) * 8;
+        col = col < c_max ? col : c_max;
+        glds16_asm(((unsigned)gm * (unsigned)ld + (unsigned)col) * 2u, ub, lds_tile + (unsigned)r0 * 256u);
     }
 }
 
@@ -1111,10 +1138,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
     stage_cols128(g.P, g.ldp, m_begin, g.M - 1, a0, g.Na - 8, smem, wave, lane);
     stage_cols128(g.Q, g.ldq, m_begin, g.M - 1, b0, g.Nb - 8, smem + 16384, wave, lane);
     __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(LDS_PTR(char))smem;
     for (int kt = 0; kt < nk; ++kt) {
         char* cur = smem + (kt & 1) * 32768;
-        // All transposing reads of this stage first: hipcc drains vmcnt(0) in front of a ds_read_tr that follows
-        // an LDS-DMA issue, which would serialise the next stage's loads behind this stage's MFMAs.
+        if (g.early_dma && kt + 1 < nk) {  // next stage's DMA first: it is in flight under the reads below as well
+            const unsigned nxt = lds0 + (unsigned)((kt + 1) & 1) * 32768u;
+            stage_cols128_asm(g.P, g.ldp, m_begin + (kt + 1) * 64, g.M - 1, a0, g.Na - 8, nxt, wave, lane);
+            stage_cols128_asm(g.Q, g.ldq, m_begin + (kt + 1) * 64, g.M - 1, b0, g.Nb - 8, nxt + 16384u, wave, lane);
+        }
+        // (builtin path) all transposing reads of this stage first: hipcc drains vmcnt(0) in front of a ds_read_tr that
+        // follows an LDS-DMA builtin, which would serialise the next stage's loads behind this stage's MFMAs.
         bf16x8 pf[2][4], qf[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1123,7 +1156,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) qf[u][j] = frag_tr(cur + 16384, u, wb * 4 + j, lane);
         }
-        if (kt + 1 < nk) {
+        if (!g.early_dma && kt + 1 < nk) {
             char* nxt = smem + ((kt + 1) & 1) * 32768;
             stage_cols128(g.P, g.ldp, m_begin + (kt + 1) * 64, g.M - 1, a0, g.Na - 8, nxt, wave, lane);
             stage_cols128(g.Q, g.ldq, m_begin + (kt + 1) * 64, g.M - 1, b0, g.Nb - 8, nxt + 16384, wave, lane);
@@ -1152,6 +1185,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
                 for (int i = 0; i < 4; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[u][i], cs[i], 0, 0, 0);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the asm-issued DMA is invisible to the compiler's own counting
         __syncthreads();
     }
     if (do_cs && lane < 16) {
@@ -1208,11 +1242,6 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 // for by hand.  The bias gradient (column sums of P) is accumulated on the VALU from the P fragments.
 // Work items = (m-range, tile) in range-major order, one contiguous eighth per XCD, one round of 256 blocks.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16_asm(unsigned voff, const char* sbase, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
-}
 struct StageOffTN { unsigned off[4]; };
 __device__ __forceinline__ void tn_offsets(StageOffTN& o, int ld, int rows_valid, int c_max, int c0, int wave, int lane) {
 #pragma unroll
@@ -1464,7 +1493,7 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     if (M <= 0 || Na <= 0 || Nb <= 0) return TVTS_EINVAL;
     if (Na % 8 || Nb % 8 || ldp % 8 || ldq % 8 || ldo % 4) return TVTS_EINVAL;
     GemmTN g;
-    g.ws = nullptr;
+    g.ws = nullptr; g.early_dma = 0; g.tiles_a = 0; g.a_fast = 0;
     g.P = (const bf16*)P; g.ldp = ldp; g.Q = (const bf16*)Q; g.ldq = ldq; g.M = M; g.Na = Na; g.Nb = Nb;
     g.out = out; g.ldo = ldo; g.colsum = colsum;
     { static const char* e = getenv("TVTS_TN_ABLATE"); g.ablate = e ? atoi(e) : 0; }
@@ -1497,6 +1526,11 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     g.tiles_ab = tiles_a * g.tiles_b;
     g.tiles_a = tiles_a;
     { const char* e = getenv("TVTS_TN_AFAST"); g.a_fast = e ? atoi(e) : (tiles_a < g.tiles_b ? 1 : 0); }
+    {
+        const char* e = getenv("TVTS_TN_EARLY");
+        const bool fits = (unsigned long long)M * (unsigned long long)(ldp > ldq ? ldp : ldq) * 2ull < (1ull << 32);
+        g.early_dma = (fits && !(e && atoi(e) == 0)) ? 1 : 0;
+    }
     // split the contraction over M into S ranges (range s lives on XCD s % 8, see the kernel).  S is chosen for
     // whole rounds of 2 blocks x 256 CUs: the smallest S reaching >= 93 % round efficiency, else the best one.
     int splits = 1;
