@@ -893,6 +893,13 @@ static int nt_tile_env() { const char* e = getenv("TVTS_NT_TILE"); return e ? at
 static int g_nt_tile = nt_tile_env();  // 0 = auto, 128 / 256 / 512 (= 256 anti-phase) forced (tools/gemm_bench.py)
 extern "C" void tvts_gemm_set_nt_tile(int t) { g_nt_tile = t; }
 
+// fewest 256x256 tiles for which the pipelined 256-tile kernel is chosen over the 128-tile one (dev knob TVTS_NT_MIN_TILES):
+// the text tower of a 192-pair step has 192 of them (M = 24 576, N = 512) and runs ~10 % faster on the 256-tile kernel
+static int nt_min_tiles() {
+    static const int v = []() { const char* e = getenv("TVTS_NT_MIN_TILES"); return e ? atoi(e) : 150; }();
+    return v;
+}
+
 extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                                  const float* bias, const float* residual, int ldr, int act, void* preact,
                                  int ldp, const void* gate_h, int ldh, int gate_act, void* out, int ldc,
@@ -921,7 +928,7 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     const bool stag = g_nt_tile == 512;
     const int ring = g_nt_tile == 1024 ? 4 : g_nt_tile == 1280 ? 5 : 0;
     if ((g_nt_tile >= 256) && (N % 8 || ldc % 8 || (preact && ldp % 8) || (gate_h && ldh % 8))) return TVTS_EINVAL;
-    const bool big = stag || ring || g_nt_tile == 768 || (g_nt_tile == 256) || (g_nt_tile == 0 && N % 256 == 0 && (long)ceil_div(M, 256) * (N / 256) >= 200);
+    const bool big = stag || ring || g_nt_tile == 768 || (g_nt_tile == 256) || (g_nt_tile == 0 && N % 256 == 0 && (long)ceil_div(M, 256) * (N / 256) >= nt_min_tiles());
     if (big) {
         g.tiles_n = ceil_div(N, 256);
         g.tiles_m = ceil_div(M, 256);
