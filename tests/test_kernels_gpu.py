@@ -686,3 +686,33 @@ def test_layernorm_fwd_fp8_output(K, W, xdt):
     q2, rs2 = torch.empty(4, W, dtype=torch.uint8, device=DEV), torch.empty(4, device=DEV)
     K.layernorm_fwd(x, g, b, 1e-5, y2, torch.empty(4, device=DEV), torch.empty(4, device=DEV), rows=rows, q8=q2, row_scale=rs2)
     assert torch.equal(y2, y0[rows.long()]) and torch.equal(q2, q_ref[rows.long()]) and torch.equal(rs2, rs_ref[rows.long()])
+
+
+@pytest.mark.parametrize("M,Na,Nb", [(5000, 768, 3072), (4097, 256, 128), (12345, 1280, 640)])
+def test_gemm_tn_dma_paths_agree(K, M, Na, Nb):
+    """The weight-gradient kernel issues its LDS-DMA from inline asm ahead of the fragment reads (32-bit offsets from a
+    uniform base); operands past 4 GiB take the builtin path.  Both paths and both tile walks must give identical bits."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    p, q = rnd(M, Na, seed=70).bfloat16().to(DEV), rnd(M, Nb, seed=71).bfloat16().to(DEV)
+    outs = []
+    try:
+        for early, afast in ((b"1", None), (b"0", None), (b"1", b"0"), (b"1", b"1")):
+            libc.setenv(b"TVTS_TN_EARLY", early, 1)
+            if afast is None:
+                libc.unsetenv(b"TVTS_TN_AFAST")
+            else:
+                libc.setenv(b"TVTS_TN_AFAST", afast, 1)
+            out = torch.full((Na, Nb), float("nan"), device=DEV)
+            cs = torch.zeros(Na, device=DEV)
+            K.gemm_tn(p, q, out, accumulate=False, colsum=cs)
+            outs.append((out, cs))
+    finally:
+        libc.unsetenv(b"TVTS_TN_EARLY")
+        libc.unsetenv(b"TVTS_TN_AFAST")
+    ref = p.float().t().double() @ q.float().double()
+    assert rel(outs[0][0], ref.cpu()) < 2e-5
+    for o, c in outs[1:]:
+        assert torch.equal(o, outs[0][0])
+        assert torch.allclose(c, outs[0][1], rtol=1e-5, atol=1e-3)   # column sums meet through fp32 atomics
+    assert torch.allclose(outs[0][1].cpu(), p.float().sum(0).cpu(), rtol=1e-3, atol=2e-2)
