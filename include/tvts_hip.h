@@ -22,14 +22,20 @@ enum { TVTS_ATTN_FULL = 0, TVTS_ATTN_SPACE = 1, TVTS_ATTN_TIME = 2, TVTS_ATTN_CL
 int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                       const float* residual, int ldr, int act, void* preact, int ldp, const void* gate_h, int ldh,
                       int gate_act, void* out, int ldc, int out_f32, hipStream_t stream);
-/* tile selection override for tools/gemm_bench.py: 0 auto, 128, 256 */
+/* tile selection override for benches and tests: 0 auto, 128 (persistent 128x128 kernel), 256 (pipelined 256x256 kernel) */
 void tvts_gemm_set_nt_tile(int t);
+/* the output tile (128 or 256) tvts_gemm_nt_bf16 picks for an [M, N] result under the current override: lets a parity
+ * test assert that the kernel it means to exercise is the one that ran */
+int tvts_gemm_nt_select(int M, int N);
 /* weight gradient: out[Na,Nb] (+)= P[M,Na]^T . Q[M,Nb], bf16 in, fp32 out (autograd of the Linear sites above) */
 /* colsum (optional): colsum[a] += sum_m P[m,a] -- the bias gradient, fused into the same pass.
  * workspace (optional, workspace_elems floats): scratch for the split-M partials; with it the kernel stores
  * partials and a reduce pass combines them (deterministic), without it the partials meet through fp32 atomics. */
 int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb, float* out, int ldo,
                       int accumulate, float* colsum, float* workspace, long workspace_elems, hipStream_t stream);
+/* test hook: force the weight-gradient kernel's LDS-DMA issue path (early_dma 0 = builtin path, the one operands past 4 GiB
+ * take) and its tile walk (a_fast 0 / 1); -1 = automatic */
+void tvts_gemm_set_tn_mode(int early_dma, int a_fast);
 /* fp8 (OCP e4m3) operands with scales in device memory, fp32 accumulate: the GEMM of BASELINE config 4's weight / activation
  * path (nn.Linear sites of video_encoder_ViT_H_14.py); K % 128 == 0, lda / ldb % 16 == 0 (bytes).  scale_b: one scale for the
  * weight; scale_a: one scale for the tensor, or (scale_a_rows != 0) M per-row scales as written by tvts_quant_fp8_rows */

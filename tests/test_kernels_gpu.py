@@ -692,24 +692,19 @@ def test_layernorm_fwd_fp8_output(K, W, xdt):
 def test_gemm_tn_dma_paths_agree(K, M, Na, Nb):
     """The weight-gradient kernel issues its LDS-DMA from inline asm ahead of the fragment reads (32-bit offsets from a
     uniform base); operands past 4 GiB take the builtin path.  Both paths and both tile walks must give identical bits."""
-    import ctypes
-    libc = ctypes.CDLL(None)
+    from tvts_amd import _lib
+    lib = _lib.load()
     p, q = rnd(M, Na, seed=70).bfloat16().to(DEV), rnd(M, Nb, seed=71).bfloat16().to(DEV)
     outs = []
     try:
-        for early, afast in ((b"1", None), (b"0", None), (b"1", b"0"), (b"1", b"1")):
-            libc.setenv(b"TVTS_TN_EARLY", early, 1)
-            if afast is None:
-                libc.unsetenv(b"TVTS_TN_AFAST")
-            else:
-                libc.setenv(b"TVTS_TN_AFAST", afast, 1)
+        for early, afast in ((-1, -1), (0, -1), (-1, 0), (-1, 1)):
+            lib.tvts_gemm_set_tn_mode(early, afast)
             out = torch.full((Na, Nb), float("nan"), device=DEV)
             cs = torch.zeros(Na, device=DEV)
             K.gemm_tn(p, q, out, accumulate=False, colsum=cs)
             outs.append((out, cs))
     finally:
-        libc.unsetenv(b"TVTS_TN_EARLY")
-        libc.unsetenv(b"TVTS_TN_AFAST")
+        lib.tvts_gemm_set_tn_mode(-1, -1)
     ref = p.float().t().double() @ q.float().double()
     assert rel(outs[0][0], ref.cpu()) < 2e-5
     for o, c in outs[1:]:

@@ -30,7 +30,7 @@ def timeit(fn, iters=20):
 def main():
     dev = "cuda:0"
     from tvts_amd import _lib
-    for tile in [int(x) for x in os.environ.get('TILES', '256,512').split(',')]:
+    for tile in [int(x) for x in os.environ.get('TILES', '0,128,256').split(',')]:
         _lib.load().tvts_gemm_set_nt_tile(tile)
         print(f"--- NT tile {tile}")
         nt(dev)

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""fp8 vs bf16 NT GEMM on the H/14 forward shapes (interleaved medians; TVTS_NT_ABLATE bits 8..11 = column group).  GPU only."""
-import ctypes
+"""fp8 vs bf16 NT GEMM on the H/14 forward shapes (interleaved medians).  GPU only."""
 import os
 import sys
 
@@ -10,7 +9,6 @@ import torch  # noqa: E402
 from tvts_amd import hip as K  # noqa: E402
 
 dev = "cuda:0"
-libc = ctypes.CDLL(None)
 M = int(os.environ.get("PAIRS", "48")) * 1233
 
 
@@ -36,17 +34,12 @@ for n, k, act in ((3840, 1280, None), (5120, 1280, "gelu"), (1280, 5120, None), 
     pre = torch.empty(M, n, dtype=torch.bfloat16, device=dev) if act else None
     fns = {"bf16": lambda: K.gemm_nt(a, b, out, bias=bias, act=act, preact=pre),
            "fp8": lambda: K.gemm_nt_fp8(a8, rs, b8, sb, out, bias=bias, act=act, preact=pre)}
-    res = {}
-    for gc in (0xf00, 0x500, 0x600) if n >= 2560 else (0xf00,):
-        for name, fn in fns.items():
-            res[(name, gc)] = []
+    res = {name: [] for name in fns}
     for rnd in range(7):
-        for (name, gc) in res:
-            libc.setenv(b"TVTS_NT_ABLATE", str(gc).encode(), 1)
-            res[(name, gc)].append(timeit(fns[name]))
-    libc.unsetenv(b"TVTS_NT_ABLATE")
+        for name in res:
+            res[name].append(timeit(fns[name]))
     line = f"N={n:5d} K={k:5d} act={act}"
-    for key, ts in res.items():
+    for name, ts in res.items():
         ms = sorted(ts)[3]
-        line += f" | {key[0]} gc={(key[1] >> 8) & 15:2d}: {ms * 1e3:6.1f}us {2.0 * M * n * k / ms / 1e9:5.0f}TF"
+        line += f" | {name}: {ms * 1e3:6.1f}us {2.0 * M * n * k / ms / 1e9:5.0f}TF"
     print(line, flush=True)

@@ -1,0 +1,274 @@
+// 256x256-tile software-pipelined NT GEMM kernel (the production forward / dgrad kernel of the TVTSv2 step) as a header,
+// so that the bench-only experiment library (csrc/exp/) can instantiate variants of the SAME source without any
+// run-time switches living in the production kernel.  Included by gemm.hip.
+#pragma once
+#include "common.h"
+
+#define BK 64
+
+struct GemmNT {
+    const bf16* A; int lda;
+    const bf16* B; int ldb;
+    int M, N, K;
+    const float* bias;
+    const float* residual; int ldr;
+    int act;
+    bf16* preact; int ldp;
+    const bf16* gate_h; int ldh; int gate_act;
+    void* out; int ldc; int out_f32;
+    int tiles_m, tiles_n;
+    int sa_rows; // fp8: scale_a holds one scale per row of A (per-token activation scales) instead of one for the tensor
+    int gc;      // 256x256 pipelined kernel: tile columns per column group (0 = plain row-major tile order)
+    const float* sa; const float* sb;  // fp8 operands: per-tensor scales (device scalars), out = sa*sb * (A B^T) + ...
+};
+
+__device__ __forceinline__ bf16x8 frag_rows128(const char* lds_tile, int row, int chunk) {
+    return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+struct StageOff256 { unsigned off[4]; };
+// byte offset (from the tile's first row, k = 0) of the 16-B chunk this lane fetches in DMA piece t; rows past
+// the matrix end are clamped to its last row.  Invariant along k, so the K loop only bumps a scalar base pointer.
+__device__ __forceinline__ void stage_offsets256(StageOff256& o, int ld, int row0, int row_max, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = (t * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        int grow = row0 + row;
+        grow = grow < row_max ? grow : row_max;
+        o.off[t] = (unsigned)(grow - row0) * (unsigned)ld * 2u + (unsigned)chunk * 16u;
+    }
+}
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {  // make wave-uniformity provable: SGPR base
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+template <int AUX = 0>
+__device__ __forceinline__ void stage_issue256(const StageOff256& o, const bf16* ubase_, char* lds_tile, int wave) {
+    const char* ubase = uniform_ptr(ubase_);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        __builtin_amdgcn_global_load_lds((const GLB_PTR(void))((const char*)ubase + o.off[t]),
+                                         (LDS_PTR(void))(lds_tile + (t * 8 + wave) * 1024), 16, 0, AUX);
+}
+// tile index -> tile origin.  gc == 0: row-major over (m, n).  gc > 0: column groups of gc tile columns, row-major
+// inside a group, so the tiles an XCD works on at one time span gc weight panels instead of all of them.
+__device__ __forceinline__ void tile_origin256(const GemmNT& g, int t, int gc, int& m0, int& n0) {
+    if (gc <= 0) { m0 = (t / g.tiles_n) * 256; n0 = (t % g.tiles_n) * 256; return; }
+    const int per_group = g.tiles_m * gc;
+    const int grp = t / per_group, r = t - grp * per_group;
+    const int c0 = grp * gc;
+    const int w = (g.tiles_n - c0) < gc ? (g.tiles_n - c0) : gc;
+    m0 = (r / w) * 256; n0 = (c0 + r % w) * 256;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256x256 tile, 512 threads = 8 waves as 2(M) x 4(N), wave tile 128x64, SOFTWARE-PIPELINED fragments.  A plain
+// load-then-multiply 256x256 kernel runs its three phases -- LDS-DMA wait, 24 ds_read_b128 per wave, 64 MFMAs per
+// wave -- back to back (round 1: MFMA alone 105 us, DMA + reads alone 95 us, epilogue 53 us, together 237 us at
+// M 50240, N 2304, K 768).  Here the fragment registers are double-buffered so that the reads of the next
+// half K-step are in flight while the matrix pipe works on the current one, and the DMA of stage s+2 is issued
+// right after the barrier that frees its buffer, a full stage ahead of its consumer:
+//     F1 <- ds_read k 32..63 (cur) | MFMA(F0) | vmcnt(0) lgkmcnt(0) barrier | DMA(s+2 -> cur) |
+//     F0 <- ds_read k 0..31 (nxt)  | MFMA(F1) | [tile end: epilogue]
+// Stages form one flat sequence over the block's persistent tile list.  LDS: 2 x 64 KiB stages + 8 x 4 KiB
+// XOR-swizzled epilogue patches = 160 KiB exactly.
+// ------------------------------------------------------------------------------------------------
+template <int ACT, int GATE>
+__device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn,
+                                                  int lane, char* patch, float scale = 1.0f,
+                                                  const float* row_scale = nullptr) {
+    // patch: 16 rows x 256 B (64 fp32), 16-B chunk c of row r stored at chunk c ^ r
+    const int nb = n0 + wn * 64;
+    const int li = lane & 15, gq = lane >> 4;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nb + j * 16 + gq * 4;
+        bias4[j] = (g.bias && n < g.N) ? *(const f32x4*)(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float sc = scale;
+        if (row_scale) {  // per-row (token) scale of the fp8 A operand; `scale` then holds the weight's tensor scale
+            const int m = m0 + wm * 128 + i * 16 + li;
+            sc *= row_scale[m < g.M ? m : g.M - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i] * sc + bias4[j];
+            acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (g.out_f32) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int idx = lane + 64 * t, r = idx >> 4, c16 = idx & 15;
+                f32x4 v = *(const f32x4*)(patch + r * 256 + ((c16 ^ r) << 4));
+                const int m = m0 + wm * 128 + i * 16 + r, n = nb + c16 * 4;
+                if (m >= g.M || n >= g.N) continue;
+                if (ACT != ACT_NONE) {
+                    if (g.preact) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
+                }
+                if (GATE != ACT_NONE) {
+                    const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
+                }
+                if (g.residual) v += *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
+                *(f32x4*)((float*)g.out + (size_t)m * g.ldc + n) = v;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int idx = lane + 64 * t, r = idx >> 3, c8 = idx & 7;
+                const f32x4 v0 = *(const f32x4*)(patch + r * 256 + (((2 * c8) ^ r) << 4));
+                const f32x4 v1 = *(const f32x4*)(patch + r * 256 + (((2 * c8 + 1) ^ r) << 4));
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const int m = m0 + wm * 128 + i * 16 + r, n = nb + c8 * 8;
+                if (m >= g.M || n >= g.N) continue;
+                if (ACT != ACT_NONE) {
+                    if (g.preact) {
+                        bf16x8 h;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = (bf16)v[e];
+                        *(bf16x8*)(g.preact + (size_t)m * g.ldp + n) = h;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], ACT);
+                }
+                if (GATE != ACT_NONE) {
+                    const bf16x8 h = *(const bf16x8*)(g.gate_h + (size_t)m * g.ldh + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= act_bwd((float)h[e], GATE);
+                }
+                if (g.residual) {
+                    const f32x4 r0 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n), r1 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *(bf16x8*)((bf16*)g.out + (size_t)m * g.ldc + n) = o;
+            }
+        }
+    }
+}
+
+#define RAW_BARRIER_P()                       \
+    do {                                      \
+        asm volatile("" ::: "memory");        \
+        __builtin_amdgcn_s_barrier();         \
+        asm volatile("" ::: "memory");        \
+    } while (0)
+
+template <int ACT, int GATE, bool FP8 = false>
+__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 32K | B 32K] + 8 x 4K patches
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    char* patch = smem + 131072 + wave * 4096;
+
+    const int total = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int q = total >> 3, rem = total & 7;
+    const int range_lo = xcd * q + (xcd < rem ? xcd : rem);
+    const int range_n = q + (xcd < rem ? 1 : 0);
+    const int nk = g.K / BK;
+    if (slot >= range_n) return;
+    const int ntl = (range_n - slot + per_xcd - 1) / per_xcd;
+    const int total_st = ntl * nk;
+    const int gc = g.gc;
+
+    // DMA cursor
+    int i_st = 0, i_kt = 0, i_tl = 0, i_m0, i_n0;
+    StageOff256 oa, ob;
+    {
+        tile_origin256(g, range_lo + slot, gc, i_m0, i_n0);
+        stage_offsets256(oa, g.lda, i_m0, g.M - 1, wave, lane);
+        stage_offsets256(ob, g.ldb, i_n0, g.N - 1, wave, lane);
+    }
+    auto issue = [&]() {
+        char* dst = smem + (i_st & 1) * 65536;
+        stage_issue256<0>(oa, g.A + (size_t)i_m0 * g.lda + i_kt * BK, dst, wave);
+        stage_issue256<0>(ob, g.B + (size_t)i_n0 * g.ldb + i_kt * BK, dst + 32768, wave);
+        ++i_st;
+        if (++i_kt == nk) {
+            i_kt = 0; ++i_tl;
+            tile_origin256(g, range_lo + slot + i_tl * per_xcd, gc, i_m0, i_n0);
+            stage_offsets256(oa, g.lda, i_m0, g.M - 1, wave, lane);
+            stage_offsets256(ob, g.ldb, i_n0, g.N - 1, wave, lane);
+        }
+    };
+    issue();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RAW_BARRIER_P();
+    if (i_st < total_st) issue();
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int kt = 0, tl = 0, m0, n0;
+    tile_origin256(g, range_lo + slot, gc, m0, n0);
+    const int arow = wm * 128 + (lane & 15), brow = wn * 64 + (lane & 15), gq = lane >> 4;
+    // fragment registers: two A half-sets (4 MFMA row-tiles each) and two B sets, refilled while the matrix pipe
+    // works on the other one
+    bf16x8 aF[2][4], bF[2][4];
+#define LOAD_A(dst, buf, ks, h)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) dst[i] = frag_rows128(buf, arow + ((h) * 4 + i) * 16, (ks) * 4 + gq)
+#define LOAD_B(dst, buf, ks)                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) dst[j] = frag_rows128((buf) + 32768, brow + j * 16, (ks) * 4 + gq)
+    // FP8: the operands are e4m3 matrices addressed as bf16 matrices of half the width (the staging and the LDS image are
+    // byte-identical); a 16-byte fragment then holds 16 k-values of its row and feeds two 16x16x32 fp8 MFMAs (its low and
+    // its high 8 bytes -- A and B use the same split, so every k meets its partner).
+    typedef __attribute__((ext_vector_type(2))) long i64x2;
+#define MFMA16(av, bv, h)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+            if (FP8) {                                                                                 \
+                const i64x2 a8 = __builtin_bit_cast(i64x2, av[i]), b8 = __builtin_bit_cast(i64x2, bv[j]); \
+                acc[j][(h) * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b8[0], a8[0], acc[j][(h) * 4 + i], 0, 0, 0); \
+                acc[j][(h) * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b8[1], a8[1], acc[j][(h) * 4 + i], 0, 0, 0); \
+            } else {                                                                                   \
+                acc[j][(h) * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[j], av[i], acc[j][(h) * 4 + i], 0, 0, 0); \
+            }                                                                                          \
+        }
+    LOAD_B(bF[0], smem, 0);
+    LOAD_A(aF[0], smem, 0, 0);
+
+    for (int st = 0; st < total_st; ++st) {
+        const char* cur = smem + (st & 1) * 65536;
+        const char* nxt = smem + ((st + 1) & 1) * 65536;
+        LOAD_A(aF[1], cur, 0, 1);
+        MFMA16(aF[0], bF[0], 0);
+        LOAD_B(bF[1], cur, 1);
+        LOAD_A(aF[0], cur, 1, 0);
+        MFMA16(aF[1], bF[0], 1);
+        LOAD_A(aF[1], cur, 1, 1);
+        MFMA16(aF[0], bF[1], 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        RAW_BARRIER_P();
+        if (i_st < total_st) issue();  // stage st+2 into the buffer every wave has just finished reading
+        if (st + 1 < total_st) {
+            LOAD_B(bF[0], nxt, 0);
+            LOAD_A(aF[0], nxt, 0, 0);
+        }
+        MFMA16(aF[1], bF[1], 1);
+        if (++kt == nk) {
+            if (FP8 && g.sa_rows) epilogue256_patch<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, patch, g.sb[0], g.sa);
+            else epilogue256_patch<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, patch, FP8 ? g.sa[0] * g.sb[0] : 1.0f);
+            kt = 0; ++tl;
+            tile_origin256(g, range_lo + slot + tl * per_xcd, gc, m0, n0);
+        }
+    }
+#undef LOAD_A
+#undef LOAD_B
+#undef MFMA16
+}
