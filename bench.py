@@ -26,26 +26,27 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MIC
 
 
 def step_flops_per_pair(a, T, caption_len=32, NT=4):
-    """SURVEY.md 8d algorithmic matmul FLOPs per pair (fwd, bwd)."""
+    """SURVEY.md 8d algorithmic matmul FLOPs per pair (fwd, bwd).  NT = 1 (WebVid-style batch): no sorting head."""
     p, W, E, Wt = a["patch"], a["width"], a["embed"], a["text_width"]
     n = int((a["image"] // p) ** 2 * (1 - a["mask_ratio"]))
     S, layers, Lt, L = 1 + T * n, a["layers"], a["text_layers"], caption_len
     So = S + NT
     patch = 2 * T * n * 3 * p * p * W
     text_gemm = NT * Lt * L * 24 * Wt * Wt
+    sort = (2 * So * 24 * E * E + 8 * So * So * E + 32 * E) if NT > 1 else 0
     fwd = (patch + layers * S * 32 * W * W + layers * (4 * n * T * (T + 1) * W + 4 * T * n * (n + 1) * W + 8 * S * W)
-           + 2 * S * W * E + text_gemm + NT * Lt * 4 * L * L * Wt + NT * 2 * Wt * E + 2 * So * 24 * E * E + 8 * So * So * E + 32 * E)
+           + 2 * S * W * E + text_gemm + NT * Lt * 4 * L * L * Wt + NT * 2 * Wt * E + sort)
     bwd = 2 * fwd - patch - (a["text_tune_from"] / Lt) * text_gemm
     return fwd, bwd
 
 
-def cpu_baseline_worker(arch_name, T, caption_len, pairs, max_seconds, threads):
+def cpu_baseline_worker(arch_name, T, caption_len, pairs, max_seconds, threads, n_trans=4):
     """The CPU oracle (oracle/tvts_oracle.py, a port) timed on this host: full step incl. HF-AdamW."""
     from oracle import tvts_oracle as O
     oarch = O.ARCHS[arch_name]
     torch.set_num_threads(threads)
     P = O.synth_params(oarch, seed=0)
-    batch = O.synth_batch(oarch, B=pairs, T=T, seed=0, caption_len=caption_len)
+    batch = O.synth_batch(oarch, B=pairs, T=T, seed=0, caption_len=caption_len, n_trans=n_trans)
     state = {}
     t0 = time.time()
     O.train_step(P, batch, oarch, state)  # first step (includes allocator warm-up)
@@ -57,23 +58,32 @@ def cpu_baseline_worker(arch_name, T, caption_len, pairs, max_seconds, threads):
             O.train_step(P, batch, oarch, state)
             n += 1
         dt = (time.time() - t0) / n
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"{n} full step(s) (fwd+bwd+HF-AdamW) of the fp32 torch-CPU oracle, {arch_name}, T={T}, "
-                      f"{pairs} pairs/step, {caption_len}-token captions, {threads} threads"}
+                      f"{pairs} pairs/step, {caption_len}-token captions x{n_trans}, {threads} torch threads on a host with "
+                      f"{os.cpu_count()} logical CPUs"}
 
 
-def cpu_baseline(arch_name, T, caption_len, pairs, max_seconds):
+def host_threads():
+    """threads for the CPU baseline: every CPU this process may run on (cgroup / affinity aware)"""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(arch_name, T, caption_len, pairs, max_seconds, n_trans=4):
     """Runs the worker in a child process with a hard wall-clock limit, so a slow host cannot stall the bench."""
     import subprocess
-    threads = min(os.cpu_count() or 1, 32)
+    threads = host_threads()
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--arch", arch_name, "--frames", str(T),
            "--caption-len", str(caption_len), "--cpu-pairs", str(pairs), "--cpu-seconds", str(max_seconds),
-           "--cpu-threads", str(threads)]
+           "--cpu-threads", str(threads), "--n-trans", str(n_trans)]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=4 * max_seconds + 60)
         return json.loads(out.stdout.strip().splitlines()[-1])
     except Exception as e:  # timeout or failure: the GPU number still stands
-        return {"value": None, "unit": "pairs/s", "cores": threads, "kind": "port",
+        return {"value": None, "unit": "pairs/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
                 "sample": f"CPU oracle step did not finish within {4 * max_seconds + 60:.0f} s ({type(e).__name__})"}
 
 
@@ -99,7 +109,7 @@ def pmc_traffic(args):
     """HBM bytes of the step's GEMM launches from a committed PMC pass of this exact workload (counters cannot be read
     live: they need rocprofv3's own passes, tools/pmc_traffic.sh).  None when no such measurement is committed."""
     import glob
-    if args.fp8:
+    if args.fp8 or args.n_trans != 4:
         return None
     pat = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                        f"*pmc_step_traffic_{args.arch}_t{args.frames}_b{args.batch}.json")
@@ -123,15 +133,18 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 4: e4m3 forward GEMMs in the ViT blocks")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-pairs", type=int, default=1)
+    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs per step of the CPU baseline (the AdamW pass over 156 M "
+                    "parameters is amortised over them, as it is over the GPU batch)")
+    ap.add_argument("--n-trans", type=int, default=4, help="captions per video: 4 = YT-Temporal batch with the sorting head, "
+                    "1 = WebVid-style batch (no sorting head / loss, SURVEY.md 8d)")
     ap.add_argument("--cpu-threads", type=int, default=8)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_worker(args.arch, args.frames, args.caption_len, args.cpu_pairs, args.cpu_seconds,
-                                             args.cpu_threads)), flush=True)
+                                             args.cpu_threads, args.n_trans)), flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,10 +194,10 @@ def main():
 
     # two resident synthetic batches (rank-dependent seeds), prepared once and used alternately: the timed step starts
     # from inputs that already live in HBM, with no staging copy
-    pool = [synth_batch(a, B, T, seed=1000 * rank + i, caption_len=args.caption_len) for i in range(2)]
+    pool = [synth_batch(a, B, T, seed=1000 * rank + i, caption_len=args.caption_len, n_trans=args.n_trans) for i in range(2)]
     model._fresh_shadows(); model._sync_requires_grad()
     pbs = [model.engine.prepare_batch(b) for b in pool]
-    labels = [b["label"].reshape(-1).to(torch.int32).to(dev) for b in pool]
+    labels = [b["label"].reshape(-1).to(torch.int32).to(dev) if "label" in b else None for b in pool]
     srcs = pbs
 
     def one_step(i, device_step):
@@ -227,9 +240,9 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-    loss = float(out["loss1"]) + float(out["loss2"])
+    loss = float(out["loss1"]) + (float(out["loss2"]) if out["loss2"] is not None else 0.0)
 
-    fwd, bwd = step_flops_per_pair(a, T, args.caption_len)
+    fwd, bwd = step_flops_per_pair(a, T, args.caption_len, args.n_trans)
     pairs_per_s = world * B * args.steps / dt
     line = {
         "metric": "video-text pairs/sec/node, TVTSv2 pretrain step", "value": pairs_per_s, "unit": "pairs/s",
@@ -237,7 +250,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp8 e4m3 forward GEMMs (ViT blocks) + bf16" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"TVTSv2 ViT-{args.arch.replace('_', '/')} {T}-frame 224^2, mask {a['mask_ratio']}, "
-                               f"{args.caption_len}-token captions x4, full pretrain step (fwd+losses+bwd+HF-AdamW)",
+                               f"{args.caption_len}-token captions x{args.n_trans}, full pretrain step (fwd+losses+bwd+HF-AdamW)",
                    "pairs_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
                    "hip_graph": bool(graphs is not None), "step_gflop_per_pair": (fwd + bwd) / 1e9,
                    "final_loss": loss},
@@ -283,7 +296,8 @@ def main():
                             "by_kernel": {k: {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]}
                                           for k, v in by.items()}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args.arch, T, args.caption_len, pairs=args.cpu_pairs, max_seconds=args.cpu_seconds)
+        line["cpu_baseline"] = cpu_baseline(args.arch, T, args.caption_len, pairs=args.cpu_pairs, max_seconds=args.cpu_seconds,
+                                            n_trans=args.n_trans)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

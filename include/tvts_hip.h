@@ -167,9 +167,11 @@ int tvts_retrieval_ranks(const float* sims, long ld, int n_text, int n_vid, int 
                          float* ranks, hipStream_t stream);
 
 /* ---- optimizer (optim.hip): transformers.AdamW as built at train_dist_TVTSv2_ViT_B_16.py:118-125 */
+/* step_dev (optional): the step counter in device memory (hipGraph replay); hyper_dev (optional, needs step_dev): lr[4] | wd[4]
+ * in device memory, read instead of the host lr4 / wd4 so that a captured launch follows the LR schedule */
 int tvts_adamw_hf(float* p, const float* g, float* m, float* v, void* shadow_bf16, const unsigned char* chunk_group,
-                  int nchunks, const float* lr4, const float* wd4, int step, const int* step_dev, double beta1,
-                  double beta2, double eps, float grad_scale, hipStream_t stream);
+                  int nchunks, const float* lr4, const float* wd4, int step, const int* step_dev, const float* hyper_dev,
+                  double beta1, double beta2, double eps, float grad_scale, hipStream_t stream);
 int tvts_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream);
 int tvts_transpose_bf16_batched(const void* src, void* dst, const void* tiles, int ntiles, hipStream_t stream);
 /* H/14 (patch 14, K = 588): video_encoder_ViT_H_14.py:336-337 conv1 weight padded to K = 640 for the MFMA GEMM */

@@ -1,0 +1,342 @@
+"""Parity ON the path bench.py times (run with -m gpu): the pipelined 256x256 NT kernel in bf16 with every epilogue
+template at the step's own sizes, one ViT-B/16 T=8 mask-0.5 engine step large enough for the dispatcher to pick that
+kernel, and the hipGraph-replayed step against eager launches and against the CPU oracle.
+
+Tolerances: kernel level = the ones of tests/test_kernels_gpu.py (bf16 output 4e-3 rel-L2, fp32 output 2e-5, activation
+outputs 5e-3); model level = SURVEY.md 8d (row cosine >= 0.9995, rel-L2 <= 2 %, |d loss| <= 1e-2, grad-norm 1 %)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tvts_oracle as O  # noqa: E402  (checker only)
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tvts_amd import hip
+    return hip
+
+
+@pytest.fixture(scope="module")
+def lib(K):
+    from tvts_amd import _lib
+    return _lib.load()
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def operands(M, N, Kd, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    a = torch.randn(M, Kd, generator=g, device=DEV).bfloat16()
+    b = (torch.randn(N, Kd, generator=g, device=DEV) * Kd ** -0.5).bfloat16()
+    bias = torch.randn(N, generator=g, device=DEV)
+    return a, b, bias
+
+
+def ref_product(a, b, bias):
+    """fp32 torch product of the bf16-rounded operands (exact products, fp32 accumulation) + bias, spot-checked in
+    float64 on the CPU over rows that include both tile edges and the ragged tail."""
+    ref = a.float() @ b.float().t() + bias
+    M = a.shape[0]
+    rows = sorted({0, 1, 255, 256, 257, M // 2, (M // 256) * 256 - 1, (M // 256) * 256, M - 2, M - 1} & set(range(M)))
+    r64 = a[rows].double().cpu() @ b.double().cpu().t() + bias.double().cpu()
+    assert rel(ref[rows].cpu(), r64) < 2e-6
+    return ref
+
+
+def guard_out(M, N, dtype):
+    """output with 3 guard rows behind it: a kernel that writes past row M-1 of a ragged last tile is caught"""
+    buf = torch.full((M + 3, N), float("nan"), dtype=dtype, device=DEV)
+    return buf, buf[:M]
+
+
+def check_guard(buf, M):
+    assert torch.isnan(buf[M:].float()).all(), "rows past M were written"
+
+
+# ------------------------------------------------------------------------------------------------ (a) the kernel
+PLAIN = [(40000, 512, 768), (150720, 2304, 768), (150720, 768, 3072), (40000, 3840, 1280), (40000, 5120, 1280),
+         (40000, 3072, 256)]
+
+
+@pytest.mark.parametrize("M,N,Kd", PLAIN)
+def test_nt256p_bf16_plain_outputs(K, lib, M, N, Kd):
+    """gemm_nt256p_kernel<0,0,false>: bf16 and fp32 outputs, ragged last row tile (40000 = 156 x 256 + 64, 150720 =
+    588 x 256 + 192), row-major walk (N = 512 / 768 / 2304) and the column-group walk (N = 3072: gc 6, 3840 / 5120: gc 5)."""
+    assert lib.tvts_gemm_nt_select(M, N) == 256
+    a, b, bias = operands(M, N, Kd, seed=100 + N)
+    ref = ref_product(a, b, bias)
+    for dt, tol in ((torch.bfloat16, 4e-3), (torch.float32, 2e-5)):
+        buf, out = guard_out(M, N, dt)
+        K.gemm_nt(a, b, out, bias=bias)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        assert rel(out.float(), ref) < tol, (dt, rel(out.float(), ref))
+        check_guard(buf, M)
+    # the 128x128 kernel on the same operands: the two tilings agree to fp32 summation-order noise
+    lib.tvts_gemm_set_nt_tile(128)
+    try:
+        assert lib.tvts_gemm_nt_select(M, N) == 128
+        o128 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        K.gemm_nt(a, b, o128, bias=bias)
+    finally:
+        lib.tvts_gemm_set_nt_tile(0)
+    assert rel(o128, out.float()) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,Kd,odt", [(150720, 768, 768, torch.float32), (150720, 768, 768, torch.bfloat16),
+                                        (40000, 3072, 256, torch.float32), (150720, 768, 3072, torch.float32)])
+def test_nt256p_bf16_residual_epilogue(K, lib, M, N, Kd, odt):
+    """fp32 residual added in the epilogue (attention / MLP output projections: s_res, x_{l+1} fp32; t_res bf16)."""
+    assert lib.tvts_gemm_nt_select(M, N) == 256
+    a, b, bias = operands(M, N, Kd, seed=200 + N + Kd)
+    res = torch.randn(M, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
+    ref = ref_product(a, b, bias) + res
+    buf, out = guard_out(M, N, odt)
+    K.gemm_nt(a, b, out, bias=bias, residual=res)
+    assert rel(out.float(), ref) < (2e-5 if odt == torch.float32 else 4e-3)
+    check_guard(buf, M)
+
+
+@pytest.mark.parametrize("M,N,Kd,act", [(150720, 3072, 768, "quick_gelu"), (40000, 5120, 1280, "gelu"),
+                                        (40000, 512, 128, "quick_gelu"), (40000, 2304, 64, "gelu")])
+def test_nt256p_bf16_activation_epilogue(K, lib, M, N, Kd, act):
+    """<1,0> QuickGELU and <2,0> erf-GELU with the pre-activation side output (MLP c_fc forward)."""
+    assert lib.tvts_gemm_nt_select(M, N) == 256
+    a, b, bias = operands(M, N, Kd, seed=300 + N)
+    pre_ref = ref_product(a, b, bias)
+    fn = O.quick_gelu if act == "quick_gelu" else O.gelu_erf
+    buf, out = guard_out(M, N, torch.bfloat16)
+    pbuf, pre = guard_out(M, N, torch.bfloat16)
+    K.gemm_nt(a, b, out, bias=bias, act=act, preact=pre)
+    assert rel(pre.float(), pre_ref) < 4e-3 and rel(out.float(), fn(pre_ref)) < 5e-3
+    check_guard(buf, M); check_guard(pbuf, M)
+    # fp32 output of the same template
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    K.gemm_nt(a, b, out32, bias=bias, act=act, preact=pre)
+    assert rel(out32, fn(pre_ref)) < 5e-5
+
+
+@pytest.mark.parametrize("M,N,Kd,act", [(150720, 3072, 768, "quick_gelu"), (40000, 3840, 640, "gelu"),
+                                        (40000, 768, 3072, "quick_gelu")])
+def test_nt256p_bf16_gate_epilogue(K, lib, M, N, Kd, act):
+    """<0,1> / <0,2>: dgrad of c_proj with the activation-gradient gate act'(h) fused (MLP backward)."""
+    assert lib.tvts_gemm_nt_select(M, N) == 256
+    a, b, _ = operands(M, N, Kd, seed=400 + N)
+    h = (torch.randn(M, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9)) * 1.5).bfloat16()
+    x = h.float().clone().requires_grad_(True)
+    (O.quick_gelu(x) if act == "quick_gelu" else O.gelu_erf(x)).sum().backward()
+    ref = ref_product(a, b, torch.zeros(N, device=DEV)) * x.grad
+    buf, out = guard_out(M, N, torch.bfloat16)
+    K.gemm_nt(a, b, out, gate_h=h, gate_act=act)
+    assert rel(out.float(), ref) < 5e-3, rel(out.float(), ref)
+    check_guard(buf, M)
+
+
+def test_nt256p_strided_views_and_forced_small_shapes(K, lib):
+    """leading dimensions wider than the matrices (the engine's packed buffers) and, with the tile forced, outputs smaller
+    than one tile / one XCD round (grid < 256 blocks)."""
+    lib.tvts_gemm_set_nt_tile(256)
+    try:
+        for (M, N, Kd) in [(100, 256, 64), (257, 512, 128), (3140, 768, 768), (1570, 2304, 768), (3000, 72, 64)]:
+            assert lib.tvts_gemm_nt_select(M, N) == 256
+            g = torch.Generator(device=DEV).manual_seed(M)
+            abig = torch.randn(M, Kd + 64, generator=g, device=DEV).bfloat16()
+            bbig = (torch.randn(N, Kd + 128, generator=g, device=DEV) * Kd ** -0.5).bfloat16()
+            obig = torch.full((M, N + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+            a, b, out = abig[:, 64:], bbig[:, :Kd], obig[:, :N]
+            K.gemm_nt(a, b, out)
+            ref = a.float() @ b.float().t()
+            assert rel(out.float(), ref) < 4e-3, (M, N, Kd, rel(out.float(), ref))
+            assert torch.isnan(obig[:, N:].float()).all()
+    finally:
+        lib.tvts_gemm_set_nt_tile(0)
+
+
+# ------------------------------------------------------------------------------------------------ (b) the engine step
+ARGS = types.SimpleNamespace(local_rank=0, rank=0, world_size=1)
+
+
+def min_cos(a, b):
+    a, b = a.detach().double().cpu().reshape(a.shape[0], -1), b.detach().double().cpu().reshape(b.shape[0], -1)
+    return float(torch.nn.functional.cosine_similarity(a, b, dim=1).min())
+
+
+def test_b16_step_at_bench_dispatch_against_oracle(K, lib):
+    """ViT-B/16, 8 frames, tube mask 0.5, 4 x 32-token captions, 24 pairs: M = 18 840 rows -> 222 / 666 / 888 tiles of 256x256,
+    so the ViT blocks' qkv / proj / MLP GEMMs (forward and dgrad, every epilogue) take gemm_nt256p_kernel exactly as in
+    the 192-pair bench step.  Forward + losses + hand-written backward against the fp32 CPU oracle."""
+    import psutil
+    if psutil.virtual_memory().available < 80 * 2 ** 30:
+        pytest.skip("the fp32 CPU oracle's autograd graph at 24 pairs needs ~40 GB of host memory")
+    from tvts_amd import arch as A
+    from tvts_amd.engine import LossHead
+    from tvts_amd.model._common import TVTSv2Base
+    B, T = 24, 8
+    a = A.ARCHS["B_16"]
+    S = 1 + T * A.n_keep(a)
+    assert lib.tvts_gemm_nt_select(B * S, 768) == 256 and lib.tvts_gemm_nt_select(B * S, 2304) == 256
+    oarch = O.ARCHS["B_16"]
+    P = O.synth_params(oarch, seed=11)
+    m = TVTSv2Base(ARGS, arch=a)
+    m.load_state_dict(P, strict=True)
+    batch = O.synth_batch(oarch, B=B, T=T, seed=12, caption_len=32)
+    # oracle
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    r1, r2, rte, rve, rpred = O.step_losses(leaves, batch, oarch)
+    (r1 + r2).backward()
+    grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    gn_ref = sum(float(g.double().norm()) ** 2 for g in grads.values()) ** 0.5
+    # engine
+    m._fresh_shadows(); m._sync_requires_grad()
+    pb = m.engine.prepare_batch(batch)
+    m.store.grad.zero_()
+    te, ve, pred = m.engine.forward(pb)
+    head = LossHead(m.store.device)
+    loss1, dv, dt = head.contrastive(ve, te)
+    loss2, dpred = head.sorting(pred, batch["label"].reshape(-1).to(torch.int32).to(DEV))
+    m.engine.backward(dt, dv, dpred)
+    torch.cuda.synchronize()
+    assert min_cos(te, rte) > 0.9995 and rel(te.cpu(), rte.detach()) < 0.02
+    assert min_cos(ve, rve) > 0.9995 and rel(ve.cpu(), rve.detach()) < 0.02, (min_cos(ve, rve), rel(ve.cpu(), rve.detach()))
+    assert abs(float(loss1) - float(r1)) < 1e-2 and abs(float(loss2) - float(r2)) < 1e-2, (float(loss1), float(r1), float(loss2), float(r2))
+    gn = 0.0
+    worst = []
+    for k, g in grads.items():
+        mine = m.store.g(k).detach().cpu()
+        assert torch.isfinite(mine).all(), k
+        gn += float(mine.double().norm()) ** 2
+        if float(g.norm()) > 1e-3 * gn_ref:
+            worst.append((float(torch.nn.functional.cosine_similarity(mine.double().flatten(), g.double().flatten(), dim=0)), k))
+    gn = gn ** 0.5
+    worst.sort()
+    assert abs(gn - gn_ref) < 0.01 * gn_ref, (gn, gn_ref, worst[:5])
+    assert worst[0][0] > 0.98, worst[:8]
+
+
+# ------------------------------------------------------------------------------------------------ (c) hipGraph replay
+def _runner(a, P, lr_mul=1.0):
+    from tvts_amd import arch as A
+    from tvts_amd.model._common import TVTSv2Base
+    from tvts_amd.optim import FusedHFAdamW
+    from tvts_amd.step import StepRunner
+    m = TVTSv2Base(ARGS, arch=a)
+    m.load_state_dict(P, strict=True)
+    groups = [[], [], [], []]
+    for name, p in m.named_parameters():
+        gi = A.param_group_of(name, a)
+        if gi < 0:
+            p.requires_grad = False
+        else:
+            groups[gi].append(p)
+    opt = FusedHFAdamW([dict(params=groups[i], lr=A.GROUP_HPARAMS[i][0] * lr_mul, weight_decay=A.GROUP_HPARAMS[i][1])
+                        for i in range(4)], m.store, model=m)
+    return m, opt, StepRunner(m, opt)
+
+
+def test_graph_replayed_steps_match_eager_steps_and_the_oracle(K, lib):
+    """bench.py at world 1 captures the whole step (zero_grad ... fused AdamW, step counter in device memory) into a hipGraph
+    and replays it.  Three replayed steps must leave the parameters where three eager steps leave them -- up to the
+    summation order of the kernels' fp32 atomics (bias / CLS / embedding gradients), which is not fixed from launch to
+    launch -- and both must track the oracle's train_step.  The 256x256 kernel is forced so that the replay exercises the
+    benchmarked GEMM kernel at this small size."""
+    from tvts_amd import arch as A
+    a = A.ARCHS["B_16"]
+    oarch = O.ARCHS["B_16"]
+    P = O.synth_params(oarch, seed=21)
+    batch = O.synth_batch(oarch, B=4, T=8, seed=22, caption_len=32)
+    lib.tvts_gemm_set_nt_tile(256)
+    try:
+        # eager
+        m1, opt1, run1 = _runner(a, P)
+        pb1 = m1.engine.prepare_batch(batch)
+        lab = batch["label"].reshape(-1).to(torch.int32).to(DEV)
+        m1._fresh_shadows(); m1._sync_requires_grad()
+        eager = []
+        for _ in range(3):
+            out = run1.run(pb1, lab, device_step=False)
+            eager.append(float(out["loss1"]) + float(out["loss2"]))
+        torch.cuda.synchronize()
+        # graph: one eager device-step warm-up would advance the state, so capture on a twin and replay 3 times
+        m2, opt2, run2 = _runner(a, P)
+        pb2 = m2.engine.prepare_batch(batch)
+        m2._fresh_shadows(); m2._sync_requires_grad()
+        opt2.sync_hyper()
+        # one eager step warms the workspaces (capture must not allocate); its effect on the state is rolled back
+        snap = {k: t.clone() for k, t in (("flat", m2.store.flat), ("m", m2.store.m), ("v", m2.store.v))}
+        run2.run(pb2, lab, device_step=True)
+        torch.cuda.synchronize()
+        m2.store.flat.copy_(snap["flat"]); m2.store.m.copy_(snap["m"]); m2.store.v.copy_(snap["v"])
+        opt2.step_dev.zero_(); opt2.global_step = 0
+        m2.store.refresh_shadows()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out2 = run2.run(pb2, lab, device_step=True)
+        torch.cuda.synchronize()
+        # capture does not execute: parameters still at the start
+        assert torch.equal(m2.store.flat, snap["flat"]) and int(opt2.step_dev.item()) == 0
+        graph = []
+        for _ in range(3):
+            g.replay()
+            torch.cuda.synchronize()
+            graph.append(float(out2["loss1"]) + float(out2["loss2"]))
+    finally:
+        lib.tvts_gemm_set_nt_tile(0)
+    assert int(opt2.step_dev.item()) == 3
+    np.testing.assert_allclose(graph, eager, rtol=2e-6, atol=2e-6)
+    d = (m2.store.flat - m1.store.flat).abs()
+    bit_identical = bool(torch.equal(m2.store.flat, m1.store.flat))
+    assert float(d.max()) < 2e-6 and rel(m2.store.flat, m1.store.flat) < 1e-6, (float(d.max()), bit_identical)
+    assert opt2.state_dict()["state"][0]["step"] == 3  # host counters re-read from the device counter
+    # the oracle's three steps
+    Pr = {k: v.clone() for k, v in P.items()}
+    state, curve = {}, []
+    for _ in range(3):
+        r1, r2, _ = O.train_step(Pr, batch, oarch, state)
+        curve.append(r1 + r2)
+    assert np.all(np.abs(np.array(graph) - np.array(curve)) < 0.02 * np.abs(np.array(curve)) + 1e-2), (graph, curve)
+    for k in ("pred_model.head.weight", "video_model.transformer.resblocks.11.timeattn.proj.weight", "video_model.proj"):
+        assert rel(m2.store.p(k).cpu(), Pr[k]) < 2e-2, k
+
+
+def test_captured_step_follows_the_learning_rate_schedule(K, lib):
+    """lr / weight decay live in a device table that sync_hyper() refreshes: a replayed graph applies the new learning
+    rate without being captured again (the epoch-end x0.1 of trainer.py:402-417)."""
+    from tvts_amd import arch as A
+    a = A.small_arch()
+    oarch = O.tiny_arch(**a)
+    P = O.synth_params(oarch, seed=3)
+    batch = O.synth_batch(oarch, B=4, T=2, seed=4, caption_len=9)
+    m, opt, run = _runner(a, P, lr_mul=10.0)
+    pb = m.engine.prepare_batch(batch)
+    lab = batch["label"].reshape(-1).to(torch.int32).to(DEV)
+    m._fresh_shadows(); m._sync_requires_grad()
+    run.run(pb, lab, device_step=True)  # eager warm-up (allocates workspaces, uploads the table)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        run.run(pb, lab, device_step=True)
+    key = "pred_model.head.weight"
+    w0 = m.store.p(key).clone()
+    g.replay(); torch.cuda.synchronize()
+    d1 = float((m.store.p(key) - w0).abs().mean())
+    for grp in opt.param_groups:
+        grp["lr"] = 0.0
+        grp["weight_decay"] = 0.0
+    opt.sync_hyper()
+    w1 = m.store.p(key).clone()
+    g.replay(); torch.cuda.synchronize()
+    assert d1 > 0 and torch.equal(m.store.p(key), w1)

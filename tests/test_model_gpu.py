@@ -169,6 +169,42 @@ def test_autograd_surface_matches_engine(gpu):
     assert list(pd.keys()) == list(O.param_shapes(oarch).keys())
 
 
+def test_autograd_path_with_a_stock_optimizer_does_not_accumulate_stale_gradients(gpu):
+    """model(data) -> loss.backward() -> torch.optim.AdamW.step() -> zero_grad() (set_to_none=True by default): the flat
+    gradient buffer must restart from zero on the next backward, and keep accumulating when .grad is left in place."""
+    from tvts_amd import arch as A
+    from tvts_amd.model._common import sim_matrix
+    from tvts_amd.model.loss import NormSoftmaxLoss
+    m, oarch, P = build(arch=A.small_arch(), seed=3)
+    batch = O.synth_batch(oarch, B=4, T=3, seed=5, caption_len=11)
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=0.0)  # lr 0: both steps see the same weights
+    crit = NormSoftmaxLoss()
+
+    def fwd_bwd():
+        te, ve, pred = m(batch)
+        loss = crit(sim_matrix(ve, te)) + 2 * torch.nn.CrossEntropyLoss()(pred.reshape(-1, 4), batch["label"].reshape(-1).to(DEV))
+        loss.backward()
+    fwd_bwd()
+    pd = dict(m.named_parameters())
+    keys = ("video_model.proj", "text_projection", "pred_model.head.weight")
+    g1 = {k: pd[k].grad.clone() for k in keys}
+    opt.step()
+    opt.zero_grad()  # default set_to_none=True
+    assert pd["video_model.proj"].grad is None
+    fwd_bwd()
+    for k in keys:
+        assert rel(pd[k].grad, g1[k]) < 1e-5, k  # NOT 2 x g1
+    fwd_bwd()  # no zero_grad in between: autograd accumulation
+    for k in keys:
+        assert rel(pd[k].grad, 2 * g1[k]) < 1e-5, k
+    # a foreign .grad tensor (not a view of the flat buffer) receives this backward's gradient by addition
+    opt.zero_grad()
+    pd["text_projection"].grad = torch.ones_like(pd["text_projection"])
+    fwd_bwd()
+    assert rel(pd["text_projection"].grad, 1 + g1["text_projection"]) < 1e-5
+    assert rel(pd["video_model.proj"].grad, g1["video_model.proj"]) < 1e-5
+
+
 def test_frozen_text_layers(gpu):
     """requires_grad=False on text resblocks below the tune range (train_dist..:89-96): no wgrad, dgrad still flows."""
     from tvts_amd import arch as A

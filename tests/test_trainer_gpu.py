@@ -23,7 +23,8 @@ class Config(dict):
     resume = None
 
     def __init__(self, save_dir, epochs):
-        super().__init__(trainer=dict(epochs=epochs, save_period=1, verbosity=2, monitor="off", init_val=True))
+        super().__init__(trainer=dict(epochs=epochs, save_period=1, verbosity=2, monitor="off", init_val=True),
+                         arch=dict(type="TVTSv2_B_16", args={}), optimizer=dict(type="AdamW", args=dict(lr=1e-4)))
         self.save_dir = save_dir
 
     def get_logger(self, name, verbosity=2):
@@ -85,3 +86,63 @@ def test_train_validate_checkpoint_resume(tmp_path, capsys):
     assert tr2.optimizer.global_step == tr.optimizer.global_step > 0
     tr2.train()
     assert (tmp_path / "checkpoint-epoch2.pth").exists()
+
+
+def test_load_checkpoint_constructor_argument(tmp_path):
+    """`TVTSv2_*(args, load_checkpoint=path)` (model_dist_TVTSv2_ViT_B_16.py:51-56) and the downstream class
+    (downstream/model_TVTSv2_ViT_B_16.py:42-46) read the file `_save_checkpoint` writes -- which carries the config OBJECT, so
+    torch.load needs weights_only=False on torch >= 2.6."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tvts_amd import arch as A
+    from tvts_amd.downstream._common import DownstreamBase
+    from tvts_amd.model._common import TVTSv2Base
+    tr, m, oarch = build(tmp_path, epochs=1)
+    tr._save_checkpoint(7)
+    path = str(tmp_path / "checkpoint-epoch7.pth")
+    a = A.small_arch()
+    m2 = TVTSv2Base(types.SimpleNamespace(local_rank=0, rank=0, world_size=1), load_checkpoint=path, arch=a, init_seed=5)
+    for k in ("video_model.proj", "text_projection", "pred_model.head.weight", "video_model.transformer.resblocks.1.ln_3.bias"):
+        assert torch.equal(m2.store.p(k), m.store.p(k)), k
+    # the `module.`-prefixed form a DDP-wrapped reference run writes, without the sorting head (released inference checkpoints)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    ck["state_dict"] = {"module." + k: v for k, v in ck["state_dict"].items() if not k.startswith("pred_model.")}
+    torch.save(ck, tmp_path / "inference.pth")
+
+    class Small(DownstreamBase):
+        ARCH_NAME = None
+    d = Small(load_checkpoint=str(tmp_path / "inference.pth"), arch=a)
+    assert torch.equal(d.store.p("video_model.proj"), m.store.p("video_model.proj"))
+    assert not any(k.startswith("pred_model.") for k in d.state_dict())
+
+
+def test_resume_with_a_different_optimizer_type_keeps_fresh_state(tmp_path):
+    """base_trainer.py:241-245: optimizer state is only restored when config['optimizer']['type'] is unchanged."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    tr, m, _ = build(tmp_path, epochs=1)
+    tr.train()
+    ck = torch.load(tmp_path / "checkpoint-epoch1.pth", map_location="cpu", weights_only=False)
+    ck["config"]["optimizer"]["type"] = "SGD"
+    torch.save(ck, tmp_path / "other.pth")
+    tr2, m2, _ = build(tmp_path, epochs=1, resume=tmp_path / "other.pth")
+    assert tr2.start_epoch == 2 and tr2.optimizer.global_step == 0
+    assert torch.equal(m2.store.p("video_model.proj"), m.store.p("video_model.proj"))
+
+
+def test_configured_temperature_reaches_the_loss_head(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tvts_amd.model.loss import NormSoftmaxLoss
+    tr, m, oarch = build(tmp_path, epochs=1)
+    assert tr.runner.head.temp == 0.05
+    import tvts_amd.trainer.trainer as T
+    tr2 = T.Trainer_TVTSv2_B_16(tr.args, m, NormSoftmaxLoss(temperature=0.07), tr.metrics, tr.optimizer, config=tr.config,
+                                data_loader=tr.data_loader, valid_data_loader=tr.valid_data_loader)
+    assert tr2.runner.head.temp == pytest.approx(0.07)
+    g = torch.Generator().manual_seed(0)
+    v, t = torch.randn(6, 32, generator=g), torch.randn(6, 32, generator=g)
+    loss, _, _ = tr2.runner.head.contrastive(v.cuda(), t.cuda())
+    x = torch.nn.functional.normalize(v, dim=1) @ torch.nn.functional.normalize(t, dim=1).t() / 0.07
+    ref = -(torch.log_softmax(x, 1).diag().mean() + torch.log_softmax(x.t(), 1).diag().mean())
+    assert abs(float(loss) - float(ref)) < 1e-4

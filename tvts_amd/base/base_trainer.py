@@ -1,6 +1,7 @@
 """Epoch driver + checkpoint layout of v2/base/base_trainer.py (Multi_BaseTrainer_dist), rebuilt for the
 HIP step engine.  What is kept bit-for-bit is the external contract: constructor arguments, the
-``config['trainer']`` keys, the monitor / early-stop rule (:117-136), the checkpoint dict
+``config['trainer']`` keys, the monitor rule (:117-136; early stopping is commented out there and absent here), the
+``nested_val_metrics`` flattening of the epoch log (:100-105), the checkpoint dict
 ``{'arch','epoch','state_dict','optimizer','monitor_best','config'}`` written by rank 0 to
 ``<save_dir>/checkpoint-epoch{N}.pth`` / ``model_best.pth`` (:165-189) and resume with the ``module.``
 prefix fix (:191-247).  There is no DistributedDataParallel wrap: gradients are averaged by
@@ -51,16 +52,23 @@ class Multi_BaseTrainer_dist:
 
     def train(self):
         not_improved_count = 0
-        if self.init_val and getattr(self, "do_validation", False):
+        if self.init_val and getattr(self, "do_validation", False):  # (:86-87; the reference's configs always validate)
             self._valid_epoch(-1)
         for epoch in range(self.start_epoch, self.epochs + 1):
             result = self._train_epoch(epoch)
             log = {"epoch": epoch}
             for key, value in result.items():
+                if self.args.rank != 0:  # only rank 0 fills the log (:95)
+                    continue
                 if key == "metrics":
                     log.update({mtr.__name__: value[i] for i, mtr in enumerate(self.metrics)})
                 elif key == "val_metrics":
                     log.update({"val_" + mtr.__name__: value[i] for i, mtr in enumerate(self.metrics)})
+                elif key == "nested_val_metrics":  # two layers of nesting, flattened into the epoch log (:100-105)
+                    for subkey, subval in value.items():
+                        for subsubkey, subsubval in subval.items():
+                            for subsubsubkey, subsubsubval in subsubval.items():
+                                log[f"val_{subkey}_{subsubkey}_{subsubsubkey}"] = subsubsubval
                 else:
                     log[key] = value
             if self.args.rank == 0:
@@ -74,15 +82,13 @@ class Multi_BaseTrainer_dist:
                 except KeyError:
                     self.logger.warning("Warning: Metric '{}' is not found. Model performance monitoring is "
                                         "disabled.".format(self.mnt_metric))
-                    self.mnt_mode, improved, not_improved_count = "off", False, 0
+                    self.mnt_mode, improved = "off", False
                 if improved:
                     self.mnt_best, not_improved_count, best = log[self.mnt_metric], 0, True
                 else:
                     not_improved_count += 1
-                if not_improved_count > self.early_stop:
-                    self.logger.info("Validation performance didn't improve for {} epochs. Training stops.".format(
-                        self.early_stop))
-                    break
+                # the reference counts the epochs without improvement but its early-stop break is commented out
+                # (:138-141): training always runs to `epochs`, and so does this trainer
             if self.args.rank == 0 and (epoch % self.save_period == 0 or best):
                 self._save_checkpoint(epoch, save_best=best)
 
@@ -109,12 +115,17 @@ class Multi_BaseTrainer_dist:
         checkpoint = torch.load(resume_path, map_location=self.device, weights_only=False)
         self.start_epoch = checkpoint["epoch"] + 1
         self.mnt_best = checkpoint["monitor_best"]
+        if checkpoint["config"]["arch"] != self.config["arch"]:  # (:205-207)
+            self.logger.warning("Warning: Architecture configuration given in config file is different from that of "
+                                "checkpoint. This may yield an exception while state_dict is being loaded.")
         sd = checkpoint["state_dict"]
-        if next(iter(sd)).startswith("module."):
+        if next(iter(sd)).startswith("module."):  # this model is never DataParallel-wrapped: only the undo case exists
             sd = {k[7:]: v for k, v in sd.items()}
         self.model.load_state_dict(sd)
-        try:
+        # optimizer state only when the optimizer type is unchanged (:241-245); a failing load is an error, as there
+        if checkpoint["config"]["optimizer"]["type"] != self.config["optimizer"]["type"]:
+            self.logger.warning("Warning: Optimizer type given in config file is different from that of checkpoint. "
+                                "Optimizer parameters not being resumed.")
+        else:
             self.optimizer.load_state_dict(checkpoint["optimizer"])
-        except Exception as e:  # different optimizer type: same rule as the reference (:241-245)
-            self.logger.warning("Warning: optimizer state not restored ({}).".format(e))
         self.logger.info("Checkpoint loaded. Resume training from epoch {}".format(self.start_epoch))

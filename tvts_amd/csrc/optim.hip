@@ -17,9 +17,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, bf16* __restrict__ shadow,
                                                     const unsigned char* __restrict__ chunk_group, AdamGroups hp, float beta1,
                                                     float beta2, float omb1, float omb2, float eps, float grad_scale,
-                                                    const int* __restrict__ step_dev) {
+                                                    const int* __restrict__ step_dev, const float* __restrict__ hyper_dev) {
     const int grp = chunk_group[blockIdx.x];
     if (grp > 3) return;
+    if (hyper_dev) {  // lr[4] | wd[4] in device memory: a captured launch follows the LR schedule without re-capture
+        hp.lr[grp] = hyper_dev[grp];
+        hp.wd[grp] = hyper_dev[4 + grp];
+    }
     if (step_dev) {  // step counter lives in device memory (hipGraph replay): bias correction computed here
         const double st = (double)step_dev[0];
         const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
@@ -45,9 +49,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 extern "C" int tvts_adamw_hf(float* p, const float* g, float* m, float* v, void* shadow_bf16,
                              const unsigned char* chunk_group, int nchunks, const float* lr4, const float* wd4, int step,
-                             const int* step_dev, double beta1, double beta2, double eps, float grad_scale,
-                             hipStream_t stream) {
+                             const int* step_dev, const float* hyper_dev, double beta1, double beta2, double eps,
+                             float grad_scale, hipStream_t stream) {
     if (nchunks <= 0 || (step <= 0 && !step_dev)) return TVTS_EINVAL;
+    if (hyper_dev && !step_dev) return TVTS_EINVAL;  // the device table is only consulted together with the device step counter
     if (step <= 0) step = 1;
     AdamGroups hp;
     const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
@@ -57,7 +62,7 @@ extern "C" int tvts_adamw_hf(float* p, const float* g, float* m, float* v, void*
         hp.step_size[i] = (float)((double)lr4[i] * sqrt(bc2) / bc1);
     }
     hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, stream, p, g, m, v, (bf16*)shadow_bf16, chunk_group, hp,
-                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, grad_scale, step_dev);
+                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, grad_scale, step_dev, hyper_dev);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

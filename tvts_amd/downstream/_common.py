@@ -21,7 +21,7 @@ class DownstreamBase(TVTSv2Base):
         super().__init__(types.SimpleNamespace(local_rank=dev, rank=0, world_size=1), load_checkpoint=None, arch=a,
                          init_seed=init_seed)
         if load_checkpoint not in ["", None]:
-            sd = torch.load(load_checkpoint, map_location=self.store.device)["state_dict"]
+            sd = torch.load(load_checkpoint, map_location=self.store.device, weights_only=False)["state_dict"]
             if next(iter(sd)).startswith("module."):
                 sd = {k[7:]: v for k, v in sd.items()}
             self.load_state_dict(sd, strict=True)

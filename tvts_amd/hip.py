@@ -387,12 +387,12 @@ def retrieval_ranks(sims, mode, valid=None):
 
 
 def adamw_hf(p, g, m, v, shadow, chunk_group, lr4, wd4, step, beta1=0.9, beta2=0.999, eps=1e-6, grad_scale=1.0,
-             step_dev=None):
+             step_dev=None, hyper_dev=None):
     lib = _lib.load()
     lr = (ctypes.c_float * 4)(*lr4)
     wd = (ctypes.c_float * 4)(*wd4)
     _chk(lib.tvts_adamw_hf(_p(p), _p(g), _p(m), _p(v), _p(shadow), _p(chunk_group), chunk_group.numel(),
-                           ctypes.cast(lr, ctypes.c_void_p), ctypes.cast(wd, ctypes.c_void_p), step, _p(step_dev), beta1, beta2, eps,
+                           ctypes.cast(lr, ctypes.c_void_p), ctypes.cast(wd, ctypes.c_void_p), step, _p(step_dev), _p(hyper_dev), beta1, beta2, eps,
                            grad_scale, _stream()), "tvts_adamw_hf")
 
 

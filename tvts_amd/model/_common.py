@@ -96,9 +96,12 @@ class _ModelFn(torch.autograd.Function):
     def backward(ctx, d_te, d_ve, d_pred):
         m = ctx.module
         m._sync_requires_grad()
+        foreign = m._prepare_grad_buffer()
         dp = d_pred.reshape(-1, d_pred.shape[-1]).contiguous().float() if ctx.has_pred else None
         m.engine.backward(d_te.contiguous().float(), d_ve.contiguous().float(), dp)
         m._install_grads()
+        for p, name in foreign:  # .grad tensors that are not views of the flat buffer: ordinary accumulation
+            p.grad.add_(m.store.g(name))
         return None, None, None
 
 
@@ -119,7 +122,7 @@ class TVTSv2Base(nn.Module):
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         self._versions = None
         if load_checkpoint not in ["", None]:
-            ckpt = torch.load(load_checkpoint, map_location=dev)
+            ckpt = torch.load(load_checkpoint, map_location=dev, weights_only=False)  # carries the ConfigParser object (base_trainer.py:171)
             sd = ckpt["state_dict"]
             if next(iter(sd)).startswith("module."):  # utils/util.py:25-50 semantics
                 sd = {k[7:]: v for k, v in sd.items()}
@@ -146,6 +149,29 @@ class TVTSv2Base(nn.Module):
         pm = self._named()
         for name in self.store.shapes:
             self.engine.requires_grad[name] = bool(pm[name].requires_grad)
+
+    def _prepare_grad_buffer(self):
+        """autograd semantics for the flat gradient buffer the engine accumulates (+=) into: a parameter whose .grad is
+        None (optimizer.zero_grad() defaults to set_to_none=True) starts from zero, one whose .grad is the flat view keeps
+        accumulating, one carrying a foreign .grad tensor gets this backward's gradient added to it afterwards."""
+        pm, st = self._named(), self.store
+        none, foreign, kept = [], [], 0
+        for name, p in pm.items():
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                none.append(name)
+            elif p.grad.data_ptr() == st.g(name).data_ptr():
+                kept += 1
+            else:
+                none.append(name)
+                foreign.append((p, name))
+        if kept == 0:
+            st.grad.zero_()  # the common case: one launch
+        else:
+            for name in none:
+                st.g(name).zero_()
+        return foreign
 
     def _install_grads(self):
         for name, p in self._named().items():

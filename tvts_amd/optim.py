@@ -48,7 +48,41 @@ class FusedHFAdamW(torch.optim.Optimizer):
         self.chunk_group = table.to(dev)
         self.global_step = 0
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)  # lr[4] | wd[4] for captured launches
+        self._hyper_host = None
         self.grad_scale = 1.0
+
+    def _hyper(self):
+        b1, b2 = self.param_groups[0]["betas"]
+        eps = self.param_groups[0]["eps"]
+        for g in self.param_groups[1:]:  # one kernel launch covers every group: these three cannot differ per group
+            if tuple(g["betas"]) != (b1, b2) or g["eps"] != eps:
+                raise ValueError("FusedHFAdamW needs the same betas / eps in every parameter group (lr and weight_decay may differ)")
+        n = len(self.param_groups)
+        lr4 = [float(g["lr"]) for g in self.param_groups] + [0.0] * (4 - n)
+        wd4 = [float(g["weight_decay"]) for g in self.param_groups] + [0.0] * (4 - n)
+        return b1, b2, eps, lr4, wd4
+
+    def sync_hyper(self):
+        """Upload lr / weight_decay of the parameter groups to the device table read by captured (device_step) launches.
+        step() calls it; when a captured hipGraph is REPLAYED, call it after changing param_groups (an LR schedule) -- the
+        replay then uses the new values without re-capture.  The copy is skipped when nothing changed."""
+        *_, lr4, wd4 = self._hyper()
+        if self._hyper_host != (lr4, wd4):
+            self.hyper_dev.copy_(torch.tensor(lr4 + wd4, dtype=torch.float32), non_blocking=False)
+            self._hyper_host = (lr4, wd4)
+
+    def _sync_step_from_device(self):
+        """Under hipGraph replay the host counters only advance at capture time: re-read the device counter."""
+        st = int(self.step_dev.item())
+        if st > self.global_step:
+            self.global_step = st
+        for s in self.state.values():
+            s["step"] = self.global_step
+
+    def state_dict(self):
+        self._sync_step_from_device()
+        return super().state_dict()
 
     def zero_grad(self, set_to_none: bool = False):
         self.store.grad.zero_()
@@ -56,15 +90,20 @@ class FusedHFAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, device_step: bool = False):
         """device_step=True keeps the step counter in device memory (hipGraph replay)."""
-        b1, b2 = self.param_groups[0]["betas"]
-        eps = self.param_groups[0]["eps"]
-        lr4 = [g["lr"] for g in self.param_groups] + [0.0] * (4 - len(self.param_groups))
-        wd4 = [g["weight_decay"] for g in self.param_groups] + [0.0] * (4 - len(self.param_groups))
+        b1, b2, eps, lr4, wd4 = self._hyper()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if device_step and not capturing:
+            self.sync_hyper()  # (a host -> device copy: not capturable; the caller syncs before capture / replay)
+        elif device_step and self._hyper_host != (lr4, wd4):
+            raise RuntimeError("FusedHFAdamW: call sync_hyper() (or run one eager device_step) before capturing the step")
         self.global_step += 1
         if device_step:
             self.step_dev.add_(1)
+        else:
+            self.step_dev.fill_(self.global_step)  # keeps the device counter in step when eager and captured steps mix
         K.adamw_hf(self.store.flat, self.store.grad, self.store.m, self.store.v, self.store.shadow, self.chunk_group,
-                   lr4, wd4, self.global_step, b1, b2, eps, self.grad_scale, step_dev=self.step_dev if device_step else None)
+                   lr4, wd4, self.global_step, b1, b2, eps, self.grad_scale, step_dev=self.step_dev if device_step else None,
+                   hyper_dev=self.hyper_dev if device_step else None)
         self.store.refresh_shadows(cast=False)
         if self.model is not None:
             self.model.mark_shadows_fresh()

@@ -79,7 +79,9 @@ class _TrainerBase(Multi_BaseTrainer_dist):
         self.allgather = AllGather_multi.apply
         self.num_clips = self.n_trans = 4
         self.base_lr = [g["lr"] for g in optimizer.param_groups]
-        self.runner = StepRunner(model, optimizer)
+        # the configured loss module's temperature drives the fused loss head (model/loss.py:11 NormSoftmaxLoss(temperature))
+        from ..engine import LossHead
+        self.runner = StepRunner(model, optimizer, LossHead(model.store.device, temperature=float(getattr(loss, "temperature", 0.05))))
 
     def _adjust_learning_rate(self, optimizer, epoch, args):
         lr_rate = 1.0
@@ -134,8 +136,8 @@ class _TrainerBase(Multi_BaseTrainer_dist):
                 if log_now:
                     self.logger.debug("Train Epoch: {} dl{} {} Loss_ct: {:.6f} Loss_ce: {:.6f} Loss: {:.6f}".format(
                         epoch, dl_idx, self._progress(batch_idx, dl_idx), float(l1), float(l2), loss))
-            if (batch_idx + 1) * self.batch_size * self.n_gpu >= self.max_samples_per_epoch:
-                break
+            # max_samples_per_epoch is stored and never read by the reference's TVTSv2 trainers (trainer.py:93,387,681):
+            # the whole YT loader is iterated, so the per-epoch LR schedule sees the same number of steps here
         log = {f"loss_{dl_idx}": total_loss[dl_idx] / self.len_epoch for dl_idx in range(len(self.data_loader))}
         if self.do_validation:
             val_log = self._valid_epoch(epoch)
