@@ -253,7 +253,9 @@ def main():
                                f"{args.caption_len}-token captions x{args.n_trans}, full pretrain step (fwd+losses+bwd+HF-AdamW)",
                    "pairs_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
                    "hip_graph": bool(graphs is not None), "step_gflop_per_pair": (fwd + bwd) / 1e9,
-                   "final_loss": loss},
+                   "final_loss": loss,
+                   "exchange": {"transport": os.environ.get("TVTS_COMM", "torch") + (f" ({backend})" if world > 1 else ""),
+                                "grad_payload": runner.sync.payload, "grad_bytes_per_step": runner.sync.bytes_sent}},
         "step_mfma_frac": pairs_per_s * (fwd + bwd) / (world * PEAK_BF16_TFLOPS * 1e12),
     }
 

@@ -173,6 +173,7 @@ int tvts_adamw_hf(float* p, const float* g, float* m, float* v, void* shadow_bf1
                   int nchunks, const float* lr4, const float* wd4, int step, const int* step_dev, const float* hyper_dev,
                   double beta1, double beta2, double eps, float grad_scale, hipStream_t stream);
 int tvts_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream);
+int tvts_cast_bf16_f32(const void* src, float* dst, long n, hipStream_t stream);
 int tvts_transpose_bf16_batched(const void* src, void* dst, const void* tiles, int ntiles, hipStream_t stream);
 /* H/14 (patch 14, K = 588): video_encoder_ViT_H_14.py:336-337 conv1 weight padded to K = 640 for the MFMA GEMM */
 int tvts_pad_rows_bf16(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, int cols_pad,

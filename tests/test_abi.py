@@ -24,6 +24,49 @@ def test_library_exports_every_declared_symbol():
     _lib.load()  # binds argtypes; raises on any mismatch between header and library
 
 
+def test_comm_library_exports_every_declared_symbol():
+    protos = _lib.parse_header(_lib.COMM_HEADER_PATH)
+    assert set(protos) == {"tvts_comm_unique_id", "tvts_comm_create", "tvts_comm_destroy", "tvts_comm_world",
+                           "tvts_comm_allgather_embeds", "tvts_comm_allreduce_bucket", "tvts_comm_wait"}
+    lib = _lib.load_comm()
+    for name in protos:
+        assert hasattr(lib, name), name
+    src = open(_lib.COMM_HEADER_PATH).read()
+    assert "trainer.py:41-51" in src and "base_trainer.py:20-25" in src  # the reference sites each entry replaces
+
+
+def test_gradient_sync_skips_frozen_runs():
+    """Engine._ready hands the gradient sync maximal runs of TRAINABLE tensors: with the reference's freeze rule (text
+    resblocks below the tune range, train_dist_TVTSv2_ViT_B_16.py:89-96) the 9 frozen text layers never travel."""
+    import types
+    from tvts_amd.engine import CH, Engine
+    a = A.ARCHS["B_16"]
+    shapes = A.param_shapes(a)
+    off, o = {}, 0
+    for n, s in shapes.items():
+        off[n] = o
+        o += -(-int(np.prod(s)) // CH) * CH
+    store = types.SimpleNamespace(shapes=shapes, off=off, _n=lambda n: int(np.prod(shapes[n])))
+    eng = Engine.__new__(Engine)
+    eng.P, eng._ranges = store, {}
+    eng.requires_grad = {n: A.param_group_of(n, a) >= 0 for n in shapes}
+    runs = eng.trainable_runs(("text_",))
+    sent = sum(e - s for s, e in runs)
+    whole = max(off[n] + -(-int(np.prod(shapes[n])) // CH) * CH for n in shapes if n.startswith("text_")) - \
+        min(off[n] for n in shapes if n.startswith("text_"))
+    frozen = sum(-(-int(np.prod(shapes[n])) // CH) * CH for n in shapes if n.startswith("text_") and not eng.requires_grad[n])
+    assert frozen > 25e6 and sent == whole - frozen and len(runs) >= 2
+    covered = np.zeros(o // CH, dtype=int)
+    for s, e in runs:
+        covered[s // CH:e // CH] += 1
+    for n in shapes:
+        if n.startswith("text_"):
+            assert covered[off[n] // CH] == (1 if eng.requires_grad[n] else 0), n
+    # the cache follows a change of requires_grad
+    eng.requires_grad = {n: True for n in shapes}
+    assert sum(e - s for s, e in eng.trainable_runs(("text_",))) == whole
+
+
 def test_header_cites_reference_sites():
     src = open(_lib.HEADER_PATH).read()
     for site in ("video_encoder_ViT_B_16.py", "CLIP/clip/model.py", "sort_transformer.py", "loss.py", "trainer.py",

@@ -27,3 +27,25 @@ def test_two_rank_bench_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
     assert d["value"] > 0 and d["roofline"]["launches"] > 300 and "cpu_baseline" not in d
+
+
+def _bench(extra, port):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "8",
+           "--no-cpu-baseline", "--no-roofline"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_graph_and_eager_bench_runs_end_at_the_same_loss():
+    """world 1 replays a captured hipGraph, world > 1 launches eagerly (bench.py): the two modes must be the same
+    computation -- same loss after the same number of optimizer steps (fp32 atomics leave ~1e-6 of play)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    g = _bench([], 0)
+    e = _bench(["--no-graph"], 0)
+    assert g["config"]["hip_graph"] is True and e["config"]["hip_graph"] is False
+    assert abs(g["config"]["final_loss"] - e["config"]["final_loss"]) < 1e-4, (g["config"]["final_loss"], e["config"]["final_loss"])
+    # WebVid-style batches (one caption per video, no sorting head) run through the same harness
+    w = _bench(["--n-trans", "1"], 0)
+    assert w["value"] > 0 and "x1" in w["config"]["workload"]

@@ -1,0 +1,102 @@
+"""The C-ABI exchange steps (include/tvts_comm.h, libtvts_comm.so) on the one GPU of the test box: RCCL with a
+world of one rank -- every entry point, the side stream's fork / join against the compute stream, and a whole
+training step routed through it (TVTS_COMM=native) against the torch.distributed transport.  (RCCL refuses two ranks on
+one device, so world > 1 of this transport runs only where the driver has more GPUs; the exchange semantics at world 2
+are covered on gloo by tests/test_dist_cpu.py and tests/test_dist_gpu.py.)"""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tvts_oracle as O  # noqa: E402  (synthetic batches / parameters only)
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def comm():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tvts_amd import dist as D
+    return D.NativeComm.get()
+
+
+def test_native_comm_world_of_one(comm):
+    assert (comm.W, comm.rank) == (1, 0)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    v, t = torch.randn(48, 512, generator=g, device=DEV), torch.randn(48, 512, generator=g, device=DEV)
+    va, ta = torch.full_like(v, float("nan")), torch.full_like(t, float("nan"))
+    comm.allgather_embeds(v, t, va, ta)
+    comm.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(va, v) and torch.equal(ta, t)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(1 << 20, generator=g, device=DEV).to(dt)
+        ref = x.clone()
+        comm.allreduce(x)
+        comm.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+
+
+def test_side_stream_orders_against_the_compute_stream(comm):
+    """producer kernel -> collective -> consumer kernel with no host synchronisation in between, many times over: the
+    collective must see the producer's output (fork) and the consumer the collective's (join)."""
+    n = 1 << 22
+    x = torch.zeros(n, device=DEV)
+    acc = torch.zeros(n, device=DEV)
+    for i in range(50):
+        x.add_(1.0)            # producer on the compute stream
+        comm.allreduce(x)      # side stream, world 1: identity
+        comm.wait()
+        acc.add_(x)            # consumer on the compute stream
+    torch.cuda.synchronize()
+    assert float(x[0]) == 50.0 and float(acc.min()) == float(acc.max()) == 50 * 51 / 2
+
+
+def _step(native: bool, payload: str):
+    from tvts_amd import arch as A
+    from tvts_amd import dist as D
+    from tvts_amd.model._common import TVTSv2Base
+    from tvts_amd.optim import FusedHFAdamW
+    from tvts_amd.step import StepRunner
+    a = A.small_arch()
+    oarch = O.tiny_arch(**a)
+    m = TVTSv2Base(types.SimpleNamespace(local_rank=0, rank=0, world_size=1), arch=a)
+    m.load_state_dict(O.synth_params(oarch, seed=1), strict=True)
+    groups = [[], [], [], []]
+    for name, p in m.named_parameters():
+        gi = A.param_group_of(name, a)
+        if gi < 0:
+            p.requires_grad = False
+        else:
+            groups[gi].append(p)
+    opt = FusedHFAdamW([dict(params=groups[i], lr=A.GROUP_HPARAMS[i][0] * 30, weight_decay=A.GROUP_HPARAMS[i][1])
+                        for i in range(4)], m.store, model=m)
+    run = StepRunner(m, opt)
+    run.sync = D.GradSync(m.store.grad, payload=payload, native=native)
+    run.gather = D.EmbedGather(native=native)
+    m.engine.grad_ready = run.sync.reduce_range if native else None
+    batch = O.synth_batch(oarch, B=4, T=2, seed=2, caption_len=9)
+    losses = []
+    for _ in range(3):
+        out = run.step(batch)
+        losses.append(float(out["loss1"]) + float(out["loss2"]))
+    torch.cuda.synchronize()
+    return losses, m.store.flat.clone(), run.sync.bytes_sent, m
+
+
+def test_training_step_through_the_native_transport(comm):
+    l0, p0, sent0, _ = _step(False, "fp32")
+    l1, p1, sent1, m = _step(True, "fp32")
+    assert sent0 == 0 and sent1 > 0
+    trainable = sum(-(-p.numel() // 1024) * 1024 for p in m.parameters() if p.requires_grad)
+    assert sent1 == 4 * trainable  # every trainable range exactly once per step, frozen ranges never
+    assert l1 == pytest.approx(l0, rel=1e-6, abs=1e-6)
+    assert float((p1 - p0).abs().max()) < 2e-6
+    # bf16 payload: gradients rounded to bf16 on the wire, half the bytes
+    l2, p2, sent2, _ = _step(True, "bf16")
+    assert sent2 * 2 == sent1
+    assert l2[0] == pytest.approx(l0[0], rel=1e-6, abs=1e-6) and l2[-1] == pytest.approx(l0[-1], rel=5e-3, abs=5e-3)

@@ -33,11 +33,25 @@ def _worker(rank, world, port, q):
     names = [k for k in P if P[k].grad is not None]
     sizes = [P[k].numel() for k in names]
     flat = torch.cat([P[k].grad.reshape(-1) for k in names])
+    flat16 = flat.clone()
     sync = D.GradSync(flat, bucket_bytes=64 << 10)
     cut = flat.numel() // 3
     sync.reduce_range(cut, flat.numel())
     sync.reduce_range(0, cut)
     flat.mul_(sync.finish())
+    # the same exchange with the bf16 payload: half the bytes, the fp32 result to bf16 rounding
+    sync16 = D.GradSync(flat16, bucket_bytes=64 << 10, payload="bf16")
+    sync16.reduce_range(cut, flat16.numel())
+    sync16.reduce_range(0, cut)
+    flat16.mul_(sync16.finish())
+    assert sync16.bytes_sent * 2 == sync.bytes_sent == flat.numel() * 4
+    err16 = float((flat16 - flat).norm() / flat.norm())
+    assert 0 < err16 < 6e-3, err16
+    # the embedding exchange through the preallocated EmbedGather gives what allgather_embeds gives
+    eg = D.EmbedGather()
+    eg.start(te.detach(), ve.detach())
+    v2, t2 = eg.result()
+    assert torch.equal(v2, v_all.detach()) and torch.equal(t2, t_all.detach())
     out, o = {}, 0
     for k, n in zip(names, sizes):
         out[k] = flat[o:o + n].view_as(P[k]).clone().numpy(); o += n

@@ -491,6 +491,41 @@ def test_losses(K, G):
     assert abs(float(l2) - float(r2)) < 1e-5 and rel(dp, pred.grad) < 1e-5
 
 
+@pytest.mark.parametrize("G,E", [(1536, 512), (4096, 512), (1000, 1024), (1537, 64)])
+def test_losses_at_gathered_batch_sizes(K, G, E):
+    """The contrastive head at the gathered sizes of 8 GPUs (G = 8 x 192 = 1536) and beyond: the G x G x E similarity and its
+    two backward products run on the fp32 MFMA kernel, the column log-sum-exp on the coalesced kernel.  Reference = the
+    same formulas in float64 torch on the GPU."""
+    from tvts_amd.engine import LossHead
+    g = torch.Generator(device=DEV).manual_seed(G)
+    v, t = torch.randn(G, E, generator=g, device=DEV), torch.randn(G, E, generator=g, device=DEV)
+    vr, tr_ = v.double().requires_grad_(True), t.double().requires_grad_(True)
+    x = torch.nn.functional.normalize(vr, dim=1) @ torch.nn.functional.normalize(tr_, dim=1).t() / 0.05
+    ref = -(torch.log_softmax(x, 1).diagonal().mean() + torch.log_softmax(x.t(), 1).diagonal().mean())
+    ref.backward()
+    head = LossHead(torch.device(DEV))
+    loss, dv, dt = head.contrastive(v, t)
+    assert abs(float(loss) - float(ref)) < 2e-5 * max(1, abs(float(ref))), (float(loss), float(ref))
+    assert rel(dv, vr.grad) < 1e-4 and rel(dt, tr_.grad) < 1e-4, (rel(dv, vr.grad), rel(dt, tr_.grad))
+
+
+@pytest.mark.parametrize("M,N,K_", [(64, 64, 16), (100, 70, 50), (1536, 1536, 512), (333, 512, 1000), (32, 32, 16), (65, 33, 17)])
+def test_gemm_small_mfma_tile_all_stride_patterns(K, M, N, K_):
+    """tvts_gemm_small_f32 on the fp32 MFMA tile (M, N >= 32, K >= 16): row-major and transposed views of both operands,
+    alpha, bias, accumulate, ragged edges.  fp32 MFMA is an exact fp32 fma chain: float64 reference to 1e-5."""
+    a, b = rnd(M, K_, seed=80).to(DEV), rnd(K_, N, seed=81).to(DEV)
+    at, bt = a.t().contiguous(), b.t().contiguous()  # [K,M], [N,K]
+    bias = rnd(N, seed=82).to(DEV)
+    ref = a.double() @ b.double()
+    for A_, sa in ((a, (K_, 1)), (at, (1, M))):
+        for B_, sb in ((b, (N, 1)), (bt, (1, K_))):
+            out = torch.full((M, N + 3), float("nan"), device=DEV)[:, :N]
+            K.gemm_small(A_, B_, out, M=M, N=N, K=K_, sa=sa, sb=sb, alpha=0.5, bias=bias)
+            assert rel(out, 0.5 * ref + bias.double()) < 1e-5, (sa, sb, rel(out, 0.5 * ref + bias.double()))
+            K.gemm_small(A_, B_, out, M=M, N=N, K=K_, sa=sa, sb=sb, accumulate=True)
+            assert rel(out, 1.5 * ref + bias.double()) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def test_adamw_and_shadows(K):
     n = 4096 * 3

@@ -14,6 +14,8 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtvts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tvts_hip.h")
+COMM_LIB_PATH = os.path.join(_HERE, "libtvts_comm.so")
+COMM_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tvts_comm.h")
 
 _CTYPES = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
@@ -74,3 +76,26 @@ def load():
 def prototypes():
     load()
     return _protos
+
+
+_comm = None
+
+
+def load_comm():
+    """libtvts_comm.so (include/tvts_comm.h): the RCCL exchange steps on a library-owned side stream.  Loaded on demand."""
+    global _comm
+    if _comm is not None:
+        return _comm
+    import torch  # noqa: F401
+    if not os.path.exists(COMM_LIB_PATH):
+        raise HipLibraryMissing(f"{COMM_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = ctypes.CDLL(COMM_LIB_PATH)
+    for name, (res, argtypes, _) in parse_header(COMM_HEADER_PATH).items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryMissing(f"{COMM_LIB_PATH} does not export {name} declared in {COMM_HEADER_PATH}") from e
+        fn.restype = res
+        fn.argtypes = argtypes
+    _comm = lib
+    return lib

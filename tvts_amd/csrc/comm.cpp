@@ -1,0 +1,110 @@
+// libtvts_comm.so: RCCL exchange steps of the data-parallel step on a library-owned side stream (include/tvts_comm.h).
+// Host code only (HIP runtime API + RCCL); one communicator per process.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include "tvts_comm.h"
+
+#define TVTS_EINVAL (-22)
+#define HIP_TRY(x)                                 \
+    do {                                           \
+        hipError_t e__ = (x);                      \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+#define NCCL_TRY(x)                                          \
+    do {                                                     \
+        ncclResult_t r__ = (x);                              \
+        if (r__ != ncclSuccess) return -(1000 + (int)r__);   \
+    } while (0)
+
+struct TvtsComm {
+    ncclComm_t nccl;
+    hipStream_t side;   // every collective runs here
+    hipEvent_t fork;    // compute stream -> side stream
+    hipEvent_t join;    // side stream -> compute stream
+    int rank, world;
+};
+
+extern "C" int tvts_comm_unique_id(void* id128) {
+    if (!id128) return TVTS_EINVAL;
+    static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int tvts_comm_create(const void* id128, int rank, int world, void** comm_out) {
+    if (!id128 || !comm_out || world < 1 || rank < 0 || rank >= world) return TVTS_EINVAL;
+    TvtsComm* c = new TvtsComm();
+    c->rank = rank; c->world = world;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCL_TRY(ncclCommInitRank(&c->nccl, world, id, rank));
+    // a high-priority side stream: its (few, short) kernels should not queue behind the persistent GEMM blocks
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
+    HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->join, hipEventDisableTiming));
+    *comm_out = c;
+    return 0;
+}
+
+extern "C" int tvts_comm_destroy(void* comm) {
+    if (!comm) return TVTS_EINVAL;
+    TvtsComm* c = (TvtsComm*)comm;
+    hipStreamSynchronize(c->side);
+    ncclCommDestroy(c->nccl);
+    hipEventDestroy(c->fork);
+    hipEventDestroy(c->join);
+    hipStreamDestroy(c->side);
+    delete c;
+    return 0;
+}
+
+extern "C" int tvts_comm_world(void* comm, int* rank, int* world) {
+    if (!comm) return TVTS_EINVAL;
+    TvtsComm* c = (TvtsComm*)comm;
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return 0;
+}
+
+static int fork_from(TvtsComm* c, hipStream_t compute_stream) {
+    HIP_TRY(hipEventRecord(c->fork, compute_stream));
+    HIP_TRY(hipStreamWaitEvent(c->side, c->fork, 0));
+    return 0;
+}
+
+extern "C" int tvts_comm_allgather_embeds(void* comm, const float* video, const float* text, int B, int E, float* video_all,
+                                          float* text_all, hipStream_t compute_stream) {
+    if (!comm || !video || !text || !video_all || !text_all || B <= 0 || E <= 0) return TVTS_EINVAL;
+    TvtsComm* c = (TvtsComm*)comm;
+    int rc = fork_from(c, compute_stream);
+    if (rc) return rc;
+    const size_t n = (size_t)B * E;
+    NCCL_TRY(ncclGroupStart());  // both tensors in one launch
+    NCCL_TRY(ncclAllGather(video, video_all, n, ncclFloat, c->nccl, c->side));
+    NCCL_TRY(ncclAllGather(text, text_all, n, ncclFloat, c->nccl, c->side));
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+}
+
+extern "C" int tvts_comm_allreduce_bucket(void* comm, void* buf, long count, int dtype, hipStream_t compute_stream) {
+    if (!comm || !buf || count <= 0 || (dtype != TVTS_COMM_F32 && dtype != TVTS_COMM_BF16)) return TVTS_EINVAL;
+    TvtsComm* c = (TvtsComm*)comm;
+    int rc = fork_from(c, compute_stream);
+    if (rc) return rc;
+    NCCL_TRY(ncclAllReduce(buf, buf, (size_t)count, dtype == TVTS_COMM_F32 ? ncclFloat : ncclBfloat16, ncclSum, c->nccl, c->side));
+    return 0;
+}
+
+extern "C" int tvts_comm_wait(void* comm, hipStream_t compute_stream) {
+    if (!comm) return TVTS_EINVAL;
+    TvtsComm* c = (TvtsComm*)comm;
+    HIP_TRY(hipEventRecord(c->join, c->side));
+    HIP_TRY(hipStreamWaitEvent(compute_stream, c->join, 0));
+    return 0;
+}

@@ -561,10 +561,74 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same strided fp32 product on the matrix cores for outputs of at least one 64x64 tile: the G x G x E similarity of
+// the gathered embeddings and its two backward products (G = world x pairs: 1536 at 8 x 192), the text / pooled
+// projections.  v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain at the fp32 vector rate (157 TF) that leaves the VALU
+// free; 64x64 block tile, 4 waves in 2 x 2 with a 32x32 accumulator each, 16-deep stages staged k-major in LDS
+// (As[k][i], Bs[k][j]: the fragment reads are unit-stride over lanes whatever the operand strides were).
+// AK1 / BJ1: the operand's unit-stride direction (A: k or i; B: j or k) -- it fixes the thread -> element mapping of
+// the staging loads so that they are coalesced for row-major and for transposed views alike.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <bool AK1, bool BJ1>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, long sai, long sak,
+                                                            const float* __restrict__ B, long sbk, long sbj, int M, int N,
+                                                            int K, float alpha, const float* __restrict__ bias,
+                                                            float* __restrict__ C, long ldc, int accumulate) {
+    __shared__ float As[16][68], Bs[16][68];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ka = AK1 ? (tid & 15) : (tid >> 6) + 4 * r, ia = AK1 ? (tid >> 4) + 16 * r : (tid & 63);
+            const int gi = i0 + ia, gk = k0 + ka;
+            As[ka][ia] = (gi < M && gk < K) ? A[gi * sai + gk * sak] : 0.f;
+            const int kb = BJ1 ? (tid >> 6) + 4 * r : (tid & 15), jb = BJ1 ? (tid & 63) : (tid >> 4) + 16 * r;
+            const int gj = j0 + jb, gkb = k0 + kb;
+            Bs[kb][jb] = (gj < N && gkb < K) ? B[gkb * sbk + gj * sbj] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int j = j0 + wn * 32 + (lane & 31);
+    if (j >= N) return;
+    const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (i >= M) continue;
+        const float v = alpha * acc[e] + bj;
+        float* c = C + (size_t)i * ldc + j;
+        *c = accumulate ? *c + v : v;
+    }
+}
+
 extern "C" int tvts_gemm_small_f32(const float* A, long sai, long sak, const float* B, long sbk, long sbj,
                                    int M, int N, int K, float alpha, const float* bias, float* C, long ldc,
                                    int accumulate, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return TVTS_EINVAL;
+    if (M >= 32 && N >= 32 && K >= 16) {  // worth a 64x64 MFMA tile; the tiny products (4-way heads, [B,E] rows) stay below
+        const dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
+        const bool ak1 = sak == 1, bj1 = sbj == 1;
+        auto kern = ak1 ? (bj1 ? gemm_f32_mfma_kernel<true, true> : gemm_f32_mfma_kernel<true, false>)
+                        : (bj1 ? gemm_f32_mfma_kernel<false, true> : gemm_f32_mfma_kernel<false, false>);
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, A, sai, sak, B, sbk, sbj, M, N, K, alpha, bias, C, ldc, accumulate);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
     hipLaunchKernelGGL(gemm_small_kernel, dim3(ceil_div(N, 16), ceil_div(M, 16)), dim3(256), 0, stream, A, sai,
                        sak, B, sbk, sbj, M, N, K, alpha, bias, C, ldc, accumulate);
     TVTS_LAUNCH_CHECK();

@@ -47,21 +47,43 @@ extern "C" int tvts_l2norm_rows_bwd(const float* dxn, const float* xn, const flo
     return TVTS_OK;
 }
 
-// x[G,G] = sim / temperature.  lse[0..G) = row log-sum-exp, lse[G..2G) = column log-sum-exp.  One wave each.
-__global__ __launch_bounds__(256) void infonce_lse_kernel(const float* __restrict__ x, int G, float* __restrict__ lse) {
+// x[G,G] = sim / temperature.  lse[0..G) = row log-sum-exp (one wave per row), lse[G..2G) = column log-sum-exp.
+__global__ __launch_bounds__(256) void infonce_row_lse_kernel(const float* __restrict__ x, int G, float* __restrict__ lse) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= 2 * G) return;
-    const bool col = w >= G;
-    const int idx = col ? w - G : w;
-    const size_t stride = col ? (size_t)G : 1, base = col ? (size_t)idx : (size_t)idx * G;
+    if (w >= G) return;
+    const float* p = x + (size_t)w * G;
     float m = -INFINITY;
-    for (int c = lane; c < G; c += 64) m = fmaxf(m, x[base + c * stride]);
+    for (int c = lane; c < G; c += 64) m = fmaxf(m, p[c]);
     m = wave_max(m);
     float s = 0.f;
-    for (int c = lane; c < G; c += 64) s += __expf(x[base + c * stride] - m);
+    for (int c = lane; c < G; c += 64) s += __expf(p[c] - m);
     s = wave_sum(s);
     if (lane == 0) lse[w] = m + __logf(s);
+}
+// columns: a block owns 64 adjacent columns (lane = column, so every load is a coalesced 256-byte row segment instead of
+// a stride-G gather), its 4 waves split the rows and keep an online (max, sum) per column, merged through LDS.
+__global__ __launch_bounds__(256) void infonce_col_lse_kernel(const float* __restrict__ x, int G, float* __restrict__ lse) {
+    __shared__ float sm[4][64], ss[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float m = -INFINITY, s = 0.f;
+    if (col < G) {
+        for (int r = wave; r < G; r += 4) {
+            const float v = x[(size_t)r * G + col];
+            if (v > m) { s = s * __expf(m - v) + 1.f; m = v; }
+            else s += __expf(v - m);
+        }
+    }
+    sm[wave][lane] = m; ss[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < G) {
+        float mm = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tot += ss[w][lane] > 0.f ? ss[w][lane] * __expf(sm[w][lane] - mm) : 0.f;
+        lse[G + col] = mm + __logf(tot);
+    }
 }
 // loss += -(1/G) sum_i [(x_ii - rowlse_i) + (x_ii - collse_i)];  dx_ij = (e^{x_ij-rowlse_i} + e^{x_ij-collse_j} - 2 d_ij)/G
 __global__ __launch_bounds__(256) void infonce_grad_kernel(const float* __restrict__ x, const float* __restrict__ lse, int G,
@@ -79,7 +101,8 @@ __global__ __launch_bounds__(256) void infonce_grad_kernel(const float* __restri
 }
 extern "C" int tvts_infonce(const float* x, int G, float* lse, float* dx, float* loss, hipStream_t stream) {
     if (G <= 0) return TVTS_EINVAL;
-    hipLaunchKernelGGL(infonce_lse_kernel, dim3(ceil_div(2 * G, 4)), dim3(256), 0, stream, x, G, lse);
+    hipLaunchKernelGGL(infonce_row_lse_kernel, dim3(ceil_div(G, 4)), dim3(256), 0, stream, x, G, lse);
+    hipLaunchKernelGGL(infonce_col_lse_kernel, dim3(ceil_div(G, 64)), dim3(256), 0, stream, x, G, lse);
     hipLaunchKernelGGL(infonce_grad_kernel, dim3((unsigned)(((long)G * G + 255) / 256)), dim3(256), 0, stream, x, lse, G, dx,
                        loss);
     TVTS_LAUNCH_CHECK();

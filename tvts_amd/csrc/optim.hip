@@ -73,6 +73,22 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
         *(bf16x4*)(dst + i * 4) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
     }
 }
+__global__ __launch_bounds__(256) void widen_kernel(const bf16* __restrict__ src, float* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const bf16x4 v = *(const bf16x4*)(src + i * 4);
+        *(f32x4*)(dst + i * 4) = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+// bf16 -> fp32 (the bf16 gradient payload read back into the fp32 gradient buffer after its all-reduce)
+extern "C" int tvts_cast_bf16_f32(const void* src, float* dst, long n, hipStream_t stream) {
+    if (n <= 0 || n % 4) return TVTS_EINVAL;
+    const size_t n4 = (size_t)n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)src, dst, n4);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
 extern "C" int tvts_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream) {
     if (n <= 0 || n % 4) return TVTS_EINVAL;
     const size_t n4 = (size_t)n / 4;

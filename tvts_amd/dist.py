@@ -1,17 +1,25 @@
-"""Data-parallel exchange steps of the TVTSv2 step: one process per GPU, torch.distributed (RCCL on ROCm).
+"""Data-parallel exchange steps of the TVTSv2 step: one process per GPU.
 
-* ``allgather_embeds`` -- the reference's ``AllGather_multi`` (v2/trainer/trainer.py:41-57): forward gathers
-  the per-rank ``[B,E]`` embeddings to ``[W*B,E]``; backward is a LOCAL ROW SLICE of the incoming gradient,
-  with no collective (``local_rows``).  Video and text embeddings travel in one fused ``[B,2E]`` message.
-* ``GradSync`` -- the DDP gradient average (v2/base/base_trainer.py:23-25) over the flat fp32 gradient
-  buffer: ranges are all-reduced (SUM) asynchronously as soon as the hand-written backward has finished
-  them, overlapping RCCL traffic over xGMI with the remaining backward GEMMs; the 1/W factor is folded
-  into the AdamW kernel.
-These functions only move tensors; they run on gloo/CPU tensors in the tests exactly as on RCCL.
+* ``allgather_embeds`` / ``EmbedGather`` -- the reference's ``AllGather_multi`` (v2/trainer/trainer.py:41-57): forward
+  gathers the per-rank ``[B,E]`` embeddings to ``[W*B,E]``; backward is a LOCAL ROW SLICE of the incoming gradient, with
+  no collective (``local_rows``).  Video and text embeddings travel in one message.
+* ``GradSync`` -- the DDP gradient average (v2/base/base_trainer.py:20-25) over the flat fp32 gradient buffer: ranges
+  are all-reduced (SUM) asynchronously as soon as the hand-written backward has finished them, overlapping RCCL traffic
+  over xGMI with the remaining backward GEMMs; the 1/W factor is folded into the AdamW kernel.  Ranges of frozen
+  parameters never reach it (Engine._ready hands over trainable runs only).  Payload fp32 (default, bit-faithful to the
+  reference's fp32 all-reduce) or bf16 (half the bytes on the links: 312 MB instead of 624 MB for ViT-B/16;
+  ``TVTS_GRAD_PAYLOAD=bf16``).
+
+Two transports, same semantics:
+  ``torch``  (default)  torch.distributed collectives (backend nccl = RCCL on the GPUs, gloo on CPU tensors in the tests);
+  ``native`` (``TVTS_COMM=native``)  the C ABI of include/tvts_comm.h: RCCL calls on a side HIP stream the library owns,
+             fork / join by events against the compute stream, no host synchronisation anywhere in the step.
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+import ctypes
+import os
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -35,59 +43,185 @@ def allgather_embeds(video_emb: torch.Tensor, text_emb: torch.Tensor, scratch=No
     return out[:, :E].contiguous(), out[:, E:].contiguous()
 
 
-class EmbedGather:
-    """The same exchange started early: `start` is called by the engine as soon as both embeddings exist (before the
-    sort head's forward), the collective runs asynchronously on RCCL's stream, `result` waits for it where the loss needs
-    the gathered rows (trainer.py:479-483)."""
-
-    def __init__(self):
-        self.W, _ = world()
-        self.pending = None
-
-    def start(self, text_emb: torch.Tensor, video_emb: torch.Tensor):
-        if self.W == 1:
-            self.pending = (None, video_emb, text_emb)
-            return
-        B, E = video_emb.shape
-        packed = torch.cat([video_emb, text_emb], dim=1).contiguous()
-        out = torch.empty(self.W * B, 2 * E, dtype=packed.dtype, device=packed.device)
-        self.pending = (dist.all_gather_into_tensor(out, packed, async_op=True), out, E)
-
-    def result(self):
-        h, a, b = self.pending
-        self.pending = None
-        if h is None:
-            return a, b
-        h.wait()
-        return a[:, :b].contiguous(), a[:, b:].contiguous()
-
-
 def local_rows(grad_all: torch.Tensor, B: int) -> torch.Tensor:
     """AllGather_multi.backward: this rank's rows of the gradient wrt the gathered tensor."""
     _, r = world()
     return grad_all[B * r:B * (r + 1)]
 
 
+# ------------------------------------------------------------------------------------------------ native transport
+class NativeComm:
+    """ctypes binding of libtvts_comm.so (include/tvts_comm.h); the unique id travels over the torch.distributed group
+    that the launcher initialised anyway (rendezvous is plumbing)."""
+
+    _inst: Optional["NativeComm"] = None
+
+    def __init__(self):
+        from . import _lib
+        self.lib = _lib.load_comm()
+        W, r = world()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if r == 0:
+            raw = (ctypes.c_ubyte * 128)()
+            self._chk(self.lib.tvts_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)), "tvts_comm_unique_id")
+            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+        if W > 1:
+            t = idbuf.to(dev) if dist.get_backend() == "nccl" else idbuf
+            dist.broadcast(t, src=0)
+            idbuf = t.cpu()
+        raw = (ctypes.c_ubyte * 128)(*idbuf.tolist())
+        h = ctypes.c_void_p()
+        self._chk(self.lib.tvts_comm_create(ctypes.cast(raw, ctypes.c_void_p), r, W, ctypes.byref(h)), "tvts_comm_create")
+        self.h, self.W, self.rank = h, W, r
+
+    @staticmethod
+    def _chk(rc, name):
+        if rc != 0:
+            raise RuntimeError(f"{name} failed with code {rc}")
+
+    @classmethod
+    def get(cls) -> "NativeComm":
+        if cls._inst is None:
+            cls._inst = NativeComm()
+        return cls._inst
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def allgather_embeds(self, video, text, video_all, text_all):
+        B, E = video.shape
+        self._chk(self.lib.tvts_comm_allgather_embeds(self.h, ctypes.c_void_p(video.data_ptr()), ctypes.c_void_p(text.data_ptr()),
+                                                     B, E, ctypes.c_void_p(video_all.data_ptr()),
+                                                     ctypes.c_void_p(text_all.data_ptr()), self._stream()),
+                  "tvts_comm_allgather_embeds")
+
+    def allreduce(self, t: torch.Tensor):
+        dt = {torch.float32: 0, torch.bfloat16: 1}[t.dtype]
+        self._chk(self.lib.tvts_comm_allreduce_bucket(self.h, ctypes.c_void_p(t.data_ptr()), t.numel(), dt, self._stream()),
+                  "tvts_comm_allreduce_bucket")
+
+    def wait(self):
+        self._chk(self.lib.tvts_comm_wait(self.h, self._stream()), "tvts_comm_wait")
+
+
+def transport() -> str:
+    t = os.environ.get("TVTS_COMM", "torch")
+    if t not in ("torch", "native"):
+        raise ValueError(f"TVTS_COMM={t!r}: expected 'torch' or 'native'")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ embedding all-gather
+class EmbedGather:
+    """The exchange started early: `start` is called by the engine as soon as both embeddings exist (before the sort
+    head's forward), the collective runs asynchronously, `result` waits for it where the loss needs the gathered rows
+    (trainer.py:479-483).  Buffers are allocated once per shape."""
+
+    def __init__(self, native: Optional[bool] = None):
+        self.W, _ = world()
+        self.pending = None
+        self.native = (transport() == "native") if native is None else native
+        self._buf = {}
+
+    def _bufs(self, B, E, ref):
+        key = (B, E, ref.dtype, ref.device)
+        b = self._buf.get(key)
+        if b is None:
+            if self.native:
+                b = (torch.empty(self.W * B, E, dtype=ref.dtype, device=ref.device),
+                     torch.empty(self.W * B, E, dtype=ref.dtype, device=ref.device))
+            else:
+                b = (torch.empty(B, 2 * E, dtype=ref.dtype, device=ref.device),
+                     torch.empty(self.W * B, 2 * E, dtype=ref.dtype, device=ref.device),
+                     torch.empty(self.W * B, E, dtype=ref.dtype, device=ref.device),
+                     torch.empty(self.W * B, E, dtype=ref.dtype, device=ref.device))
+            self._buf[key] = b
+        return b
+
+    def start(self, text_emb: torch.Tensor, video_emb: torch.Tensor):
+        if self.W == 1 and not self.native:
+            self.pending = ("local", video_emb, text_emb)
+            return
+        B, E = video_emb.shape
+        if self.native:
+            v_all, t_all = self._bufs(B, E, video_emb)
+            NativeComm.get().allgather_embeds(video_emb, text_emb, v_all, t_all)
+            self.pending = ("native", v_all, t_all)
+            return
+        packed, out, v_all, t_all = self._bufs(B, E, video_emb)
+        packed[:, :E].copy_(video_emb)
+        packed[:, E:].copy_(text_emb)
+        self.pending = ("torch", dist.all_gather_into_tensor(out, packed, async_op=True), out, v_all, t_all, E)
+
+    def result(self):
+        p, self.pending = self.pending, None
+        if p[0] == "local":
+            return p[1], p[2]
+        if p[0] == "native":
+            NativeComm.get().wait()
+            return p[1], p[2]
+        _, h, out, v_all, t_all, E = p
+        h.wait()
+        v_all.copy_(out[:, :E])
+        t_all.copy_(out[:, E:])
+        return v_all, t_all
+
+
+# ------------------------------------------------------------------------------------------------ gradient all-reduce
 class GradSync:
     """Asynchronous bucketed all-reduce of ranges of one flat gradient buffer."""
 
-    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20):
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, payload: Optional[str] = None,
+                 native: Optional[bool] = None):
         self.g = flat_grad
         self.W, _ = world()
         self.handles: List = []
-        self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
+        self.payload = payload or os.environ.get("TVTS_GRAD_PAYLOAD", "fp32")
+        if self.payload not in ("fp32", "bf16"):
+            raise ValueError(f"gradient payload {self.payload!r}: expected 'fp32' or 'bf16'")
+        self.native = ((transport() == "native") if native is None else native) and flat_grad.is_cuda
+        esize = 2 if self.payload == "bf16" else flat_grad.element_size()
+        self.bucket_elems = max(1, bucket_bytes // esize)
+        # bf16 payload: a staging buffer the size of the gradient, filled / read back range by range
+        self.stage = (torch.empty(flat_grad.shape, dtype=torch.bfloat16, device=flat_grad.device)
+                      if (self.payload == "bf16" and (self.W > 1 or self.native)) else None)
+        self.bytes_sent = 0  # per step, for the tests and the bench line
+
+    def _cast(self, src, dst):
+        if src.is_cuda:
+            from . import hip as K
+            (K.cast_f32_bf16 if dst.dtype == torch.bfloat16 else K.cast_bf16_f32)(src, dst)
+        else:
+            dst.copy_(src)
 
     def reduce_range(self, start: int, end: int):
         """Called once the backward no longer writes grad[start:end]."""
-        if self.W == 1 or end <= start:
+        if (self.W == 1 and not self.native) or end <= start:
             return
         for s in range(start, end, self.bucket_elems):
             e = min(end, s + self.bucket_elems)
-            self.handles.append(dist.all_reduce(self.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+            if self.stage is not None:
+                buf = self.stage[s:e]
+                self._cast(self.g[s:e], buf)
+            else:
+                buf = self.g[s:e]
+            self.bytes_sent += buf.numel() * buf.element_size()
+            if self.native:
+                NativeComm.get().allreduce(buf)
+                self.handles.append((None, s, e))
+            else:
+                self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), s, e))
 
     def finish(self) -> float:
         """Wait for outstanding reductions; returns the scale (1/W) still to be applied to the sum."""
-        for h in self.handles:
-            h.wait()
+        if self.native and self.handles:
+            NativeComm.get().wait()
+        for h, s, e in self.handles:
+            if h is not None:
+                h.wait()
+            if self.stage is not None:
+                self._cast(self.stage[s:e], self.g[s:e])
         self.handles = []
         return 1.0 / self.W

@@ -169,21 +169,38 @@ class Engine:
         self._ranges: dict = {}
 
     def _ready(self, *prefixes: str):
-        """The gradients of every parameter whose name starts with one of `prefixes` are final: hand their flat range
-        (contiguous in state-dict order, whichever registration order the architecture uses) to the gradient sync."""
+        """The gradients of every parameter whose name starts with one of `prefixes` are final: hand their flat ranges
+        (contiguous in state-dict order, whichever registration order the architecture uses) to the gradient sync --
+        maximal runs of TRAINABLE tensors only: the frozen text layers below the tune range (train_dist..:89-96, ~28 M
+        parameters of all-zero gradient for ViT-B/16) never travel."""
         if self.grad_ready is None:
             return
+        for lo, hi in self.trainable_runs(prefixes):
+            self.grad_ready(lo, hi)
+
+    def trainable_runs(self, prefixes):
         P = self.P
-        key = prefixes
-        rng = self._ranges.get(key)
-        if rng is None:
+        ent = self._ranges.get(prefixes)
+        if ent is None:
             names = [n for n in P.shapes if n.startswith(prefixes)]
             lo = min(P.off[n] for n in names)
             hi = max(P.off[n] + -(-P._n(n) // CH) * CH for n in names)
             inside = [n for n in P.shapes if lo <= P.off[n] < hi]
             assert inside == names, f"parameters {prefixes} are not contiguous in the flat buffer"
-            rng = self._ranges[key] = (lo, hi)
-        self.grad_ready(*rng)
+            ent = self._ranges[prefixes] = dict(names=names, sig=None, runs=None)
+        sig = tuple(self.requires_grad[n] for n in ent["names"])
+        if sig != ent["sig"]:
+            runs = []
+            for n, tr in zip(ent["names"], sig):
+                if not tr:
+                    continue
+                s, e = P.off[n], P.off[n] + -(-P._n(n) // CH) * CH
+                if runs and runs[-1][1] == s:
+                    runs[-1][1] = e
+                else:
+                    runs.append([s, e])
+            ent["sig"], ent["runs"] = sig, [tuple(r) for r in runs]
+        return ent["runs"]
 
     # ------------------------------------------------------------------ workspace
     def _b(self, name, shape, dtype=torch.bfloat16, zero=False):

@@ -401,6 +401,11 @@ def cast_f32_bf16(src, dst):
     _chk(lib.tvts_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "tvts_cast_f32_bf16")
 
 
+def cast_bf16_f32(src, dst):
+    lib = _lib.load()
+    _chk(lib.tvts_cast_bf16_f32(_p(src), _p(dst), src.numel(), _stream()), "tvts_cast_bf16_f32")
+
+
 def pad_rows_bf16(src, dst):
     """dst[r, :] = src[r, :] zero-extended to dst's width (bf16, row-major 2-D)."""
     lib = _lib.load()

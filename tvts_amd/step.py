@@ -20,7 +20,7 @@ class StepRunner:
         self.head = loss_head or LossHead(self.store.device)
         self.sync = D.GradSync(self.store.grad)
         self.fused = hasattr(optimizer, "chunk_group")
-        self.eng.grad_ready = self.sync.reduce_range if self.sync.W > 1 else None
+        self.eng.grad_ready = self.sync.reduce_range if (self.sync.W > 1 or self.sync.native) else None
         self.gather = D.EmbedGather()
 
     def losses_and_grads(self, pb, te, ve, pred, labels):
@@ -45,6 +45,7 @@ class StepRunner:
     def run(self, pb, labels, device_step=False):
         """The device-side part of the step (capturable in a hipGraph when world == 1)."""
         self.store.grad.zero_()
+        self.sync.bytes_sent = 0
         self.eng.embeds_ready = self.gather.start  # only the training step gathers; eval / autograd forwards do not
         try:
             te, ve, pred = self.eng.forward(pb)
