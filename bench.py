@@ -75,7 +75,8 @@ def host_threads():
 def cpu_baseline(arch_name, T, caption_len, pairs, max_seconds, n_trans=4):
     """Runs the worker in a child process with a hard wall-clock limit, so a slow host cannot stall the bench."""
     import subprocess
-    threads = host_threads()
+    # 32 torch threads: measured best on the 256-CPU host (0.98 pairs/s; 64 threads 0.52, 128 threads 0.25, 256 time out)
+    threads = min(host_threads(), 32)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--arch", arch_name, "--frames", str(T),
            "--caption-len", str(caption_len), "--cpu-pairs", str(pairs), "--cpu-seconds", str(max_seconds),
            "--cpu-threads", str(threads), "--n-trans", str(n_trans)]

@@ -99,6 +99,18 @@ int tvts_attn_fwd_divided(int mode, const void* qkv, int ld, int B, int heads, i
                       float* lse2, float* cls_ws, long cls_ws_elems, hipStream_t stream);
 
 /* the same entry points for head dim 80 (ViT-H/14, 1280 / 16 heads); qkv is [rows, 3*heads*80] */
+/* FULL attention over sequences padded to S with the padded keys masked: keys at positions >= kv_len[b] (device int32[B]) get
+ * probability 0 -- the attention_mask of the v1 text tower (transformers DistilBERT MultiHeadSelfAttention, reached from
+ * v1/model/model_dist_TVTS.py:131-141).  bwd_len = delta + dQ + dK/dV; the dK / dV rows of the padded positions are NOT written
+ * (their gradient is zero): zero dqkv first. */
+int tvts_attn_fwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, void* out, int ldo, float* lse2,
+                      hipStream_t stream);
+int tvts_attn_bwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,
+                      const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream);
+int tvts_attn80_fwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, void* out, int ldo, float* lse2,
+                        hipStream_t stream);
+int tvts_attn80_bwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,
+                        const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream);
 int tvts_attn80_fwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, void* out, int ldo,
                   float* lse2, hipStream_t stream);
 int tvts_attn80_delta(const void* dO, int lddo, const void* O, int ldo, int rows, int heads, float* delta,
@@ -137,10 +149,16 @@ int tvts_patch_gather_u8(const unsigned char* frames, int H0, int W0, const int*
  * random keys of sample number first_sample + b -- an unsorted prefix of a uniformly random permutation, shared by all
  * frames of the clip; ppf <= 1024; seed / first_sample are taken as unsigned 64-bit values */
 int tvts_tube_mask(long seed, long first_sample, int B, int ppf, int n_keep, int* keep, hipStream_t stream);
+/* keep_per_frame 0: keep[B, n], one tube mask for all frames of a clip (v2); 1: keep[B, T, n], one per frame / tubelet (v1) */
 int tvts_vit_assemble(const float* patch, int ldp, const float* cls, const float* pos, const float* temporal,
-                      const int* keep, int B, int T, int n, int W, float* tok, int ldt, hipStream_t stream);
-int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int B, int T, int n, int W, void* dpatch, int ldp,
-                          float* dcls, float* dpos, float* dtemporal, hipStream_t stream);
+                      const int* keep, int keep_per_frame, int B, int T, int n, int W, float* tok, int ldt, hipStream_t stream);
+int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int keep_per_frame, int B, int T, int n, int W,
+                          void* dpatch, int ldp, float* dcls, float* dpos, float* dtemporal, hipStream_t stream);
+/* v1 (TVTS) Conv3d tubelet embedding as im2col over the kept patches of every tube (v1/model/video_encoder.py:78-99,199-206):
+ * video fp32 [B, tubes * tubelet, 3, img, img], keep int32 [B, tubes, n] -> bf16 rows [B * tubes * n, 3 * tubelet * patch^2]
+ * in the Conv3d weight's (c, t, py, px) column order; patch % 8 == 0 */
+int tvts_patch_gather_tube(const float* video, const int* keep, int B, int tubes, int tubelet, int n, int img, int patch,
+                           void* out, int ldo, hipStream_t stream);
 int tvts_text_embed(const int* ids, int ld_ids, int N, int L, const float* emb, const float* pos, int Wt, float* x, int ldx,
                     hipStream_t stream);
 int tvts_text_embed_bwd(const float* dx, int ldx, const int* ids, int ld_ids, int N, int L, int Wt, float* demb, float* dpos,
@@ -151,6 +169,8 @@ int tvts_sort_assemble(const float* tok, int ldt, int B, int S, int off, int Sv,
                        const float* type, int E, float* xs, int ldx, hipStream_t stream);
 int tvts_sort_assemble_bwd(const float* dxs, int ldx, int B, int S, int off, int Sv, int NT, const float* dvid, int E,
                            void* dout, int ldo, float* dtype, hipStream_t stream);
+/* out = relu(x) (dy NULL) or out = dy * (x > 0) (its backward): the nn.ReLU of v1's txt_proj (v1/model/model_dist_TVTS.py:65-68) */
+int tvts_relu(const float* x, const float* dy, float* out, long n, hipStream_t stream);
 int tvts_rows_gather(const float* src, int ld_src, const int* rows, int R, int W, float* dst, int ld_dst, int scatter_add,
                      hipStream_t stream);
 

@@ -246,12 +246,65 @@ def _runner(a, P, lr_mul=1.0):
     return m, opt, StepRunner(m, opt)
 
 
-def test_graph_replayed_steps_match_eager_steps_and_the_oracle(K, lib):
+def _three_steps(a, P, batch, mode):
+    """mode: 'eager' (device-side step counter, plain launches) or 'graph' (captured once, replayed)."""
+    m, opt, run = _runner(a, P)
+    pb = m.engine.prepare_batch(batch)
+    lab = batch["label"].reshape(-1).to(torch.int32).to(DEV)
+    m._fresh_shadows(); m._sync_requires_grad()
+    losses, gnorm = [], []
+    if mode == "eager":
+        for _ in range(3):
+            out = run.run(pb, lab, device_step=True)
+            torch.cuda.synchronize()
+            losses.append(float(out["loss1"]) + float(out["loss2"])); gnorm.append(float(m.store.grad.double().norm()))
+        return m, opt, losses, gnorm
+    opt.sync_hyper()
+    # one eager step warms the workspaces (capture must not allocate); its effect on the state is rolled back
+    snap = {k: t.clone() for k, t in (("flat", m.store.flat), ("m", m.store.m), ("v", m.store.v))}
+    run.run(pb, lab, device_step=True)
+    torch.cuda.synchronize()
+    m.store.flat.copy_(snap["flat"]); m.store.m.copy_(snap["m"]); m.store.v.copy_(snap["v"])
+    opt.step_dev.zero_(); opt.global_step = 0
+    m.store.refresh_shadows()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = run.run(pb, lab, device_step=True)
+    torch.cuda.synchronize()
+    assert torch.equal(m.store.flat, snap["flat"]) and int(opt.step_dev.item()) == 0  # capture does not execute
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        losses.append(float(out["loss1"]) + float(out["loss2"])); gnorm.append(float(m.store.grad.double().norm()))
+    assert int(opt.step_dev.item()) == 3
+    assert opt.state_dict()["state"][0]["step"] == 3  # host counters re-read from the device counter
+    return m, opt, losses, gnorm
+
+
+def test_graph_replay_is_the_eager_step_on_a_deterministic_model(K, lib):
     """bench.py at world 1 captures the whole step (zero_grad ... fused AdamW, step counter in device memory) into a hipGraph
-    and replays it.  Three replayed steps must leave the parameters where three eager steps leave them -- up to the
-    summation order of the kernels' fp32 atomics (bias / CLS / embedding gradients), which is not fixed from launch to
-    launch -- and both must track the oracle's train_step.  The 256x256 kernel is forced so that the replay exercises the
-    benchmarked GEMM kernel at this small size."""
+    and replays it.  On the small architecture the step is run-to-run reproducible (losses bit for bit), so three replays must
+    leave the state three plain launches leave (round 2 found the captured step wrong from its second replay on: a
+    hipMemsetAsync node did not zero the CLS-gradient accumulators on replay; the zeroing is a kernel now)."""
+    from tvts_amd import arch as A
+    a = A.small_arch()
+    oarch = O.tiny_arch(**a)
+    P = O.synth_params(oarch, seed=21)
+    batch = O.synth_batch(oarch, B=4, T=2, seed=22, caption_len=9)
+    me, _, le, ge = _three_steps(a, P, batch, "eager")
+    mg, _, lg, gg = _three_steps(a, P, batch, "graph")
+    assert lg == le, (lg, le)                      # the losses bit for bit
+    assert gg == pytest.approx(ge, rel=1e-7), (gg, ge)  # gradient norms: a few fp32 atomics (bias / CLS sums) reorder
+    assert float((mg.store.flat - me.store.flat).abs().max()) < 1e-7
+    assert float((mg.store.m - me.store.m).abs().max()) < 1e-6
+
+
+def test_graph_replayed_steps_match_eager_steps_and_the_oracle(K, lib):
+    """The same on the headline architecture with the 256x256 kernel forced (so the replay exercises the benchmarked GEMM
+    kernel at this small size).  ViT-B/16's gradients are not bit-reproducible from run to run (fp32 atomics in the bias /
+    CLS / embedding gradients, amplified by Adam's sign-like first steps: two eager runs differ by ~1e-4 in the third
+    loss), so graph vs eager is held to 1e-3 and both to the oracle's train_step within the 2 % gate."""
     from tvts_amd import arch as A
     a = A.ARCHS["B_16"]
     oarch = O.ARCHS["B_16"]
@@ -259,57 +312,22 @@ def test_graph_replayed_steps_match_eager_steps_and_the_oracle(K, lib):
     batch = O.synth_batch(oarch, B=4, T=8, seed=22, caption_len=32)
     lib.tvts_gemm_set_nt_tile(256)
     try:
-        # eager
-        m1, opt1, run1 = _runner(a, P)
-        pb1 = m1.engine.prepare_batch(batch)
-        lab = batch["label"].reshape(-1).to(torch.int32).to(DEV)
-        m1._fresh_shadows(); m1._sync_requires_grad()
-        eager = []
-        for _ in range(3):
-            out = run1.run(pb1, lab, device_step=False)
-            eager.append(float(out["loss1"]) + float(out["loss2"]))
-        torch.cuda.synchronize()
-        # graph: one eager device-step warm-up would advance the state, so capture on a twin and replay 3 times
-        m2, opt2, run2 = _runner(a, P)
-        pb2 = m2.engine.prepare_batch(batch)
-        m2._fresh_shadows(); m2._sync_requires_grad()
-        opt2.sync_hyper()
-        # one eager step warms the workspaces (capture must not allocate); its effect on the state is rolled back
-        snap = {k: t.clone() for k, t in (("flat", m2.store.flat), ("m", m2.store.m), ("v", m2.store.v))}
-        run2.run(pb2, lab, device_step=True)
-        torch.cuda.synchronize()
-        m2.store.flat.copy_(snap["flat"]); m2.store.m.copy_(snap["m"]); m2.store.v.copy_(snap["v"])
-        opt2.step_dev.zero_(); opt2.global_step = 0
-        m2.store.refresh_shadows()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out2 = run2.run(pb2, lab, device_step=True)
-        torch.cuda.synchronize()
-        # capture does not execute: parameters still at the start
-        assert torch.equal(m2.store.flat, snap["flat"]) and int(opt2.step_dev.item()) == 0
-        graph = []
-        for _ in range(3):
-            g.replay()
-            torch.cuda.synchronize()
-            graph.append(float(out2["loss1"]) + float(out2["loss2"]))
+        me, _, le, ge = _three_steps(a, P, batch, "eager")
+        mg, _, lg, gg = _three_steps(a, P, batch, "graph")
     finally:
         lib.tvts_gemm_set_nt_tile(0)
-    assert int(opt2.step_dev.item()) == 3
-    np.testing.assert_allclose(graph, eager, rtol=2e-6, atol=2e-6)
-    d = (m2.store.flat - m1.store.flat).abs()
-    bit_identical = bool(torch.equal(m2.store.flat, m1.store.flat))
-    assert float(d.max()) < 2e-6 and rel(m2.store.flat, m1.store.flat) < 1e-6, (float(d.max()), bit_identical)
-    assert opt2.state_dict()["state"][0]["step"] == 3  # host counters re-read from the device counter
-    # the oracle's three steps
+    assert lg[0] == le[0] and gg[0] == pytest.approx(ge[0], rel=1e-5)
+    np.testing.assert_allclose(lg, le, rtol=1e-3)
+    np.testing.assert_allclose(gg, ge, rtol=5e-3)  # gradient norms of every replay: garbage would show here first
+    assert rel(mg.store.flat, me.store.flat) < 1e-4
     Pr = {k: v.clone() for k, v in P.items()}
     state, curve = {}, []
     for _ in range(3):
         r1, r2, _ = O.train_step(Pr, batch, oarch, state)
         curve.append(r1 + r2)
-    assert np.all(np.abs(np.array(graph) - np.array(curve)) < 0.02 * np.abs(np.array(curve)) + 1e-2), (graph, curve)
+    assert np.all(np.abs(np.array(lg) - np.array(curve)) < 0.02 * np.abs(np.array(curve)) + 1e-2), (lg, curve)
     for k in ("pred_model.head.weight", "video_model.transformer.resblocks.11.timeattn.proj.weight", "video_model.proj"):
-        assert rel(m2.store.p(k).cpu(), Pr[k]) < 2e-2, k
+        assert rel(mg.store.p(k).cpu(), Pr[k]) < 2e-2, k
 
 
 def test_captured_step_follows_the_learning_rate_schedule(K, lib):

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""A/B of NT GEMM kernel variants from the bench-only experiment library (tvts_amd/csrc/exp -> libtvts_exp.so) against the
+production kernel on the B/16 step's shapes: interleaved rounds in one process, medians (dev tool, GPU only).
+
+    python tools/gemm_ab.py [PAIRS=192] [ROUNDS=7]
+"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from tvts_amd import hip as K  # noqa: E402
+
+lib = ctypes.CDLL(os.path.join(ROOT, "tvts_amd", "libtvts_exp.so"))
+vp, ci = ctypes.c_void_p, ctypes.c_int
+lib.tvts_exp_gemm_nt.argtypes = [ci, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, ci, vp, ci, ci, vp, ci, ci, vp]
+lib.tvts_exp_gemm_nt.restype = ci
+ACT = {"": 0, "quick_gelu": 1, "gelu": 2}
+
+
+def P(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def exp_gemm(variant, gc, stag, a, b, out, bias=None, residual=None, act="", preact=None, gate_h=None, gate_act=""):
+    M, Kd = a.shape
+    N = b.shape[0]
+    rc = lib.tvts_exp_gemm_nt(variant, gc, stag[0], stag[1], P(a), a.stride(0), P(b), b.stride(0), M, N, Kd, P(bias), P(residual),
+                              residual.stride(0) if residual is not None else 0, ACT[act], P(preact),
+                              preact.stride(0) if preact is not None else 0, P(gate_h), gate_h.stride(0) if gate_h is not None else 0,
+                              ACT[gate_act], P(out), out.stride(0), 1 if out.dtype == torch.float32 else 0,
+                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+
+
+def timeit(fn, iters=8):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 192
+    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+    M = pairs * 785
+    dev = "cuda:0"
+    cases = [  # (name, M, N, K, kind)
+        ("qkv fwd", M, 2304, 768, "plain"), ("proj f32+res", M, 768, 768, "res32"), ("proj bf16", M, 768, 768, "plain"),
+        ("fc1 fwd gelu+pre", M, 3072, 768, "act"), ("fc2 dgrad gate", M, 3072, 768, "gate"), ("fc2 fwd f32+res", M, 768, 3072, "res32"),
+        ("fc1 dgrad", M, 768, 3072, "plain"), ("qkv dgrad", M, 768, 2304, "plain"), ("square", 4096, 4096, 4096, "plain")]
+    variants = [("prod", 0, -1, (0, 0)), ("m32", 1, -1, (0, 0)), ("m32+prio", 2, -1, (0, 0)),
+                ("m32 stag2x3", 1, -1, (2, 3)), ("m32 stag4x2", 1, -1, (4, 2))]
+    tot = {v[0]: 0.0 for v in variants}
+    for name, m, n, k, kind in cases:
+        g = torch.Generator(device=dev).manual_seed(n + k)
+        a = torch.randn(m, k, generator=g, device=dev).bfloat16()
+        b = (torch.randn(n, k, generator=g, device=dev) * k ** -0.5).bfloat16()
+        bias = torch.randn(n, generator=g, device=dev)
+        kw = dict(bias=bias)
+        odt = torch.bfloat16
+        if kind == "res32":
+            kw["residual"] = torch.randn(m, n, generator=g, device=dev); odt = torch.float32
+        elif kind == "act":
+            kw.update(act="quick_gelu", preact=torch.empty(m, n, dtype=torch.bfloat16, device=dev))
+        elif kind == "gate":
+            kw = dict(gate_h=torch.randn(m, n, generator=g, device=dev).bfloat16(), gate_act="quick_gelu")
+        out = torch.empty(m, n, dtype=odt, device=dev)
+        ref = torch.empty(m, n, dtype=odt, device=dev)
+        exp_gemm(0, -1, (0, 0), a, b, ref, **kw)
+        extra = [("prod gc3", 0, 3, (0, 0)), ("m32 gc3", 1, 3, (0, 0))] if n == 2304 else []
+        extra += [("prod gc0", 0, 0, (0, 0))] if n == 3072 else []
+        vs = variants + extra
+        for vn, v, gc, stag in vs:  # correctness of every variant against the production kernel's output
+            out.fill_(float("nan"))
+            exp_gemm(v, gc, stag, a, b, out, **kw)
+            err = float((out.float() - ref.float()).norm() / ref.float().norm())
+            assert err < (3e-3 if odt == torch.bfloat16 else 1e-5), (name, vn, err)
+        ts = {vn: [] for vn, *_ in vs}
+        for _ in range(rounds):
+            for vn, v, gc, stag in vs:
+                ts[vn].append(timeit(lambda: exp_gemm(v, gc, stag, a, b, out, **kw)))
+        fl = 2.0 * m * n * k
+        line = f"{name:18s} {m}x{n}x{k}:"
+        for vn, *_ in vs:
+            med = sorted(ts[vn])[len(ts[vn]) // 2]
+            if vn in tot:
+                tot[vn] += med
+            line += f" | {vn} {med * 1e3:7.1f}us {fl / med / 1e9:5.0f}TF"
+        print(line, flush=True)
+    print("sum of medians (ms):", {k: round(v, 3) for k, v in tot.items()})
+
+
+if __name__ == "__main__":
+    main()

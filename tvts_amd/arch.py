@@ -44,6 +44,77 @@ def small_arch_h(**over) -> dict:
     return a
 
 
+# ---- v1 TVTS: v1/model/model_dist_TVTS.py:38-47,62-76, v1/configs/dist-yt-pt.json,
+#      v1/data_loader/YTTemporal_dataset.py:68 (mask ratio 0.75), distilbert-base-uncased text tower
+ARCH_V1 = dict(name="v1", family="v1", image=224, patch=16, tubelet=2, width=768, heads=12, layers=12, num_frames=16,
+               mask_ratio=0.75, text_width=768, text_heads=12, text_layers=6, text_ffn=3072, vocab=30522, max_pos=512,
+               embed=256, sort_width=768, sort_heads=12, sort_depth=2, n_trans=4, act="gelu", tail="all_tokens")
+ARCHS["v1"] = ARCH_V1
+
+
+def small_arch_v1(**over) -> dict:
+    """reduced v1 architecture inside the HIP kernels' tiling constraints (head dim 64, GEMM K % 64 == 0)"""
+    a = dict(ARCH_V1, name="v1_small", image=64, width=128, heads=2, layers=2, num_frames=8, mask_ratio=0.5, text_width=128,
+             text_heads=2, text_layers=2, text_ffn=256, vocab=1000, max_pos=40, embed=64, sort_width=128, sort_heads=2)
+    a.update(over)
+    return a
+
+
+def param_shapes_v1(a) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state-dict keys of v1 `TVTS` in registration order: text_model (Hugging Face DistilBertModel), video_model, txt_proj,
+    vid_proj, pred_model (model_dist_TVTS.py:34,58,62-76)"""
+    o: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    Wt, Ff, W, E, Ws = a["text_width"], a["text_ffn"], a["width"], a["embed"], a["sort_width"]
+    o["text_model.embeddings.word_embeddings.weight"] = (a["vocab"], Wt)
+    o["text_model.embeddings.position_embeddings.weight"] = (a["max_pos"], Wt)
+    o["text_model.embeddings.LayerNorm.weight"] = (Wt,)
+    o["text_model.embeddings.LayerNorm.bias"] = (Wt,)
+    for i in range(a["text_layers"]):
+        p = f"text_model.transformer.layer.{i}."
+        for lin in ("q_lin", "k_lin", "v_lin", "out_lin"):
+            o[p + f"attention.{lin}.weight"] = (Wt, Wt)
+            o[p + f"attention.{lin}.bias"] = (Wt,)
+        o[p + "sa_layer_norm.weight"] = (Wt,)
+        o[p + "sa_layer_norm.bias"] = (Wt,)
+        o[p + "ffn.lin1.weight"] = (Ff, Wt)
+        o[p + "ffn.lin1.bias"] = (Ff,)
+        o[p + "ffn.lin2.weight"] = (Wt, Ff)
+        o[p + "ffn.lin2.bias"] = (Wt,)
+        o[p + "output_layer_norm.weight"] = (Wt,)
+        o[p + "output_layer_norm.bias"] = (Wt,)
+    o["video_model.cls_token"] = (1, 1, W)
+    o["video_model.pos_embed"] = (1, patches_per_frame(a) + 1, W)
+    o["video_model.temporal_embed"] = (1, a["num_frames"] // a["tubelet"], W)
+    o["video_model.patch_embed.proj.weight"] = (W, 3, a["tubelet"], a["patch"], a["patch"])
+    o["video_model.patch_embed.proj.bias"] = (W,)
+    for i in range(a["layers"]):
+        p = f"video_model.blocks.{i}."
+        for k, shp in (("norm1.weight", (W,)), ("norm1.bias", (W,)), ("attn.qkv.weight", (3 * W, W)), ("attn.qkv.bias", (3 * W,)),
+                       ("attn.proj.weight", (W, W)), ("attn.proj.bias", (W,)), ("norm2.weight", (W,)), ("norm2.bias", (W,)),
+                       ("mlp.fc1.weight", (4 * W, W)), ("mlp.fc1.bias", (4 * W,)), ("mlp.fc2.weight", (W, 4 * W)),
+                       ("mlp.fc2.bias", (W,))):
+            o[p + k] = shp
+    o["video_model.norm.weight"] = (W,)
+    o["video_model.norm.bias"] = (W,)
+    o["txt_proj.1.weight"] = (E, Wt)
+    o["txt_proj.1.bias"] = (E,)
+    o["vid_proj.0.weight"] = (E, W)
+    o["vid_proj.0.bias"] = (E,)
+    o["pred_model.type_embed"] = (1, 2, Ws)
+    for i in range(a["sort_depth"]):
+        p = f"pred_model.blocks.{i}."
+        for k, shp in (("norm1.weight", (Ws,)), ("norm1.bias", (Ws,)), ("attn.qkv.weight", (3 * Ws, Ws)), ("attn.qkv.bias", (3 * Ws,)),
+                       ("attn.proj.weight", (Ws, Ws)), ("attn.proj.bias", (Ws,)), ("norm2.weight", (Ws,)), ("norm2.bias", (Ws,)),
+                       ("mlp.fc1.weight", (4 * Ws, Ws)), ("mlp.fc1.bias", (4 * Ws,)), ("mlp.fc2.weight", (Ws, 4 * Ws)),
+                       ("mlp.fc2.bias", (Ws,))):
+            o[p + k] = shp
+    o["pred_model.norm.weight"] = (Ws,)
+    o["pred_model.norm.bias"] = (Ws,)
+    o["pred_model.head.weight"] = (a["n_trans"], Ws)
+    o["pred_model.head.bias"] = (a["n_trans"],)
+    return o
+
+
 def patches_per_frame(arch) -> int:
     return (arch["image"] // arch["patch"]) ** 2
 
@@ -54,6 +125,8 @@ def n_keep(arch) -> int:
 
 
 def param_shapes(arch) -> "OrderedDict[str, Tuple[int, ...]]":
+    if arch.get("family") == "v1":
+        return param_shapes_v1(arch)
     W, E, Wt, p = arch["width"], arch["embed"], arch["text_width"], arch["patch"]
     o: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     o["text_positional_embedding"] = (arch["context"], Wt)
@@ -131,8 +204,10 @@ def param_shapes(arch) -> "OrderedDict[str, Tuple[int, ...]]":
 
 def is_mfma_weight(name: str, shape) -> bool:
     """Parameters consumed by the bf16 MFMA GEMMs (they get bf16 shadows, plain and transposed)."""
-    if name in ("video_model.proj", "video_model.conv1.weight"):
+    if name in ("video_model.proj", "video_model.conv1.weight", "video_model.patch_embed.proj.weight"):
         return True
+    if name in ("txt_proj.1.weight", "vid_proj.0.weight"):  # v1 projections of [N, W] rows: the small fp32 kernel
+        return False
     if name.startswith("pred_model.head"):
         return False
     return len(shape) == 2 and name.endswith(("weight", "in_proj_weight")) and "embedding" not in name
@@ -143,7 +218,10 @@ GROUP_HPARAMS = ((1e-4, 0.05), (1e-4, 0.0), (1e-7, 0.05), (1e-7, 0.0))
 
 
 def param_group_of(name: str, arch) -> int:
-    """0 new-decay, 1 new-nodecay, 2 clip-decay, 3 clip-nodecay, -1 frozen (requires_grad False)."""
+    """0 new-decay, 1 new-nodecay, 2 clip-decay, 3 clip-nodecay, -1 frozen (requires_grad False).
+    v1: ONE group, every parameter (v1/train_dist_TVTS.py:68-69, configs/dist-yt-pt.json: AdamW lr 1e-4, weight_decay 0)."""
+    if arch.get("family") == "v1":
+        return 0
     no_decay = ["bias", "LayerNorm", "ln_", "norm"]
     if arch["name"] == "H_14":
         no_decay += ["ls_", "LayerScale"]

@@ -56,6 +56,7 @@ struct AttnGeom {
     float scale2;           // dh^-0.5 * log2(e)
     float scale;            // dh^-0.5
     int ablate;             // dev knob (TVTS_ATTN_ABLATE): 1 skip phase A, 2 skip phase B, 4 skip global loads
+    const int* kv_len;      // FULL only, optional: valid keys per sequence (keys >= kv_len[b] are padding and masked)
 };
 
 struct Grp { int b, h, sub, nq, nk; };
@@ -76,7 +77,10 @@ __device__ __forceinline__ Grp decode(const AttnGeom& g, int gid) {
     if (MODE == MODE_SPACE) { r.sub = gid % g.T; r.b = gid / g.T; r.nq = g.n; r.nk = g.n + 1; }
     else if (MODE == MODE_TIME) { r.sub = gid % g.n; r.b = gid / g.n; r.nq = g.T; r.nk = g.T + 1; }
     else if (MODE == MODE_CLS) { r.sub = 0; r.b = gid; r.nq = 1; r.nk = g.S; }
-    else { r.sub = 0; r.b = gid; r.nq = g.S; r.nk = g.S; }
+    else {
+        r.sub = 0; r.b = gid; r.nq = g.S; r.nk = g.S;
+        if (g.kv_len) { const int l = g.kv_len[gid]; r.nk = l < 1 ? 1 : (l < g.S ? l : g.S); }
+    }
     return r;
 }
 // token row of query i / key j of a group
@@ -1809,7 +1813,7 @@ static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int 
     if (B <= 0 || heads <= 0 || S <= 0 || ld % 8) return TVTS_EINVAL;
     if ((mode == MODE_SPACE || mode == MODE_TIME) && (T <= 0 || n <= 0 || S != 1 + T * n)) return TVTS_EINVAL;
     if (mode < MODE_FULL || mode > MODE_CLS) return TVTS_EINVAL;
-    g.B = B; g.heads = heads; g.S = S; g.T = T; g.n = n; g.causal = causal; g.ld = ld; g.W = heads * DH;
+    g.B = B; g.heads = heads; g.S = S; g.T = T; g.n = n; g.causal = causal; g.ld = ld; g.W = heads * DH; g.kv_len = nullptr;
     g.scale = 1.0f / sqrtf((float)DH);
     g.scale2 = g.scale * 1.4426950408889634f;
     static int abl = -1;
@@ -1850,12 +1854,13 @@ static int items_k(const AttnGeom& g, int mode) {
     } while (0)
 
 // out[rows, ldo] (heads merged, the layout the output projection consumes), lse2[rows, heads]
-extern "C" int ABI(fwd)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
-                             void* out, int ldo, float* lse2, hipStream_t stream) {
+static int fwd_impl(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const int* kv_len,
+                    void* out, int ldo, float* lse2, hipStream_t stream) {
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
-    if (ldo % 4) return TVTS_EINVAL;
+    if (ldo % 4 || (kv_len && mode != MODE_FULL)) return TVTS_EINVAL;
+    g.kv_len = kv_len;
     if (g_shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
         const int nq = mode == MODE_SPACE ? g.n : g.S;
         const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : g.B * g.heads;
@@ -1873,6 +1878,18 @@ extern "C" int ABI(fwd)(int mode, const void* qkv, int ld, int B, int heads, int
     return TVTS_OK;
 }
 
+extern "C" int ABI(fwd)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+                             void* out, int ldo, float* lse2, hipStream_t stream) {
+    return fwd_impl(mode, qkv, ld, B, heads, S, T, n, causal, nullptr, out, ldo, lse2, stream);
+}
+// FULL attention over sequences padded to S: keys at positions >= kv_len[b] are masked out (the attention_mask of the v1
+// text tower, transformers DistilBERT MultiHeadSelfAttention); kv_len is a device int32[B]
+extern "C" int ABI(fwd_len)(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, void* out, int ldo,
+                                 float* lse2, hipStream_t stream) {
+    if (!kv_len) return TVTS_EINVAL;
+    return fwd_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, out, ldo, lse2, stream);
+}
+
 extern "C" int ABI(delta)(const void* dO, int lddo, const void* O, int ldo, int rows, int heads, float* delta,
                                hipStream_t stream) {
     if (rows <= 0 || heads <= 0 || lddo % 8 || ldo % 8) return TVTS_EINVAL;
@@ -1883,13 +1900,14 @@ extern "C" int ABI(delta)(const void* dO, int lddo, const void* O, int ldo, int 
     return TVTS_OK;
 }
 
-extern "C" int ABI(bwd_dq)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
-                                const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
-                                hipStream_t stream) {
+static int bwd_dq_impl(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const int* kv_len,
+                       const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
+                       hipStream_t stream) {
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     if (lddo % 8 || lddq % 4) return TVTS_EINVAL;
+    g.kv_len = kv_len;
     if (g_shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
         const int nq = mode == MODE_SPACE ? g.n : g.S;
         const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : g.B * g.heads;
@@ -1909,15 +1927,22 @@ extern "C" int ABI(bwd_dq)(int mode, const void* qkv, int ld, int B, int heads, 
     return TVTS_OK;
 }
 
+extern "C" int ABI(bwd_dq)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+                                const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
+                                hipStream_t stream) {
+    return bwd_dq_impl(mode, qkv, ld, B, heads, S, T, n, causal, nullptr, dO, lddo, lse2, delta, dqkv, lddq, stream);
+}
+
 // cls_acc: fp32 [B, heads, 3, dh] (dK | dV | dQ of the CLS token), zeroed by the caller before the SPACE/TIME pass, consumed by
 // tvts_attn_cls_finalize afterwards (unused for FULL).
-extern "C" int ABI(bwd_dkv)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
-                                 const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
-                                 float* cls_acc, hipStream_t stream) {
+static int bwd_dkv_impl(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const int* kv_len,
+                        const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
+                        float* cls_acc, hipStream_t stream) {
     AttnGeom g;
     if (mode == MODE_CLS) return TVTS_EINVAL;  // the CLS query is folded into the SPACE/TIME pass
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
+    g.kv_len = kv_len;
     if (lddo % 8 || lddq % 4) return TVTS_EINVAL;
     if ((mode == MODE_SPACE || mode == MODE_TIME) && !cls_acc) return TVTS_EINVAL;
     if (g_shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
@@ -1946,6 +1971,24 @@ extern "C" int ABI(bwd_dkv)(int mode, const void* qkv, int ld, int B, int heads,
     return TVTS_OK;
 }
 
+extern "C" int ABI(bwd_dkv)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+                                 const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
+                                 float* cls_acc, hipStream_t stream) {
+    return bwd_dkv_impl(mode, qkv, ld, B, heads, S, T, n, causal, nullptr, dO, lddo, lse2, delta, dqkv, lddq, cls_acc, stream);
+}
+// whole backward of FULL attention with padded keys masked (see fwd_len).  The dK / dV rows of the padded positions are not
+// written: the caller zeroes dqkv beforehand (their true gradient is zero).
+extern "C" int ABI(bwd_len)(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,
+                                 const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq,
+                                 hipStream_t stream) {
+    if (!kv_len || lddo % 8 || ldo % 8 || lddq % 4) return TVTS_EINVAL;
+    int rc = ABI(delta)(dO, lddo, O, ldo, B * S, heads, delta, stream);
+    if (rc) return rc;
+    rc = bwd_dq_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, dO, lddo, lse2, delta, dqkv, lddq, stream);
+    if (rc) return rc;
+    return bwd_dkv_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, dO, lddo, lse2, delta, dqkv, lddq, nullptr, stream);
+}
+
 extern "C" int ABI(cls_finalize)(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq,
                                       hipStream_t stream) {
     const int total = B * heads * 3 * DH;
@@ -1953,6 +1996,11 @@ extern "C" int ABI(cls_finalize)(const float* cls_acc, int B, int heads, int S, 
                        heads * DH, 0, (bf16*)dqkv, lddq);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
+}
+
+static __global__ void zero_f32_kernel(float* __restrict__ p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
 }
 
 // Whole backward of one attention site: D = rowsum(dO*O), dQ, dK, dV (and, for the divided space / time geometries,
@@ -1970,7 +2018,10 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
     const bool divided = mode == MODE_SPACE || mode == MODE_TIME;
     if (divided) {
         if (!cls_acc) return TVTS_EINVAL;
-        if (hipMemsetAsync(cls_acc, 0, (size_t)B * heads * 3 * DH * sizeof(float), stream) != hipSuccess) return TVTS_EINVAL;
+        // a kernel, not hipMemsetAsync: captured memset nodes did not reliably zero this buffer on hipGraph replay (ROCm 7.x:
+        // the second and later replays of the captured training step produced garbage CLS gradients, tools/dbg/graph_vs_eager.py)
+        const int nz = B * heads * 3 * DH;
+        hipLaunchKernelGGL(zero_f32_kernel, dim3(ceil_div(nz, 256)), dim3(256), 0, stream, cls_acc, nz);
     }
     const bool fused_space = g_fused && g_use_tr && mode == MODE_SPACE && n + 1 <= FUSED_MAX_TILES * 16;
     const bool fused_time = g_fused && g_use_tr && mode == MODE_TIME && T + 1 <= 32;

@@ -65,6 +65,38 @@ extern "C" int tvts_patch_gather(const float* video, const int* keep, int B, int
     return TVTS_OK;
 }
 
+// v1 (TVTS) tubelet embedding: Conv3d(3, W, kernel = stride = (tb, p, p)) over [B, C, T, H, W] (v1/model/video_encoder.py:78-99)
+// as an im2col product over the KEPT patches of every tube only.  Row (b, tube, i) = patch keep[b, tube, i] of tube `tube`,
+// columns in the Conv3d weight's (c, t, py, px) order: K = 3 * tb * p * p.  keep differs from tube to tube here
+// (v1/data_loader/YTTemporal_dataset.py:211-215); video arrives as [B, T, 3, H, W] (the model permutes it itself, :179).
+__global__ __launch_bounds__(256) void patch_gather_tube_kernel(const float* __restrict__ video, const int* __restrict__ keep,
+                                                                int B, int tubes, int tb, int n, int img, int p,
+                                                                bf16* __restrict__ out, int ldo) {
+    const int pp = p * p, K = 3 * tb * pp;
+    const int row = blockIdx.x;  // (b, tube, i)
+    const int i = row % n, tu = (row / n) % tubes, b = row / (n * tubes);
+    const int g = img / p;
+    const int pi = keep[(size_t)(b * tubes + tu) * n + i];
+    const int gy = pi / g, gx = pi % g;
+    const int T = tubes * tb;
+    for (int c8 = threadIdx.x * 8; c8 < K; c8 += 256 * 8) {
+        const int ch = c8 / (tb * pp), r1 = c8 % (tb * pp), t = r1 / pp, rem = r1 % pp, py = rem / p, px = rem % p;  // px % 8 == 0
+        const float* src = video + ((((size_t)(b * T + tu * tb + t) * 3 + ch) * img + gy * p + py) * img + gx * p + px);
+        const f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + 4);
+        bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)c[0], (bf16)c[1], (bf16)c[2], (bf16)c[3]};
+        *(bf16x8*)(out + (size_t)row * ldo + c8) = o;
+    }
+}
+extern "C" int tvts_patch_gather_tube(const float* video, const int* keep, int B, int tubes, int tubelet, int n, int img,
+                                      int patch, void* out, int ldo, hipStream_t stream) {
+    if (B <= 0 || tubes <= 0 || tubelet <= 0 || n <= 0 || patch <= 0 || img % patch || patch % 8 || ldo != 3 * tubelet * patch * patch)
+        return TVTS_EINVAL;
+    hipLaunchKernelGGL(patch_gather_tube_kernel, dim3(B * tubes * n), dim3(256), 0, stream, video, keep, B, tubes, tubelet, n, img,
+                       patch, (bf16*)out, ldo);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
 // uint8 wire format: the frames arrive as the decoder leaves them -- uint8, H x W x 3 interleaved, already
 // resized on the host -- and the rest of the reference's transform chain runs here, fused into the tube-mask gather:
 // crop (video_transform.CenterCrop / RandomCrop = an offset per sample), ClipToTensor (float32 / 255) and Normalize
@@ -109,7 +141,8 @@ extern "C" int tvts_patch_gather_u8(const unsigned char* frames, int H0, int W0,
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch, int ldp,
                                                            const float* __restrict__ cls, const float* __restrict__ pos,
                                                            const float* __restrict__ temporal, const int* __restrict__ keep,
-                                                           int B, int T, int n, int W, float* __restrict__ tok, int ldt) {
+                                                           int keep_per_frame, int B, int T, int n, int W,
+                                                           float* __restrict__ tok, int ldt) {
     const int S = 1 + T * n;
     const int row = blockIdx.x;  // b*S + s
     const int b = row / S, s = row % S;
@@ -120,25 +153,28 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restri
         } else {
             const int f = (s - 1) / n, i = (s - 1) % n;
             v = *(const f32x4*)(patch + (size_t)((b * T + f) * n + i) * ldp + c) +
-                *(const f32x4*)(pos + (size_t)(1 + keep[b * n + i]) * W + c) + *(const f32x4*)(temporal + (size_t)f * W + c);
+                *(const f32x4*)(pos + (size_t)(1 + keep[keep_per_frame ? (b * T + f) * n + i : b * n + i]) * W + c) +
+                *(const f32x4*)(temporal + (size_t)f * W + c);
         }
         *(f32x4*)(tok + (size_t)row * ldt + c) = v;
     }
 }
 
 extern "C" int tvts_vit_assemble(const float* patch, int ldp, const float* cls, const float* pos, const float* temporal,
-                                 const int* keep, int B, int T, int n, int W, float* tok, int ldt, hipStream_t stream) {
+                                 const int* keep, int keep_per_frame, int B, int T, int n, int W, float* tok, int ldt,
+                                 hipStream_t stream) {
     if (W % 4 || ldp % 4 || ldt % 4) return TVTS_EINVAL;
     hipLaunchKernelGGL(vit_assemble_kernel, dim3(B * (1 + T * n)), dim3(256), 0, stream, patch, ldp, cls, pos, temporal,
-                       keep, B, T, n, W, tok, ldt);
+                       keep, keep_per_frame, B, T, n, W, tok, ldt);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
 
 // one block per (b, f): d_patch rows (bf16, compact im2col row order), dpos scatter, dtemporal / dcls sums
 __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __restrict__ dtok, int ldt,
-                                                               const int* __restrict__ keep, int B, int T, int n, int W,
-                                                               bf16* __restrict__ dpatch, int ldp, float* __restrict__ dcls,
+                                                               const int* __restrict__ keep, int keep_per_frame, int B, int T,
+                                                               int n, int W, bf16* __restrict__ dpatch, int ldp,
+                                                               float* __restrict__ dcls,
                                                                float* __restrict__ dpos, float* __restrict__ dtemporal) {
     const int S = 1 + T * n;
     const int b = blockIdx.x / T, f = blockIdx.x % T;
@@ -147,7 +183,7 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __re
         for (int i = 0; i < n; ++i) {
             const float v = dtok[(size_t)(b * S + 1 + f * n + i) * ldt + c];
             dpatch[(size_t)((b * T + f) * n + i) * ldp + c] = (bf16)v;
-            atomicAdd(dpos + (size_t)(1 + keep[b * n + i]) * W + c, v);
+            atomicAdd(dpos + (size_t)(1 + keep[keep_per_frame ? (b * T + f) * n + i : b * n + i]) * W + c, v);
             ts += v;
         }
         atomicAdd(dtemporal + (size_t)f * W + c, ts);
@@ -159,9 +195,9 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __re
     }
 }
 
-extern "C" int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int B, int T, int n, int W, void* dpatch,
-                                     int ldp, float* dcls, float* dpos, float* dtemporal, hipStream_t stream) {
-    hipLaunchKernelGGL(vit_assemble_bwd_kernel, dim3(B * T), dim3(256), 0, stream, dtok, ldt, keep, B, T, n, W,
+extern "C" int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int keep_per_frame, int B, int T, int n, int W,
+                                     void* dpatch, int ldp, float* dcls, float* dpos, float* dtemporal, hipStream_t stream) {
+    hipLaunchKernelGGL(vit_assemble_bwd_kernel, dim3(B * T), dim3(256), 0, stream, dtok, ldt, keep, keep_per_frame, B, T, n, W,
                        (bf16*)dpatch, ldp, dcls, dpos, dtemporal);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
@@ -309,6 +345,21 @@ __global__ void rows_gather_kernel(const float* __restrict__ src, int lds_, cons
 extern "C" int tvts_rows_gather(const float* src, int ld_src, const int* rows, int R, int W, float* dst, int ld_dst,
                                 int scatter_add, hipStream_t stream) {
     hipLaunchKernelGGL(rows_gather_kernel, dim3(R), dim3(256), 0, stream, src, ld_src, rows, R, W, dst, ld_dst, scatter_add);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- ReLU (v1 txt_proj)
+// y = max(x, 0) / dx = dy * (x > 0): the nn.ReLU in front of the v1 text projection (v1/model/model_dist_TVTS.py:65-68)
+__global__ void relu_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    out[i] = dy ? (v > 0.f ? dy[i] : 0.f) : (v > 0.f ? v : 0.f);
+}
+extern "C" int tvts_relu(const float* x, const float* dy, float* out, long n, hipStream_t stream) {
+    if (n <= 0) return TVTS_EINVAL;
+    hipLaunchKernelGGL(relu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, dy, out, n);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

@@ -75,11 +75,75 @@ __device__ __forceinline__ void tile_origin256(const GemmNT& g, int t, int gc, i
 // Stages form one flat sequence over the block's persistent tile list.  LDS: 2 x 64 KiB stages + 8 x 4 KiB
 // XOR-swizzled epilogue patches = 160 KiB exactly.
 // ------------------------------------------------------------------------------------------------
+// read-out half of the epilogue: the wave-private patch holds a 16-row x 64-column fp32 slab of the output tile (rows
+// m_base .. m_base + 15, columns nb .. nb + 63; 16-B chunk c of row r stored at chunk c ^ r, bias already added); it leaves as
+// whole row segments -- every store / residual load / gate load instruction covers full 128-B (bf16) or 256-B (fp32) pieces
+// of output rows -- with the activation (+ pre-activation side output), the activation-gradient gate and the fp32 residual.
+template <int ACT, int GATE>
+__device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch, int m_base, int nb, int lane) {
+    if (g.out_f32) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = lane + 64 * t, r = idx >> 4, c16 = idx & 15;
+            f32x4 v = *(const f32x4*)(patch + r * 256 + ((c16 ^ r) << 4));
+            const int m = m_base + r, n = nb + c16 * 4;
+            if (m >= g.M || n >= g.N) continue;
+            if (ACT != ACT_NONE) {
+                if (g.preact) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
+            }
+            if (GATE != ACT_NONE) {
+                const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
+            }
+            if (g.residual) v += *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
+            *(f32x4*)((float*)g.out + (size_t)m * g.ldc + n) = v;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int idx = lane + 64 * t, r = idx >> 3, c8 = idx & 7;
+            const f32x4 v0 = *(const f32x4*)(patch + r * 256 + (((2 * c8) ^ r) << 4));
+            const f32x4 v1 = *(const f32x4*)(patch + r * 256 + (((2 * c8 + 1) ^ r) << 4));
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const int m = m_base + r, n = nb + c8 * 8;
+            if (m >= g.M || n >= g.N) continue;
+            if (ACT != ACT_NONE) {
+                if (g.preact) {
+                    bf16x8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (bf16)v[e];
+                    *(bf16x8*)(g.preact + (size_t)m * g.ldp + n) = h;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], ACT);
+            }
+            if (GATE != ACT_NONE) {
+                const bf16x8 h = *(const bf16x8*)(g.gate_h + (size_t)m * g.ldh + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= act_bwd((float)h[e], GATE);
+            }
+            if (g.residual) {
+                const f32x4 r0 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n), r1 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+            *(bf16x8*)((bf16*)g.out + (size_t)m * g.ldc + n) = o;
+        }
+    }
+}
+
+// epilogue of a 128x64 wave sub-tile held as 8 x 4 accumulator tiles of v_mfma_f32_16x16x32 (lane: row m = lane & 15 of MFMA
+// row-tile i, 4 consecutive n at 16 j + 4 (lane >> 4)): one 16-row slab per pass through the patch
 template <int ACT, int GATE>
 __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn,
                                                   int lane, char* patch, float scale = 1.0f,
                                                   const float* row_scale = nullptr) {
-    // patch: 16 rows x 256 B (64 fp32), 16-B chunk c of row r stored at chunk c ^ r
     const int nb = n0 + wn * 64;
     const int li = lane & 15, gq = lane >> 4;
     f32x4 bias4[4];
@@ -100,61 +164,7 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
             *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i] * sc + bias4[j];
             acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if (g.out_f32) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int idx = lane + 64 * t, r = idx >> 4, c16 = idx & 15;
-                f32x4 v = *(const f32x4*)(patch + r * 256 + ((c16 ^ r) << 4));
-                const int m = m0 + wm * 128 + i * 16 + r, n = nb + c16 * 4;
-                if (m >= g.M || n >= g.N) continue;
-                if (ACT != ACT_NONE) {
-                    if (g.preact) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
-                }
-                if (GATE != ACT_NONE) {
-                    const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
-                }
-                if (g.residual) v += *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
-                *(f32x4*)((float*)g.out + (size_t)m * g.ldc + n) = v;
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int idx = lane + 64 * t, r = idx >> 3, c8 = idx & 7;
-                const f32x4 v0 = *(const f32x4*)(patch + r * 256 + (((2 * c8) ^ r) << 4));
-                const f32x4 v1 = *(const f32x4*)(patch + r * 256 + (((2 * c8 + 1) ^ r) << 4));
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                const int m = m0 + wm * 128 + i * 16 + r, n = nb + c8 * 8;
-                if (m >= g.M || n >= g.N) continue;
-                if (ACT != ACT_NONE) {
-                    if (g.preact) {
-                        bf16x8 h;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) h[e] = (bf16)v[e];
-                        *(bf16x8*)(g.preact + (size_t)m * g.ldp + n) = h;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], ACT);
-                }
-                if (GATE != ACT_NONE) {
-                    const bf16x8 h = *(const bf16x8*)(g.gate_h + (size_t)m * g.ldh + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= act_bwd((float)h[e], GATE);
-                }
-                if (g.residual) {
-                    const f32x4 r0 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n), r1 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-                }
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                *(bf16x8*)((bf16*)g.out + (size_t)m * g.ldc + n) = o;
-            }
-        }
+        patch_readout<ACT, GATE>(g, patch, m0 + wm * 128 + i * 16, nb, lane);
     }
 }
 

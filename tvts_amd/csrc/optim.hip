@@ -211,9 +211,10 @@ __global__ __launch_bounds__(256) void quant_fp8_kernel(const T* __restrict__ x,
             else *(int*)(out + r * ldo + c) = pk[0];
         }
 }
+static __global__ void zero1_kernel(float* p) { *p = 0.f; }
 extern "C" int tvts_amax(const void* x, int is_f32, long ld, int rows, int cols, float* amax, hipStream_t stream) {
     if (rows <= 0 || cols <= 0 || cols % (is_f32 ? 4 : 8) || ld % (is_f32 ? 4 : 8)) return TVTS_EINVAL;
-    if (hipMemsetAsync(amax, 0, sizeof(float), stream) != hipSuccess) return TVTS_EINVAL;
+    hipLaunchKernelGGL(zero1_kernel, dim3(1), dim3(1), 0, stream, amax);  // a kernel, not a memset node (see attention.hip)
     const int blocks = rows < 1024 ? rows : 1024;
     if (is_f32) hipLaunchKernelGGL(amax_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, ld, rows, cols, amax);
     else hipLaunchKernelGGL(amax_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, ld, rows, cols, amax);

@@ -67,7 +67,8 @@ class ParamStore:
         self.n_tiles = len(tiles)
         self.tile_table = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
         # patch-embedding GEMM: K = 3*p*p must be a multiple of 64 for the MFMA kernel; H/14 (588) gets a zero-padded copy
-        kc = 3 * arch["patch"] ** 2
+        self.conv_name = "video_model.patch_embed.proj.weight" if arch.get("family") == "v1" else "video_model.conv1.weight"
+        kc = 3 * arch.get("tubelet", 1) * arch["patch"] ** 2
         self.conv_k = kc
         self.conv_kpad = -(-kc // 64) * 64
         self.conv_pad = (torch.zeros(arch["width"], self.conv_kpad, dtype=torch.bfloat16, device=device)
@@ -120,7 +121,7 @@ class ParamStore:
         if self.n_tiles:
             K.transpose_batched(self.shadow, self.shadow_t, self.tile_table, self.n_tiles)
         if self.conv_pad is not None:
-            K.pad_rows_bf16(self.w("video_model.conv1.weight"), self.conv_pad)
+            K.pad_rows_bf16(self.w(self.conv_name), self.conv_pad)
         if self.arch.get("fp8"):  # BASELINE config 4: e4m3 copies (+ per-tensor scales) of the ViT blocks' linear weights
             for name in self.fp8_names:
                 if name not in self.w8:
@@ -133,7 +134,7 @@ class ParamStore:
 
     def w_conv(self) -> torch.Tensor:
         """bf16 patch-embedding weight [W, K padded to 64]."""
-        return self.conv_pad if self.conv_pad is not None else self.w("video_model.conv1.weight")
+        return self.conv_pad if self.conv_pad is not None else self.w(self.conv_name)
 
 
 _TEXT_NAMES = dict(ln1="ln_1", qkv_w="attn.in_proj_weight", qkv_b="attn.in_proj_bias", o_w="attn.out_proj.weight",
@@ -153,9 +154,10 @@ class Engine:
             raise ValueError(f"unknown tail {a['tail']!r}")
         self.dh = a["width"] // a["heads"]            # ViT head dim: 64 (B/32, B/16) or 80 (H/14)
         self.dh_text = a["text_width"] // a["text_heads"]
-        self.dh_sort = a["embed"] // a["sort_heads"]
+        self.sort_width = a.get("sort_width", a["embed"])  # v2: the sort head works on the projected tokens (E); v1: on the ViT width
+        self.dh_sort = self.sort_width // a["sort_heads"]
         for d, w, h in ((self.dh, a["width"], a["heads"]), (self.dh_text, a["text_width"], a["text_heads"]),
-                        (self.dh_sort, a["embed"], a["sort_heads"])):
+                        (self.dh_sort, self.sort_width, a["sort_heads"])):
             if d not in (64, 80) or d * h != w:
                 raise NotImplementedError(f"attention kernels are built for head dim 64 and 80, not {w}/{h}")
         self.pooled_tail = a["tail"] == "pooled_and_patches"
@@ -495,7 +497,7 @@ class Engine:
     # ------------------------------------------------------------------ sort head
     def sort_forward(self, out, text_before, B, S, NT):
         a = self.arch
-        E, hs = a["embed"], a["sort_heads"]
+        E, hs = self.sort_width, a["sort_heads"]
         off = 1 if self.pooled_tail else 0  # H/14 hands the sort head the patch tokens without CLS
         Sv = S - off
         So = Sv + NT
@@ -519,7 +521,7 @@ class Engine:
     def sort_backward(self, dpred, B, S, NT):
         """-> fp32 grad of the sort-head input xs [B*So, E]."""
         a, B_ = self.arch, self.buf
-        E, hs, C = a["embed"], a["sort_heads"], a["n_trans"]
+        E, hs, C = self.sort_width, a["sort_heads"], a["n_trans"]
         So = S - (1 if self.pooled_tail else 0) + NT
         Mo, R = B * So, B * NT
         nf = B_["srt.nf"]

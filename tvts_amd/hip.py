@@ -215,6 +215,22 @@ def attn_fwd(mode, qkv, out, lse2, *, B, heads, S, T=0, n=0, causal=False, head_
     _chk(rc, "tvts_attn_fwd")
 
 
+def attn_fwd_len(qkv, kv_len, out, lse2, *, B, heads, S, head_dim=64):
+    """FULL attention, keys at positions >= kv_len[b] masked (padding)."""
+    lib = _lib.load()
+    assert kv_len.dtype == torch.int32 and kv_len.numel() == B
+    _chk(_attn_fn(lib, "fwd_len", head_dim)(_p(qkv), _ld(qkv), B, heads, S, _p(kv_len), _p(out), _ld(out), _p(lse2), _stream()),
+         "tvts_attn_fwd_len")
+
+
+def attn_bwd_len(qkv, kv_len, dO, O, lse2, delta, dqkv, *, B, heads, S, head_dim=64):
+    """backward of attn_fwd_len into dqkv (zeroed here first: the padded positions' dK / dV rows are not written)."""
+    lib = _lib.load()
+    dqkv.zero_()
+    _chk(_attn_fn(lib, "bwd_len", head_dim)(_p(qkv), _ld(qkv), B, heads, S, _p(kv_len), _p(dO), _ld(dO), _p(O), _ld(O), _p(lse2),
+                                            _p(delta), _p(dqkv), _ld(dqkv), _stream()), "tvts_attn_bwd_len")
+
+
 def attn_delta(dO, O, delta, *, rows, heads, head_dim=64):
     lib = _lib.load()
     _chk(_attn_fn(lib, "delta", head_dim)(_p(dO), _ld(dO), _p(O), _ld(O), rows, heads, _p(delta), _stream()), "tvts_attn_delta")
@@ -297,15 +313,24 @@ def tube_mask(seed, first_sample, B, ppf, n_keep, out=None, device=None):
 
 
 def vit_assemble(patch, cls, pos, temporal, keep, tok, *, B, T, n):
+    """keep [B, n] (one tube mask per clip, v2) or [B, T, n] (one per frame / tubelet, v1)"""
     lib = _lib.load()
-    _chk(lib.tvts_vit_assemble(_p(patch), _ld(patch), _p(cls), _p(pos), _p(temporal), _p(keep), B, T, n, tok.shape[1],
-                               _p(tok), _ld(tok), _stream()), "tvts_vit_assemble")
+    _chk(lib.tvts_vit_assemble(_p(patch), _ld(patch), _p(cls), _p(pos), _p(temporal), _p(keep), 1 if keep.dim() == 3 else 0,
+                               B, T, n, tok.shape[1], _p(tok), _ld(tok), _stream()), "tvts_vit_assemble")
 
 
 def vit_assemble_bwd(dtok, keep, dpatch, dcls, dpos, dtemporal, *, B, T, n):
     lib = _lib.load()
-    _chk(lib.tvts_vit_assemble_bwd(_p(dtok), _ld(dtok), _p(keep), B, T, n, dtok.shape[1], _p(dpatch), _ld(dpatch),
-                                   _p(dcls), _p(dpos), _p(dtemporal), _stream()), "tvts_vit_assemble_bwd")
+    _chk(lib.tvts_vit_assemble_bwd(_p(dtok), _ld(dtok), _p(keep), 1 if keep.dim() == 3 else 0, B, T, n, dtok.shape[1],
+                                   _p(dpatch), _ld(dpatch), _p(dcls), _p(dpos), _p(dtemporal), _stream()), "tvts_vit_assemble_bwd")
+
+
+def patch_gather_tube(video, keep, out, *, B, tubes, tubelet, n, img, patch):
+    """v1 tubelet im2col: video fp32 [B, T, 3, img, img], keep int32 [B, tubes, n] -> out bf16 [B*tubes*n, 3*tubelet*patch^2]"""
+    lib = _lib.load()
+    assert video.dtype == torch.float32 and keep.dtype == torch.int32 and keep.dim() == 3
+    _chk(lib.tvts_patch_gather_tube(_p(video), _p(keep), B, tubes, tubelet, n, img, patch, _p(out), _ld(out), _stream()),
+         "tvts_patch_gather_tube")
 
 
 def text_embed(ids, emb, pos, x, *, N, L):
@@ -342,6 +367,12 @@ def sort_assemble_bwd(dxs, dvid, dout, dtype, *, B, S, off, Sv, NT):
     E = dout.shape[1]
     _chk(lib.tvts_sort_assemble_bwd(_p(dxs), _ld(dxs) if dxs is not None else 0, B, S, off, Sv, NT, _p(dvid), E,
                                     _p(dout), _ld(dout), _p(dtype), _stream()), "tvts_sort_assemble_bwd")
+
+
+def relu(x, out, dy=None):
+    """out = relu(x), or with dy: out = dy * (x > 0)"""
+    lib = _lib.load()
+    _chk(lib.tvts_relu(_p(x), _p(dy), _p(out), x.numel(), _stream()), "tvts_relu")
 
 
 def rows_gather(src, rows, dst, *, scatter_add=False):

@@ -107,6 +107,8 @@ class _ModelFn(torch.autograd.Function):
 
 class TVTSv2Base(nn.Module):
     ARCH_NAME = None
+    ENGINE = Engine
+    INIT = staticmethod(reference_init_)
 
     def __init__(self, args, load_checkpoint=None, arch=None, init_seed=0):
         super().__init__()
@@ -116,8 +118,8 @@ class TVTSv2Base(nn.Module):
         self.n_trans = self.arch["n_trans"]
         dev = _require_gpu(getattr(args, "local_rank", 0))
         self.store = ParamStore(self.arch, dev)
-        self.engine = Engine(self.store)
-        reference_init_(self.store, init_seed)
+        self.engine = self.ENGINE(self.store)
+        self.INIT(self.store, init_seed)
         self._register_tree()
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         self._versions = None

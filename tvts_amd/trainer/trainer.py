@@ -18,7 +18,7 @@ from ..base import Multi_BaseTrainer_dist
 from ..model._common import sim_matrix  # noqa: F401  (the reference re-exports it at module scope)
 from ..step import StepRunner
 
-__all__ = ["AllGather", "AllGather_multi", "Trainer_TVTSv2_B_32", "Trainer_TVTSv2_B_16", "Trainer_TVTSv2_H_14"]
+__all__ = ["AllGather", "AllGather_multi", "Trainer_TVTSv2_B_32", "Trainer_TVTSv2_B_16", "Trainer_TVTSv2_H_14", "Trainer_TVTS"]
 
 
 class AllGather_multi(torch.autograd.Function):
@@ -51,6 +51,7 @@ class AllGather(AllGather_multi):
 
 class _TrainerBase(Multi_BaseTrainer_dist):
     TRUNCATE = True
+    LOG_LINE = "Train Epoch: {} dl{} {} Loss_ct: {:.6f} Loss_ce: {:.6f} Loss: {:.6f}"  # v2/trainer/trainer.py:505-512
 
     def __init__(self, args, model, loss, metrics, optimizer, config, data_loader, valid_data_loader=None,
                  lr_scheduler=None, len_epoch=None, writer=None, visualizer=None, tokenizer=None,
@@ -134,8 +135,7 @@ class _TrainerBase(Multi_BaseTrainer_dist):
                 loss = float(l1 + l2)  # the reference syncs once per step as well (trainer.py:503)
                 total_loss[dl_idx] += loss
                 if log_now:
-                    self.logger.debug("Train Epoch: {} dl{} {} Loss_ct: {:.6f} Loss_ce: {:.6f} Loss: {:.6f}".format(
-                        epoch, dl_idx, self._progress(batch_idx, dl_idx), float(l1), float(l2), loss))
+                    self.logger.debug(self.LOG_LINE.format(epoch, dl_idx, self._progress(batch_idx, dl_idx), float(l1), float(l2), loss))
             # max_samples_per_epoch is stored and never read by the reference's TVTSv2 trainers (trainer.py:93,387,681):
             # the whole YT loader is iterated, so the per-epoch LR schedule sees the same number of steps here
         log = {f"loss_{dl_idx}": total_loss[dl_idx] / self.len_epoch for dl_idx in range(len(self.data_loader))}
@@ -225,3 +225,35 @@ class Trainer_TVTSv2_B_16(_TrainerBase):
 
 class Trainer_TVTSv2_H_14(_TrainerBase):
     TRUNCATE = False
+
+
+class Trainer_TVTS(_TrainerBase):
+    """v1/trainer/trainer.py:40-310: the same epoch loop over the v1 model.  Differences kept from the
+    reference: the epoch follows the LONGEST loader (:50-54), captions go through the Hugging Face tokenizer call
+    ``tokenizer(text, return_tensors='pt', padding=True, truncation=True, max_length=50)`` (:121-131), the debug line says
+    Loss_align / Loss_sort (:164-172), and the learning rate is recomputed from the base rate at every epoch end --
+    lr = base_lr * 0.1 ** (number of milestones reached) (:80-91) -- instead of being decayed in place."""
+    LOG_LINE = "Train Epoch: {} dl{} {} Loss_align: {:.6f} Loss_sort: {:.6f} Loss: {:.6f}"
+
+    def __init__(self, args, model, loss, metrics, optimizer, config, data_loader, valid_data_loader=None, lr_scheduler=None,
+                 len_epoch=None, writer=None, visualizer=None, tokenizer=None, max_samples_per_epoch=50000):
+        if len_epoch is None:
+            len_epoch = max(len(x) for x in data_loader)
+        super().__init__(args, model, loss, metrics, optimizer, config, data_loader, valid_data_loader, lr_scheduler, len_epoch,
+                         writer, visualizer, tokenizer, max_samples_per_epoch)
+        self.base_lr = optimizer.state_dict()["param_groups"][0]["lr"]  # v1/base/base_trainer.py:30
+
+    def _adjust_learning_rate(self, optimizer, epoch, args):
+        lr = self.base_lr
+        for milestone in getattr(args, "schedule", []):
+            lr *= 0.1 if epoch >= milestone else 1.0
+        for group in optimizer.param_groups:
+            group["lr"] = lr
+
+    def _tokenize(self, data):
+        if self.tokenizer is not None and not isinstance(data["text"], dict):
+            text_all = []
+            for clip_texts in data["text"]:
+                text_all = text_all + list(clip_texts)
+            data["text"] = self.tokenizer(text_all, return_tensors="pt", padding=True, truncation=True, max_length=50)
+        return data
