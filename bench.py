@@ -40,13 +40,47 @@ def step_flops_per_pair(a, T, caption_len=32, NT=4):
     return fwd, bwd
 
 
+def step_flops_per_pair_v1(a, T, caption_len=32, NT=4):
+    """v1 TVTS: tubelet embedding on kept patches, joint attention over S = 1 + tubes * n tokens, DistilBERT
+    at the padded caption length, sorting head on the 768-wide tokens; no dgrad for the patch embedding."""
+    p, W, E, Wt, Ws = a["patch"], a["width"], a["embed"], a["text_width"], a["sort_width"]
+    tubes = T // a["tubelet"]
+    n = int((a["image"] // p) ** 2 * (1 - a["mask_ratio"]))
+    S, L, Lt = 1 + tubes * n, caption_len, a["text_layers"]
+    So = S + NT
+    patch = 2 * tubes * n * 3 * a["tubelet"] * p * p * W
+    sort = (2 * So * 24 * Ws * Ws + 8 * So * So * Ws + 2 * NT * Ws * a["n_trans"]) if NT > 1 else 0
+    fwd = (patch + a["layers"] * (S * 24 * W * W + 4 * S * S * W) + 2 * W * E
+           + NT * (Lt * (L * (8 * Wt * Wt + 4 * Wt * a["text_ffn"]) + 4 * L * L * Wt) + 2 * Wt * E) + sort)
+    return fwd, 2 * fwd - patch
+
+
 def cpu_baseline_worker(arch_name, T, caption_len, pairs, max_seconds, threads, n_trans=4):
     """The CPU oracle (oracle/tvts_oracle.py, a port) timed on this host: full step incl. HF-AdamW."""
     from oracle import tvts_oracle as O
-    oarch = O.ARCHS[arch_name]
     torch.set_num_threads(threads)
-    P = O.synth_params(oarch, seed=0)
-    batch = O.synth_batch(oarch, B=pairs, T=T, seed=0, caption_len=caption_len, n_trans=n_trans)
+    if arch_name == "v1":
+        from oracle import tvts_v1_oracle as V
+        oarch = V.ARCH
+        P = V.synth_params(oarch, seed=0)
+        batch = V.synth_batch(oarch, B=pairs, T=T, seed=0, caption_len=caption_len, n_trans=n_trans)
+        mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in P.items()}
+
+        class _O:  # the v1 step: one AdamW group, lr 1e-4, weight_decay 0 (v1/configs/dist-yt-pt.json)
+            @staticmethod
+            def train_step(P, batch, oarch, state):
+                state["t"] = state.get("t", 0) + 1
+                leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+                l1, l2, *_ = V.step_losses(leaves, batch, oarch)
+                (l1 + l2).backward()
+                for k in P:
+                    g = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(P[k])
+                    O.hf_adamw_step(P[k], g, mom[k][0], mom[k][1], state["t"], 1e-4, 0.0)
+        O = _O  # noqa: N806
+    else:
+        oarch = O.ARCHS[arch_name]
+        P = O.synth_params(oarch, seed=0)
+        batch = O.synth_batch(oarch, B=pairs, T=T, seed=0, caption_len=caption_len, n_trans=n_trans)
     state = {}
     t0 = time.time()
     O.train_step(P, batch, oarch, state)  # first step (includes allocator warm-up)
@@ -168,8 +202,9 @@ def main():
 
     from tvts_amd import arch as A
     from tvts_amd import hip as K
-    from tvts_amd.data_loader import synth_batch
+    from tvts_amd.data_loader import synth_batch, synth_batch_v1
     from tvts_amd.model._common import TVTSv2Base
+    from tvts_amd.model.model_dist_TVTS import TVTS
     from tvts_amd.optim import FusedHFAdamW
     from tvts_amd.step import StepRunner
 
@@ -179,7 +214,13 @@ def main():
     if args.fp8:
         a["fp8"] = True
     margs = types.SimpleNamespace(local_rank=local_rank, rank=rank, world_size=world)
-    model = TVTSv2Base(margs, arch=a, init_seed=0)
+    v1 = a.get("family") == "v1"
+    if v1:
+        synth_batch = synth_batch_v1
+        hp = ((1e-4, 0.0),) * 4  # one parameter group in the v1 entrypoint (configs/dist-yt-pt.json)
+    else:
+        hp = A.GROUP_HPARAMS
+    model = (TVTS if v1 else TVTSv2Base)(margs, arch=a, init_seed=0)
     groups = [[], [], [], []]
     for name, p in model.named_parameters():
         gi = A.param_group_of(name, a)
@@ -187,8 +228,8 @@ def main():
             p.requires_grad = False
         else:
             groups[gi].append(p)
-    opt = FusedHFAdamW([dict(params=groups[i], lr=A.GROUP_HPARAMS[i][0], weight_decay=A.GROUP_HPARAMS[i][1])
-                        for i in range(4)], model.store, model=model)
+    opt = FusedHFAdamW([dict(params=groups[i], lr=hp[i][0], weight_decay=hp[i][1]) for i in range(4) if groups[i]],
+                       model.store, model=model)
     runner = StepRunner(model, opt)
     B, T = args.batch, args.frames
     dev = model.store.device
@@ -243,15 +284,16 @@ def main():
         dt = float(t[0])
     loss = float(out["loss1"]) + (float(out["loss2"]) if out["loss2"] is not None else 0.0)
 
-    fwd, bwd = step_flops_per_pair(a, T, args.caption_len, args.n_trans)
+    fwd, bwd = (step_flops_per_pair_v1 if v1 else step_flops_per_pair)(a, T, args.caption_len, args.n_trans)
     pairs_per_s = world * B * args.steps / dt
     line = {
         "metric": "video-text pairs/sec/node, TVTSv2 pretrain step", "value": pairs_per_s, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp8 e4m3 forward GEMMs (ViT blocks) + bf16" if args.fp8 else "bf16", "data": "synthetic",
-        "config": {"workload": f"TVTSv2 ViT-{args.arch.replace('_', '/')} {T}-frame 224^2, mask {a['mask_ratio']}, "
-                               f"{args.caption_len}-token captions x{args.n_trans}, full pretrain step (fwd+losses+bwd+HF-AdamW)",
+        "config": {"workload": (f"TVTS v1 ViT-B/16 tubelet 2, {T}-frame 224^2, mask {a['mask_ratio']}, DistilBERT, " if v1 else
+                                f"TVTSv2 ViT-{args.arch.replace('_', '/')} {T}-frame 224^2, mask {a['mask_ratio']}, ")
+                               + f"{args.caption_len}-token captions x{args.n_trans}, full pretrain step (fwd+losses+bwd+HF-AdamW)",
                    "pairs_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
                    "hip_graph": bool(graphs is not None), "step_gflop_per_pair": (fwd + bwd) / 1e9,
                    "final_loss": loss,

@@ -176,7 +176,15 @@ static void (*pick_m32(int act, int gate_act, bool gated))(GemmNT, ExpArgs) {
          : act == ACT_GELU_ERF ? gemm_nt256m32_kernel<2, 0, PRIO> : nullptr;
 }
 
-// variant: 0 production kernel, 1 M32, 2 M32 + setprio around the MFMA groups.  gc < 0: the production column-group rule.
+template <int ABL>
+static void (*pick_abl(int act, int gate_act, bool gated))(GemmNT) {
+    if (gated) return gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, ABL> : gemm_nt256p_kernel<0, 2, false, ABL>;
+    return act == ACT_NONE ? gemm_nt256p_kernel<0, 0, false, ABL> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, false, ABL>
+         : gemm_nt256p_kernel<2, 0, false, ABL>;
+}
+
+// variant: 0 production kernel, 1 M32, 2 M32 + setprio, 10 + ABL: the production kernel with epilogue ablation ABL (1 none, 2 no side
+// loads, 4 no stores, 6 neither).  gc < 0: the production column-group rule.
 extern "C" int tvts_exp_gemm_nt(int variant, int gc, int stagger_phases, int stagger_units, const void* A, int lda, const void* B,
                                 int ldb, int M, int N, int K, const float* bias, const float* residual, int ldr, int act,
                                 void* preact, int ldp, const void* gate_h, int ldh, int gate_act, void* out, int ldc, int out_f32,
@@ -194,10 +202,16 @@ extern "C" int tvts_exp_gemm_nt(int variant, int gc, int stagger_phases, int sta
     const int grid = total_tiles < 256 ? ((total_tiles + 7) / 8) * 8 : 256;
     ExpArgs x{stagger_phases, stagger_units};
     const bool gated = gate_h != nullptr;
-    if (variant == 0) {
-        void (*kern)(GemmNT) = gated ? (gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false> : gemm_nt256p_kernel<0, 2, false>)
-                             : act == ACT_NONE ? gemm_nt256p_kernel<0, 0, false> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, false>
-                             : gemm_nt256p_kernel<2, 0, false>;
+    if (variant == 0 || variant >= 10) {
+        void (*kern)(GemmNT) = nullptr;
+        switch (variant) {
+            case 0: kern = pick_abl<0>(act, gate_act, gated); break;
+            case 11: kern = pick_abl<1>(act, gate_act, gated); break;
+            case 12: kern = pick_abl<2>(act, gate_act, gated); break;
+            case 14: kern = pick_abl<4>(act, gate_act, gated); break;
+            case 16: kern = pick_abl<6>(act, gate_act, gated); break;
+            default: return TVTS_EINVAL;
+        }
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 163840, stream, g);

@@ -572,31 +572,79 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <bool AK1, bool BJ1>
+// One operand's 64 x 32 stage (64 rows / columns of the output tile x 32 k) held in registers between its global loads and its
+// LDS stores: 8 floats per thread.  U1 = the operand is unit-stride along k; VEC = 16-byte loads are legal (alignment and
+// extents checked by the dispatcher), else scalar loads with bounds checks.
+template <bool U1, bool VEC>
+struct StageF32 {
+    float v[8];
+    // element e of this thread: (x = output row / column inside the tile, k inside the stage)
+    static __device__ __forceinline__ void coord(int tid, int e, int& x, int& k) {
+        if (U1) { x = (tid >> 3) + 32 * (e >> 2); k = (tid & 7) * 4 + (e & 3); }   // float4 along k, two row groups
+        else    { k = (tid >> 4) + 16 * (e >> 2); x = (tid & 15) * 4 + (e & 3); }  // float4 along x, two k groups
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ base, long sx, long sk, int x0, int k0, int X, int Kd, int tid) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int x, k;
+            coord(tid, 4 * h, x, k);
+            const int gx = x0 + x, gk = k0 + k;
+            if (VEC) {
+                const bool ok = U1 ? (gx < X && gk < Kd) : (gk < Kd && gx < X);  // extents are multiples of 4 along the vector
+                const f32x4 t = ok ? *(const f32x4*)(base + gx * sx + gk * sk) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * h + e] = t[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int xe, ke;
+                    coord(tid, 4 * h + e, xe, ke);
+                    v[4 * h + e] = (x0 + xe < X && k0 + ke < Kd) ? base[(x0 + xe) * sx + (k0 + ke) * sk] : 0.f;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float (*S)[68], int tid) const {  // S[k][x]
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int x, k;
+            coord(tid, 4 * h, x, k);
+            if (U1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[k + e][x] = v[4 * h + e];
+            } else {
+                *(f32x4*)&S[k][x] = (f32x4){v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+            }
+        }
+    }
+};
+
+template <bool AK1, bool BJ1, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, long sai, long sak,
                                                             const float* __restrict__ B, long sbk, long sbj, int M, int N,
                                                             int K, float alpha, const float* __restrict__ bias,
                                                             float* __restrict__ C, long ldc, int accumulate) {
-    __shared__ float As[16][68], Bs[16][68];
+    __shared__ __attribute__((aligned(16))) float As[32][68], Bs[32][68];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ka = AK1 ? (tid & 15) : (tid >> 6) + 4 * r, ia = AK1 ? (tid >> 4) + 16 * r : (tid & 63);
-            const int gi = i0 + ia, gk = k0 + ka;
-            As[ka][ia] = (gi < M && gk < K) ? A[gi * sai + gk * sak] : 0.f;
-            const int kb = BJ1 ? (tid >> 6) + 4 * r : (tid & 15), jb = BJ1 ? (tid & 63) : (tid >> 4) + 16 * r;
-            const int gj = j0 + jb, gkb = k0 + kb;
-            Bs[kb][jb] = (gj < N && gkb < K) ? B[gkb * sbk + gj * sbj] : 0.f;
-        }
+    StageF32<AK1, VEC> ra;
+    StageF32<!BJ1, VEC> rb;  // B is indexed (k, j): unit stride along k iff NOT along j
+    ra.load(A, sai, sak, i0, 0, M, K, tid);
+    rb.load(B, sbj, sbk, j0, 0, N, K, tid);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        ra.store(As, tid);
+        rb.store(Bs, tid);
         __syncthreads();
+        if (k0 + 32 < K) {  // the next stage's global loads fly under this stage's MFMAs
+            ra.load(A, sai, sak, i0, k0 + 32, M, K, tid);
+            rb.load(B, sbj, sbk, j0, k0 + 32, N, K, tid);
+        }
 #pragma unroll
-        for (int kk = 0; kk < 16; kk += 2) {
+        for (int kk = 0; kk < 32; kk += 2) {
             const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
             const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -623,8 +671,15 @@ extern "C" int tvts_gemm_small_f32(const float* A, long sai, long sak, const flo
     if (M >= 32 && N >= 32 && K >= 16) {  // worth a 64x64 MFMA tile; the tiny products (4-way heads, [B,E] rows) stay below
         const dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
         const bool ak1 = sak == 1, bj1 = sbj == 1;
-        auto kern = ak1 ? (bj1 ? gemm_f32_mfma_kernel<true, true> : gemm_f32_mfma_kernel<true, false>)
-                        : (bj1 ? gemm_f32_mfma_kernel<false, true> : gemm_f32_mfma_kernel<false, false>);
+        // 16-byte loads: unit stride in one direction, the other stride and the extent along the vector multiples of 4, bases aligned
+        const bool va = ak1 ? (sai % 4 == 0 && K % 4 == 0) : (sai == 1 && sak % 4 == 0 && M % 4 == 0);
+        const bool vb = bj1 ? (sbk % 4 == 0 && N % 4 == 0) : (sbk == 1 && sbj % 4 == 0 && K % 4 == 0);
+        const bool vec = va && vb && ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0);
+        void (*kern)(const float*, long, long, const float*, long, long, int, int, int, float, const float*, float*, long, int);
+        if (vec) kern = ak1 ? (bj1 ? gemm_f32_mfma_kernel<true, true, true> : gemm_f32_mfma_kernel<true, false, true>)
+                            : (bj1 ? gemm_f32_mfma_kernel<false, true, true> : gemm_f32_mfma_kernel<false, false, true>);
+        else kern = ak1 ? (bj1 ? gemm_f32_mfma_kernel<true, true, false> : gemm_f32_mfma_kernel<true, false, false>)
+                        : (bj1 ? gemm_f32_mfma_kernel<false, true, false> : gemm_f32_mfma_kernel<false, false, false>);
         hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, A, sai, sak, B, sbk, sbj, M, N, K, alpha, bias, C, ldc, accumulate);
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;

@@ -79,7 +79,9 @@ __device__ __forceinline__ void tile_origin256(const GemmNT& g, int t, int gc, i
 // m_base .. m_base + 15, columns nb .. nb + 63; 16-B chunk c of row r stored at chunk c ^ r, bias already added); it leaves as
 // whole row segments -- every store / residual load / gate load instruction covers full 128-B (bf16) or 256-B (fp32) pieces
 // of output rows -- with the activation (+ pre-activation side output), the activation-gradient gate and the fp32 residual.
-template <int ACT, int GATE>
+// ABL (compile-time, 0 in every production instantiation; csrc/exp instantiates the others to price the epilogue's parts):
+// 2 = side inputs (residual / gate) are not loaded, 4 = results are not stored (one never-taken store keeps them live).
+template <int ACT, int GATE, int ABL = 0>
 __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch, int m_base, int nb, int lane) {
     if (g.out_f32) {
 #pragma unroll
@@ -89,17 +91,17 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
             const int m = m_base + r, n = nb + c16 * 4;
             if (m >= g.M || n >= g.N) continue;
             if (ACT != ACT_NONE) {
-                if (g.preact) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                if (g.preact && (!(ABL & 4) || v[0] == 1.2345e33f)) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
             }
             if (GATE != ACT_NONE) {
-                const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
+                const bf16x4 h = (ABL & 2) ? (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]} : *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
             }
-            if (g.residual) v += *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
-            *(f32x4*)((float*)g.out + (size_t)m * g.ldc + n) = v;
+            if (g.residual && !(ABL & 2)) v += *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
+            if (!(ABL & 4) || v[0] == 1.2345e33f) *(f32x4*)((float*)g.out + (size_t)m * g.ldc + n) = v;
         }
     } else {
 #pragma unroll
@@ -111,7 +113,7 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
             const int m = m_base + r, n = nb + c8 * 8;
             if (m >= g.M || n >= g.N) continue;
             if (ACT != ACT_NONE) {
-                if (g.preact) {
+                if (g.preact && (!(ABL & 4) || v[0] == 1.2345e33f)) {
                     bf16x8 h;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) h[e] = (bf16)v[e];
@@ -121,11 +123,17 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
                 for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], ACT);
             }
             if (GATE != ACT_NONE) {
-                const bf16x8 h = *(const bf16x8*)(g.gate_h + (size_t)m * g.ldh + n);
+                bf16x8 h;
+                if (ABL & 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (bf16)v[e];
+                } else {
+                    h = *(const bf16x8*)(g.gate_h + (size_t)m * g.ldh + n);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= act_bwd((float)h[e], GATE);
             }
-            if (g.residual) {
+            if (g.residual && !(ABL & 2)) {
                 const f32x4 r0 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n), r1 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
@@ -133,17 +141,26 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-            *(bf16x8*)((bf16*)g.out + (size_t)m * g.ldc + n) = o;
+            if (!(ABL & 4) || v[0] == 1.2345e33f) *(bf16x8*)((bf16*)g.out + (size_t)m * g.ldc + n) = o;
         }
     }
 }
 
 // epilogue of a 128x64 wave sub-tile held as 8 x 4 accumulator tiles of v_mfma_f32_16x16x32 (lane: row m = lane & 15 of MFMA
 // row-tile i, 4 consecutive n at 16 j + 4 (lane >> 4)): one 16-row slab per pass through the patch
-template <int ACT, int GATE>
+template <int ACT, int GATE, int ABL = 0>
 __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn,
                                                   int lane, char* patch, float scale = 1.0f,
                                                   const float* row_scale = nullptr) {
+    if (ABL & 1) {  // no epilogue at all: the accumulators are consumed by a never-taken store and cleared
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s += acc[j][i][0] + acc[j][i][3]; acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (s == 1.2345e33f) *(float*)g.out = s;
+        return;
+    }
     const int nb = n0 + wn * 64;
     const int li = lane & 15, gq = lane >> 4;
     f32x4 bias4[4];
@@ -164,7 +181,7 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
             *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i] * sc + bias4[j];
             acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        patch_readout<ACT, GATE>(g, patch, m0 + wm * 128 + i * 16, nb, lane);
+        patch_readout<ACT, GATE, ABL>(g, patch, m0 + wm * 128 + i * 16, nb, lane);
     }
 }
 
@@ -175,7 +192,7 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
         asm volatile("" ::: "memory");        \
     } while (0)
 
-template <int ACT, int GATE, bool FP8 = false>
+template <int ACT, int GATE, bool FP8 = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 32K | B 32K] + 8 x 4K patches
     const int tid = threadIdx.x;
@@ -272,8 +289,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         }
         MFMA16(aF[1], bF[1], 1);
         if (++kt == nk) {
-            if (FP8 && g.sa_rows) epilogue256_patch<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, patch, g.sb[0], g.sa);
-            else epilogue256_patch<ACT, GATE>(g, acc, m0, n0, wm, wn, lane, patch, FP8 ? g.sa[0] * g.sb[0] : 1.0f);
+            if (FP8 && g.sa_rows) epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, g.sb[0], g.sa);
+            else epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, FP8 ? g.sa[0] * g.sb[0] : 1.0f);
             kt = 0; ++tl;
             tile_origin256(g, range_lo + slot + tl * per_xcd, gc, m0, n0);
         }

@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, bf16* __restrict__ shadow,
                                                     const unsigned char* __restrict__ chunk_group, AdamGroups hp, float beta1,
                                                     float beta2, float omb1, float omb2, float eps, float grad_scale,
-                                                    const int* __restrict__ step_dev, const float* __restrict__ hyper_dev) {
+                                                    const int* __restrict__ step_dev, const float* __restrict__ hyper_dev,
+                                                    double beta1d, double beta2d) {
     const int grp = chunk_group[blockIdx.x];
     if (grp > 3) return;
     if (hyper_dev) {  // lr[4] | wd[4] in device memory: a captured launch follows the LR schedule without re-capture
@@ -26,7 +27,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
     if (step_dev) {  // step counter lives in device memory (hipGraph replay): bias correction computed here
         const double st = (double)step_dev[0];
-        const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
+        // the betas in double, as the host path has them: both paths then produce the same step size bit for bit (with the
+        // float betas the step differed by 8e-6 relative, enough to flip a few dozen bf16 shadow roundings per step)
+        const double bc1 = 1.0 - pow(beta1d, st), bc2 = 1.0 - pow(beta2d, st);
         hp.step_size[grp] = (float)((double)hp.lr[grp] * sqrt(bc2) / bc1);
     }
     const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
@@ -62,7 +65,7 @@ extern "C" int tvts_adamw_hf(float* p, const float* g, float* m, float* v, void*
         hp.step_size[i] = (float)((double)lr4[i] * sqrt(bc2) / bc1);
     }
     hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, stream, p, g, m, v, (bf16*)shadow_bf16, chunk_group, hp,
-                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, grad_scale, step_dev, hyper_dev);
+                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, grad_scale, step_dev, hyper_dev, beta1, beta2);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

@@ -1,1 +1,1 @@
-from .synthetic import SyntheticTextVideoLoader, synth_batch  # noqa: F401
+from .synthetic import SyntheticTextVideoLoader, synth_batch, synth_batch_v1  # noqa: F401

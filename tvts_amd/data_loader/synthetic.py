@@ -33,6 +33,30 @@ def synth_batch(arch, B, T, seed=0, n_trans=None, caption_len=32, device="cpu"):
     return batch
 
 
+def synth_batch_v1(arch, B, T, seed=0, n_trans=None, caption_len=32, device="cpu"):
+    """v1 (TVTS) batch dict: text = the Hugging Face tokenizer's {'input_ids', 'attention_mask'} [NT*B, L] right-padded to the
+    longest caption of the batch, [CLS] 101 first / [SEP] 102 last (v1/trainer/trainer.py:121-131); keep_ind [B, n_tubes, n_keep]
+    with one tube mask PER TUBE (v1/data_loader/YTTemporal_dataset.py:207-215)."""
+    NT = arch["n_trans"] if n_trans is None else n_trans
+    g = torch.Generator().manual_seed(seed)
+    video = torch.randn(B, T, 3, arch["image"], arch["image"], generator=g, dtype=torch.float32)
+    N, L = NT * B, caption_len
+    lens = torch.randint(max(3, L // 2), L + 1, (N,), generator=g)
+    lens[0] = L
+    pos = torch.arange(L)[None, :]
+    mask = (pos < lens[:, None]).to(torch.int64)
+    cls_id, sep_id = (101, 102) if arch["vocab"] > 1000 else (arch["vocab"] - 2, arch["vocab"] - 1)
+    ids = torch.randint(1, min(arch["vocab"], 30000) - 2, (N, L), generator=g) * mask
+    ids[:, 0] = cls_id
+    ids[torch.arange(N), lens - 1] = sep_id
+    ppf, nk, tubes = patches_per_frame(arch), n_keep(arch), T // arch["tubelet"]
+    keep = torch.stack([torch.stack([torch.randperm(ppf, generator=g)[:nk] for _ in range(tubes)]) for _ in range(B)])
+    batch = {"video": video.to(device), "text": {"input_ids": ids, "attention_mask": mask}, "keep_ind": keep.to(torch.int64)}
+    if NT == arch["n_trans"]:
+        batch["label"] = torch.arange(arch["n_trans"]).repeat(B, 1)
+    return batch
+
+
 class _Sampler:
     def set_epoch(self, epoch):
         self.epoch = epoch
