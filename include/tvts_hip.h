@@ -144,6 +144,12 @@ int tvts_patch_gather(const float* video, const int* keep, int B, int T, int n, 
  * device [B,2] (top, left) or NULL for the centre crop */
 int tvts_patch_gather_u8(const unsigned char* frames, int H0, int W0, const int* crop, const int* keep, int B, int T, int n,
                          int img, int patch, const float* mean3, const float* std3, void* out, int ldo, hipStream_t stream);
+/* the same with the transform chain's Resize in front (video_transforms/videoaug.py:12,21 -> video_transform.py:171-188 ->
+ * functional.py:47-64: PIL nearest-neighbour to (H0, W0)): frames are the decoder's Hs x Ws pictures, ytab[H0] / xtab[W0]
+ * (device int32) hold Pillow's source index of every resized row / column (tvts_amd/data_loader/transforms.py) */
+int tvts_patch_gather_u8_resized(const unsigned char* frames, int Hs, int Ws, const int* ytab, const int* xtab, int H0, int W0,
+                                 const int* crop, const int* keep, int B, int T, int n, int img, int patch, const float* mean3,
+                                 const float* std3, void* out, int ldo, hipStream_t stream);
 /* tube mask drawn on the device (replaces the per-sample np.random.shuffle(arange(ppf))[:n_keep] of the dataset worker,
  * v2/data_loader/YTTemporal_dataset.py:207-213): keep[b, :] = the n_keep patch indices with the smallest counter-based
  * random keys of sample number first_sample + b -- an unsorted prefix of a uniformly random permutation, shared by all

@@ -361,7 +361,8 @@ def frames_to_video(frames_u8: Tensor, image: int, crop: Optional[Tensor] = None
     mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32)[:, None, None]
     std = torch.tensor(IMAGENET_STD, dtype=torch.float32)[:, None, None]
     for b in range(B):
-        y0, x0 = ((H0 - image) // 2, (W0 - image) // 2) if crop is None else (int(crop[b, 0]), int(crop[b, 1]))
+        # CenterCrop: int(round((im - size) / 2.)) -- Python's round, i.e. half to even (video_transform.py:454-455)
+        y0, x0 = (int(round((H0 - image) / 2.)), int(round((W0 - image) / 2.))) if crop is None else (int(crop[b, 0]), int(crop[b, 1]))
         clip = frames_u8[b, :, y0:y0 + image, x0:x0 + image, :].permute(0, 3, 1, 2).float().div(255)
         out[b] = clip.sub(mean).div(std)
     return out

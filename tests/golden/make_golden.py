@@ -505,6 +505,57 @@ def gen_transform():
     save("transform", frames=frames, out=out, image=32)
 
 
+def gen_transform_resize():
+    """The reference's WHOLE eval transform on decoder-sized pictures (video_transforms/videoaug.py:19-27): PIL images as
+    TensorToNumpy leaves them -> Resize(int(crop * 1.2)) (nearest, the class default) -> CenterCrop -> ClipToTensor -> Normalize,
+    and the train chain's RandomCrop position replaced by a fixed offset (the crop op itself, functional.crop_clip)."""
+    from PIL import Image
+    _stub("cv2"); _stub("skimage"); _stub("skimage.transform"); _stub("torchvision")
+    _stub("torchvision.transforms")
+    vt_pkg = _stub("video_transforms")
+    vt_pkg.functional = _load("video_transforms.functional", os.path.join(REF, "video_transforms/functional.py"))
+    vt = _load("video_transforms.video_transform", os.path.join(REF, "video_transforms/video_transform.py"))
+    rng = np.random.RandomState(12)
+    out = {}
+    for tag, (hs, ws) in {"wide": (57, 90), "tall": (101, 64), "same": (48, 70)}.items():
+        frames = rng.randint(0, 256, size=(3, hs, ws, 3)).astype(np.uint8)
+        clip = [Image.fromarray(frames[t]).convert("RGB") for t in range(3)]
+        clip = vt.Resize(int(40 * 1.2))(clip)
+        ten = vt.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])(vt.ClipToTensor(channel_nb=3)(vt.CenterCrop(40)(clip)))
+        out["frames_" + tag] = frames
+        out["out_" + tag] = ten.permute(1, 0, 2, 3)
+        out["resized_hw_" + tag] = np.array([clip[0].size[1], clip[0].size[0]])
+        # a fixed off-centre crop (what RandomCrop does once its offsets are drawn, video_transform.py:204-232)
+        y1, x1 = 3, 5
+        crop = vt_pkg.functional.crop_clip(clip, y1, x1, 40, 40)
+        ten2 = vt.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])(vt.ClipToTensor(channel_nb=3)(crop))
+        out["out_crop_" + tag] = ten2.permute(1, 0, 2, 3)
+    save("transform_resize", image=40, size=48, crop_yx=np.array([3, 5]), **out)
+
+
+def gen_tokenize():
+    """clip.tokenize (CLIP/clip/clip.py:197-237) on a few captions, with and without truncation: the rows the caption cache must
+    reproduce.  ftfy is absent from the image: its fix_text is the identity on these ASCII captions."""
+    _stub("ftfy", fix_text=lambda t: t)
+    _stub("torchvision"); _stub("torchvision.transforms", Compose=object, Resize=object, CenterCrop=object, ToTensor=object,
+                                Normalize=object, InterpolationMode=types.SimpleNamespace(BICUBIC=3))
+    pkg = _stub("CLIP"); sub = _stub("CLIP.clip")
+    _load("CLIP.clip.simple_tokenizer", os.path.join(REF, "CLIP/clip/simple_tokenizer.py"))
+    _load("CLIP.clip.model", os.path.join(REF, "CLIP/clip/model.py"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("CLIP.clip.clip", os.path.join(REF, "CLIP/clip/clip.py"),
+                                                  submodule_search_locations=None)
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = "CLIP.clip"
+    sys.modules["CLIP.clip.clip"] = mod
+    spec.loader.exec_module(mod)
+    caps = ["a person is cooking pasta in a kitchen", "then add the onions and stir", "now we cut the wood",
+            "a person is cooking pasta in a kitchen", "hello world", " ".join(["very long caption word"] * 30)]
+    toks = mod.tokenize(caps, truncate=True)
+    save("tokenize", captions=np.array(caps), tokens=toks.numpy().astype(np.int32),
+         tokens_short=mod.tokenize(caps[:5]).numpy().astype(np.int32))
+
+
 def gen_downstream_more():
     """The other two downstream copies: TVTSv2_B_32 (49 unmasked patches: the fused SPACE kernels' range) and the full-size
     TVTSv2_H_14 (256 unmasked patches, head dim 80, pooled tail; OpenCLIP.create_model replaced as in gen_model_h14)."""
@@ -655,7 +706,7 @@ def gen_ddp2():
 
 
 GENS = {"block": gen_block, "vit": gen_vit, "text": gen_text, "sort": gen_sort, "model_tiny": gen_model_tiny,
-        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream, "transform": gen_transform, "downstream_more": gen_downstream_more, "model_b16": gen_model_b16}
+        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream, "transform": gen_transform, "transform_resize": gen_transform_resize, "tokenize": gen_tokenize, "downstream_more": gen_downstream_more, "model_b16": gen_model_b16}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

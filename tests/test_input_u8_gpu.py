@@ -74,3 +74,50 @@ def test_step_on_uint8_frames_equals_step_on_fp32_clip(gpu):
         _, vc8, _ = m(dict(b, video=frames))
         _, vc, _ = m(dict(b, video=O.frames_to_video(frames, a["image"])))
     assert torch.equal(vc8, vc) and not torch.equal(vc8, ve8)
+
+
+@pytest.mark.parametrize("tag", ["wide", "tall", "same"])
+def test_resize_fused_into_the_gather_bit_exact(gpu, golden, tag):
+    """decoder-sized uint8 pictures -> Resize(48) (PIL nearest) -> CenterCrop(40) / a fixed RandomCrop offset -> ClipToTensor ->
+    Normalize, all inside the tube-mask gather, against the reference's own chain (tests/golden/transform_resize.npz).  The odd
+    size differences here (75 - 40) also pin CenterCrop's int(round(x / 2.)) = round-half-to-even offset."""
+    from tvts_amd import hip as K
+    from tvts_amd.data_loader.transforms import resize_tables
+    f = golden("transform_resize")
+    img, size = int(f["image"]), int(f["size"])
+    frames = torch.tensor(f["frames_" + tag]).unsqueeze(0)  # [1, T, Hs, Ws, 3]
+    T, hs, ws = frames.shape[1:4]
+    tabs = resize_tables(hs, ws, size, DEV)
+    assert [tabs[0].numel(), tabs[1].numel()] == list(f["resized_hw_" + tag])
+    patch, g = 8, img // 8
+    keep = torch.arange(g * g, dtype=torch.int32).unsqueeze(0)
+    for crop, key in ((None, "out_" + tag), (torch.tensor([[3, 5]], dtype=torch.int32), "out_crop_" + tag)):
+        cols = torch.empty(T * g * g, 3 * patch * patch, dtype=torch.bfloat16, device=DEV)
+        K.patch_gather_u8(frames.to(DEV), keep.to(DEV), cols, B=1, T=T, n=g * g, img=img, patch=patch,
+                          crop=None if crop is None else crop.to(DEV), resize=tabs)
+        out = torch.tensor(f[key]).unsqueeze(0)  # [1, T, 3, img, img] from the reference
+        px = out.reshape(1, T, 3, g, patch, g, patch).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, 3 * patch * patch)
+        assert torch.equal(cols.float().cpu(), px.bfloat16().float()), key
+
+
+def test_step_on_decoder_frames_with_resize(gpu):
+    """model(data) with data['resize'] = 76: the step on raw 90 x 120 pictures equals the step on the clip the reference's
+    Resize -> CenterCrop -> ToTensor -> Normalize would have produced (restated with the same index tables on the CPU)."""
+    import numpy as np
+    from tvts_amd import arch as A
+    from tvts_amd.data_loader.transforms import pil_nearest_table, resize_sizes
+    from tvts_amd.model._common import TVTSv2Base
+    a = A.small_arch()
+    oarch = O.tiny_arch(**a)
+    m = TVTSv2Base(types.SimpleNamespace(local_rank=0, rank=0, world_size=1), arch=a)
+    m.load_state_dict(O.synth_params(oarch, seed=2), strict=True)
+    b = O.synth_batch(oarch, B=3, T=2, seed=4, caption_len=9)
+    frames = torch.randint(0, 256, (3, 2, 90, 121, 3), generator=torch.Generator().manual_seed(7), dtype=torch.uint8)
+    size = 77
+    h0, w0 = resize_sizes(90, 121, size)
+    yt, xt = np.array(pil_nearest_table(90, h0)), np.array(pil_nearest_table(121, w0))
+    resized = frames[:, :, yt][:, :, :, xt]
+    with torch.no_grad():
+        _, v8, _ = m(dict(b, video=frames, resize=size))
+        _, vr, _ = m(dict(b, video=O.frames_to_video(resized, a["image"])))
+    assert torch.equal(v8, vr)

@@ -102,24 +102,32 @@ extern "C" int tvts_patch_gather_tube(const float* video, const int* keep, int B
 // crop (video_transform.CenterCrop / RandomCrop = an offset per sample), ClipToTensor (float32 / 255) and Normalize
 // ((v - mean) / std, fp32, same operation order -> bit-identical to v2/video_transforms/video_transform.py:24-75,
 // functional.py:81-97), then the bf16 rounding of the im2col row.  4x less PCIe / HBM traffic than fp32 frames.
+// ytab / xtab (optional): the RESIZE in front of the crop (video_transform.Resize -> PIL nearest-neighbour, videoaug.py:12,21):
+// frames are the decoder's Hs x Ws pictures, ytab[H0] / xtab[W0] give the source row / column of every row / column of the
+// (virtual) resized H0 x W0 picture -- Pillow's own index table, built by tvts_amd/data_loader/transforms.py.
 __global__ __launch_bounds__(256) void patch_gather_u8_kernel(const unsigned char* __restrict__ frames, int H0, int W0,
                                                               const int* __restrict__ crop, const int* __restrict__ keep,
                                                               int B, int T, int n, int img, int p, float m0, float m1,
                                                               float m2, float s0, float s1, float s2,
-                                                              bf16* __restrict__ out, int ldo) {
+                                                              bf16* __restrict__ out, int ldo, const int* __restrict__ ytab,
+                                                              const int* __restrict__ xtab, int Hs, int Ws) {
     const int K = 3 * p * p;
     const int row = blockIdx.x;  // (b, f, i)
     const int i = row % n, f = (row / n) % T, b = row / (n * T);
     const int g = img / p;
     const int pi = keep[b * n + i];
     const int gy = pi / g, gx = pi % g;
-    const int y0 = crop ? crop[2 * b] : (H0 - img) / 2, x0 = crop ? crop[2 * b + 1] : (W0 - img) / 2;
-    const unsigned char* fr = frames + (size_t)(b * T + f) * H0 * W0 * 3;
+    // centre crop: int(round((H0 - img) / 2.)) with Python's round-half-to-even (video_transform.py:454-455)
+    const int dy = H0 - img, dx = W0 - img;
+    const int y0 = crop ? crop[2 * b] : (dy >> 1) + ((dy & 1) & (dy >> 1)), x0 = crop ? crop[2 * b + 1] : (dx >> 1) + ((dx & 1) & (dx >> 1));
+    const unsigned char* fr = frames + (size_t)(b * T + f) * Hs * Ws * 3;
     for (int c = threadIdx.x; c < ldo; c += 256) {
         float v = 0.f;
         if (c < K) {
             const int ch = c / (p * p), rem = c % (p * p), py = rem / p, px = rem % p;
-            const float u = (float)fr[((size_t)(y0 + gy * p + py) * W0 + (x0 + gx * p + px)) * 3 + ch];
+            int sy = y0 + gy * p + py, sx = x0 + gx * p + px;  // pixel of the (resized) H0 x W0 picture
+            if (ytab) { sy = ytab[sy]; sx = xtab[sx]; }
+            const float u = (float)fr[((size_t)sy * Ws + sx) * 3 + ch];
             const float mean = ch == 0 ? m0 : ch == 1 ? m1 : m2, sd = ch == 0 ? s0 : ch == 1 ? s1 : s2;
             v = (u / 255.0f - mean) / sd;
         }
@@ -132,7 +140,19 @@ extern "C" int tvts_patch_gather_u8(const unsigned char* frames, int H0, int W0,
     if (B <= 0 || T <= 0 || n <= 0 || patch <= 0 || img % patch || H0 < img || W0 < img || ldo % 8 || ldo < 3 * patch * patch)
         return TVTS_EINVAL;
     hipLaunchKernelGGL(patch_gather_u8_kernel, dim3(B * T * n), dim3(256), 0, stream, frames, H0, W0, crop, keep, B, T, n, img,
-                       patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (bf16*)out, ldo);
+                       patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (bf16*)out, ldo, nullptr, nullptr, H0, W0);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+// the same with the nearest-neighbour resize Hs x Ws -> H0 x W0 in front (ytab / xtab: device int32 [H0] / [W0])
+extern "C" int tvts_patch_gather_u8_resized(const unsigned char* frames, int Hs, int Ws, const int* ytab, const int* xtab, int H0,
+                                            int W0, const int* crop, const int* keep, int B, int T, int n, int img, int patch,
+                                            const float* mean3, const float* std3, void* out, int ldo, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || n <= 0 || patch <= 0 || img % patch || H0 < img || W0 < img || ldo % 8 || ldo < 3 * patch * patch ||
+        !ytab || !xtab || Hs <= 0 || Ws <= 0)
+        return TVTS_EINVAL;
+    hipLaunchKernelGGL(patch_gather_u8_kernel, dim3(B * T * n), dim3(256), 0, stream, frames, H0, W0, crop, keep, B, T, n, img,
+                       patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (bf16*)out, ldo, ytab, xtab, Hs, Ws);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

@@ -210,6 +210,11 @@ extern "C" int tvts_exp_gemm_nt(int variant, int gc, int stagger_phases, int sta
             case 12: kern = pick_abl<2>(act, gate_act, gated); break;
             case 14: kern = pick_abl<4>(act, gate_act, gated); break;
             case 16: kern = pick_abl<6>(act, gate_act, gated); break;
+            case 18: kern = pick_abl<8>(act, gate_act, gated); break;    // 2-phase stagger
+            case 26: kern = pick_abl<16>(act, gate_act, gated); break;   // 4-phase stagger
+            case 42: kern = pick_abl<32>(act, gate_act, gated); break;   // sc1 stores
+            case 74: kern = pick_abl<64>(act, gate_act, gated); break;   // plain stores (round 1)
+            case 138: kern = pick_abl<128>(act, gate_act, gated); break; // nt stores + nt side loads
             default: return TVTS_EINVAL;
         }
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);

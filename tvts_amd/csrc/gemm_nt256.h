@@ -79,6 +79,32 @@ __device__ __forceinline__ void tile_origin256(const GemmNT& g, int t, int gc, i
 // m_base .. m_base + 15, columns nb .. nb + 63; 16-B chunk c of row r stored at chunk c ^ r, bias already added); it leaves as
 // whole row segments -- every store / residual load / gate load instruction covers full 128-B (bf16) or 256-B (fp32) pieces
 // of output rows -- with the activation (+ pre-activation side output), the activation-gradient gate and the fp32 residual.
+// 16-byte global store of a result that this kernel never reads again.  Production policy: NON-TEMPORAL.  The 256 CUs write a
+// 256x256 tile each at about the same time (32 MB of bf16 per round: the capacity of all eight L2s); as plain stores those
+// lines displace the weight / activation panels the next tiles re-read, as nt stores they leave first.  Measured on the step's
+// shapes (M = 150 720, tools/gemm_ab.py, profiles/r02_gemm_ab_store_policy.txt): qkv forward 565 -> 467 us (943 -> 1142 TF),
+// proj 188 -> 158 us, fc1 + QuickGELU + pre-activation 917 -> 767 us; sc1 (write-through) stores and staggered block starts
+// changed nothing.  ABL & 64 = plain stores, ABL & 32 = sc1 (experiment library only).
+template <int ABL, typename V16>
+__device__ __forceinline__ void store16(void* p, const V16& v) {
+    static_assert(sizeof(V16) == 16, "16-byte vector");
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    if constexpr ((ABL & 32) != 0) {
+        const u32x4 d = __builtin_bit_cast(u32x4, v);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+    } else if constexpr ((ABL & 64) != 0) {
+        *(V16*)p = v;
+    } else {
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), (u32x4*)p);
+    }
+}
+// side input of the epilogue (fp32 residual, bf16 pre-activation of the gate): read once; ABL & 128 = non-temporal load
+template <int ABL, typename V>
+__device__ __forceinline__ V side_load(const void* p) {
+    if constexpr ((ABL & 128) != 0) return __builtin_nontemporal_load((const V*)p);
+    else return *(const V*)p;
+}
+
 // ABL (compile-time, 0 in every production instantiation; csrc/exp instantiates the others to price the epilogue's parts):
 // 2 = side inputs (residual / gate) are not loaded, 4 = results are not stored (one never-taken store keeps them live).
 template <int ACT, int GATE, int ABL = 0>
@@ -96,12 +122,12 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
             }
             if (GATE != ACT_NONE) {
-                const bf16x4 h = (ABL & 2) ? (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]} : *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
+                const bf16x4 h = (ABL & 2) ? (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]} : side_load<ABL, bf16x4>(g.gate_h + (size_t)m * g.ldh + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
             }
-            if (g.residual && !(ABL & 2)) v += *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
-            if (!(ABL & 4) || v[0] == 1.2345e33f) *(f32x4*)((float*)g.out + (size_t)m * g.ldc + n) = v;
+            if (g.residual && !(ABL & 2)) v += side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
+            if (!(ABL & 4) || v[0] == 1.2345e33f) store16<ABL>((float*)g.out + (size_t)m * g.ldc + n, v);
         }
     } else {
 #pragma unroll
@@ -117,7 +143,7 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
                     bf16x8 h;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) h[e] = (bf16)v[e];
-                    *(bf16x8*)(g.preact + (size_t)m * g.ldp + n) = h;
+                    store16<ABL>(g.preact + (size_t)m * g.ldp + n, h);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], ACT);
@@ -128,20 +154,20 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
 #pragma unroll
                     for (int e = 0; e < 8; ++e) h[e] = (bf16)v[e];
                 } else {
-                    h = *(const bf16x8*)(g.gate_h + (size_t)m * g.ldh + n);
+                    h = side_load<ABL, bf16x8>(g.gate_h + (size_t)m * g.ldh + n);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= act_bwd((float)h[e], GATE);
             }
             if (g.residual && !(ABL & 2)) {
-                const f32x4 r0 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n), r1 = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n + 4);
+                const f32x4 r0 = side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n), r1 = side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
             }
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-            if (!(ABL & 4) || v[0] == 1.2345e33f) *(bf16x8*)((bf16*)g.out + (size_t)m * g.ldc + n) = o;
+            if (!(ABL & 4) || v[0] == 1.2345e33f) store16<ABL>((bf16*)g.out + (size_t)m * g.ldc + n, o);
         }
     }
 }
@@ -211,6 +237,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     const int ntl = (range_n - slot + per_xcd - 1) / per_xcd;
     const int total_st = ntl * nk;
     const int gc = g.gc;
+    if constexpr ((ABL & 24) != 0) {  // experiment: blocks start in 2 (8) / 4 (16) phases spread over one tile time (~1 us per stage)
+        const int phases = (ABL & 16) ? 4 : 2;
+        const int ph = slot % phases;
+        for (int i = 0; i < ph * nk / (2 * phases); ++i) __builtin_amdgcn_s_sleep(127);  // 127 * 64 cycles ~ 3.9 us
+    }
 
     // DMA cursor
     int i_st = 0, i_kt = 0, i_tl = 0, i_m0, i_n0;

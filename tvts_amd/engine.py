@@ -360,7 +360,8 @@ class Engine:
         M, Mp, Kp = B * S, B * T * n, self.P.conv_kpad
         cols = self._b("vit.im2col", (Mp, Kp))
         if video.dtype == torch.uint8:
-            K.patch_gather_u8(video, keep_dev, cols, B=B, T=T, n=n, img=a["image"], patch=p, crop=self.ctx.get("crop"))
+            K.patch_gather_u8(video, keep_dev, cols, B=B, T=T, n=n, img=a["image"], patch=p, crop=self.ctx.get("crop"),
+                              resize=self.ctx.get("resize"))
         else:
             K.patch_gather(video, keep_dev, cols, B=B, T=T, n=n, img=a["image"], patch=p)
         pe = self._f("vit.patch", (Mp, W))
@@ -548,7 +549,7 @@ class Engine:
         """Host-side (plumbing): dtype/device normalisation of the reference batch dict."""
         a = self.arch
         video = data["video"]
-        crop = None
+        crop = resize = None
         if video.dtype == torch.uint8:
             # uint8 wire format (SURVEY.md 8f N3): [B, T, H0, W0, 3] frames as decoded + resized; crop / 255 / normalise
             # happen inside the patch gather.  data["crop"]: [B, 2] (top, left) of a random crop, absent = centre crop.
@@ -558,6 +559,9 @@ class Engine:
             video = video.to(self.dev).contiguous()
             if data.get("crop") is not None:
                 crop = data["crop"].to(torch.int32).contiguous().to(self.dev)
+            if data.get("resize") is not None:  # the frames are the decoder's pictures: Resize(size) happens inside the gather
+                from .data_loader.transforms import resize_tables
+                resize = resize_tables(video.shape[2], video.shape[3], int(data["resize"]), self.dev)
         else:
             if video.dim() == 4:
                 video = video.unsqueeze(1)
@@ -590,7 +594,7 @@ class Engine:
         So = Sv + NT
         sort_rows = (torch.arange(B)[:, None] * So + Sv + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev)
         vid_rows = (torch.arange(B) * S).to(torch.int32).to(self.dev)
-        return dict(video=video, crop=crop, ids=ids_dev, eot_rows=eot_rows, keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
+        return dict(video=video, crop=crop, resize=resize, ids=ids_dev, eot_rows=eot_rows, keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
                     sort_rows=sort_rows, vid_rows=vid_rows)
 
     def forward(self, pb: dict):

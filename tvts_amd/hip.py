@@ -290,12 +290,21 @@ def patch_gather(video, keep, out, *, B, T, n, img, patch):
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)  # video_transforms/videoaug.py:17,26
 
 
-def patch_gather_u8(frames, keep, out, *, B, T, n, img, patch, crop=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
-    """frames: uint8 [B, T, H0, W0, 3] on the device; crop: int32 [B, 2] (top, left) or None (centre crop)."""
+def patch_gather_u8(frames, keep, out, *, B, T, n, img, patch, crop=None, mean=IMAGENET_MEAN, std=IMAGENET_STD, resize=None):
+    """frames: uint8 [B, T, H0, W0, 3] on the device; crop: int32 [B, 2] (top, left) or None (centre crop).
+    resize = (ytab int32 [H0], xtab int32 [W0]) device tables: the frames are the decoder's pictures and the crop applies to
+    their nearest-neighbour resize to H0 x W0 (the reference's video_transform.Resize)."""
     import ctypes
     lib = _lib.load()
     assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.shape[-1] == 3 and keep.dtype == torch.int32
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    if resize is not None:
+        ytab, xtab = resize
+        assert ytab.dtype == torch.int32 and xtab.dtype == torch.int32
+        _chk(lib.tvts_patch_gather_u8_resized(_p(frames), frames.shape[2], frames.shape[3], _p(ytab), _p(xtab), ytab.numel(),
+                                              xtab.numel(), _p(crop), _p(keep), B, T, n, img, patch, m3, s3, _p(out), _ld(out),
+                                              _stream()), "tvts_patch_gather_u8_resized")
+        return
     _chk(lib.tvts_patch_gather_u8(_p(frames), frames.shape[2], frames.shape[3], _p(crop), _p(keep), B, T, n, img, patch, m3, s3,
                                   _p(out), _ld(out), _stream()), "tvts_patch_gather_u8")
 

@@ -51,6 +51,7 @@ class AllGather(AllGather_multi):
 
 class _TrainerBase(Multi_BaseTrainer_dist):
     TRUNCATE = True
+    CACHE_CAPTIONS = True
     LOG_LINE = "Train Epoch: {} dl{} {} Loss_ct: {:.6f} Loss_ce: {:.6f} Loss: {:.6f}"  # v2/trainer/trainer.py:505-512
 
     def __init__(self, args, model, loss, metrics, optimizer, config, data_loader, valid_data_loader=None,
@@ -74,7 +75,9 @@ class _TrainerBase(Multi_BaseTrainer_dist):
         self.batch_size = self.data_loader[0].batch_size
         self.log_step = max(1, int(np.sqrt(self.batch_size)))
         self.total_batch_sum = sum(x.batch_size for x in self.data_loader)
-        self.tokenizer = tokenizer
+        # tokenised-caption cache keyed by caption text: rows identical to calling the tokenizer directly
+        from ..data_loader.transforms import CaptionCache
+        self.tokenizer = CaptionCache(tokenizer) if (tokenizer is not None and self.CACHE_CAPTIONS) else tokenizer
         self.max_samples_per_epoch = max_samples_per_epoch
         self.n_gpu = self.args.world_size
         self.allgather = AllGather_multi.apply
@@ -234,6 +237,7 @@ class Trainer_TVTS(_TrainerBase):
     Loss_align / Loss_sort (:164-172), and the learning rate is recomputed from the base rate at every epoch end --
     lr = base_lr * 0.1 ** (number of milestones reached) (:80-91) -- instead of being decayed in place."""
     LOG_LINE = "Train Epoch: {} dl{} {} Loss_align: {:.6f} Loss_sort: {:.6f} Loss: {:.6f}"
+    CACHE_CAPTIONS = False  # the Hugging Face tokenizer pads to the longest caption of the BATCH: rows are not per-caption constants
 
     def __init__(self, args, model, loss, metrics, optimizer, config, data_loader, valid_data_loader=None, lr_scheduler=None,
                  len_epoch=None, writer=None, visualizer=None, tokenizer=None, max_samples_per_epoch=50000):
