@@ -172,6 +172,7 @@ extern "C" int tvts_gemm_nt_select(int M, int N) { return nt_use_256(M, N) ? 256
 static int nt_column_group(int N) {
     const int tn = ceil_div(N, 256);
     if (tn >= 10) return tn % 6 == 0 ? 6 : tn % 5 == 0 ? 5 : 0;
+    if (tn == 9) return 3;  // qkv (N = 2304): 553 -> 520 us at M = 150 720 (tools/gemm_ab.py with rotating buffers, round 2)
     return 0;
 }
 

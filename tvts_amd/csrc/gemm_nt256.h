@@ -79,12 +79,13 @@ __device__ __forceinline__ void tile_origin256(const GemmNT& g, int t, int gc, i
 // m_base .. m_base + 15, columns nb .. nb + 63; 16-B chunk c of row r stored at chunk c ^ r, bias already added); it leaves as
 // whole row segments -- every store / residual load / gate load instruction covers full 128-B (bf16) or 256-B (fp32) pieces
 // of output rows -- with the activation (+ pre-activation side output), the activation-gradient gate and the fp32 residual.
-// 16-byte global store of a result that this kernel never reads again.  Production policy: NON-TEMPORAL.  The 256 CUs write a
-// 256x256 tile each at about the same time (32 MB of bf16 per round: the capacity of all eight L2s); as plain stores those
-// lines displace the weight / activation panels the next tiles re-read, as nt stores they leave first.  Measured on the step's
-// shapes (M = 150 720, tools/gemm_ab.py, profiles/r02_gemm_ab_store_policy.txt): qkv forward 565 -> 467 us (943 -> 1142 TF),
-// proj 188 -> 158 us, fc1 + QuickGELU + pre-activation 917 -> 767 us; sc1 (write-through) stores and staggered block starts
-// changed nothing.  ABL & 64 = plain stores, ABL & 32 = sc1 (experiment library only).
+// 16-byte global store of a result that this kernel never reads again: non-temporal, so that the 32 MB of tile results the 256
+// CUs write per round leave the L2s before the operand panels do.  Worth 1.5 % over plain stores on the step's shapes when the
+// operands are NOT cache-resident from a previous launch (tools/gemm_ab.py rotates three buffer sets; with one set the same
+// change reads as +20 % because the 231 MB activation operand then survives in the Infinity Cache between iterations -- an
+// artefact the training step never sees).  sc1 (write-through) stores and staggered block starts change nothing: the store tail
+// of a tile is bound by the CU's own store path (~13 B/clk/CU, 128 KB in ~4.8 us), not by chip-wide HBM bandwidth.
+// ABL & 64 = plain stores, ABL & 32 = sc1 (experiment library only).
 template <int ABL, typename V16>
 __device__ __forceinline__ void store16(void* p, const V16& v) {
     static_assert(sizeof(V16) == 16, "16-byte vector");
