@@ -52,13 +52,15 @@ def main():
     M = pairs * 785
     dev = "cuda:0"
     cases = [  # (name, M, N, K, kind)
-        ("qkv fwd", M, 2304, 768, "plain"), ("proj f32+res", M, 768, 768, "res32"), ("proj bf16", M, 768, 768, "plain"),
+        ("qkv fwd", M, 2304, 768, "plain"), ("proj f32+res", M, 768, 768, "res32"), ("proj bf16+res", M, 768, 768, "res16"), ("proj bf16", M, 768, 768, "plain"),
         ("fc1 fwd gelu+pre", M, 3072, 768, "act"), ("fc2 dgrad gate", M, 3072, 768, "gate"), ("fc2 fwd f32+res", M, 768, 3072, "res32"),
         ("fc1 dgrad", M, 768, 3072, "plain"), ("qkv dgrad", M, 768, 2304, "plain"), ("square", 4096, 4096, 4096, "plain")]
     # variant 10 + ABL = the production kernel with a compile-time epilogue ablation (results are wrong by construction, not checked):
     # 11 no epilogue, 12 no side-input loads (residual / gate), 14 no stores, 16 neither loads nor stores (LDS transpose + math only)
-    variants = [("prod(nt st)", 0, -1, (0, 0)), ("no-epi", 11, -1, (0, 0)), ("plain st", 74, -1, (0, 0)), ("nt st+nt side ld", 138, -1, (0, 0)),
-                ("no-side-loads", 12, -1, (0, 0)), ("no-stores", 14, -1, (0, 0)), ("lds+math only", 16, -1, (0, 0))]
+    variants = [("prod", 0, -1, (0, 0)), ("side prefetch", 266, -1, (0, 0)), ("prefetch+nt ld", 394, -1, (0, 0)), ("no-side-loads", 12, -1, (0, 0))]
+    if os.environ.get("AB_FULL"):
+        variants += [("no-epi", 11, -1, (0, 0)), ("plain st", 74, -1, (0, 0)), ("nt side ld", 138, -1, (0, 0)), ("no-stores", 14, -1, (0, 0)),
+                     ("lds+math only", 16, -1, (0, 0))]
     if os.environ.get("AB_ABL"):
         variants += [("no-side-loads", 12, -1, (0, 0)), ("no-stores", 14, -1, (0, 0)), ("lds+math only", 16, -1, (0, 0))]
     if os.environ.get("AB_M32"):
@@ -78,6 +80,8 @@ def main():
             odt = torch.bfloat16
             if kind == "res32":
                 kw["residual"] = torch.randn(m, n, generator=g, device=dev); odt = torch.float32
+            elif kind == "res16":
+                kw["residual"] = torch.randn(m, n, generator=g, device=dev)
             elif kind == "act":
                 kw.update(act="quick_gelu", preact=torch.empty(m, n, dtype=torch.bfloat16, device=dev))
             elif kind == "gate":

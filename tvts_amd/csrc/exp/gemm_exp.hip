@@ -66,7 +66,7 @@ __device__ __forceinline__ void epilogue256_patch_m32(const GemmNT& g, f32x16 (&
                         *(f32x4*)(patch + r16 * 256 + ((c ^ r16) << 4)) = v + b4;
                     }
             }
-            patch_readout<ACT, GATE>(g, patch, m0 + wm * 128 + i * 32 + p * 16, nb, lane);
+            patch_readout<ACT, GATE>(g, patch, m0 + wm * 128 + i * 32 + p * 16, nb, lane, SideSlab());
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -215,6 +215,8 @@ extern "C" int tvts_exp_gemm_nt(int variant, int gc, int stagger_phases, int sta
             case 42: kern = pick_abl<32>(act, gate_act, gated); break;   // sc1 stores
             case 74: kern = pick_abl<64>(act, gate_act, gated); break;   // plain stores (round 1)
             case 138: kern = pick_abl<128>(act, gate_act, gated); break; // nt stores + nt side loads
+            case 266: kern = pick_abl<256>(act, gate_act, gated); break; // side inputs prefetched one slab ahead
+            case 394: kern = pick_abl<384>(act, gate_act, gated); break; // prefetch + nt side loads
             default: return TVTS_EINVAL;
         }
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);

@@ -191,6 +191,10 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_
         kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, FP8> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, FP8>
              : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, FP8> : nullptr;
     }
+    // fp32 residual in the epilogue, no activation: the instantiation that requests the residual of slab i + 1 as soon as slab i
+    // has consumed its registers (ABL 256: proj + residual 334 -> 294 us, fc2 + residual 749 -> 713 us at M = 150 720; it costs the
+    // plain / activation / gate kernels 1-12 %, so they keep the in-place loads)
+    if (!gated && act == ACT_NONE && g.residual) kern = gemm_nt256p_kernel<0, 0, FP8, 256>;
     if (!kern) return TVTS_EINVAL;
     const int lds_bytes = 163840;  // 2 x 64 KiB stages + 8 x 4 KiB epilogue patches
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

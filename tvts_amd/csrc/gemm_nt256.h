@@ -106,10 +106,54 @@ __device__ __forceinline__ V side_load(const void* p) {
     else return *(const V*)p;
 }
 
+// side inputs of one 16-row slab in this lane's read-out layout (fp32 out: 4 x (row idx>>4, 4 columns); bf16 out: 2 x (row idx>>3,
+// 8 columns)): fetched ONE SLAB AHEAD of their use so that their latency hides under the previous slab's LDS round trip and
+// stores instead of serialising eight load -> compute -> store chains per tile
+struct SideSlab {
+    f32x4 res[4];   // fp32 residual
+    bf16x8 gate[2]; // bf16 pre-activation of the gate (fp32-out path uses the halves)
+};
+template <int GATE, int ABL>
+__device__ __forceinline__ void side_prefetch(const GemmNT& g, int m_base, int nb, int lane, SideSlab& s) {
+    if (ABL & 2) return;
+    if (g.out_f32) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = lane + 64 * t, r = idx >> 4, c16 = idx & 15;
+            int m = m_base + r;
+            const int n = nb + c16 * 4;
+            m = m < g.M ? m : g.M - 1;
+            if (n >= g.N) continue;
+            if (GATE == ACT_NONE && g.residual) s.res[t] = side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
+            if (GATE != ACT_NONE) {
+                const bf16x4 h = side_load<ABL, bf16x4>(g.gate_h + (size_t)m * g.ldh + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s.gate[t >> 1][(t & 1) * 4 + e] = h[e];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int idx = lane + 64 * t, r = idx >> 3, c8 = idx & 7;
+            int m = m_base + r;
+            const int n = nb + c8 * 8;
+            m = m < g.M ? m : g.M - 1;
+            if (n >= g.N) continue;
+            if (GATE == ACT_NONE && g.residual) {
+                s.res[2 * t] = side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
+                s.res[2 * t + 1] = side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n + 4);
+            }
+            if (GATE != ACT_NONE) s.gate[t] = side_load<ABL, bf16x8>(g.gate_h + (size_t)m * g.ldh + n);
+        }
+    }
+}
+
 // ABL (compile-time, 0 in every production instantiation; csrc/exp instantiates the others to price the epilogue's parts):
 // 2 = side inputs (residual / gate) are not loaded, 4 = results are not stored (one never-taken store keeps them live).
+// ABL & 256 = side inputs come from `side` (prefetched one slab ahead) instead of being loaded here.
 template <int ACT, int GATE, int ABL = 0>
-__device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch, int m_base, int nb, int lane) {
+__device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch, int m_base, int nb, int lane, const SideSlab& side) {
+    constexpr bool PF = (ABL & 256) != 0;
     if (g.out_f32) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -123,11 +167,13 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
             }
             if (GATE != ACT_NONE) {
-                const bf16x4 h = (ABL & 2) ? (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]} : side_load<ABL, bf16x4>(g.gate_h + (size_t)m * g.ldh + n);
+                const bf16x4 h = (ABL & 2) ? (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}
+                               : PF ? (bf16x4){side.gate[t >> 1][(t & 1) * 4], side.gate[t >> 1][(t & 1) * 4 + 1], side.gate[t >> 1][(t & 1) * 4 + 2], side.gate[t >> 1][(t & 1) * 4 + 3]}
+                                    : side_load<ABL, bf16x4>(g.gate_h + (size_t)m * g.ldh + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
             }
-            if (g.residual && !(ABL & 2)) v += side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
+            if (g.residual && !(ABL & 2)) v += (PF && GATE == ACT_NONE) ? side.res[t] : side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
             if (!(ABL & 4) || v[0] == 1.2345e33f) store16<ABL>((float*)g.out + (size_t)m * g.ldc + n, v);
         }
     } else {
@@ -155,13 +201,14 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
 #pragma unroll
                     for (int e = 0; e < 8; ++e) h[e] = (bf16)v[e];
                 } else {
-                    h = side_load<ABL, bf16x8>(g.gate_h + (size_t)m * g.ldh + n);
+                    h = PF ? side.gate[t] : side_load<ABL, bf16x8>(g.gate_h + (size_t)m * g.ldh + n);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= act_bwd((float)h[e], GATE);
             }
             if (g.residual && !(ABL & 2)) {
-                const f32x4 r0 = side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n), r1 = side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n + 4);
+                const f32x4 r0 = (PF && GATE == ACT_NONE) ? side.res[2 * t] : side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
+                const f32x4 r1 = (PF && GATE == ACT_NONE) ? side.res[2 * t + 1] : side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
             }
@@ -196,6 +243,10 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
         const int n = nb + j * 16 + gq * 4;
         bias4[j] = (g.bias && n < g.N) ? *(const f32x4*)(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    constexpr bool PF = (ABL & 256) != 0;
+    SideSlab side;  // ONE buffer: slab i + 1 is requested as soon as slab i has consumed it (a second buffer spills)
+    const bool has_side = (g.residual != nullptr) || GATE != ACT_NONE;
+    if (PF && has_side) side_prefetch<GATE, ABL>(g, m0 + wm * 128, nb, lane, side);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         float sc = scale;
@@ -208,7 +259,8 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
             *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i] * sc + bias4[j];
             acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        patch_readout<ACT, GATE, ABL>(g, patch, m0 + wm * 128 + i * 16, nb, lane);
+        patch_readout<ACT, GATE, ABL>(g, patch, m0 + wm * 128 + i * 16, nb, lane, side);
+        if (PF && has_side && i + 1 < 8) side_prefetch<GATE, ABL>(g, m0 + wm * 128 + (i + 1) * 16, nb, lane, side);
     }
 }
 
