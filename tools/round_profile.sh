@@ -1,0 +1,33 @@
+#!/bin/bash
+# The round's measurement set on one MI355X (run through gpurun from the repo root):  tools/round_profile.sh r02
+#   1. rocprofv3 --kernel-trace of the default bench step (eager launches)  -> gpurun_out/<tag>/kernel_summary_default_b192.txt
+#   2. tools/pmc_traffic.sh (FETCH_SIZE / WRITE_SIZE passes) + the per-shape join -> pmc_step_traffic_*.json, pmc_gemm_traffic_by_shape.txt
+#   3. bench lines: default, the reference's per-GPU batch (12 pairs), WebVid-style NT = 1, B/32 (configs[1]), H/14 16 frames
+#      bf16 and fp8, v1 -> bench_*.json(l)
+tag=${1:-r02}
+out=$GRAFT_REPO_ROOT/gpurun_out/$tag
+mkdir -p $out
+cd $GRAFT_REPO_ROOT
+python -c "import torch" > /dev/null 2>&1
+python bench.py --steps 20 --warmup 5 > $out/bench_default_b192.json 2> $out/bench_default.err
+tools/profile_step.sh ${tag}_default > $out/profile_step.log 2>&1
+cp gpurun_out/prof_${tag}_default/summary.txt $out/kernel_summary_default_b192.txt
+cp gpurun_out/prof_${tag}_default/kernel_stats.csv $out/kernel_stats_default_b192.csv
+tools/pmc_traffic.sh > $out/pmc_traffic.log 2>&1
+cp gpurun_out/pmc_step_traffic.json $out/pmc_step_traffic_B_16_t8_b192.json
+TVTS_BENCH_ORDER=gpurun_out/gemm_order.json python bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline > /dev/null 2> $out/order.err
+python tools/pmc_join.py gpurun_out/gemm_order.json gpurun_out > $out/pmc_gemm_traffic_by_shape.txt 2>> $out/order.err
+{ python bench.py --batch 12 --steps 20 --warmup 5 --no-cpu-baseline
+  python bench.py --batch 24 --steps 20 --warmup 5 --no-cpu-baseline
+  python bench.py --n-trans 1 --steps 20 --warmup 5 --no-cpu-baseline; } 2>/dev/null | grep '^{' > $out/bench_reference_batches.jsonl
+{ python bench.py --arch B_32 --batch 384 --steps 20 --warmup 5 --no-cpu-baseline
+  python bench.py --arch B_32 --batch 24 --steps 20 --warmup 5 --no-cpu-baseline; } 2>/dev/null | grep '^{' > $out/bench_b32_t8.jsonl
+{ python bench.py --arch H_14 --frames 16 --batch 48 --steps 8 --warmup 3 --no-cpu-baseline
+  python bench.py --arch H_14 --frames 16 --batch 48 --steps 8 --warmup 3 --no-cpu-baseline --fp8; } 2>/dev/null | grep '^{' > $out/bench_h14_t16_b48.jsonl
+{ python bench.py --arch v1 --frames 4 --batch 256 --steps 20 --warmup 5 --cpu-pairs 8
+  python bench.py --arch v1 --frames 16 --batch 64 --steps 20 --warmup 5 --no-cpu-baseline; } 2>/dev/null | grep '^{' > $out/bench_v1.jsonl
+tools/profile_step.sh ${tag}_v1 --arch v1 --frames 4 --batch 256 > $out/profile_v1.log 2>&1
+cp gpurun_out/prof_${tag}_v1/summary.txt $out/kernel_summary_v1_t4_b256.txt
+ls -la $out
+head -12 $out/kernel_summary_default_b192.txt
+cut -c1-160 $out/bench_default_b192.json | tail -1
