@@ -36,6 +36,11 @@ int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int
 /* test hook: force the weight-gradient kernel's LDS-DMA issue path (early_dma 0 = builtin path, the one operands past 4 GiB
  * take) and its tile walk (a_fast 0 / 1); -1 = automatic */
 void tvts_gemm_set_tn_mode(int early_dma, int a_fast);
+/* weight-gradient tile override for benches and tests: 0 auto, 128 (128x128 kernel, two blocks per CU), 256 (pipelined 256x256
+ * kernel); tvts_gemm_tn_select returns the tile tvts_gemm_tn_bf16 picks for M rows into an [Na, Nb] output under the current
+ * override */
+void tvts_gemm_set_tn_tile(int t);
+int tvts_gemm_tn_select(int M, int Na, int Nb);
 /* fp8 (OCP e4m3) operands with scales in device memory, fp32 accumulate: the GEMM of BASELINE config 4's weight / activation
  * path (nn.Linear sites of video_encoder_ViT_H_14.py); K % 128 == 0, lda / ldb % 16 == 0 (bytes).  scale_b: one scale for the
  * weight; scale_a: one scale for the tensor, or (scale_a_rows != 0) M per-row scales as written by tvts_quant_fp8_rows */

@@ -113,6 +113,47 @@ def test_gemm_tn(K, M, Na, Nb):
     assert rel(out, ref) < 3e-5
 
 
+@pytest.mark.parametrize("M,Na,Nb", [(64, 256, 256), (200, 512, 256), (1000, 768, 256), (9420, 768, 768), (37, 512, 128), (4097, 1280, 640),
+                                     (40001, 2304, 768), (333, 248, 264)])
+def test_gemm_tn_256_tile(K, M, Na, Nb):
+    """The pipelined 256x256 weight-gradient kernel (forced; the dispatcher picks it for M >= 32768 and >= 1.5 M outputs): whole
+    and ragged tiles, m-ranges that end inside a stage, the fused bias gradient, workspace and fp32-atomic partials, and bit
+    equality of the workspace path with itself across two launches (deterministic reduce)."""
+    from tvts_amd import _lib
+    lib = _lib.load()
+    p, q = bf(rnd(M, Na, seed=19)), bf(rnd(M, Nb, seed=20))
+    ref = p.float().t().double() @ q.float().double()
+    try:
+        lib.tvts_gemm_set_tn_tile(256)
+        assert lib.tvts_gemm_tn_select(M, Na, Nb) == 256
+        out = torch.full((Na, Nb), float("nan"), dtype=torch.float32, device=DEV)
+        K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=False)
+        assert rel(out, ref) < 3e-5, rel(out, ref)
+        out2 = torch.full((Na, Nb), float("nan"), dtype=torch.float32, device=DEV)
+        K.gemm_tn(p.to(DEV), q.to(DEV), out2, accumulate=False)
+        assert torch.equal(out, out2)
+        cs = torch.ones(Na, device=DEV)
+        K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True, colsum=cs)
+        assert rel(out, 2 * ref) < 3e-5
+        assert rel(cs, 1 + p.float().sum(0)) < 2e-5, rel(cs, 1 + p.float().sum(0))
+        K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True, workspace=False)  # fp32-atomic fallback (no workspace)
+        assert rel(out, 3 * ref) < 3e-5
+        K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=False, workspace=False)
+        assert rel(out, ref) < 3e-5
+    finally:
+        lib.tvts_gemm_set_tn_tile(0)
+
+
+def test_gemm_tn_tile_selection(K):
+    """The step's big weight gradients take the 256x256 kernel, the projections and the text tower the 128x128 one."""
+    from tvts_amd import _lib
+    lib = _lib.load()
+    M = 192 * 785
+    assert lib.tvts_gemm_tn_select(M, 2304, 768) == 256 and lib.tvts_gemm_tn_select(M, 768, 3072) == 256
+    assert lib.tvts_gemm_tn_select(M, 768, 768) == 128 and lib.tvts_gemm_tn_select(24576, 2048, 512) == 128
+    assert lib.tvts_gemm_tn_select(12 * 785, 2304, 768) == 128
+
+
 def test_gemm_tn_views(K):
     """P and Q as column slices of wider buffers (leading dimension != width)."""
     M = 500

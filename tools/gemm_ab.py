@@ -57,14 +57,11 @@ def main():
         ("fc1 dgrad", M, 768, 3072, "plain"), ("qkv dgrad", M, 768, 2304, "plain"), ("square", 4096, 4096, 4096, "plain")]
     # variant 10 + ABL = the production kernel with a compile-time epilogue ablation (results are wrong by construction, not checked):
     # 11 no epilogue, 12 no side-input loads (residual / gate), 14 no stores, 16 neither loads nor stores (LDS transpose + math only)
-    variants = [("prod", 0, -1, (0, 0)), ("side prefetch", 266, -1, (0, 0)), ("prefetch+nt ld", 394, -1, (0, 0)), ("no-side-loads", 12, -1, (0, 0))]
-    if os.environ.get("AB_FULL"):
-        variants += [("no-epi", 11, -1, (0, 0)), ("plain st", 74, -1, (0, 0)), ("nt side ld", 138, -1, (0, 0)), ("no-stores", 14, -1, (0, 0)),
-                     ("lds+math only", 16, -1, (0, 0))]
-    if os.environ.get("AB_ABL"):
-        variants += [("no-side-loads", 12, -1, (0, 0)), ("no-stores", 14, -1, (0, 0)), ("lds+math only", 16, -1, (0, 0))]
-    if os.environ.get("AB_M32"):
-        variants += [("m32", 1, -1, (0, 0))]
+    catalog = {"prod": 0, "no-epi": 11, "no-side-loads": 12, "no-stores": 14, "lds+math only": 16, "stag2": 18, "stag4": 26, "sc1 st": 42,
+               "plain st": 74, "nt side ld": 138, "side prefetch": 266, "prefetch+nt ld": 394, "cnt vmcnt": 522, "reg": 1034,
+               "reg+cnt": 1546, "reg+cnt+stag4": 1562, "m32": 1}
+    names = os.environ.get("AB_VARIANTS", "prod,side prefetch,no-side-loads").split(",")
+    variants = [(n, catalog[n], -1, (0, 0)) for n in names]
     tot = {v[0]: 0.0 for v in variants}
     # NSETS independent operand / output sets used round-robin inside the timed loop: in the training step a GEMM's activations
     # were written by the previous kernel and its output is read by the next one -- nothing is re-read from one launch to the
@@ -99,8 +96,11 @@ def main():
                 continue
             out.fill_(float("nan"))
             exp_gemm(v, gc, stag, a, b, out, **kw)
-            err = float((out.float() - ref.float()).norm() / ref.float().norm())
-            assert err < (3e-3 if odt == torch.bfloat16 else 1e-5), (name, vn, err)
+            d = (out.float() - ref.float())
+            err, amax = float(d.norm() / ref.float().norm()), float(d.abs().max())  # NaN if anything was left unwritten
+            ok = err < (3e-3 if odt == torch.bfloat16 else 1e-5) and amax <= (0.13 if odt == torch.bfloat16 else 2e-4)
+            if not ok:
+                print(f"  WRONG {name} / {vn}: rel {err:.3e} max-abs {amax:.3e}", flush=True)
         ts = {vn: [] for vn, *_ in vs}
         def run_sets(v, gc, stag):
             for a_, kw_, out_ in sets:

@@ -176,12 +176,24 @@ static void (*pick_m32(int act, int gate_act, bool gated))(GemmNT, ExpArgs) {
          : act == ACT_GELU_ERF ? gemm_nt256m32_kernel<2, 0, PRIO> : nullptr;
 }
 
+// register-path epilogue variants: the output kind (fp32 output, fp32 residual) is a template argument
+template <int ABL>
+static void (*pick_reg(int act, int gate_act, bool gated, int out_f32, bool res))(GemmNT) {
+    if (gated) return out_f32 || res ? nullptr : gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, ABL, 0> : gemm_nt256p_kernel<0, 2, false, ABL, 0>;
+    if (act != ACT_NONE) return out_f32 || res ? nullptr : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, false, ABL, 0> : gemm_nt256p_kernel<2, 0, false, ABL, 0>;
+    return out_f32 ? (res ? gemm_nt256p_kernel<0, 0, false, ABL, 3> : gemm_nt256p_kernel<0, 0, false, ABL, 1>)
+                   : (res ? gemm_nt256p_kernel<0, 0, false, ABL, 2> : gemm_nt256p_kernel<0, 0, false, ABL, 0>);
+}
+
 template <int ABL>
 static void (*pick_abl(int act, int gate_act, bool gated))(GemmNT) {
     if (gated) return gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, ABL> : gemm_nt256p_kernel<0, 2, false, ABL>;
     return act == ACT_NONE ? gemm_nt256p_kernel<0, 0, false, ABL> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, false, ABL>
          : gemm_nt256p_kernel<2, 0, false, ABL>;
 }
+
+static void* g_trace = nullptr;  // [grid][32 tiles][6] u64 time stamps (variants with ABL & 2048)
+extern "C" void tvts_exp_set_trace(void* p) { g_trace = p; }
 
 // variant: 0 production kernel, 1 M32, 2 M32 + setprio, 10 + ABL: the production kernel with epilogue ablation ABL (1 none, 2 no side
 // loads, 4 no stores, 6 neither).  gc < 0: the production column-group rule.
@@ -217,8 +229,17 @@ extern "C" int tvts_exp_gemm_nt(int variant, int gc, int stagger_phases, int sta
             case 138: kern = pick_abl<128>(act, gate_act, gated); break; // nt stores + nt side loads
             case 266: kern = pick_abl<256>(act, gate_act, gated); break; // side inputs prefetched one slab ahead
             case 394: kern = pick_abl<384>(act, gate_act, gated); break; // prefetch + nt side loads
+            case 2058: kern = pick_abl<2048>(act, gate_act, gated); g.sa = (const float*)g_trace; break;  // production + time stamps
+            case 2074: kern = pick_abl<2064>(act, gate_act, gated); g.sa = (const float*)g_trace; break;  // 4-phase stagger + time stamps
+            case 3594: kern = pick_reg<3584>(act, gate_act, gated, out_f32, residual != nullptr); g.sa = (const float*)g_trace; break;  // reg + cnt + stamps
+            case 522: kern = pick_abl<512>(act, gate_act, gated); break;   // counted vmcnt behind the epilogue
+            case 1034: kern = pick_reg<1024>(act, gate_act, gated, out_f32, residual != nullptr); break; // register-path epilogue
+            case 1546: kern = pick_reg<1536>(act, gate_act, gated, out_f32, residual != nullptr); break; // ... + counted vmcnt
+            case 1562: kern = pick_reg<1552>(act, gate_act, gated, out_f32, residual != nullptr); break; // ... + 4-phase stagger
             default: return TVTS_EINVAL;
         }
+        if (!kern) return TVTS_EINVAL;
+        if (variant >= 1034 && variant != 2058 && variant != 2074 && K < 2 * BK) return TVTS_EINVAL;  // the register-path epilogue requests the bias two stages before the tile ends
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 163840, stream, g);

@@ -475,9 +475,23 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
+#include "gemm_tn256.h"
+
 // test / bench hook (no environment reads on the launch path): -1 = automatic choice
 static int g_tn_early = -1, g_tn_afast = -1;
 extern "C" void tvts_gemm_set_tn_mode(int early_dma, int a_fast) { g_tn_early = early_dma; g_tn_afast = a_fast; }
+// tile selection: the pipelined 256x256 kernel for long contractions into large outputs -- M >= 32 768 rows, at least 1.5 M
+// output elements, at most 15 % of the 256-tiling's area wasted: the qkv / fc1 / fc2 weight gradients of the ViT blocks
+// (tools/tn_ab.py, M = 150 720: 958 -> 1038, 978 -> 1078, 994 -> 1067 TF) -- else the 128x128 kernel, which is the faster one
+// on the 768 x 768 projections (926 vs 880 TF) and on the text tower's M = 24 576.  0 auto, 128 / 256 force.
+static int g_tn_tile = 0;
+extern "C" void tvts_gemm_set_tn_tile(int t) { g_tn_tile = (t == 128 || t == 256) ? t : 0; }
+static bool tn_use_256(int M, int Na, int Nb) {
+    if (g_tn_tile) return g_tn_tile == 256;
+    const double area = 65536.0 * ceil_div(Na, 256) * ceil_div(Nb, 256), elems = (double)Na * (double)Nb;
+    return M >= 32768 && elems >= 1.5e6 && area <= 1.15 * elems;
+}
+extern "C" int tvts_gemm_tn_select(int M, int Na, int Nb) { return tn_use_256(M, Na, Nb) ? 256 : 128; }
 
 extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb,
                                  float* out, int ldo, int accumulate, float* colsum, float* workspace,
@@ -488,8 +502,10 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     g.ws = nullptr; g.early_dma = 0; g.tiles_a = 0; g.a_fast = 0;
     g.P = (const bf16*)P; g.ldp = ldp; g.Q = (const bf16*)Q; g.ldq = ldq; g.M = M; g.Na = Na; g.Nb = Nb;
     g.out = out; g.ldo = ldo; g.colsum = colsum;
-    const int tiles_a = ceil_div(Na, 128);
-    g.tiles_b = ceil_div(Nb, 128);
+    const bool t256 = tn_use_256(M, Na, Nb);
+    const int tile = t256 ? 256 : 128;
+    const int tiles_a = ceil_div(Na, tile);
+    g.tiles_b = ceil_div(Nb, tile);
     g.tiles_ab = tiles_a * g.tiles_b;
     g.tiles_a = tiles_a;
     g.a_fast = g_tn_afast >= 0 ? g_tn_afast : (tiles_a < g.tiles_b ? 1 : 0);  // walk the tiles of an m-range with the SHORTER tile dimension fastest
@@ -504,7 +520,8 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
         for (int sp = 1; sp <= 64; ++sp) {
             if (sp > 1 && M / sp < 768) break;
             const long blocks = (long)g.tiles_ab * sp;
-            const double eff = (double)blocks / (512.0 * (double)((blocks + 511) / 512));
+            const long slots = t256 ? 256 : 512;  // co-resident blocks: one 512-thread block per CU, or two 256-thread ones
+            const double eff = (double)blocks / ((double)slots * (double)((blocks + slots - 1) / slots));
             if (eff > best + 1e-9) { best = eff; splits = sp; }
             if (eff >= 0.93) { splits = sp; break; }
         }
@@ -525,11 +542,17 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
         if (e != hipSuccess) return (int)e;
     }
     g.atomic = (accumulate || splits > 1) ? 1 : 0;
-    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    if (e2 != hipSuccess) return (int)e2;
     g.n_items = g.tiles_ab * splits;
     const int grid = ceil_div(g.n_items, 8) * 8;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(NTHREADS), 65536, stream, g);
+    if (t256) {
+        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e2 != hipSuccess) return (int)e2;
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3(grid), dim3(512), 131072, stream, g);
+    } else {
+        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e2 != hipSuccess) return (int)e2;
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(NTHREADS), 65536, stream, g);
+    }
     if (use_ws) {
         const long n4 = (long)Na * Nb / 4;
         int rb = (int)((n4 + 255) / 256);

@@ -264,6 +264,211 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-path epilogue (ABL & 1024): no LDS round trip.  fp32 results leave in the accumulator layout itself (a store
+// instruction covers 16 rows x 64 contiguous bytes).  bf16 results: v_permlane16_swap_b32 between the accumulator tiles of
+// column pairs (j, j + 1) hands every lane 8 consecutive columns of its row -- lane (li, gq) ends up with columns
+// 16 (2p + (gq & 1)) + 8 (gq >> 1) .. + 7 of pair p -- so that a store instruction again covers 16 rows x 64 contiguous bytes.
+// Side inputs (residual / gate) are requested TWO row-tiles ahead and always BEFORE the stores of the current one: the
+// memory counter retires in order, so a side load issued behind a store cannot be consumed before that store is acknowledged.
+// hipcc waits vmcnt(0) for every ordinary load it tracks while an LDS-DMA is in flight (which is always, here), so on wave
+// tiles that lie wholly inside the matrix (FULL) the side loads are inline asm and their waits are counted by hand:
+//   issue order  L0 L1 | L2 S0 | L3 S1 | ... | L7 S5 | S6 | S7      (Lk / Sk = the NL loads / NS stores of row-tile k)
+//   wait before consuming Lk:  k = 0: NL,  k = 1: NL + NS,  2 <= k <= 6: NL + 2 NS,  k = 7: 2 NS  operations may stay outstanding.
+// The bias is already in the accumulators: the K loop requests it two stages before the tile ends and adds it during the last one.
+// ------------------------------------------------------------------------------------------------
+struct SideReg {
+    f32x4 res[4];   // fp32 out: residual of column tile j; bf16 out: the two halves of pair p at [2p], [2p + 1]
+    bf16x8 gate[2]; // bf16 out: pre-activation of pair p; fp32 out: column tiles 2p, 2p + 1 in the halves
+};
+// 16-byte load the compiler does not track: uniform base (SGPR pair) + per-lane 32-bit byte offset + immediate
+template <int ABL, int IMM, typename V>
+__device__ __forceinline__ void asm_load16(V& d, const void* base, unsigned voff) {
+    static_assert(sizeof(V) == 16, "16-byte vector");
+    if constexpr ((ABL & 128) != 0) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(d) : "v"(voff), "s"(base), "i"(IMM) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(base), "i"(IMM) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void asm_wait_vm(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void asm_wait_vm(bf16x8& a, bf16x8& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
+}
+
+// side inputs of one row-tile, FULL wave tiles: inline-asm loads at byte offset voff (this lane's row and first column) from the
+// side matrix's base; the column tiles / pairs are immediates
+template <int GATE, int ABL, int CFG>
+__device__ __forceinline__ void side_load_asm(const GemmNT& g, unsigned voff, SideReg& s) {
+    constexpr bool out_f32 = (CFG & 1) != 0;
+    if constexpr (GATE != ACT_NONE) {
+        static_assert(!out_f32, "gate + fp32 output takes the tracked loads");
+        asm_load16<ABL, 0>(s.gate[0], g.gate_h, voff);
+        asm_load16<ABL, 64>(s.gate[1], g.gate_h, voff);
+    } else if constexpr (out_f32) {
+        asm_load16<ABL, 0>(s.res[0], g.residual, voff);
+        asm_load16<ABL, 64>(s.res[1], g.residual, voff);
+        asm_load16<ABL, 128>(s.res[2], g.residual, voff);
+        asm_load16<ABL, 192>(s.res[3], g.residual, voff);
+    } else {
+        asm_load16<ABL, 0>(s.res[0], g.residual, voff);
+        asm_load16<ABL, 16>(s.res[1], g.residual, voff);
+        asm_load16<ABL, 128>(s.res[2], g.residual, voff);
+        asm_load16<ABL, 144>(s.res[3], g.residual, voff);
+    }
+}
+// any wave tile: compiler-tracked loads, rows / columns clamped
+template <int GATE, int ABL, int CFG>
+__device__ __forceinline__ void side_load_reg(const GemmNT& g, int m, int nb, int gq, SideReg& s) {
+    constexpr bool out_f32 = (CFG & 1) != 0, has_res = (CFG & 2) != 0;
+    m = m < g.M ? m : g.M - 1;
+    if (out_f32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = nb + 16 * j + 4 * gq;
+            n = n < g.N ? n : g.N - 4;  // clamped, not skipped: a predicated load would make every later use wait for it
+            if (GATE == ACT_NONE && has_res) s.res[j] = side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
+            if (GATE != ACT_NONE) {
+                const bf16x4 h = side_load<ABL, bf16x4>(g.gate_h + (size_t)m * g.ldh + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s.gate[j >> 1][(j & 1) * 4 + e] = h[e];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            int n = nb + 16 * (2 * p + (gq & 1)) + 8 * (gq >> 1);
+            n = n < g.N ? n : g.N - 8;
+            if (GATE == ACT_NONE && has_res) {
+                s.res[2 * p] = side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
+                s.res[2 * p + 1] = side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n + 4);
+            }
+            if (GATE != ACT_NONE) s.gate[p] = side_load<ABL, bf16x8>(g.gate_h + (size_t)m * g.ldh + n);
+        }
+    }
+}
+
+template <int I> struct IC { static constexpr int value = I; };
+
+// FULL: the wave tile (128 rows x 64 columns) lies inside the matrix -- no clamps, no predicates, counted waits.
+// CFG bit 0: fp32 output, bit 1: fp32 residual present.
+template <int ACT, int GATE, int ABL, int CFG, bool FULL>
+__device__ __forceinline__ void epilogue256_reg(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn, int lane) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    constexpr bool out_f32 = (CFG & 1) != 0, has_res = (CFG & 2) != 0;
+    constexpr bool GATED = GATE != ACT_NONE;
+    constexpr bool has_side = has_res || GATED;
+    // asm loads + counted waits exist for: fp32 out + residual, bf16 out + residual, bf16 out + gate
+    constexpr bool ASM = FULL && has_side && !(out_f32 && GATED);
+    constexpr int NL = GATED ? 2 : 4;
+    constexpr int NS = out_f32 ? 4 : 2;
+    static_assert(!(has_side && ACT != ACT_NONE), "activation epilogues take no side input");
+    const int nb = n0 + wn * 64;
+    const int li = lane & 15, gq = lane >> 4;
+    const int mb = m0 + wm * 128 + li;
+    SideReg sA, sB;
+    // ASM: byte offset of this lane's first side element (its row, its first column) and the step of 16 rows; < 4 GiB (dispatch)
+    const int col0 = out_f32 ? 4 * gq : 16 * (gq & 1) + 8 * (gq >> 1);
+    const unsigned esz = GATED ? 2u : 4u, lds_ = GATED ? (unsigned)g.ldh : (unsigned)g.ldr;
+    unsigned voff = ((unsigned)mb * lds_ + (unsigned)(nb + col0)) * esz;
+    const unsigned vstep = 16u * lds_ * esz;
+    if (has_side) {
+        if constexpr (ASM) {
+            side_load_asm<GATE, ABL, CFG>(g, voff, sA);
+            side_load_asm<GATE, ABL, CFG>(g, voff + vstep, sB);
+            voff += 2 * vstep;
+        }
+    }
+    auto slab = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int m = mb + i * 16;
+        SideReg& s = (i & 1) ? sB : sA;
+        if (has_side && !ASM) side_load_reg<GATE, ABL, CFG>(g, m, nb, gq, s);  // edge tiles: fetched in place (few tiles, few registers)
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = acc[j][i];  // bias included (added inside the K loop)
+            acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (ASM) {
+            constexpr int N = i == 0 ? NL : i == 1 ? NL + NS : i == 7 ? 2 * NS : NL + 2 * NS;
+            if constexpr (GATED) asm_wait_vm<N>(s.gate[0], s.gate[1]);
+            else asm_wait_vm<N>(s.res[0], s.res[1], s.res[2], s.res[3]);
+        }
+        if constexpr (out_f32) {
+            bf16x4 pre[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ACT != ACT_NONE) {
+                    pre[j] = (bf16x4){(bf16)v[j][0], (bf16)v[j][1], (bf16)v[j][2], (bf16)v[j][3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j][e] = act_fwd(v[j][e], ACT);
+                }
+                if (GATED) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j][e] *= act_bwd((float)s.gate[j >> 1][(j & 1) * 4 + e], GATE);
+                }
+                if (!GATED && has_res) v[j] += s.res[j];
+            }
+            if constexpr (ASM && i + 2 < 8) { side_load_asm<GATE, ABL, CFG>(g, voff, s); voff += vstep; }
+            if (FULL || m < g.M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nb + 16 * j + 4 * gq;
+                    if (!FULL && n >= g.N) continue;
+                    if (ACT != ACT_NONE && g.preact) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = pre[j];
+                    store16<ABL>((float*)g.out + (size_t)m * g.ldc + n, v[j]);
+                }
+            }
+        } else {
+            // hand every lane 8 consecutive columns: swap row 1 / 3 (gq odd) of tile 2p with row 0 / 2 (gq even) of tile 2p + 1
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // (element copies first: __builtin_bit_cast applied to a vector element reads element 0 whatever e is)
+                    const float xa = v[2 * p][e], xb = v[2 * p + 1][e];
+                    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
+                    const unsigned r0 = r[0], r1 = r[1];
+                    v[2 * p][e] = __uint_as_float(r0);
+                    v[2 * p + 1][e] = __uint_as_float(r1);
+                }
+            bf16x8 pre[2], o[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float w[8] = {v[2 * p][0], v[2 * p][1], v[2 * p][2], v[2 * p][3], v[2 * p + 1][0], v[2 * p + 1][1], v[2 * p + 1][2], v[2 * p + 1][3]};
+                if (ACT != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { pre[p][e] = (bf16)w[e]; w[e] = act_fwd(w[e], ACT); }
+                }
+                if (GATED) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] *= act_bwd((float)s.gate[p][e], GATE);
+                }
+                if (!GATED && has_res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { w[e] += s.res[2 * p][e]; w[4 + e] += s.res[2 * p + 1][e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[p][e] = (bf16)w[e];
+            }
+            if constexpr (ASM && i + 2 < 8) { side_load_asm<GATE, ABL, CFG>(g, voff, s); voff += vstep; }
+            if (FULL || m < g.M) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int n = nb + 16 * (2 * p + (gq & 1)) + 8 * (gq >> 1);
+                    if (!FULL && n >= g.N) continue;
+                    if (ACT != ACT_NONE && g.preact) store16<ABL>(g.preact + (size_t)m * g.ldp + n, pre[p]);
+                    store16<ABL>((bf16*)g.out + (size_t)m * g.ldc + n, o[p]);
+                }
+            }
+        }
+    };
+    slab(IC<0>{}); slab(IC<1>{}); slab(IC<2>{}); slab(IC<3>{});
+    slab(IC<4>{}); slab(IC<5>{}); slab(IC<6>{}); slab(IC<7>{});
+}
+
 #define RAW_BARRIER_P()                       \
     do {                                      \
         asm volatile("" ::: "memory");        \
@@ -271,7 +476,9 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
         asm volatile("" ::: "memory");        \
     } while (0)
 
-template <int ACT, int GATE, bool FP8 = false, int ABL = 0>
+// CFG >= 0 (register-path epilogue): the output kind is compiled in -- bit 0 fp32 output, bit 1 fp32 residual -- so that the
+// plain instantiations do not carry the residual's registers; CFG < 0: read from the arguments
+template <int ACT, int GATE, bool FP8 = false, int ABL = 0, int CFG = -1>
 __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 32K | B 32K] + 8 x 4K patches
     const int tid = threadIdx.x;
@@ -327,6 +534,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int kt = 0, tl = 0, m0, n0;
+    int young_stores = 0;
+    bool trace_next = false;
+    f32x4 bias4[4];  // register-path epilogue only
     tile_origin256(g, range_lo + slot, gc, m0, n0);
     const int arow = wm * 128 + (lane & 15), brow = wn * 64 + (lane & 15), gq = lane >> 4;
     // fragment registers: two A half-sets (4 MFMA row-tiles each) and two B sets, refilled while the matrix pipe
@@ -364,19 +574,98 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         MFMA16(aF[1], bF[0], 1);
         LOAD_A(aF[1], cur, 1, 1);
         MFMA16(aF[0], bF[1], 0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr ((ABL & 512) != 0) {
+            // the stage this wait is for was requested BEFORE the previous tile's epilogue; the counter retires in order, so
+            // leaving as many operations outstanding as the epilogue's tail issued stores still proves the stage has landed
+            if (young_stores == 32) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+            else if (young_stores == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            else if (young_stores == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (young_stores == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            young_stores = 0;
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
         RAW_BARRIER_P();
+        if constexpr ((ABL & 2048) != 0) {  // first barrier behind an epilogue: every wave of the block has finished its stores' issue
+            if (trace_next) {
+                if (wave == 0 && lane == 0 && tl - 1 < 32) {
+                    unsigned long long* tr = (unsigned long long*)g.sa + ((size_t)blockIdx.x * 32 + tl - 1) * 6;
+                    tr[4] = __builtin_amdgcn_s_memrealtime(); tr[5] = __builtin_amdgcn_s_memtime();
+                }
+                trace_next = false;
+            }
+        }
+        if constexpr ((ABL & 1024) != 0) {
+            // the tile's bias slice (this lane's 4 x 4 columns), requested two stages before the tile ends and AHEAD of this
+            // step's DMA, so that the next step's vmcnt wait retires it and the epilogue starts without a memory wait
+            if (kt == nk - 2) {
+                if (g.bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int n = n0 + wn * 64 + j * 16 + gq * 4;
+                        n = n < g.N ? n : g.N - 4;
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias4[j]) : "v"(g.bias + n) : "memory");
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bias4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            // ... and added into the accumulators one stage later (it has landed: the vmcnt wait above), under the tile's last
+            // MFMAs -- the matrix pipe keeps accumulating on top, and the epilogue holds no bias registers
+            if (kt == nk - 1) {
+                asm volatile("" : "+v"(bias4[0]), "+v"(bias4[1]), "+v"(bias4[2]), "+v"(bias4[3]));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[j][i] += bias4[j];
+            }
+        }
         if (i_st < total_st) issue();  // stage st+2 into the buffer every wave has just finished reading
-        if (st + 1 < total_st) {
+        // register-path epilogue: the next tile's first fragments are read behind the epilogue instead of across it (32 registers)
+        const bool defer_frag = (ABL & 1024) != 0 && kt + 1 == nk;
+        if (st + 1 < total_st && !defer_frag) {
             LOAD_B(bF[0], nxt, 0);
             LOAD_A(aF[0], nxt, 0, 0);
         }
         MFMA16(aF[1], bF[1], 1);
         if (++kt == nk) {
-            if (FP8 && g.sa_rows) epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, g.sb[0], g.sa);
-            else epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, FP8 ? g.sa[0] * g.sb[0] : 1.0f);
+            if constexpr ((ABL & 2048) != 0) {  // experiment library: per-tile time stamps of wave 0 (g.sa carries the trace buffer)
+                if (wave == 0 && lane == 0 && tl < 32) {
+                    unsigned long long* tr = (unsigned long long*)g.sa + ((size_t)blockIdx.x * 32 + tl) * 6;
+                    tr[0] = __builtin_amdgcn_s_memrealtime(); tr[1] = __builtin_amdgcn_s_memtime();
+                }
+            }
+            if constexpr ((ABL & 1024) != 0) {
+                static_assert(!FP8 && CFG >= 0, "register-path epilogue: bf16 operands, output kind compiled in");
+                const bool full = (m0 + wm * 128 + 128 <= g.M) && (n0 + wn * 64 + 64 <= g.N);
+                if (full) epilogue256_reg<ACT, GATE, ABL, CFG, true>(g, acc, m0, n0, wm, wn, lane);
+                else epilogue256_reg<ACT, GATE, ABL, CFG, false>(g, acc, m0, n0, wm, wn, lane);
+            } else {
+                if (FP8 && g.sa_rows) epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, g.sb[0], g.sa);
+                else epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, FP8 ? g.sa[0] * g.sb[0] : 1.0f);
+            }
+            if constexpr ((ABL & 2048) != 0) {
+                if (wave == 0 && lane == 0 && tl < 32) {
+                    unsigned long long* tr = (unsigned long long*)g.sa + ((size_t)blockIdx.x * 32 + tl) * 6;
+                    tr[2] = __builtin_amdgcn_s_memrealtime(); tr[3] = __builtin_amdgcn_s_memtime();
+                }
+                trace_next = true;
+            }
+            if constexpr ((ABL & 512) != 0) {
+                // a lower bound of the memory operations the epilogue issued: its stores (every row / column of the wave tile inside
+                // the matrix, else rows were skipped and the bound does not hold)
+                const bool full = (m0 + wm * 128 + 128 <= g.M) && (n0 + wn * 64 + 64 <= g.N);
+                const int per_slab = (g.out_f32 ? 4 : 2) * ((ACT != ACT_NONE && g.preact) ? 2 : 1);
+                young_stores = full ? (per_slab >= 4 ? 32 : 16) : 0;
+            }
             kt = 0; ++tl;
             tile_origin256(g, range_lo + slot + tl * per_xcd, gc, m0, n0);
+            if ((ABL & 1024) != 0 && st + 1 < total_st) {
+                LOAD_B(bF[0], nxt, 0);
+                LOAD_A(aF[0], nxt, 0, 0);
+            }
         }
     }
 #undef LOAD_A
