@@ -16,8 +16,12 @@ __device__ __forceinline__ unsigned tn_frag_off(int ct, int lane) {
     return (unsigned)(row * 256 + ((ct ^ (row & 7)) << 5) + (i & 3) * 8);
 }
 // the 8 k-slots of MFMA k-step u (32 rows of m) for the column block whose lane offset is `off`: rows u*32 + half*16 + ...
+#ifndef TN_ABL
+#define TN_ABL 0   // timing ablations, tools/dbg/tn_abl.sh (wrong results): 1 = no LDS-DMA behind the prologue, 2 = one ds_read_b128 per fragment
+#endif
 __device__ __forceinline__ bf16x8 tn_frag(const char* tile, unsigned off, int u) {
     typedef __attribute__((ext_vector_type(8))) short s16x8;
+    if (TN_ABL & 2) return *(const bf16x8*)(tile + ((off + u * 8192) & ~15u));
     const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + off + u * 8192));
     const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + off + u * 8192 + 4096));
     const s16x8 both = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmTN g) {
         TN_CS(pF[0], 0);                                                                               \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
         RAW_BARRIER_P();                                                                               \
-        if (i_st < nk) issue(); /* stage st+2 into the buffer every wave has just finished reading */  \
+        if (i_st < nk && !(TN_ABL & 1)) issue(); /* stage st+2 into the buffer every wave has just finished reading */  \
         if (st + 1 < nk) {                                                                             \
             TN_LOAD_Q(qF[0], nxt, 0);                                                                  \
             TN_LOAD_P(pF[0], nxt, 0, 0, valid_n);                                                      \
