@@ -345,6 +345,25 @@ def test_fp8_forward_path(gpu):
     assert min_cos(ve, fve) > 0.995 and abs(l1 - f1) < 5e-2 and abs(l2 - f2) < 5e-2, (min_cos(ve, fve), l1, f1, l2, f2)
 
 
+def test_fp8_forward_path_h14_structure(gpu):
+    """The same e4m3 forward path on BASELINE config 4's STRUCTURE: head dim 80, 14x14 patches, erf-GELU MLP (the fp8 GEMM's
+    gelu + pre-activation epilogue), OpenCLIP block order, pooled tail; width 640 so that every quantised GEMM has K % 128 == 0
+    like the real H/14 (1280 / 5120).  Tolerances as in test_fp8_forward_path."""
+    from tvts_amd import arch as A
+    a = A.small_arch_h(fp8=True, width=640, heads=8)
+    m, oarch, P = build(arch=a, seed=4)
+    batch = O.synth_batch(oarch, B=4, T=3, seed=6, caption_len=11)
+    r1, r2, rte, rve, rpred, grads = oracle_step(P, batch, oarch)
+    l1, l2, te, ve, pred, store = engine_step(m, batch)
+    assert len(store.w8) == 6 * a["layers"]
+    assert rel(te, rte) < 0.02
+    assert min_cos(ve, rve) > 0.999 and rel(ve, rve) < 0.04, (min_cos(ve, rve), rel(ve, rve))
+    assert abs(l1 - r1) < 2e-2 and abs(l2 - r2) < 2e-2, (l1, r1, l2, r2)
+    check_grads(store, grads, gn_tol=0.05, cos_tol=0.9)
+    f1, f2, fte, fve, fpred, fgrads = oracle_step(P, batch, dict(oarch, fp8=False))
+    assert min_cos(ve, fve) > 0.995 and abs(l1 - f1) < 5e-2 and abs(l2 - f2) < 5e-2, (min_cos(ve, fve), l1, f1, l2, f2)
+
+
 def test_b16_config2_against_reference_golden(gpu, golden):
     """The headline architecture (BASELINE config 2's model): the real TVTSv2_B_16 class ran in the build container at
     B=2, T=4 with tube mask 0.5 (98 of 196 patches kept: the fused SPACE / TIME attention kernels' shapes)."""
