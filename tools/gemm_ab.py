@@ -59,7 +59,7 @@ def main():
     # 11 no epilogue, 12 no side-input loads (residual / gate), 14 no stores, 16 neither loads nor stores (LDS transpose + math only)
     catalog = {"prod": 0, "no-epi": 11, "no-side-loads": 12, "no-stores": 14, "lds+math only": 16, "stag2": 18, "stag4": 26, "sc1 st": 42,
                "plain st": 74, "nt side ld": 138, "side prefetch": 266, "prefetch+nt ld": 394, "cnt vmcnt": 522, "reg": 1034,
-               "reg+cnt": 1546, "reg+cnt+stag4": 1562, "m32": 1}
+               "reg+cnt": 1546, "reg+cnt+stag4": 1562, "m32": 1, "pasm": 8202, "pasm+cnt": 8714}
     names = os.environ.get("AB_VARIANTS", "prod,side prefetch,no-side-loads").split(",")
     variants = [(n, catalog[n], -1, (0, 0)) for n in names]
     tot = {v[0]: 0.0 for v in variants}
@@ -95,6 +95,8 @@ def main():
             if v in (11, 12, 14, 16):
                 continue
             out.fill_(float("nan"))
+            if v >= 8202 and kind not in ("res32", "res16", "gate"):
+                continue
             exp_gemm(v, gc, stag, a, b, out, **kw)
             d = (out.float() - ref.float())
             err, amax = float(d.norm() / ref.float().norm()), float(d.abs().max())  # NaN if anything was left unwritten
@@ -105,12 +107,15 @@ def main():
         def run_sets(v, gc, stag):
             for a_, kw_, out_ in sets:
                 exp_gemm(v, gc, stag, a_, b, out_, **kw_)
+        vs = [x for x in vs if not (x[1] >= 8202 and kind not in ("res32", "res16", "gate"))]
         for _ in range(rounds):
             for vn, v, gc, stag in vs:
                 ts[vn].append(timeit(lambda: run_sets(v, gc, stag), iters=4) / len(sets))
         fl = 2.0 * m * n * k
         line = f"{name:18s} {m}x{n}x{k}:"
         for vn, *_ in vs:
+            if not ts[vn]:
+                continue
             med = sorted(ts[vn])[len(ts[vn]) // 2]
             if vn in tot:
                 tot[vn] += med

@@ -185,6 +185,15 @@ static void (*pick_reg(int act, int gate_act, bool gated, int out_f32, bool res)
                    : (res ? gemm_nt256p_kernel<0, 0, false, ABL, 2> : gemm_nt256p_kernel<0, 0, false, ABL, 0>);
 }
 
+// patch epilogue with counted side loads: gate (bf16 out) and fp32-residual (fp32 / bf16 out) kernels only
+template <int ABL>
+static void (*pick_pasm(int act, int gate_act, bool gated, int out_f32, bool res))(GemmNT) {
+    if (act != ACT_NONE) return nullptr;
+    if (gated) return out_f32 || res ? nullptr : gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, ABL, 0> : gemm_nt256p_kernel<0, 2, false, ABL, 0>;
+    if (!res) return nullptr;
+    return out_f32 ? gemm_nt256p_kernel<0, 0, false, ABL, 3> : gemm_nt256p_kernel<0, 0, false, ABL, 2>;
+}
+
 template <int ABL>
 static void (*pick_abl(int act, int gate_act, bool gated))(GemmNT) {
     if (gated) return gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, ABL> : gemm_nt256p_kernel<0, 2, false, ABL>;
@@ -232,6 +241,8 @@ extern "C" int tvts_exp_gemm_nt(int variant, int gc, int stagger_phases, int sta
             case 2058: kern = pick_abl<2048>(act, gate_act, gated); g.sa = (const float*)g_trace; break;  // production + time stamps
             case 2074: kern = pick_abl<2064>(act, gate_act, gated); g.sa = (const float*)g_trace; break;  // 4-phase stagger + time stamps
             case 3594: kern = pick_reg<3584>(act, gate_act, gated, out_f32, residual != nullptr); g.sa = (const float*)g_trace; break;  // reg + cnt + stamps
+            case 8202: kern = pick_pasm<8192>(act, gate_act, gated, out_f32, residual != nullptr); break;        // patch + counted side loads
+            case 8714: kern = pick_pasm<8192 + 512>(act, gate_act, gated, out_f32, residual != nullptr); break;  // ... + counted vmcnt behind the epilogue
             case 522: kern = pick_abl<512>(act, gate_act, gated); break;   // counted vmcnt behind the epilogue
             case 1034: kern = pick_reg<1024>(act, gate_act, gated, out_f32, residual != nullptr); break; // register-path epilogue
             case 1546: kern = pick_reg<1536>(act, gate_act, gated, out_f32, residual != nullptr); break; // ... + counted vmcnt

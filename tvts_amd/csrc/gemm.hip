@@ -195,6 +195,16 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_
     // has consumed its registers (ABL 256: proj + residual 334 -> 294 us, fc2 + residual 749 -> 713 us at M = 150 720; it costs the
     // plain / activation / gate kernels 1-12 %, so they keep the in-place loads)
     if (!gated && act == ACT_NONE && g.residual) kern = gemm_nt256p_kernel<0, 0, FP8, 256>;
+    // QuickGELU gate (fc2 dgrad of the B models), bf16 output: the patch epilogue whose pre-activation loads are inline asm, two
+    // row-tiles ahead and ahead of the stores, with hand-counted waits (ABL 8192: 969 -> 854 us at M = 150 720, N = 3072, K = 768;
+    // the residual kernels gain nothing over ABL 256, the erf-GELU gate spills).  Whole tile columns, K of two stages or more,
+    // 32-bit byte offsets into the gate and output matrices.
+    if constexpr (!FP8) {
+        if (gated && gate_act == ACT_QUICK_GELU && !g.out_f32 && !g.residual && g.N % 256 == 0 && g.K >= 2 * BK &&
+            (unsigned long long)g.M * (unsigned long long)g.ldh * 2ull < (1ull << 32) &&
+            (unsigned long long)g.M * (unsigned long long)g.ldc * 2ull < (1ull << 32))
+            kern = gemm_nt256p_kernel<0, 1, false, 8192, 0>;
+    }
     if (!kern) return TVTS_EINVAL;
     const int lds_bytes = 163840;  // 2 x 64 KiB stages + 8 x 4 KiB epilogue patches
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

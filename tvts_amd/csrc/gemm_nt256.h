@@ -288,6 +288,13 @@ __device__ __forceinline__ void asm_load16(V& d, const void* base, unsigned voff
     if constexpr ((ABL & 128) != 0) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(d) : "v"(voff), "s"(base), "i"(IMM) : "memory");
     else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(base), "i"(IMM) : "memory");
 }
+// 16-byte non-temporal store the compiler does not track: uniform base + per-lane 32-bit byte offset (s_nop 1: the data registers
+// of a 4-dword store may not be overwritten by the very next instruction)
+template <typename V>
+__device__ __forceinline__ void asm_store16(const V& d, void* base, unsigned voff) {
+    static_assert(sizeof(V) == 16, "16-byte vector");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"(voff), "v"(d), "s"(base) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void asm_wait_vm(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
@@ -469,6 +476,156 @@ __device__ __forceinline__ void epilogue256_reg(const GemmNT& g, f32x4 (&acc)[4]
     slab(IC<4>{}); slab(IC<5>{}); slab(IC<6>{}); slab(IC<7>{});
 }
 
+// ------------------------------------------------------------------------------------------------
+// Patch epilogue with hand-counted side loads (ABL & 8192; FULL wave tiles of the residual / gate kernels).  The LDS patch keeps
+// the stores and side loads at whole 128-B (bf16) / 256-B (fp32) row segments -- the register path's 64-B segments cost more
+// than its missing LDS round trip returns -- and the side inputs of row-tile k + 2 are requested (inline asm: hipcc would wait
+// vmcnt(0) for a tracked load while an LDS-DMA is in flight) BEFORE the stores of row-tile k, so that consuming them never waits
+// for a store younger than two row-tiles (issue order and wait counts as in the register path: L0 L1 | L2 S0 | L3 S1 | ...).
+// The bias is already in the accumulators.  CFG bit 0: fp32 output, bit 1: fp32 residual.
+// ------------------------------------------------------------------------------------------------
+template <int GATE, int ABL, int CFG, bool FULLT>
+__device__ __forceinline__ void side_load_patch_asm(const GemmNT& g, int m_base, int r0, unsigned col_off, unsigned row_step, SideSlab& s) {
+    constexpr bool out_f32 = (CFG & 1) != 0;
+    // read-out layout: fp32 out t < 4: rows t * 4 + (lane >> 4), 4 columns; bf16 out t < 2: rows t * 8 + (lane >> 3), 8 columns.
+    // FULLT: ONE per-lane offset, the row groups ride in the scalar base; edge tiles: every row clamped to the matrix on its own
+    if constexpr (FULLT) {
+        const unsigned voff = (unsigned)r0 * row_step + col_off;
+        const char* b = (const char*)(GATE != ACT_NONE ? (const void*)g.gate_h : (const void*)g.residual) + (size_t)m_base * row_step;
+        if constexpr (GATE != ACT_NONE) {
+            asm_load16<ABL, 0>(s.gate[0], b, voff);
+            asm_load16<ABL, 0>(s.gate[1], b + (size_t)8 * row_step, voff);
+        } else if constexpr (out_f32) {
+            asm_load16<ABL, 0>(s.res[0], b, voff);
+            asm_load16<ABL, 0>(s.res[1], b + (size_t)4 * row_step, voff);
+            asm_load16<ABL, 0>(s.res[2], b + (size_t)8 * row_step, voff);
+            asm_load16<ABL, 0>(s.res[3], b + (size_t)12 * row_step, voff);
+        } else {
+            asm_load16<ABL, 0>(s.res[0], b, voff);
+            asm_load16<ABL, 16>(s.res[1], b, voff);
+            asm_load16<ABL, 0>(s.res[2], b + (size_t)8 * row_step, voff);
+            asm_load16<ABL, 16>(s.res[3], b + (size_t)8 * row_step, voff);
+        }
+        return;
+    }
+    auto off = [&](int dr) -> unsigned {
+        int m = m_base + r0 + dr;
+        m = m < g.M ? m : g.M - 1;
+        return (unsigned)m * row_step + col_off;
+    };
+    if constexpr (GATE != ACT_NONE) {
+        static_assert(!out_f32, "gate + fp32 output takes the tracked loads");
+        asm_load16<ABL, 0>(s.gate[0], g.gate_h, off(0));
+        asm_load16<ABL, 0>(s.gate[1], g.gate_h, off(8));
+    } else if constexpr (out_f32) {
+        asm_load16<ABL, 0>(s.res[0], g.residual, off(0));
+        asm_load16<ABL, 0>(s.res[1], g.residual, off(4));
+        asm_load16<ABL, 0>(s.res[2], g.residual, off(8));
+        asm_load16<ABL, 0>(s.res[3], g.residual, off(12));
+    } else {
+        const unsigned o0 = off(0), o8 = off(8);
+        asm_load16<ABL, 0>(s.res[0], g.residual, o0);
+        asm_load16<ABL, 16>(s.res[1], g.residual, o0);
+        asm_load16<ABL, 0>(s.res[2], g.residual, o8);
+        asm_load16<ABL, 16>(s.res[3], g.residual, o8);
+    }
+}
+// FULLT: the wave tile lies inside the matrix (counted waits, no predicates); else rows clamped / stores predicated and every
+// wait is vmcnt(0) (predicated stores may not issue, which breaks the counts)
+template <int GATE, int ABL, int CFG, bool FULLT>
+__device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn, int lane,
+                                                      char* patch) {
+    constexpr bool out_f32 = (CFG & 1) != 0, has_res = (CFG & 2) != 0;
+    constexpr bool GATED = GATE != ACT_NONE;
+    static_assert(has_res != GATED, "one side input: the fp32 residual or the gate's pre-activation");
+    constexpr int NL = GATED ? 2 : 4;
+    constexpr int NS = out_f32 ? 4 : 2;
+    // the lane-derived constants below are recomputed from an opaque copy of the lane id: sharing them with the K loop's would keep
+    // them live across it, and the register allocator then spills them and reloads them here behind an s_waitcnt vmcnt(0)
+    asm volatile("" : "+v"(lane));
+    const int nb = n0 + wn * 64;
+    const int li = lane & 15, gq = lane >> 4;
+    const int mw = m0 + wm * 128;
+    const unsigned esz = GATED ? 2u : 4u, lds_ = GATED ? (unsigned)g.ldh : (unsigned)g.ldr;
+    const unsigned row_step = lds_ * esz;  // bytes per row of the side matrix (the matrix fits 4 GiB: dispatcher)
+    const int r0 = out_f32 ? (lane >> 4) : (lane >> 3), c0 = out_f32 ? (lane & 15) * 4 : (lane & 7) * 8;
+    const unsigned col_off = (unsigned)(nb + c0) * esz;
+    const unsigned out_step = (unsigned)g.ldc * (out_f32 ? 4u : 2u);  // bytes per output row
+    const unsigned out_voff = (unsigned)r0 * out_step + (unsigned)(nb + c0) * (out_f32 ? 4u : 2u);
+    SideSlab sA, sB;
+    if constexpr (FULLT) {
+        side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, mw, r0, col_off, row_step, sA);
+        side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, mw + 16, r0, col_off, row_step, sB);
+    }
+    auto slab = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        SideSlab& s = (FULLT && (i & 1)) ? sB : sA;
+        if constexpr (!FULLT) side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, mw + i * 16, r0, col_off, row_step, s);  // edge tiles: in place
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i];
+            acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        constexpr int N = !FULLT ? 0 : i == 0 ? NL : i == 1 ? NL + NS : i == 7 ? 2 * NS : NL + 2 * NS;
+        if constexpr (GATED) asm_wait_vm<N>(s.gate[0], s.gate[1]);
+        else asm_wait_vm<N>(s.res[0], s.res[1], s.res[2], s.res[3]);
+        const int m_base = mw + i * 16;
+        if constexpr (out_f32) {
+            f32x4 v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int idx = lane + 64 * t, r = idx >> 4, c16 = idx & 15;
+                v[t] = *(const f32x4*)(patch + r * 256 + ((c16 ^ r) << 4));
+                v[t] += s.res[t];
+            }
+            if constexpr (FULLT && i + 2 < 8) side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, m_base + 32, r0, col_off, row_step, s);
+            if constexpr (FULLT) {
+                char* ob = (char*)g.out + (size_t)m_base * out_step;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) asm_store16(v[t], ob + (size_t)(4 * t) * out_step, out_voff);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int idx = lane + 64 * t, r = idx >> 4, c16 = idx & 15;
+                    if (m_base + r < g.M) store16<ABL>((float*)g.out + (size_t)(m_base + r) * g.ldc + nb + c16 * 4, v[t]);
+                }
+            }
+        } else {
+            bf16x8 o[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int idx = lane + 64 * t, r = idx >> 3, c8 = idx & 7;
+                const f32x4 v0 = *(const f32x4*)(patch + r * 256 + (((2 * c8) ^ r) << 4));
+                const f32x4 v1 = *(const f32x4*)(patch + r * 256 + (((2 * c8 + 1) ^ r) << 4));
+                float w[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if constexpr (GATED) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] *= act_bwd((float)s.gate[t][e], GATE);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { w[e] += s.res[2 * t][e]; w[4 + e] += s.res[2 * t + 1][e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[t][e] = (bf16)w[e];
+            }
+            if constexpr (FULLT && i + 2 < 8) side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, m_base + 32, r0, col_off, row_step, s);
+            if constexpr (FULLT) {
+                char* ob = (char*)g.out + (size_t)m_base * out_step;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) asm_store16(o[t], ob + (size_t)(8 * t) * out_step, out_voff);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int idx = lane + 64 * t, r = idx >> 3, c8 = idx & 7;
+                    if (m_base + r < g.M) store16<ABL>((bf16*)g.out + (size_t)(m_base + r) * g.ldc + nb + c8 * 8, o[t]);
+                }
+            }
+        }
+    };
+    slab(IC<0>{}); slab(IC<1>{}); slab(IC<2>{}); slab(IC<3>{});
+    slab(IC<4>{}); slab(IC<5>{}); slab(IC<6>{}); slab(IC<7>{});
+}
+
 #define RAW_BARRIER_P()                       \
     do {                                      \
         asm volatile("" ::: "memory");        \
@@ -596,7 +753,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                 trace_next = false;
             }
         }
-        if constexpr ((ABL & 1024) != 0) {
+        if constexpr ((ABL & (1024 | 8192)) != 0) {
             // the tile's bias slice (this lane's 4 x 4 columns), requested two stages before the tile ends and AHEAD of this
             // step's DMA, so that the next step's vmcnt wait retires it and the epilogue starts without a memory wait
             if (kt == nk - 2) {
@@ -624,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         }
         if (i_st < total_st) issue();  // stage st+2 into the buffer every wave has just finished reading
         // register-path epilogue: the next tile's first fragments are read behind the epilogue instead of across it (32 registers)
-        const bool defer_frag = (ABL & 1024) != 0 && kt + 1 == nk;
+        const bool defer_frag = (ABL & (1024 | 8192)) != 0 && kt + 1 == nk;
         if (st + 1 < total_st && !defer_frag) {
             LOAD_B(bF[0], nxt, 0);
             LOAD_A(aF[0], nxt, 0, 0);
@@ -637,7 +794,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                     tr[0] = __builtin_amdgcn_s_memrealtime(); tr[1] = __builtin_amdgcn_s_memtime();
                 }
             }
-            if constexpr ((ABL & 1024) != 0) {
+            if constexpr ((ABL & 8192) != 0) {
+                static_assert(!FP8 && CFG >= 0 && ACT == ACT_NONE, "counted-side-load epilogue: bf16 operands, residual or gate");
+                // (the 256-tile dispatch guarantees N % 256 == 0 for this instantiation: only rows can stick out)
+                const bool full = m0 + wm * 128 + 128 <= g.M;
+                if (full) epilogue256_patch_asm<GATE, ABL, CFG, true>(g, acc, m0, n0, wm, wn, lane, patch);
+                else epilogue256_patch_asm<GATE, ABL, CFG, false>(g, acc, m0, n0, wm, wn, lane, patch);
+            } else if constexpr ((ABL & 1024) != 0) {
                 static_assert(!FP8 && CFG >= 0, "register-path epilogue: bf16 operands, output kind compiled in");
                 const bool full = (m0 + wm * 128 + 128 <= g.M) && (n0 + wn * 64 + 64 <= g.N);
                 if (full) epilogue256_reg<ACT, GATE, ABL, CFG, true>(g, acc, m0, n0, wm, wn, lane);
@@ -662,7 +825,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
             }
             kt = 0; ++tl;
             tile_origin256(g, range_lo + slot + tl * per_xcd, gc, m0, n0);
-            if ((ABL & 1024) != 0 && st + 1 < total_st) {
+            if ((ABL & (1024 | 8192)) != 0 && st + 1 < total_st) {
                 LOAD_B(bF[0], nxt, 0);
                 LOAD_A(aF[0], nxt, 0, 0);
             }
