@@ -185,13 +185,13 @@ static void (*pick_reg(int act, int gate_act, bool gated, int out_f32, bool res)
                    : (res ? gemm_nt256p_kernel<0, 0, false, ABL, 2> : gemm_nt256p_kernel<0, 0, false, ABL, 0>);
 }
 
-// patch epilogue with counted side loads: gate (bf16 out) and fp32-residual (fp32 / bf16 out) kernels only
+// hand-scheduled patch epilogue (bias inside the K loop, asm stores from scalar bases, asm side loads with counted waits)
 template <int ABL>
 static void (*pick_pasm(int act, int gate_act, bool gated, int out_f32, bool res))(GemmNT) {
-    if (act != ACT_NONE) return nullptr;
-    if (gated) return out_f32 || res ? nullptr : gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, ABL, 0> : gemm_nt256p_kernel<0, 2, false, ABL, 0>;
-    if (!res) return nullptr;
-    return out_f32 ? gemm_nt256p_kernel<0, 0, false, ABL, 3> : gemm_nt256p_kernel<0, 0, false, ABL, 2>;
+    if (act != ACT_NONE) return (gated || out_f32 || res) ? nullptr : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, false, ABL, 0> : nullptr;
+    if (gated) return out_f32 || res ? nullptr : gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, ABL, 0> : nullptr;
+    return out_f32 ? (res ? gemm_nt256p_kernel<0, 0, false, ABL, 3> : gemm_nt256p_kernel<0, 0, false, ABL, 1>)
+                   : (res ? gemm_nt256p_kernel<0, 0, false, ABL, 2> : gemm_nt256p_kernel<0, 0, false, ABL, 0>);
 }
 
 template <int ABL>

@@ -195,15 +195,28 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_
     // has consumed its registers (ABL 256: proj + residual 334 -> 294 us, fc2 + residual 749 -> 713 us at M = 150 720; it costs the
     // plain / activation / gate kernels 1-12 %, so they keep the in-place loads)
     if (!gated && act == ACT_NONE && g.residual) kern = gemm_nt256p_kernel<0, 0, FP8, 256>;
-    // QuickGELU gate (fc2 dgrad of the B models), bf16 output: the patch epilogue whose pre-activation loads are inline asm, two
-    // row-tiles ahead and ahead of the stores, with hand-counted waits (ABL 8192: 969 -> 854 us at M = 150 720, N = 3072, K = 768;
-    // the residual kernels gain nothing over ABL 256, the erf-GELU gate spills).  Whole tile columns, K of two stages or more,
-    // 32-bit byte offsets into the gate and output matrices.
+    // The hand-scheduled patch epilogue (ABL 8192: bias added inside the K loop, stores by inline asm from scalar bases, side
+    // inputs by inline asm two row-tiles ahead of their use and ahead of the stores, hand-counted vmcnt) where tools/gemm_ab.py
+    // measures a gain at M = 150 720: QuickGELU gate 927 -> 817 us (fc2 dgrad), QuickGELU + pre-activation 908 -> 880 us (fc1),
+    // bf16 + fp32 residual 260 -> 247 us, fp32 + residual 743 -> 712 us (K = 3072; = ABL 256 at K = 768), plain bf16 at N = 2304
+    // 535 -> 524 us; plain N = 768 outputs lose 0-2 % and keep the generic epilogue, the erf-GELU forms spill and keep it too.
+    // Needs whole tile columns, K of two stages or more and 32-bit byte offsets into the output / side matrices.
     if constexpr (!FP8) {
-        if (gated && gate_act == ACT_QUICK_GELU && !g.out_f32 && !g.residual && g.N % 256 == 0 && g.K >= 2 * BK &&
-            (unsigned long long)g.M * (unsigned long long)g.ldh * 2ull < (1ull << 32) &&
-            (unsigned long long)g.M * (unsigned long long)g.ldc * 2ull < (1ull << 32))
-            kern = gemm_nt256p_kernel<0, 1, false, 8192, 0>;
+        const unsigned long long lim = 1ull << 32, Mu = (unsigned long long)g.M;
+        const bool fits = g.N % 256 == 0 && g.K >= 2 * BK && Mu * (unsigned long long)g.ldc * (g.out_f32 ? 4ull : 2ull) < lim &&
+                          (!g.residual || Mu * (unsigned long long)g.ldr * 4ull < lim) &&
+                          (!g.preact || Mu * (unsigned long long)g.ldp * 2ull < lim) &&
+                          (!gated || Mu * (unsigned long long)g.ldh * 2ull < lim);
+        if (fits) {
+            if (gated) {
+                if (gate_act == ACT_QUICK_GELU && !g.out_f32 && !g.residual) kern = gemm_nt256p_kernel<0, 1, false, 8192, 0>;
+            } else if (act == ACT_QUICK_GELU) {
+                if (!g.out_f32 && !g.residual) kern = gemm_nt256p_kernel<1, 0, false, 8192, 0>;
+            } else if (act == ACT_NONE) {
+                if (g.residual) kern = g.out_f32 ? gemm_nt256p_kernel<0, 0, false, 8192, 3> : gemm_nt256p_kernel<0, 0, false, 8192, 2>;
+                else if (!g.out_f32 && g.N >= 2304) kern = gemm_nt256p_kernel<0, 0, false, 8192, 0>;
+            }
+        }
     }
     if (!kern) return TVTS_EINVAL;
     const int lds_bytes = 163840;  // 2 x 64 KiB stages + 8 x 4 KiB epilogue patches

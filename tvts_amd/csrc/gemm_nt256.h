@@ -532,12 +532,13 @@ __device__ __forceinline__ void side_load_patch_asm(const GemmNT& g, int m_base,
 }
 // FULLT: the wave tile lies inside the matrix (counted waits, no predicates); else rows clamped / stores predicated and every
 // wait is vmcnt(0) (predicated stores may not issue, which breaks the counts)
-template <int GATE, int ABL, int CFG, bool FULLT>
+template <int ACT, int GATE, int ABL, int CFG, bool FULLT>
 __device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn, int lane,
                                                       char* patch) {
     constexpr bool out_f32 = (CFG & 1) != 0, has_res = (CFG & 2) != 0;
     constexpr bool GATED = GATE != ACT_NONE;
-    static_assert(has_res != GATED, "one side input: the fp32 residual or the gate's pre-activation");
+    constexpr bool SIDE = has_res || GATED;
+    static_assert(!(has_res && GATED) && !(SIDE && ACT != ACT_NONE) && !(ACT != ACT_NONE && out_f32), "one side input at most; activation: bf16 out");
     constexpr int NL = GATED ? 2 : 4;
     constexpr int NS = out_f32 ? 4 : 2;
     // the lane-derived constants below are recomputed from an opaque copy of the lane id: sharing them with the K loop's would keep
@@ -553,14 +554,16 @@ __device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&a
     const unsigned out_step = (unsigned)g.ldc * (out_f32 ? 4u : 2u);  // bytes per output row
     const unsigned out_voff = (unsigned)r0 * out_step + (unsigned)(nb + c0) * (out_f32 ? 4u : 2u);
     SideSlab sA, sB;
-    if constexpr (FULLT) {
+    if constexpr (FULLT && SIDE) {
         side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, mw, r0, col_off, row_step, sA);
         side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, mw + 16, r0, col_off, row_step, sB);
     }
+    const unsigned pre_step = (unsigned)g.ldp * 2u;  // activation kernels: bytes per row of the pre-activation side output
+    const unsigned pre_voff = (unsigned)r0 * pre_step + (unsigned)(nb + c0) * 2u;
     auto slab = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
         SideSlab& s = (FULLT && (i & 1)) ? sB : sA;
-        if constexpr (!FULLT) side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, mw + i * 16, r0, col_off, row_step, s);  // edge tiles: in place
+        if constexpr (!FULLT && SIDE) side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, mw + i * 16, r0, col_off, row_step, s);  // edge tiles: in place
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i];
@@ -568,7 +571,7 @@ __device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&a
         }
         constexpr int N = !FULLT ? 0 : i == 0 ? NL : i == 1 ? NL + NS : i == 7 ? 2 * NS : NL + 2 * NS;
         if constexpr (GATED) asm_wait_vm<N>(s.gate[0], s.gate[1]);
-        else asm_wait_vm<N>(s.res[0], s.res[1], s.res[2], s.res[3]);
+        else if constexpr (has_res) asm_wait_vm<N>(s.res[0], s.res[1], s.res[2], s.res[3]);
         const int m_base = mw + i * 16;
         if constexpr (out_f32) {
             f32x4 v[4];
@@ -576,9 +579,9 @@ __device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&a
             for (int t = 0; t < 4; ++t) {
                 const int idx = lane + 64 * t, r = idx >> 4, c16 = idx & 15;
                 v[t] = *(const f32x4*)(patch + r * 256 + ((c16 ^ r) << 4));
-                v[t] += s.res[t];
+                if constexpr (has_res) v[t] += s.res[t];
             }
-            if constexpr (FULLT && i + 2 < 8) side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, m_base + 32, r0, col_off, row_step, s);
+            if constexpr (FULLT && SIDE && i + 2 < 8) side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, m_base + 32, r0, col_off, row_step, s);
             if constexpr (FULLT) {
                 char* ob = (char*)g.out + (size_t)m_base * out_step;
 #pragma unroll
@@ -591,33 +594,45 @@ __device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&a
                 }
             }
         } else {
-            bf16x8 o[2];
+            bf16x8 o[2], pre[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int idx = lane + 64 * t, r = idx >> 3, c8 = idx & 7;
                 const f32x4 v0 = *(const f32x4*)(patch + r * 256 + (((2 * c8) ^ r) << 4));
                 const f32x4 v1 = *(const f32x4*)(patch + r * 256 + (((2 * c8 + 1) ^ r) << 4));
                 float w[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if constexpr (ACT != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { pre[t][e] = (bf16)w[e]; w[e] = act_fwd(w[e], ACT); }
+                }
                 if constexpr (GATED) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w[e] *= act_bwd((float)s.gate[t][e], GATE);
-                } else {
+                } else if constexpr (has_res) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { w[e] += s.res[2 * t][e]; w[4 + e] += s.res[2 * t + 1][e]; }
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[t][e] = (bf16)w[e];
             }
-            if constexpr (FULLT && i + 2 < 8) side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, m_base + 32, r0, col_off, row_step, s);
+            if constexpr (FULLT && SIDE && i + 2 < 8) side_load_patch_asm<GATE, ABL, CFG, FULLT>(g, m_base + 32, r0, col_off, row_step, s);
             if constexpr (FULLT) {
                 char* ob = (char*)g.out + (size_t)m_base * out_step;
+                if (ACT != ACT_NONE && g.preact) {
+                    char* pb = (char*)g.preact + (size_t)m_base * pre_step;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) asm_store16(pre[t], pb + (size_t)(8 * t) * pre_step, pre_voff);
+                }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) asm_store16(o[t], ob + (size_t)(8 * t) * out_step, out_voff);
             } else {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int idx = lane + 64 * t, r = idx >> 3, c8 = idx & 7;
-                    if (m_base + r < g.M) store16<ABL>((bf16*)g.out + (size_t)(m_base + r) * g.ldc + nb + c8 * 8, o[t]);
+                    if (m_base + r < g.M) {
+                        if (ACT != ACT_NONE && g.preact) store16<ABL>(g.preact + (size_t)(m_base + r) * g.ldp + nb + c8 * 8, pre[t]);
+                        store16<ABL>((bf16*)g.out + (size_t)(m_base + r) * g.ldc + nb + c8 * 8, o[t]);
+                    }
                 }
             }
         }
@@ -795,11 +810,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                 }
             }
             if constexpr ((ABL & 8192) != 0) {
-                static_assert(!FP8 && CFG >= 0 && ACT == ACT_NONE, "counted-side-load epilogue: bf16 operands, residual or gate");
+                static_assert(!FP8 && CFG >= 0, "hand-scheduled patch epilogue: bf16 operands, output kind compiled in");
                 // (the 256-tile dispatch guarantees N % 256 == 0 for this instantiation: only rows can stick out)
                 const bool full = m0 + wm * 128 + 128 <= g.M;
-                if (full) epilogue256_patch_asm<GATE, ABL, CFG, true>(g, acc, m0, n0, wm, wn, lane, patch);
-                else epilogue256_patch_asm<GATE, ABL, CFG, false>(g, acc, m0, n0, wm, wn, lane, patch);
+                if (full) epilogue256_patch_asm<ACT, GATE, ABL, CFG, true>(g, acc, m0, n0, wm, wn, lane, patch);
+                else epilogue256_patch_asm<ACT, GATE, ABL, CFG, false>(g, acc, m0, n0, wm, wn, lane, patch);
             } else if constexpr ((ABL & 1024) != 0) {
                 static_assert(!FP8 && CFG >= 0, "register-path epilogue: bf16 operands, output kind compiled in");
                 const bool full = (m0 + wm * 128 + 128 <= g.M) && (n0 + wn * 64 + 64 <= g.N);
