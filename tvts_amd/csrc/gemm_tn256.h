@@ -16,8 +16,11 @@ __device__ __forceinline__ unsigned tn_frag_off(int ct, int lane) {
     return (unsigned)(row * 256 + ((ct ^ (row & 7)) << 5) + (i & 3) * 8);
 }
 // the 8 k-slots of MFMA k-step u (32 rows of m) for the column block whose lane offset is `off`: rows u*32 + half*16 + ...
+#ifndef TN_STAGGER_DMA
+#define TN_STAGGER_DMA 1
+#endif
 #ifndef TN_ABL
-#define TN_ABL 0   // timing ablations, tools/dbg/tn_abl.sh (wrong results): 1 = no LDS-DMA behind the prologue, 2 = one ds_read_b128 per fragment
+#define TN_ABL 0   // timing ablations, tools/dbg/tn_abl.sh (wrong results): 1 = no LDS-DMA behind the prologue, 2 = one ds_read_b128 per fragment, 4 = L2-hot DMA (every stage re-reads the first)
 #endif
 __device__ __forceinline__ bf16x8 tn_frag(const char* tile, unsigned off, int u) {
     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -58,6 +61,7 @@ __device__ __forceinline__ void glds16_asm_imm(unsigned voff, const char* sbase,
 // general form (tiles / stages that stick out of the matrix): every address clamped on its own
 __device__ __forceinline__ void tn_stage_issue_clamped(const GemmTN& g, int a0, int b0, int m_stage, const char* baseP, const char* baseQ,
                                                        unsigned lds_stage, int wave, int lane) {
+    asm volatile("" : "+v"(lane));  // opaque: this rare path recomputes its lane constants instead of keeping them live in the K loop
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int tile = q >> 1;
@@ -115,8 +119,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmTN g) {
     auto issue = [&]() {
         const int m_stage = m_begin + i_st * 64;
         const unsigned dst = lds0 + (unsigned)(i_st & 1) * 65536u + (unsigned)wave * 1024u;
-        const char* bp = baseP + (size_t)i_st * stepP;
-        const char* bq = baseQ + (size_t)i_st * stepQ;
+        const char* bp = baseP + ((TN_ABL & 4) ? 0 : (size_t)i_st * stepP);  // TN_ABL 4: every stage re-reads the first one (L2-hot DMA)
+        const char* bq = baseQ + ((TN_ABL & 4) ? 0 : (size_t)i_st * stepQ);
         if (cols_inside && m_stage + 64 <= g.M) {
             glds16_asm_imm<0>(offP, bp, dst);
             glds16_asm_imm<0>(offP, bp + halfP, dst + 8192u);
@@ -204,13 +208,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmTN g) {
         TN_CS(pF[0], 0);                                                                               \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
         RAW_BARRIER_P();                                                                               \
-        if (i_st < nk && !(TN_ABL & 1)) issue(); /* stage st+2 into the buffer every wave has just finished reading */  \
+        /* stage st+2 goes into the buffer every wave has just finished reading.  The two waves of a SIMD (w, w + 4) do not issue */ \
+        /* their 8 LDS-DMA pieces at the same time (a piece costs ~100+ cycles of VMEM issue and both would sit in it with the */ \
+        /* matrix pipe idle): waves 0..3 issue here, waves 4..7 behind the stage's last MFMA group */ \
+        const bool do_issue = i_st < nk && !(TN_ABL & 1);                                              \
+        if (do_issue && (!TN_STAGGER_DMA || wave < 4)) issue();                                        \
         if (st + 1 < nk) {                                                                             \
             TN_LOAD_Q(qF[0], nxt, 0);                                                                  \
             TN_LOAD_P(pF[0], nxt, 0, 0, valid_n);                                                      \
         }                                                                                              \
         TN_MFMA16(pF[1], qF[1], 1);                                                                    \
         TN_CS(pF[1], 1);                                                                               \
+        if (do_issue && TN_STAGGER_DMA && wave >= 4) issue();                                          \
         valid = valid_n;                                                                               \
     }
     int st = 0;
