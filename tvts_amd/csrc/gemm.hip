@@ -505,8 +505,8 @@ static int g_tn_early = -1, g_tn_afast = -1;
 extern "C" void tvts_gemm_set_tn_mode(int early_dma, int a_fast) { g_tn_early = early_dma; g_tn_afast = a_fast; }
 // tile selection: the pipelined 256x256 kernel for long contractions into large outputs -- M >= 32 768 rows, at least 1.5 M
 // output elements, at most 15 % of the 256-tiling's area wasted: the qkv / fc1 / fc2 weight gradients of the ViT blocks
-// (tools/tn_ab.py, M = 150 720: 958 -> 1038, 978 -> 1078, 994 -> 1067 TF) -- else the 128x128 kernel, which is the faster one
-// on the 768 x 768 projections (926 vs 880 TF) and on the text tower's M = 24 576.  0 auto, 128 / 256 force.
+// (tools/tn_ab.py, M = 150 720: 934 -> 1109, 955 -> 1131, 984 -> 1134 TF) -- else the 128x128 kernel, which is as fast on the
+// 768 x 768 projections (905 vs 925 TF) and faster on the text tower's M = 24 576.  0 auto, 128 / 256 force.
 static int g_tn_tile = 0;
 extern "C" void tvts_gemm_set_tn_tile(int t) { g_tn_tile = (t == 128 || t == 256) ? t : 0; }
 static bool tn_use_256(int M, int Na, int Nb) {
