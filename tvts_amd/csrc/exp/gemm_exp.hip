@@ -243,6 +243,9 @@ extern "C" int tvts_exp_gemm_nt(int variant, int gc, int stagger_phases, int sta
             case 3594: kern = pick_reg<3584>(act, gate_act, gated, out_f32, residual != nullptr); g.sa = (const float*)g_trace; break;  // reg + cnt + stamps
             case 8202: kern = pick_pasm<8192>(act, gate_act, gated, out_f32, residual != nullptr); break;        // patch + counted side loads
             case 8714: kern = pick_pasm<8192 + 512>(act, gate_act, gated, out_f32, residual != nullptr); break;  // ... + counted vmcnt behind the epilogue
+            case 32778: kern = pick_abl<32768>(act, gate_act, gated); break;                                             // generic epilogue + staggered DMA issue
+            case 40970: kern = pick_pasm<8192 + 32768>(act, gate_act, gated, out_f32, residual != nullptr); break;    // hand-scheduled epilogue + staggered DMA issue
+            case 32779: kern = pick_abl<32768 + 1>(act, gate_act, gated); break;                                        // no epilogue + staggered DMA issue
             case 522: kern = pick_abl<512>(act, gate_act, gated); break;   // counted vmcnt behind the epilogue
             case 1034: kern = pick_reg<1024>(act, gate_act, gated, out_f32, residual != nullptr); break; // register-path epilogue
             case 1546: kern = pick_reg<1536>(act, gate_act, gated, out_f32, residual != nullptr); break; // ... + counted vmcnt

@@ -183,18 +183,21 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_
     g.gc = nt_column_group(g.N);
     const int total_tiles = g.tiles_m * g.tiles_n;
     const int grid = total_tiles < 256 ? ((total_tiles + 7) / 8) * 8 : 256;  // persistent: one block per CU, multiple of 8 (XCDs)
+    // every production instantiation staggers the LDS-DMA issue of the two waves of a SIMD (ABL 32768: +1-3 % on every shape of
+    // the step, tools/gemm_ab.py; the same change is worth 6-10 % on the weight-gradient kernel)
+    constexpr int SD = 32768;
     void (*kern)(GemmNT) = nullptr;
     if (gated) {
         if (act != ACT_NONE || FP8) return TVTS_EINVAL;
-        kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false> : gate_act == ACT_GELU_ERF ? gemm_nt256p_kernel<0, 2, false> : nullptr;
+        kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, SD> : gate_act == ACT_GELU_ERF ? gemm_nt256p_kernel<0, 2, false, SD> : nullptr;
     } else {
-        kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, FP8> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, FP8>
-             : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, FP8> : nullptr;
+        kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, FP8, SD> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, FP8, SD>
+             : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, FP8, SD> : nullptr;
     }
     // fp32 residual in the epilogue, no activation: the instantiation that requests the residual of slab i + 1 as soon as slab i
     // has consumed its registers (ABL 256: proj + residual 334 -> 294 us, fc2 + residual 749 -> 713 us at M = 150 720; it costs the
     // plain / activation / gate kernels 1-12 %, so they keep the in-place loads)
-    if (!gated && act == ACT_NONE && g.residual) kern = gemm_nt256p_kernel<0, 0, FP8, 256>;
+    if (!gated && act == ACT_NONE && g.residual) kern = gemm_nt256p_kernel<0, 0, FP8, 256 | SD>;
     // The hand-scheduled patch epilogue (ABL 8192: bias added inside the K loop, stores by inline asm from scalar bases, side
     // inputs by inline asm two row-tiles ahead of their use and ahead of the stores, hand-counted vmcnt) where tools/gemm_ab.py
     // measures a gain at M = 150 720: QuickGELU gate 927 -> 817 us (fc2 dgrad), QuickGELU + pre-activation 908 -> 880 us (fc1),
@@ -209,12 +212,12 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_
                           (!gated || Mu * (unsigned long long)g.ldh * 2ull < lim);
         if (fits) {
             if (gated) {
-                if (gate_act == ACT_QUICK_GELU && !g.out_f32 && !g.residual) kern = gemm_nt256p_kernel<0, 1, false, 8192, 0>;
+                if (gate_act == ACT_QUICK_GELU && !g.out_f32 && !g.residual) kern = gemm_nt256p_kernel<0, 1, false, 8192 | SD, 0>;
             } else if (act == ACT_QUICK_GELU) {
-                if (!g.out_f32 && !g.residual) kern = gemm_nt256p_kernel<1, 0, false, 8192, 0>;
+                if (!g.out_f32 && !g.residual) kern = gemm_nt256p_kernel<1, 0, false, 8192 | SD, 0>;
             } else if (act == ACT_NONE) {
-                if (g.residual) kern = g.out_f32 ? gemm_nt256p_kernel<0, 0, false, 8192, 3> : gemm_nt256p_kernel<0, 0, false, 8192, 2>;
-                else if (!g.out_f32 && g.N >= 2304) kern = gemm_nt256p_kernel<0, 0, false, 8192, 0>;
+                if (g.residual) kern = g.out_f32 ? gemm_nt256p_kernel<0, 0, false, 8192 | SD, 3> : gemm_nt256p_kernel<0, 0, false, 8192 | SD, 2>;
+                else if (!g.out_f32 && g.N >= 2304) kern = gemm_nt256p_kernel<0, 0, false, 8192 | SD, 0>;
             }
         }
     }

@@ -794,7 +794,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                     for (int i = 0; i < 8; ++i) acc[j][i] += bias4[j];
             }
         }
-        if (i_st < total_st) issue();  // stage st+2 into the buffer every wave has just finished reading
+        // stage st+2 goes into the buffer every wave has just finished reading.  ABL & 32768: the two waves of a SIMD (w, w + 4) do
+        // not issue their 8 LDS-DMA pieces at the same time (both would sit in ~100 cycles of VMEM issue per piece with the matrix
+        // pipe idle): waves 0..3 issue here, waves 4..7 behind the stage's last MFMA group
+        const bool do_issue = i_st < total_st;
+        if (do_issue && ((ABL & 32768) == 0 || wave < 4)) issue();
         // register-path epilogue: the next tile's first fragments are read behind the epilogue instead of across it (32 registers)
         const bool defer_frag = (ABL & (1024 | 8192)) != 0 && kt + 1 == nk;
         if (st + 1 < total_st && !defer_frag) {
@@ -802,6 +806,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
             LOAD_A(aF[0], nxt, 0, 0);
         }
         MFMA16(aF[1], bF[1], 1);
+        if (do_issue && (ABL & 32768) != 0 && wave >= 4) issue();
         if (++kt == nk) {
             if constexpr ((ABL & 2048) != 0) {  // experiment library: per-tile time stamps of wave 0 (g.sa carries the trace buffer)
                 if (wave == 0 && lane == 0 && tl < 32) {
