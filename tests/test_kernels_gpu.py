@@ -145,12 +145,13 @@ def test_gemm_tn_256_tile(K, M, Na, Nb):
 
 
 def test_gemm_tn_tile_selection(K):
-    """The step's big weight gradients take the 256x256 kernel, the projections and the text tower the 128x128 one."""
+    """The ViT blocks' weight gradients take the 256x256 kernel, the text tower and small outputs the 128x128 one."""
     from tvts_amd import _lib
     lib = _lib.load()
     M = 192 * 785
     assert lib.tvts_gemm_tn_select(M, 2304, 768) == 256 and lib.tvts_gemm_tn_select(M, 768, 3072) == 256
-    assert lib.tvts_gemm_tn_select(M, 768, 768) == 128 and lib.tvts_gemm_tn_select(24576, 2048, 512) == 128
+    assert lib.tvts_gemm_tn_select(M, 768, 768) == 256 and lib.tvts_gemm_tn_select(24576, 2048, 512) == 128
+    assert lib.tvts_gemm_tn_select(M, 512, 512) == 128
     assert lib.tvts_gemm_tn_select(12 * 785, 2304, 768) == 128
 
 

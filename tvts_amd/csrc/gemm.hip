@@ -506,16 +506,16 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 // test / bench hook (no environment reads on the launch path): -1 = automatic choice
 static int g_tn_early = -1, g_tn_afast = -1;
 extern "C" void tvts_gemm_set_tn_mode(int early_dma, int a_fast) { g_tn_early = early_dma; g_tn_afast = a_fast; }
-// tile selection: the pipelined 256x256 kernel for long contractions into large outputs -- M >= 32 768 rows, at least 1.5 M
-// output elements, at most 15 % of the 256-tiling's area wasted: the qkv / fc1 / fc2 weight gradients of the ViT blocks
-// (tools/tn_ab.py, M = 150 720: 934 -> 1109, 955 -> 1131, 984 -> 1134 TF) -- else the 128x128 kernel, which is as fast on the
-// 768 x 768 projections (905 vs 925 TF) and faster on the text tower's M = 24 576.  0 auto, 128 / 256 force.
+// tile selection: the pipelined 256x256 kernel for long contractions -- M >= 32 768 rows, at least 0.5 M output elements, at
+// most 15 % of the 256-tiling's area wasted: every weight gradient of the ViT blocks (tools/tn_ab.py, M = 150 720: qkv 934 ->
+// 1109, fc1 955 -> 1131, fc2 984 -> 1134, proj 905 -> 925 TF) -- else the 128x128 kernel, which is the faster one on the text
+// tower's M = 24 576 (819 vs 757 TF).  0 auto, 128 / 256 force.
 static int g_tn_tile = 0;
 extern "C" void tvts_gemm_set_tn_tile(int t) { g_tn_tile = (t == 128 || t == 256) ? t : 0; }
 static bool tn_use_256(int M, int Na, int Nb) {
     if (g_tn_tile) return g_tn_tile == 256;
     const double area = 65536.0 * ceil_div(Na, 256) * ceil_div(Nb, 256), elems = (double)Na * (double)Nb;
-    return M >= 32768 && elems >= 1.5e6 && area <= 1.15 * elems;
+    return M >= 32768 && elems >= 0.5e6 && area <= 1.15 * elems;
 }
 extern "C" int tvts_gemm_tn_select(int M, int Na, int Nb) { return tn_use_256(M, Na, Nb) ? 256 : 128; }
 
