@@ -17,7 +17,8 @@ tools/pmc_traffic.sh > $out/pmc_traffic.log 2>&1
 cp gpurun_out/pmc_step_traffic.json $out/pmc_step_traffic_B_16_t8_b192.json
 TVTS_BENCH_ORDER=gpurun_out/gemm_order.json python bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline > /dev/null 2> $out/order.err
 python tools/pmc_join.py gpurun_out/gemm_order.json gpurun_out > $out/pmc_gemm_traffic_by_shape.txt 2>> $out/order.err
-{ python bench.py --batch 12 --steps 20 --warmup 5 --no-cpu-baseline
+{ python bench.py --batch 2 --steps 20 --warmup 5 --no-cpu-baseline
+  python bench.py --batch 12 --steps 20 --warmup 5 --no-cpu-baseline
   python bench.py --batch 24 --steps 20 --warmup 5 --no-cpu-baseline
   python bench.py --n-trans 1 --steps 20 --warmup 5 --no-cpu-baseline; } 2>/dev/null | grep '^{' > $out/bench_reference_batches.jsonl
 { python bench.py --arch B_32 --batch 384 --steps 20 --warmup 5 --no-cpu-baseline
