@@ -112,6 +112,19 @@ int tvts_attn_fwd_len(const void* qkv, int ld, int B, int heads, int S, const in
                       hipStream_t stream);
 int tvts_attn_bwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,
                       const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream);
+/* FULL attention (no mask) whose only QUERIES are the last nq (<= 16) tokens of every sequence, all S tokens keys: the last block
+ * of the transcript-sorting head -- SortTransformer.forward_features reads its output at the transcript positions only
+ * (v2/model/sort_transformer.py:131-141: x = self.norm(x[:, x_len:])), so the other rows of that block's attention output, MLP and
+ * residual are never used by the loss.  out / lse2 / dO / O / delta are indexed by token row (only the query rows are touched);
+ * bwd_tail = delta + dQ (query rows) + dK / dV (every row): the caller zeroes the dQ third of the non-query rows of dqkv. */
+int tvts_attn_fwd_tail(const void* qkv, int ld, int B, int heads, int S, int nq, void* out, int ldo, float* lse2,
+                       hipStream_t stream);
+int tvts_attn_bwd_tail(const void* qkv, int ld, int B, int heads, int S, int nq, const void* dO, int lddo, const void* O, int ldo,
+                       const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream);
+int tvts_attn80_fwd_tail(const void* qkv, int ld, int B, int heads, int S, int nq, void* out, int ldo, float* lse2,
+                         hipStream_t stream);
+int tvts_attn80_bwd_tail(const void* qkv, int ld, int B, int heads, int S, int nq, const void* dO, int lddo, const void* O, int ldo,
+                         const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream);
 int tvts_attn80_fwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, void* out, int ldo, float* lse2,
                         hipStream_t stream);
 int tvts_attn80_bwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,

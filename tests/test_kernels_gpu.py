@@ -407,6 +407,32 @@ def test_full_attention(K, B, heads, S, causal, tr, dh):
         K.attn_set_transpose_read(True)
 
 
+@pytest.mark.parametrize("dh", [64, 80])
+@pytest.mark.parametrize("B,heads,S,nq", [(3, 2, 200, 4), (2, 8, 789, 4), (2, 1, 37, 1), (1, 2, 130, 16)])
+def test_tail_query_attention(K, B, heads, S, nq, dh):
+    """FULL attention whose only queries are the last nq tokens of every sequence (the sort head's last block): output rows and
+    dQ of the query rows, dK / dV of every row, against autograd of the same restriction."""
+    W = heads * dh
+    qkv, dO = bf(rnd(B, S, 3 * W, seed=41)), bf(rnd(B, S, W, seed=42))
+    dO[:, :S - nq] = 0  # only the query rows carry an upstream gradient
+    ref_out, ref_d = _ref_full(qkv.float(), heads, False, dO.float())
+    qd, dOd = qkv.reshape(B * S, 3 * W).to(DEV), dO.reshape(B * S, W).to(DEV)
+    out = torch.full((B * S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse, delta = torch.full((B * S, heads), float("nan"), device=DEV), torch.full((B * S, heads), float("nan"), device=DEV)
+    K.attn_fwd_tail(qd, out, lse, B=B, heads=heads, S=S, nq=nq, head_dim=dh)
+    o = out.float().view(B, S, W).cpu()
+    assert torch.isnan(o[:, :S - nq]).all() and torch.isfinite(o[:, S - nq:]).all()   # only the query rows are written
+    assert rel(o[:, S - nq:], ref_out[:, S - nq:]) < 8e-3
+    dqkv = torch.zeros(B * S, 3 * W, dtype=torch.bfloat16, device=DEV)
+    dOd2 = dOd.clone(); dOd2.view(B, S, W)[:, :S - nq] = float("nan")                 # ... and only they are read
+    K.attn_bwd_tail(qd, dOd2, out, lse, delta, dqkv, B=B, heads=heads, S=S, nq=nq, head_dim=dh)
+    got = dqkv.float().view(B, S, 3 * W).cpu()
+    assert torch.isfinite(got).all()
+    assert (got[:, :S - nq, :W] == 0).all()
+    for nm, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
+        assert rel(got[..., sl], ref_d[..., sl]) < 2e-2, (nm, rel(got[..., sl], ref_d[..., sl]))
+
+
 def test_attention_softmax_spike(K):
     """Online-softmax rescale across key tiles: one key far above the rest in a late tile."""
     B, heads, S = 1, 1, 200

@@ -231,6 +231,21 @@ def attn_bwd_len(qkv, kv_len, dO, O, lse2, delta, dqkv, *, B, heads, S, head_dim
                                             _p(delta), _p(dqkv), _ld(dqkv), _stream()), "tvts_attn_bwd_len")
 
 
+def attn_fwd_tail(qkv, out, lse2, *, B, heads, S, nq, head_dim=64):
+    """FULL attention whose only queries are the last nq tokens of every sequence (rows b*S + S-nq .. of out / lse2 are written)."""
+    lib = _lib.load()
+    _chk(_attn_fn(lib, "fwd_tail", head_dim)(_p(qkv), _ld(qkv), B, heads, S, nq, _p(out), _ld(out), _p(lse2), _stream()),
+         "tvts_attn_fwd_tail")
+
+
+def attn_bwd_tail(qkv, dO, O, lse2, delta, dqkv, *, B, heads, S, nq, head_dim=64):
+    """backward of attn_fwd_tail: dQ into the query rows, dK / dV into every row of dqkv; the dQ third of the other rows is the
+    caller's to zero."""
+    lib = _lib.load()
+    _chk(_attn_fn(lib, "bwd_tail", head_dim)(_p(qkv), _ld(qkv), B, heads, S, nq, _p(dO), _ld(dO), _p(O), _ld(O), _p(lse2), _p(delta),
+                                             _p(dqkv), _ld(dqkv), _stream()), "tvts_attn_bwd_tail")
+
+
 def attn_delta(dO, O, delta, *, rows, heads, head_dim=64):
     lib = _lib.load()
     _chk(_attn_fn(lib, "delta", head_dim)(_p(dO), _ld(dO), _p(O), _ld(O), rows, heads, _p(delta), _stream()), "tvts_attn_delta")
