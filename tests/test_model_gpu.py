@@ -321,6 +321,45 @@ def test_h14_full_size_against_reference_golden(gpu, golden):
     assert rel(store.g("video_model.conv1.weight")[:4].reshape(4, -1), torch.tensor(f["g_conv"])) < 0.1
 
 
+@pytest.mark.parametrize("h14", [False, True])
+def test_sort_head_used_rows_only(gpu, h14):
+    """The sort head's last block evaluated on the rows the model reads (the NT transcript rows: sort_transformer.py:131-141)
+    gives the loss, prediction and EVERY parameter gradient of the dense evaluation the reference performs, and both track the
+    oracle."""
+    from tvts_amd import arch as A
+    m, oarch, P = build(arch=A.small_arch_h() if h14 else A.small_arch(), seed=11)
+    batch = O.synth_batch(oarch, B=4, T=3, seed=12, caption_len=11)
+    assert m.engine.sort_used_rows_only
+    l1, l2, te, ve, pred, store = engine_step(m, batch)
+    g_used = store.grad.clone()
+    m.engine.sort_used_rows_only = False
+    d1, d2, dte, dve, dpred, store = engine_step(m, batch)
+    g_dense = store.grad.clone()
+    m.engine.sort_used_rows_only = True
+    assert abs(l1 - d1) < 1e-5 and abs(l2 - d2) < 2e-3, (l1, d1, l2, d2)
+    assert rel(pred, dpred) < 5e-3
+    names = list(O.param_shapes(oarch).keys())
+    gu, gd = g_used.double(), g_dense.double()
+    assert abs(float(gu.norm()) - float(gd.norm())) < 2e-3 * float(gd.norm())
+    assert float((gu * gd).sum() / (gu.norm() * gd.norm())) > 0.99995
+    worst = []
+    for k in names:
+        if not k.startswith("pred_model."):
+            continue
+        store.grad.copy_(g_used); u = store.g(k).double().clone()
+        store.grad.copy_(g_dense); d = store.g(k).double().clone()
+        if float(d.norm()) > 0:
+            c = float((u * d).sum() / (u.norm() * d.norm() + 1e-30))
+            worst.append((c, k, float(u.norm()), float(d.norm())))
+    worst.sort()
+    assert worst and worst[0][0] > 0.999, worst[:5]
+    # and against the oracle
+    r1, r2, rte, rve, rpred, grads = oracle_step(P, batch, oarch)
+    store.grad.copy_(g_used)
+    assert abs(l2 - r2) < 1e-2 and rel(pred.view_as(rpred), rpred) < 0.03
+    check_grads(store, grads)
+
+
 def test_fp8_forward_path(gpu):
     """BASELINE config 4's weight / activation format on a small model: the six linear layers of every ViT block run their
     FORWARD product on per-tensor-scaled e4m3 copies (tvts_gemm_nt_fp8), the backward keeps the bf16 operands.  Checked

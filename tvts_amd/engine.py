@@ -161,6 +161,7 @@ class Engine:
             if d not in (64, 80) or d * h != w:
                 raise NotImplementedError(f"attention kernels are built for head dim 64 and 80, not {w}/{h}")
         self.pooled_tail = a["tail"] == "pooled_and_patches"
+        self.sort_used_rows_only = bool(a.get("sort_used_rows_only", True))  # last sort block on the rows the head reads (sort_forward)
         self.has_sort_head = bool(a.get("sort_head", True))
         self.dev = store.device
         self.buf: Dict[str, torch.Tensor] = {}
@@ -506,18 +507,83 @@ class Engine:
         xs = self._f("srt.x0", (Mo, E))
         K.sort_assemble(out, text_before, self.P.p("pred_model.type_embed").view(2, E), xs, B=B, S=S, off=off, Sv=Sv, NT=NT)
         x = xs
+        rows = self.ctx["sort_rows"]
+        nf = self._f("srt.nf", (B * NT, E))
+        last = a["sort_depth"] - 1
         for l in range(a["sort_depth"]):
+            if l == last and self.sort_used_rows_only and NT <= 16:
+                # the head reads the last block's output at the NT transcript rows only (sort_transformer.py:131-141)
+                xr = self._sort_last_fwd(f"pred_model.blocks.{l}.", x, f"srt{l}", Mo, E, hs, B, So, NT)
+                self._ln(xr, "pred_model.norm", 1e-6, nf, "srt.norm")
+                break
             xo = self._f(f"srt.x{l + 1}", (Mo, E))
             self._block_fwd(f"pred_model.blocks.{l}.", _SORT_NAMES, x, xo, f"srt{l}", Mo, E, hs, B, So, False, "gelu", 1e-6)
             x = xo
-        rows = self.ctx["sort_rows"]
-        nf = self._f("srt.nf", (B * NT, E))
-        self._ln(x, "pred_model.norm", 1e-6, nf, "srt.norm", rows=rows)
+        else:
+            self._ln(x, "pred_model.norm", 1e-6, nf, "srt.norm", rows=rows)
         pred = self._f("srt.pred", (B * NT, a["n_trans"]))
         C = a["n_trans"]
         K.gemm_small(nf, self.P.p("pred_model.head.weight"), pred, M=B * NT, N=C, K=E, sa=(E, 1), sb=(1, E),
                      bias=self.P.p("pred_model.head.bias"))
         return pred
+
+    # ---- the LAST block of the sort head on the rows the model uses.  SortTransformer.forward_features normalises and classifies
+    # x[:, x_len:] only (v2/model/sort_transformer.py:131-141): of the last block's [B, Sv + NT, E] output the NT transcript rows of
+    # every sample are read, the Sv video rows never are, and no gradient enters them.  Keys and values of the block's attention
+    # still come from every token, so LayerNorm 1 and the qkv projection run on all rows; the attention output, the output
+    # projection, the residual, LayerNorm 2 and the MLP are computed for the R = B * NT used rows, and in the backward dQ exists for
+    # those rows only while dK / dV (and through them the gradient of every input row) are dense.  Same loss, same gradient for
+    # every parameter and every input row as the dense evaluation (tests/test_model_gpu.py::test_sort_head_used_rows_only);
+    # arch["sort_used_rows_only"] = False evaluates the block densely like the reference does.
+    def _sort_last_fwd(self, pre, x_in, tag, Mo, E, heads, B, So, NT):
+        nm, hd, R = _SORT_NAMES, E // heads, B * NT
+        rows64 = self.ctx["sort_rows64"]
+        ln1 = self._b(tag + ".ln1", (Mo, E))
+        self._ln(x_in, pre + nm["ln1"], 1e-6, ln1, tag + ".ln1")
+        qkv = self._b(tag + ".qkv", (Mo, 3 * E))
+        self._lin(ln1, pre + nm["qkv_w"], pre + nm["qkv_b"], qkv, Mo)
+        att, lse = self._b(tag + ".att", (Mo, E)), self._f(tag + ".lse", (Mo, heads))
+        K.attn_fwd_tail(qkv, att, lse, B=B, heads=heads, S=So, nq=NT, head_dim=hd)
+        att_r, x_r = self._b(tag + ".att_r", (R, E)), self._f(tag + ".x_r", (R, E))
+        torch.index_select(att, 0, rows64, out=att_r)   # (row gathers of R x E elements: plumbing)
+        torch.index_select(x_in, 0, rows64, out=x_r)
+        mid = self._f(tag + ".mid", (R, E))
+        self._lin(att_r, pre + nm["o_w"], pre + nm["o_b"], mid, R, residual=x_r)
+        ln2 = self._b(tag + ".ln2", (R, E))
+        self._ln(mid, pre + nm["ln2"], 1e-6, ln2, tag + ".ln2")
+        h, act = self._b(tag + ".h", (R, 4 * E)), self._b(tag + ".a", (R, 4 * E))
+        self._lin(ln2, pre + nm["fc_w"], pre + nm["fc_b"], act, R, act="gelu", preact=h)
+        xo = self._f(tag + ".xo_r", (R, E))
+        self._lin(act, pre + nm["pj_w"], pre + nm["pj_b"], xo, R, residual=mid)
+        return xo
+
+    def _sort_last_bwd(self, pre, x_in, dxr, dxbr, dx_in, dxb_in, tag, Mo, E, heads, B, So, NT):
+        """dxr / dxbr: fp32 / bf16 gradient of the block output at the R used rows; writes the gradient of every input row."""
+        nm, hd, R, B_ = _SORT_NAMES, E // heads, B * NT, self.buf
+        rows64 = self.ctx["sort_rows64"]
+        dh, dln = self._b("srt.s.dh_r", (R, 4 * E)), self._b("srt.s.dln_r", (R, E))
+        self._lin_bwd(dxbr, B_[tag + ".a"], pre + nm["pj_w"], pre + nm["pj_b"], dh, R, gate_h=B_[tag + ".h"], gate_act="gelu")
+        self._lin_bwd(dh, B_[tag + ".ln2"], pre + nm["fc_w"], pre + nm["fc_b"], dln, R)
+        dmid, dmidb = self._f("srt.s.dmid_r", (R, E)), self._b("srt.s.dmidb_r", (R, E))
+        self._ln_bwd(dln, B_[tag + ".mid"], pre + nm["ln2"], tag + ".ln2", dmid, dx_bf16=dmidb, res1=dxr)
+        datt_r = self._b("srt.s.datt_r", (R, E))
+        self._lin_bwd(dmidb, B_[tag + ".att_r"], pre + nm["o_w"], pre + nm["o_b"], datt_r, R)
+        datt = self._b("srt.s.datt", (Mo, E))            # token-row indexed like the attention output; only the R rows are read
+        datt.index_copy_(0, rows64, datt_r)
+        dqkv = self._b("srt.s.dqkv", (Mo, 3 * E))
+        dqkv[:, :E].zero_()                              # dQ of the rows that are no queries
+        delta = self._f("srt.s.delta", (Mo, heads))
+        K.attn_bwd_tail(B_[tag + ".qkv"], datt, B_[tag + ".att"], B_[tag + ".lse"], delta, dqkv, B=B, heads=heads, S=So, nq=NT,
+                        head_dim=hd)
+        dlnf = self._b("srt.s.dln", (Mo, E))
+        self._lin_bwd(dqkv, B_[tag + ".ln1"], pre + nm["qkv_w"], pre + nm["qkv_b"], dlnf, Mo)
+        self._ln_bwd(dlnf, x_in, pre + nm["ln1"], tag + ".ln1", dx_in, dx_bf16=dxb_in)
+        # the residual path: + dmid at the used rows (fp32 sum, bf16 copy refreshed for those rows)
+        dx_in.index_add_(0, rows64, dmid)
+        tmp, tmpb = self._f("srt.s.tmp_r", (R, E)), self._b("srt.s.tmpb_r", (R, E))
+        torch.index_select(dx_in, 0, rows64, out=tmp)
+        tmpb.copy_(tmp)
+        dxb_in.index_copy_(0, rows64, tmpb)
 
     def sort_backward(self, dpred, B, S, NT):
         """-> fp32 grad of the sort-head input xs [B*So, E]."""
@@ -533,12 +599,21 @@ class Engine:
                      accumulate=True)
         dnf = self._f("srt.dnf", (R, E))
         K.gemm_small(dpred, self.P.p("pred_model.head.weight"), dnf, M=R, N=E, K=C, sa=(C, 1), sb=(E, 1))
-        dx = self._f("srt.dxA", (Mo, E), zero=True)
-        dxb = self._b("srt.dxbA", (Mo, E), zero=True)
-        self._ln_bwd(dnf, B_[f"srt.x{a['sort_depth']}"], "pred_model.norm", "srt.norm", dx, dx_bf16=dxb, rows=self.ctx["sort_rows"])
+        pruned = self.sort_used_rows_only and NT <= 16
+        if pruned:  # gradient of the last block's output exists at the transcript rows only: [R, E]
+            dx, dxb = self._f("srt.dx_r", (R, E)), self._b("srt.dxb_r", (R, E))
+            self._ln_bwd(dnf, B_[f"srt{a['sort_depth'] - 1}.xo_r"], "pred_model.norm", "srt.norm", dx, dx_bf16=dxb)
+        else:
+            dx = self._f("srt.dxA", (Mo, E), zero=True)
+            dxb = self._b("srt.dxbA", (Mo, E), zero=True)
+            self._ln_bwd(dnf, B_[f"srt.x{a['sort_depth']}"], "pred_model.norm", "srt.norm", dx, dx_bf16=dxb, rows=self.ctx["sort_rows"])
         for l in reversed(range(a["sort_depth"])):
             nx = "B" if (a["sort_depth"] - l) % 2 == 1 else "A"
             dxi, dxbi = self._f("srt.dx" + nx, (Mo, E)), self._b("srt.dxb" + nx, (Mo, E))
+            if pruned and l == a["sort_depth"] - 1:
+                self._sort_last_bwd(f"pred_model.blocks.{l}.", B_[f"srt.x{l}"], dx, dxb, dxi, dxbi, f"srt{l}", Mo, E, hs, B, So, NT)
+                dx, dxb = dxi, dxbi
+                continue
             self._block_bwd(f"pred_model.blocks.{l}.", _SORT_NAMES, B_[f"srt.x{l}"], dx, dxb, dxi, dxbi, f"srt{l}", Mo, E,
                             hs, B, So, False, "gelu", "srt.s")
             dx, dxb = dxi, dxbi
@@ -595,7 +670,7 @@ class Engine:
         sort_rows = (torch.arange(B)[:, None] * So + Sv + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev)
         vid_rows = (torch.arange(B) * S).to(torch.int32).to(self.dev)
         return dict(video=video, crop=crop, resize=resize, ids=ids_dev, eot_rows=eot_rows, keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
-                    sort_rows=sort_rows, vid_rows=vid_rows)
+                    sort_rows=sort_rows, sort_rows64=sort_rows.long(), vid_rows=vid_rows)
 
     def forward(self, pb: dict):
         """-> (text_emb [B,E], video_emb [B,E], pred [B*NT, n_trans] | None); all fp32 workspace tensors."""

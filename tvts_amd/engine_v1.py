@@ -198,7 +198,8 @@ class EngineV1(Engine):
         return dict(video=video, ids=ids[:, :L].to(torch.int32).contiguous().to(self.dev), kv_len=lens.to(torch.int32).to(self.dev),
                     txt_cls_rows=(torch.arange(N) * L).to(torch.int32).to(self.dev), keep=keep, B=B, T=T, tubes=tubes, N=N, NT=NT, L=L,
                     n=n, S=S, vid_rows=(torch.arange(B) * S).to(torch.int32).to(self.dev),
-                    sort_rows=(torch.arange(B)[:, None] * So + S + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev))
+                    sort_rows=(torch.arange(B)[:, None] * So + S + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev),
+                    sort_rows64=(torch.arange(B)[:, None] * So + S + torch.arange(NT)[None, :]).reshape(-1).to(self.dev))
 
     def forward(self, pb: dict):
         a = self.arch
