@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--batch", type=int, default=192, help="pairs per GPU (the reference config uses 12 on V100)")
     ap.add_argument("--caption-len", type=int, default=32)
+    ap.add_argument("--dense-sort-head", action="store_true", help="evaluate the sort head's last block on every row like the "
+                    "reference does (default: on the NT transcript rows the model reads -- same loss and gradients)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 4: e4m3 forward GEMMs in the ViT blocks")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,6 +215,8 @@ def main():
         a["num_frames"] = args.frames
     if args.fp8:
         a["fp8"] = True
+    if args.dense_sort_head:
+        a["sort_used_rows_only"] = False
     margs = types.SimpleNamespace(local_rank=local_rank, rank=rank, world_size=world)
     v1 = a.get("family") == "v1"
     if v1:
@@ -285,6 +289,13 @@ def main():
     loss = float(out["loss1"]) + (float(out["loss2"]) if out["loss2"] is not None else 0.0)
 
     fwd, bwd = (step_flops_per_pair_v1 if v1 else step_flops_per_pair)(a, T, args.caption_len, args.n_trans)
+    # matmul FLOPs the step does NOT execute when the sort head's last block runs on the rows the model reads (engine.sort_forward):
+    # attention output / projection / MLP of the Sv video rows of that block, forward and backward (its qkv projection stays dense)
+    skipped = 0.0
+    if args.n_trans > 1 and args.n_trans <= 16 and not args.dense_sort_head:
+        Es = a.get("sort_width", a["embed"])
+        So_ = int(pbs[0]["S"]) - (1 if a["tail"] == "pooled_and_patches" else 0) + args.n_trans
+        skipped = 3.0 * (So_ - args.n_trans) * (18 * Es * Es + 4 * So_ * Es)
     pairs_per_s = world * B * args.steps / dt
     line = {
         "metric": "video-text pairs/sec/node, TVTSv2 pretrain step", "value": pairs_per_s, "unit": "pairs/s",
@@ -296,10 +307,12 @@ def main():
                                + f"{args.caption_len}-token captions x{args.n_trans}, full pretrain step (fwd+losses+bwd+HF-AdamW)",
                    "pairs_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
                    "hip_graph": bool(graphs is not None), "step_gflop_per_pair": (fwd + bwd) / 1e9,
+                   "executed_gflop_per_pair": (fwd + bwd - skipped) / 1e9,
+                   "sort_head_last_block": "dense" if (args.dense_sort_head or args.n_trans == 1) else "rows the model reads (NT per sample)",
                    "final_loss": loss,
                    "exchange": {"transport": os.environ.get("TVTS_COMM", "torch") + (f" ({backend})" if world > 1 else ""),
                                 "grad_payload": runner.sync.payload, "grad_bytes_per_step": runner.sync.bytes_sent}},
-        "step_mfma_frac": pairs_per_s * (fwd + bwd) / (world * PEAK_BF16_TFLOPS * 1e12),
+        "step_mfma_frac": pairs_per_s * (fwd + bwd - skipped) / (world * PEAK_BF16_TFLOPS * 1e12),
     }
 
     if not args.no_roofline:
