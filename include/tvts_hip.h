@@ -125,6 +125,17 @@ int tvts_attn80_fwd_tail(const void* qkv, int ld, int B, int heads, int S, int n
                          hipStream_t stream);
 int tvts_attn80_bwd_tail(const void* qkv, int ld, int B, int heads, int S, int nq, const void* dO, int lddo, const void* O, int ldo,
                          const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream);
+/* ONE query per sequence, at token qpos[b] (device int32[B]), that sees the keys 0 .. qpos[b]: the last block of the CLIP text tower,
+ * whose output the model reads at the EOT token only (v2/CLIP/clip/model.py:343-354).  Conventions of the tail form; the dK / dV
+ * rows behind the query are not written (zero gradient): zero dqkv first. */
+int tvts_attn_fwd_rowq(const void* qkv, int ld, int B, int heads, int S, const int* qpos, void* out, int ldo, float* lse2,
+                       hipStream_t stream);
+int tvts_attn_bwd_rowq(const void* qkv, int ld, int B, int heads, int S, const int* qpos, const void* dO, int lddo, const void* O,
+                       int ldo, const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream);
+int tvts_attn80_fwd_rowq(const void* qkv, int ld, int B, int heads, int S, const int* qpos, void* out, int ldo, float* lse2,
+                         hipStream_t stream);
+int tvts_attn80_bwd_rowq(const void* qkv, int ld, int B, int heads, int S, const int* qpos, const void* dO, int lddo, const void* O,
+                         int ldo, const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream);
 int tvts_attn80_fwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, void* out, int ldo, float* lse2,
                         hipStream_t stream);
 int tvts_attn80_bwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,

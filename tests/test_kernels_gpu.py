@@ -433,6 +433,34 @@ def test_tail_query_attention(K, B, heads, S, nq, dh):
         assert rel(got[..., sl], ref_d[..., sl]) < 2e-2, (nm, rel(got[..., sl], ref_d[..., sl]))
 
 
+@pytest.mark.parametrize("dh", [64, 80])
+@pytest.mark.parametrize("B,heads,S", [(5, 2, 32), (3, 8, 77), (2, 1, 9)])
+def test_row_query_attention(K, B, heads, S, dh):
+    """One query per sequence at a ragged position (the EOT token of the text tower's last block) under the causal mask."""
+    W = heads * dh
+    qkv, dO = bf(rnd(B, S, 3 * W, seed=43)), bf(rnd(B, S, W, seed=44))
+    qpos = torch.tensor([(7 * b + 3) % S for b in range(B)], dtype=torch.int32)
+    qpos[0] = S - 1
+    keep = torch.zeros(B, S, 1)
+    keep[torch.arange(B), qpos.long()] = 1
+    dO = dO * keep.to(dO.dtype)
+    ref_out, ref_d = _ref_full(qkv.float(), heads, True, dO.float())
+    qd, dOd = qkv.reshape(B * S, 3 * W).to(DEV), dO.reshape(B * S, W).to(DEV)
+    out = torch.full((B * S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse, delta = torch.full((B * S, heads), float("nan"), device=DEV), torch.full((B * S, heads), float("nan"), device=DEV)
+    K.attn_fwd_rowq(qd, qpos.to(DEV), out, lse, B=B, heads=heads, S=S, head_dim=dh)
+    o = out.float().view(B, S, W).cpu()
+    idx = (torch.arange(B), qpos.long())
+    assert torch.isfinite(o[idx]).all() and int(torch.isfinite(o).all(-1).sum()) == B
+    assert rel(o[idx], ref_out[idx]) < 8e-3
+    dqkv = torch.full((B * S, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
+    K.attn_bwd_rowq(qd, qpos.to(DEV), dOd, torch.nan_to_num(out), lse, delta, dqkv, B=B, heads=heads, S=S, head_dim=dh)
+    got = dqkv.float().view(B, S, 3 * W).cpu()
+    assert torch.isfinite(got).all()
+    for nm, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
+        assert rel(got[..., sl], ref_d[..., sl]) < 2e-2, (nm, rel(got[..., sl], ref_d[..., sl]))
+
+
 def test_attention_softmax_spike(K):
     """Online-softmax rescale across key tiles: one key far above the rest in a late tile."""
     B, heads, S = 1, 1, 200

@@ -58,6 +58,7 @@ struct AttnGeom {
     int ablate;             // dev knob (TVTS_ATTN_ABLATE): 1 skip phase A, 2 skip phase B, 4 skip global loads
     const int* kv_len;      // FULL only, optional: valid keys per sequence (keys >= kv_len[b] are padding and masked)
     int cls_nq, cls_q0;     // CLS geometry generalised: cls_nq (<= 16) queries at tokens cls_q0 .. of the sequence (1, 0 = the CLS token)
+    const int* cls_qpos;    // ... or ONE query per sequence at token cls_qpos[b] that sees the keys 0 .. cls_qpos[b] (causal)
 };
 
 struct Grp { int b, h, sub, nq, nk; };
@@ -77,7 +78,10 @@ __device__ __forceinline__ Grp decode(const AttnGeom& g, int gid) {
     gid /= g.heads;
     if (MODE == MODE_SPACE) { r.sub = gid % g.T; r.b = gid / g.T; r.nq = g.n; r.nk = g.n + 1; }
     else if (MODE == MODE_TIME) { r.sub = gid % g.n; r.b = gid / g.n; r.nq = g.T; r.nk = g.T + 1; }
-    else if (MODE == MODE_CLS) { r.sub = 0; r.b = gid; r.nq = g.cls_nq; r.nk = g.S; }
+    else if (MODE == MODE_CLS) {
+        r.sub = 0; r.b = gid; r.nq = g.cls_nq; r.nk = g.S;
+        if (g.cls_qpos) { r.nq = 1; r.nk = g.cls_qpos[gid] + 1; }
+    }
     else {
         r.sub = 0; r.b = gid; r.nq = g.S; r.nk = g.S;
         if (g.kv_len) { const int l = g.kv_len[gid]; r.nk = l < 1 ? 1 : (l < g.S ? l : g.S); }
@@ -90,7 +94,7 @@ __device__ __forceinline__ int q_row(const AttnGeom& g, const Grp& r, int i) {
     const int base = r.b * g.S;
     if (MODE == MODE_SPACE) return base + 1 + r.sub * g.n + i;
     if (MODE == MODE_TIME) return base + 1 + i * g.n + r.sub;
-    if (MODE == MODE_CLS) return base + g.cls_q0 + i;
+    if (MODE == MODE_CLS) return base + (g.cls_qpos ? g.cls_qpos[r.b] : g.cls_q0) + i;
     return base + i;
 }
 template <int MODE>
@@ -1815,7 +1819,7 @@ static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int 
     if ((mode == MODE_SPACE || mode == MODE_TIME) && (T <= 0 || n <= 0 || S != 1 + T * n)) return TVTS_EINVAL;
     if (mode < MODE_FULL || mode > MODE_CLS) return TVTS_EINVAL;
     g.B = B; g.heads = heads; g.S = S; g.T = T; g.n = n; g.causal = causal; g.ld = ld; g.W = heads * DH; g.kv_len = nullptr;
-    g.cls_nq = 1; g.cls_q0 = 0;
+    g.cls_nq = 1; g.cls_q0 = 0; g.cls_qpos = nullptr;
     g.scale = 1.0f / sqrtf((float)DH);
     g.scale2 = g.scale * 1.4426950408889634f;
     static int abl = -1;
@@ -1998,11 +2002,12 @@ extern "C" int ABI(bwd_len)(const void* qkv, int ld, int B, int heads, int S, co
 // zeroes the dQ third of the other rows.  The CLS-query kernels do the work: one block per (sequence, head), key tiles dealt to
 // the four waves.
 static __global__ __launch_bounds__(256) void attn_delta_tail_kernel(const bf16* __restrict__ dO, int lddo, const bf16* __restrict__ O,
-                                                              int ldo, int B, int S, int nq, int heads, float* __restrict__ delta) {
+                                                              int ldo, int B, int S, int nq, const int* __restrict__ qpos, int heads,
+                                                              float* __restrict__ delta) {
     const long rh = (long)blockIdx.x * 256 + threadIdx.x;  // (sequence, query, head)
     if (rh >= (long)B * nq * heads) return;
     const int h = (int)(rh % heads), qi = (int)((rh / heads) % nq), b = (int)(rh / ((long)heads * nq));
-    const size_t row = (size_t)b * S + S - nq + qi;
+    const size_t row = (size_t)b * S + (qpos ? qpos[b] : S - nq) + qi;
     float s = 0.f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -2033,7 +2038,40 @@ extern "C" int ABI(bwd_tail)(const void* qkv, int ld, int B, int heads, int S, i
     g.cls_nq = nq; g.cls_q0 = S - nq;
     const long total = (long)B * nq * heads;
     hipLaunchKernelGGL(attn_delta_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16*)dO, lddo,
-                       (const bf16*)O, ldo, B, S, nq, heads, delta);
+                       (const bf16*)O, ldo, B, S, nq, (const int*)nullptr, heads, delta);
+    DISPATCH_MODE(attn_bwd_dq_kernel, MODE_CLS, dim3(B * heads), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo,
+                  lse2, delta, (bf16*)dqkv, lddq);
+    const int blocks = ceil_div(B * heads * ceil_div(S, 16), 4);
+    DISPATCH_MODE(attn_bwd_dkv_kernel, MODE_CLS, dim3(blocks), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo,
+                  lse2, delta, (bf16*)dqkv, lddq, (float*)nullptr);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ---- ONE query per sequence at token qpos[b] (device int32[B]) that sees the keys 0 .. qpos[b]: the last block of the CLIP text
+// tower, whose output the model reads at the EOT token only (v2/CLIP/clip/model.py:343-354: x[arange, text.argmax(-1)]).  Same
+// conventions as the tail form; dK / dV of the keys behind the query are not written (their gradient is zero): zero dqkv first.
+extern "C" int ABI(fwd_rowq)(const void* qkv, int ld, int B, int heads, int S, const int* qpos, void* out, int ldo, float* lse2,
+                             hipStream_t stream) {
+    AttnGeom g;
+    int rc = make_geom(g, MODE_CLS, B, heads, S, 0, 0, 0, ld);
+    if (rc) return rc;
+    if (!qpos || ldo % 4) return TVTS_EINVAL;
+    g.cls_qpos = qpos;
+    DISPATCH_MODE(attn_fwd_kernel, MODE_CLS, dim3(B * heads), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+extern "C" int ABI(bwd_rowq)(const void* qkv, int ld, int B, int heads, int S, const int* qpos, const void* dO, int lddo,
+                             const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream) {
+    AttnGeom g;
+    int rc = make_geom(g, MODE_CLS, B, heads, S, 0, 0, 0, ld);
+    if (rc) return rc;
+    if (!qpos || lddo % 8 || ldo % 8 || lddq % 4) return TVTS_EINVAL;
+    g.cls_qpos = qpos;
+    const long total = (long)B * heads;
+    hipLaunchKernelGGL(attn_delta_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16*)dO, lddo,
+                       (const bf16*)O, ldo, B, S, 1, qpos, heads, delta);
     DISPATCH_MODE(attn_bwd_dq_kernel, MODE_CLS, dim3(B * heads), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo,
                   lse2, delta, (bf16*)dqkv, lddq);
     const int blocks = ceil_div(B * heads * ceil_div(S, 16), 4);

@@ -246,6 +246,22 @@ def attn_bwd_tail(qkv, dO, O, lse2, delta, dqkv, *, B, heads, S, nq, head_dim=64
                                              _p(dqkv), _ld(dqkv), _stream()), "tvts_attn_bwd_tail")
 
 
+def attn_fwd_rowq(qkv, qpos, out, lse2, *, B, heads, S, head_dim=64):
+    """one query per sequence at token qpos[b] (int32 device tensor) attending the keys 0 .. qpos[b]; row b*S + qpos[b] of out / lse2."""
+    lib = _lib.load()
+    assert qpos.dtype == torch.int32 and qpos.numel() == B
+    _chk(_attn_fn(lib, "fwd_rowq", head_dim)(_p(qkv), _ld(qkv), B, heads, S, _p(qpos), _p(out), _ld(out), _p(lse2), _stream()),
+         "tvts_attn_fwd_rowq")
+
+
+def attn_bwd_rowq(qkv, qpos, dO, O, lse2, delta, dqkv, *, B, heads, S, head_dim=64):
+    """backward of attn_fwd_rowq into dqkv (zeroed here first: only the query row's dQ and the dK / dV of the keys it sees exist)."""
+    lib = _lib.load()
+    dqkv.zero_()
+    _chk(_attn_fn(lib, "bwd_rowq", head_dim)(_p(qkv), _ld(qkv), B, heads, S, _p(qpos), _p(dO), _ld(dO), _p(O), _ld(O), _p(lse2),
+                                             _p(delta), _p(dqkv), _ld(dqkv), _stream()), "tvts_attn_bwd_rowq")
+
+
 def attn_delta(dO, O, delta, *, rows, heads, head_dim=64):
     lib = _lib.load()
     _chk(_attn_fn(lib, "delta", head_dim)(_p(dO), _ld(dO), _p(O), _ld(O), rows, heads, _p(delta), _stream()), "tvts_attn_delta")
