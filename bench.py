@@ -165,8 +165,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--batch", type=int, default=192, help="pairs per GPU (the reference config uses 12 on V100)")
     ap.add_argument("--caption-len", type=int, default=32)
-    ap.add_argument("--dense-sort-head", action="store_true", help="evaluate the sort head's last block on every row like the "
-                    "reference does (default: on the NT transcript rows the model reads -- same loss and gradients)")
+    ap.add_argument("--dense-sort-head", action="store_true", help="evaluate the last block of the sort head and of the text tower on every row like "
+                    "the reference does (default: on the rows the model reads -- NT transcript rows / EOT row; same loss and gradients)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 4: e4m3 forward GEMMs in the ViT blocks")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -296,6 +296,9 @@ def main():
         Es = a.get("sort_width", a["embed"])
         So_ = int(pbs[0]["S"]) - (1 if a["tail"] == "pooled_and_patches" else 0) + args.n_trans
         skipped = 3.0 * (So_ - args.n_trans) * (18 * Es * Es + 4 * So_ * Es)
+    if not args.dense_sort_head and not v1:  # ... and the text tower's last block on the EOT row of every caption
+        Wt_, L_ = a["text_width"], args.caption_len
+        skipped += 3.0 * args.n_trans * (L_ - 1) * (18 * Wt_ * Wt_ + 4 * L_ * Wt_)
     pairs_per_s = world * B * args.steps / dt
     line = {
         "metric": "video-text pairs/sec/node, TVTSv2 pretrain step", "value": pairs_per_s, "unit": "pairs/s",
@@ -308,7 +311,7 @@ def main():
                    "pairs_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
                    "hip_graph": bool(graphs is not None), "step_gflop_per_pair": (fwd + bwd) / 1e9,
                    "executed_gflop_per_pair": (fwd + bwd - skipped) / 1e9,
-                   "sort_head_last_block": "dense" if (args.dense_sort_head or args.n_trans == 1) else "rows the model reads (NT per sample)",
+                   "last_blocks": "dense" if args.dense_sort_head else "sort head / text tower last block on the rows the model reads (NT transcript rows / EOT row)",
                    "final_loss": loss,
                    "exchange": {"transport": os.environ.get("TVTS_COMM", "torch") + (f" ({backend})" if world > 1 else ""),
                                 "grad_payload": runner.sync.payload, "grad_bytes_per_step": runner.sync.bytes_sent}},

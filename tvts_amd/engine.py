@@ -162,6 +162,7 @@ class Engine:
                 raise NotImplementedError(f"attention kernels are built for head dim 64 and 80, not {w}/{h}")
         self.pooled_tail = a["tail"] == "pooled_and_patches"
         self.sort_used_rows_only = bool(a.get("sort_used_rows_only", True))  # last sort block on the rows the head reads (sort_forward)
+        self.text_used_rows_only = bool(a.get("text_used_rows_only", a.get("sort_used_rows_only", True)))  # last text block: EOT rows
         self.has_sort_head = bool(a.get("sort_head", True))
         self.dev = store.device
         self.buf: Dict[str, torch.Tensor] = {}
@@ -301,18 +302,36 @@ class Engine:
         self._ln_bwd(dln, x_in, pre + nm["ln1"], tag + ".ln1", dx_in, dx_bf16=dxb_in, res1=dmid)
 
     # ------------------------------------------------------------------ text tower
+    def _eot_index(self, eot_rows, L):
+        """(int64 copy of the EOT rows, int32 position of the EOT token inside its caption): made once per eot_rows tensor (plumbing)"""
+        c = getattr(self, "_eot_cache", None)
+        if c is None or c[0] is not eot_rows or c[1] != L:
+            pos = (eot_rows - torch.arange(eot_rows.numel(), device=eot_rows.device, dtype=torch.int32) * L).contiguous()
+            c = self._eot_cache = (eot_rows, L, eot_rows.long(), pos)
+        return c[2], c[3]
+
     def text_forward(self, ids_dev, eot_rows, N, L):
         a = self.arch
         Wt, M = a["text_width"], N * L
         x = self._f("txt.x0", (M, Wt))
         K.text_embed(ids_dev, self.P.p("text_token_embedding.weight"), self.P.p("text_positional_embedding"), x, N=N, L=L)
+        lnf = self._f("txt.lnf", (N, Wt))
+        last = a["text_layers"] - 1
         for l in range(a["text_layers"]):
+            if l == last and self.text_used_rows_only:
+                # the model reads the last block's output at the EOT token of every caption only (CLIP/clip/model.py:343-354)
+                ht, hd = a["text_heads"], Wt // a["text_heads"]
+                rows64, pos = self._eot_index(eot_rows, L)
+                xr = self._used_rows_fwd(f"text_model.resblocks.{l}.", _TEXT_NAMES, x, f"txt{l}", M, Wt, ht, rows64, a["act"], 1e-5,
+                                         lambda qkv, att, lse: K.attn_fwd_rowq(qkv, pos, att, lse, B=N, heads=ht, S=L, head_dim=hd))
+                self._ln(xr, "text_ln_final", 1e-5, lnf, "txt.lnf")
+                break
             xo = self._f(f"txt.x{l + 1}", (M, Wt))
             self._block_fwd(f"text_model.resblocks.{l}.", _TEXT_NAMES, x, xo, f"txt{l}", M, Wt, a["text_heads"], N, L, True,
                             a["act"], 1e-5)
             x = xo
-        lnf = self._f("txt.lnf", (N, Wt))
-        self._ln(x, "text_ln_final", 1e-5, lnf, "txt.lnf", rows=eot_rows)
+        else:
+            self._ln(x, "text_ln_final", 1e-5, lnf, "txt.lnf", rows=eot_rows)
         t = self._f("txt.t", (N, a["embed"]))
         K.gemm_small(lnf, self.P.p("text_projection"), t, M=N, N=a["embed"], K=Wt, sa=(Wt, 1), sb=(a["embed"], 1))
         return t
@@ -325,13 +344,27 @@ class Engine:
             K.gemm_small(lnf, dt, self.P.g("text_projection"), M=Wt, N=E, K=N, sa=(1, Wt), sb=(E, 1), accumulate=True)
         dlnf = self._f("txt.dlnf", (N, Wt))
         K.gemm_small(dt, self.P.p("text_projection"), dlnf, M=N, N=Wt, K=E, sa=(E, 1), sb=(1, E))
-        dx = self._f("txt.dxA", (M, Wt), zero=True)
-        dxb = self._b("txt.dxbA", (M, Wt), zero=True)
-        self._ln_bwd(dlnf, self.buf[f"txt.x{a['text_layers']}"], "text_ln_final", "txt.lnf", dx, dx_bf16=dxb, rows=eot_rows)
+        pruned = self.text_used_rows_only
+        if pruned:  # the gradient of the last block's output exists at the EOT rows only: [N, Wt]
+            dx, dxb = self._f("txt.dx_r", (N, Wt)), self._b("txt.dxb_r", (N, Wt))
+            self._ln_bwd(dlnf, self.buf[f"txt{a['text_layers'] - 1}.xo_r"], "text_ln_final", "txt.lnf", dx, dx_bf16=dxb)
+        else:
+            dx = self._f("txt.dxA", (M, Wt), zero=True)
+            dxb = self._b("txt.dxbA", (M, Wt), zero=True)
+            self._ln_bwd(dlnf, self.buf[f"txt.x{a['text_layers']}"], "text_ln_final", "txt.lnf", dx, dx_bf16=dxb, rows=eot_rows)
         for l in reversed(range(a["text_layers"])):
             nx = "B" if (a["text_layers"] - l) % 2 == 1 else "A"
             dxi = self._f("txt.dx" + nx, (M, Wt))
             dxbi = self._b("txt.dxb" + nx, (M, Wt))
+            if pruned and l == a["text_layers"] - 1:
+                ht, hd = a["text_heads"], Wt // a["text_heads"]
+                rows64, pos = self._eot_index(eot_rows, L)
+                self._used_rows_bwd(f"text_model.resblocks.{l}.", _TEXT_NAMES, self.buf[f"txt.x{l}"], dx, dxb, dxi, dxbi, f"txt{l}",
+                                    "txt.s", M, Wt, ht, rows64, a["act"],
+                                    lambda qkv, datt, att, lse, delta, dqkv: K.attn_bwd_rowq(
+                                        qkv, pos, datt, att, lse, delta, dqkv, B=N, heads=ht, S=L, head_dim=hd))
+                dx, dxb = dxi, dxbi
+                continue
             self._block_bwd(f"text_model.resblocks.{l}.", _TEXT_NAMES, self.buf[f"txt.x{l}"], dx, dxb, dxi, dxbi, f"txt{l}",
                             M, Wt, a["text_heads"], N, L, True, a["act"], "txt.s")
             dx, dxb = dxi, dxbi
@@ -536,51 +569,63 @@ class Engine:
     # every parameter and every input row as the dense evaluation (tests/test_model_gpu.py::test_sort_head_used_rows_only);
     # arch["sort_used_rows_only"] = False evaluates the block densely like the reference does.
     def _sort_last_fwd(self, pre, x_in, tag, Mo, E, heads, B, So, NT):
-        nm, hd, R = _SORT_NAMES, E // heads, B * NT
-        rows64 = self.ctx["sort_rows64"]
-        ln1 = self._b(tag + ".ln1", (Mo, E))
-        self._ln(x_in, pre + nm["ln1"], 1e-6, ln1, tag + ".ln1")
-        qkv = self._b(tag + ".qkv", (Mo, 3 * E))
-        self._lin(ln1, pre + nm["qkv_w"], pre + nm["qkv_b"], qkv, Mo)
-        att, lse = self._b(tag + ".att", (Mo, E)), self._f(tag + ".lse", (Mo, heads))
-        K.attn_fwd_tail(qkv, att, lse, B=B, heads=heads, S=So, nq=NT, head_dim=hd)
-        att_r, x_r = self._b(tag + ".att_r", (R, E)), self._f(tag + ".x_r", (R, E))
-        torch.index_select(att, 0, rows64, out=att_r)   # (row gathers of R x E elements: plumbing)
-        torch.index_select(x_in, 0, rows64, out=x_r)
-        mid = self._f(tag + ".mid", (R, E))
-        self._lin(att_r, pre + nm["o_w"], pre + nm["o_b"], mid, R, residual=x_r)
-        ln2 = self._b(tag + ".ln2", (R, E))
-        self._ln(mid, pre + nm["ln2"], 1e-6, ln2, tag + ".ln2")
-        h, act = self._b(tag + ".h", (R, 4 * E)), self._b(tag + ".a", (R, 4 * E))
-        self._lin(ln2, pre + nm["fc_w"], pre + nm["fc_b"], act, R, act="gelu", preact=h)
-        xo = self._f(tag + ".xo_r", (R, E))
-        self._lin(act, pre + nm["pj_w"], pre + nm["pj_b"], xo, R, residual=mid)
-        return xo
+        return self._used_rows_fwd(pre, _SORT_NAMES, x_in, tag, Mo, E, heads, self.ctx["sort_rows64"], "gelu", 1e-6,
+                                   lambda qkv, att, lse: K.attn_fwd_tail(qkv, att, lse, B=B, heads=heads, S=So, nq=NT, head_dim=E // heads))
 
     def _sort_last_bwd(self, pre, x_in, dxr, dxbr, dx_in, dxb_in, tag, Mo, E, heads, B, So, NT):
+        def attn_bwd(qkv, datt, att, lse, delta, dqkv):
+            dqkv[:, :E].zero_()  # dQ of the rows that are no queries (dK / dV are written for every row)
+            K.attn_bwd_tail(qkv, datt, att, lse, delta, dqkv, B=B, heads=heads, S=So, nq=NT, head_dim=E // heads)
+        self._used_rows_bwd(pre, _SORT_NAMES, x_in, dxr, dxbr, dx_in, dxb_in, tag, "srt.s", Mo, E, heads, self.ctx["sort_rows64"],
+                            "gelu", attn_bwd)
+
+    # A pre-LN block whose output the model reads at R rows only (rows64: their token rows), and into whose other output rows no
+    # gradient enters.  LayerNorm 1 and the qkv projection stay dense (keys / values of every token); the attention output
+    # (attn_fwd: a query-restricted kernel writing the used rows of `att`), the output projection, the residual, LayerNorm 2 and the
+    # MLP are computed for the R used rows; backward: dQ for those rows, dK / dV -- and through them the gradient of every input
+    # row -- dense.  Returns the block output at the used rows, [R, Wd] fp32.
+    def _used_rows_fwd(self, pre, nm, x_in, tag, M, Wd, heads, rows64, act, eps, attn_fwd):
+        R = rows64.numel()
+        ln1 = self._b(tag + ".ln1", (M, Wd))
+        self._ln(x_in, pre + nm["ln1"], eps, ln1, tag + ".ln1")
+        qkv = self._b(tag + ".qkv", (M, 3 * Wd))
+        self._lin(ln1, pre + nm["qkv_w"], pre + nm["qkv_b"], qkv, M)
+        att, lse = self._b(tag + ".att", (M, Wd)), self._f(tag + ".lse", (M, heads))
+        attn_fwd(qkv, att, lse)
+        att_r, x_r = self._b(tag + ".att_r", (R, Wd)), self._f(tag + ".x_r", (R, Wd))
+        torch.index_select(att, 0, rows64, out=att_r)   # (row gathers of R x Wd elements: plumbing)
+        torch.index_select(x_in, 0, rows64, out=x_r)
+        mid = self._f(tag + ".mid", (R, Wd))
+        self._lin(att_r, pre + nm["o_w"], pre + nm["o_b"], mid, R, residual=x_r)
+        ln2 = self._b(tag + ".ln2", (R, Wd))
+        self._ln(mid, pre + nm["ln2"], eps, ln2, tag + ".ln2")
+        h, hact = self._b(tag + ".h", (R, 4 * Wd)), self._b(tag + ".a", (R, 4 * Wd))
+        self._lin(ln2, pre + nm["fc_w"], pre + nm["fc_b"], hact, R, act=act, preact=h)
+        xo = self._f(tag + ".xo_r", (R, Wd))
+        self._lin(hact, pre + nm["pj_w"], pre + nm["pj_b"], xo, R, residual=mid)
+        return xo
+
+    def _used_rows_bwd(self, pre, nm, x_in, dxr, dxbr, dx_in, dxb_in, tag, scr, M, Wd, heads, rows64, act, attn_bwd):
         """dxr / dxbr: fp32 / bf16 gradient of the block output at the R used rows; writes the gradient of every input row."""
-        nm, hd, R, B_ = _SORT_NAMES, E // heads, B * NT, self.buf
-        rows64 = self.ctx["sort_rows64"]
-        dh, dln = self._b("srt.s.dh_r", (R, 4 * E)), self._b("srt.s.dln_r", (R, E))
-        self._lin_bwd(dxbr, B_[tag + ".a"], pre + nm["pj_w"], pre + nm["pj_b"], dh, R, gate_h=B_[tag + ".h"], gate_act="gelu")
+        R, B_ = rows64.numel(), self.buf
+        dh, dln = self._b(scr + ".dh_r", (R, 4 * Wd)), self._b(scr + ".dln_r", (R, Wd))
+        self._lin_bwd(dxbr, B_[tag + ".a"], pre + nm["pj_w"], pre + nm["pj_b"], dh, R, gate_h=B_[tag + ".h"], gate_act=act)
         self._lin_bwd(dh, B_[tag + ".ln2"], pre + nm["fc_w"], pre + nm["fc_b"], dln, R)
-        dmid, dmidb = self._f("srt.s.dmid_r", (R, E)), self._b("srt.s.dmidb_r", (R, E))
+        dmid, dmidb = self._f(scr + ".dmid_r", (R, Wd)), self._b(scr + ".dmidb_r", (R, Wd))
         self._ln_bwd(dln, B_[tag + ".mid"], pre + nm["ln2"], tag + ".ln2", dmid, dx_bf16=dmidb, res1=dxr)
-        datt_r = self._b("srt.s.datt_r", (R, E))
+        datt_r = self._b(scr + ".datt_r", (R, Wd))
         self._lin_bwd(dmidb, B_[tag + ".att_r"], pre + nm["o_w"], pre + nm["o_b"], datt_r, R)
-        datt = self._b("srt.s.datt", (Mo, E))            # token-row indexed like the attention output; only the R rows are read
+        datt = self._b(scr + ".datt", (M, Wd))            # token-row indexed like the attention output; only the R rows are read
         datt.index_copy_(0, rows64, datt_r)
-        dqkv = self._b("srt.s.dqkv", (Mo, 3 * E))
-        dqkv[:, :E].zero_()                              # dQ of the rows that are no queries
-        delta = self._f("srt.s.delta", (Mo, heads))
-        K.attn_bwd_tail(B_[tag + ".qkv"], datt, B_[tag + ".att"], B_[tag + ".lse"], delta, dqkv, B=B, heads=heads, S=So, nq=NT,
-                        head_dim=hd)
-        dlnf = self._b("srt.s.dln", (Mo, E))
-        self._lin_bwd(dqkv, B_[tag + ".ln1"], pre + nm["qkv_w"], pre + nm["qkv_b"], dlnf, Mo)
+        dqkv = self._b(scr + ".dqkv", (M, 3 * Wd))
+        delta = self._f(scr + ".delta", (M, heads))
+        attn_bwd(B_[tag + ".qkv"], datt, B_[tag + ".att"], B_[tag + ".lse"], delta, dqkv)
+        dlnf = self._b(scr + ".dln", (M, Wd))
+        self._lin_bwd(dqkv, B_[tag + ".ln1"], pre + nm["qkv_w"], pre + nm["qkv_b"], dlnf, M)
         self._ln_bwd(dlnf, x_in, pre + nm["ln1"], tag + ".ln1", dx_in, dx_bf16=dxb_in)
         # the residual path: + dmid at the used rows (fp32 sum, bf16 copy refreshed for those rows)
         dx_in.index_add_(0, rows64, dmid)
-        tmp, tmpb = self._f("srt.s.tmp_r", (R, E)), self._b("srt.s.tmpb_r", (R, E))
+        tmp, tmpb = self._f(scr + ".tmp_r", (R, Wd)), self._b(scr + ".tmpb_r", (R, Wd))
         torch.index_select(dx_in, 0, rows64, out=tmp)
         tmpb.copy_(tmp)
         dxb_in.index_copy_(0, rows64, tmpb)
