@@ -10,6 +10,7 @@ mkdir -p $out
 cd $GRAFT_REPO_ROOT
 python -c "import torch" > /dev/null 2>&1
 python bench.py --steps 20 --warmup 5 > $out/bench_default_b192.json 2> $out/bench_default.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dense-sort-head 2>/dev/null | grep '^{' > $out/bench_dense_sort_head.json
 tools/profile_step.sh ${tag}_default > $out/profile_step.log 2>&1
 cp gpurun_out/prof_${tag}_default/summary.txt $out/kernel_summary_default_b192.txt
 cp gpurun_out/prof_${tag}_default/kernel_stats.csv $out/kernel_stats_default_b192.csv
