@@ -10,26 +10,27 @@ root = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
 
 
 def rows(c):
-    out = {"gemm_nt": [], "gemm_tn": []}
-    red = []
+    """per-kind value lists of the SECOND of the two identical steps; a tn_reduce dispatch is added to the gemm_tn dispatch it
+    follows (weight gradients whose contraction is not split have none)"""
+    ev = []
     for r in csv.DictReader(open(f"{root}/pmc_{c}/p_counter_collection.csv")):
         if r["Counter_Name"] != c:
             continue
         k = r["Kernel_Name"]
         v = float(r["Counter_Value"]) * 1024 * (2 if c == "FETCH_SIZE" else 1)
-        if "tn_reduce" in k:
-            red.append((int(r["Dispatch_Id"]), v))
-        elif "gemm_tn" in k:
-            out["gemm_tn"].append((int(r["Dispatch_Id"]), v))
-        elif "gemm_nt" in k:
-            out["gemm_nt"].append((int(r["Dispatch_Id"]), v))
+        kind = "red" if "tn_reduce" in k else "gemm_tn" if "gemm_tn" in k else "gemm_nt" if "gemm_nt" in k else None
+        if kind:
+            ev.append((int(r["Dispatch_Id"]), kind, v))
+    ev.sort()
+    out = {"gemm_nt": [], "gemm_tn": []}
+    for _, kind, v in ev:
+        if kind == "red":
+            out["gemm_tn"][-1] += v
+        else:
+            out[kind].append(v)
     for k in out:
-        out[k].sort()
-        out[k] = [v for _, v in out[k]]
         out[k] = out[k][len(out[k]) // 2:]          # two identical steps in the process: keep the second
-    red.sort()
-    red = [v for _, v in red][len(red) // 2:]
-    return out, red
+    return out, None
 
 
 F, Fr = rows("FETCH_SIZE")
@@ -39,8 +40,6 @@ agg = collections.OrderedDict()
 for kind, shp, ms, alg in order:
     i = idx[kind]; idx[kind] += 1
     f, w = F[kind][i], W[kind][i]
-    if kind == "gemm_tn":
-        f += Fr[i]; w += Wr[i]
     d = agg.setdefault((kind,) + tuple(shp), [0, 0.0, 0.0, 0.0, 0.0])
     d[0] += 1; d[1] += ms; d[2] += f; d[3] += w; d[4] += alg
 assert idx["gemm_nt"] == len(F["gemm_nt"]) and idx["gemm_tn"] == len(F["gemm_tn"]), (idx, len(F["gemm_nt"]), len(F["gemm_tn"]))
