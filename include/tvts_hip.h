@@ -47,6 +47,9 @@ int tvts_gemm_tn_select(int M, int Na, int Nb);
 int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
                      int scale_a_rows, const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact, int ldp,
                      void* out, int ldc, int out_f32, hipStream_t stream);
+/* main loop of tvts_gemm_nt_fp8: 1 (default) v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (the fp8 issue rate of gfx950),
+ * 0 the 16x16x32 fp8 form (bf16 issue rate); both accumulate the same products in fp32 -- for benches and parity tests */
+void tvts_gemm_set_fp8_mx(int on);
 /* per-tensor fp8 quantisation: amax[0] = max |x| ; q = rne(x * 448 / amax) as e4m3, scale_out[0] = amax / 448 */
 int tvts_amax(const void* x, int is_f32, long ld, int rows, int cols, float* amax, hipStream_t stream);
 int tvts_quant_fp8(const void* x, int is_f32, long ld, int rows, int cols, const float* amax, void* out, long ldo,

@@ -408,6 +408,41 @@ def test_full_attention(K, B, heads, S, causal, tr, dh):
 
 
 @pytest.mark.parametrize("dh", [64, 80])
+@pytest.mark.parametrize("B,heads,S,causal", [(5, 2, 32, True), (3, 8, 32, False), (7, 3, 20, True), (4, 2, 16, True), (6, 1, 9, False),
+                                              (3, 2, 2, True), (900, 8, 32, True)])
+def test_short_sequence_attention(K, B, heads, S, causal, dh):
+    """FULL attention over sequences of <= 32 tokens (the text tower's captions): the wave-per-(sequence, head) kernels behind
+    tvts_attn_fwd / tvts_attn_bwd (D in registers, one launch) against autograd, and against the streaming kernels they replace.
+    The last case has more groups than resident waves: the grid-stride walk with the next group's rows prefetched."""
+    W = heads * dh
+    qkv, dO = bf(rnd(B, S, 3 * W, seed=51)), bf(rnd(B, S, W, seed=52))
+    qd, dOd = qkv.reshape(B * S, 3 * W).to(DEV), dO.reshape(B * S, W).to(DEV)
+
+    def run():
+        out = torch.full((B * S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lse, delta = torch.full((B * S, heads), float("nan"), device=DEV), torch.empty(B * S, heads, device=DEV)
+        K.attn_fwd("full", qd, out, lse, B=B, heads=heads, S=S, causal=causal, head_dim=dh)
+        dqkv = torch.full((B * S, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        K.attn_bwd("full", qd, dOd, out, lse, delta, dqkv, B=B, heads=heads, S=S, causal=causal, head_dim=dh)
+        return out.float().cpu(), lse.cpu(), dqkv.float().cpu()
+
+    out, lse, got = run()
+    K.attn_set_fused(False)
+    try:
+        out_s, lse_s, got_s = run()
+    finally:
+        K.attn_set_fused(True)
+    assert torch.isfinite(out).all() and torch.isfinite(lse).all() and torch.isfinite(got).all()
+    assert rel(out, out_s) < 4e-3 and (lse - lse_s).abs().max() < 1e-3 and rel(got, got_s) < 8e-3
+    if B <= 16:
+        ref_out, ref_d = _ref_full(qkv.float(), heads, causal, dO.float())
+        assert rel(out.view(B, S, W), ref_out) < 8e-3
+        g3 = got.view(B, S, 3 * W)
+        for nm, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
+            assert rel(g3[..., sl], ref_d[..., sl]) < 2e-2, (nm, rel(g3[..., sl], ref_d[..., sl]))
+
+
+@pytest.mark.parametrize("dh", [64, 80])
 @pytest.mark.parametrize("B,heads,S,nq", [(3, 2, 200, 4), (2, 8, 789, 4), (2, 1, 37, 1), (1, 2, 130, 16)])
 def test_tail_query_attention(K, B, heads, S, nq, dh):
     """FULL attention whose only queries are the last nq tokens of every sequence (the sort head's last block): output rows and

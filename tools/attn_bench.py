@@ -52,6 +52,11 @@ def run(mode, Bn, heads, S, T=0, n=0, causal=False):
             tf.append(timeit(lambda: K.attn_fwd_divided(mode, qkv, out, lse, ws, B=Bn, heads=heads, S=S, T=T, n=n)))
         K.attn_set_fused(True)
         site = f"  site-fwd fused {tf[0]:7.1f} us / split {tf[1]:7.1f} us\n"
+    if mode == "full" and S <= 32:  # short sequences: wave-per-group kernels vs the streaming ones
+        K.attn_set_fused(False)
+        fs = timeit(lambda: K.attn_fwd(mode, qkv, out, lse, **kw))
+        K.attn_set_fused(True)
+        site = f"  fwd fused {f:7.1f} us / streaming {fs:7.1f} us\n"
     if mode != "cls":
         extra = dict(cls_acc=acc) if mode in ("space", "time") else {}
         K.attn_fwd(mode, qkv, out, lse, **kw)

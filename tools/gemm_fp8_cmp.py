@@ -32,8 +32,14 @@ for n, k, act in ((3840, 1280, None), (5120, 1280, "gelu"), (1280, 5120, None), 
     b8, sb = K.quantize_fp8(b)
     out = torch.empty(M, n, dtype=torch.bfloat16, device=dev)
     pre = torch.empty(M, n, dtype=torch.bfloat16, device=dev) if act else None
+    def fp8(mx):
+        K.gemm_set_fp8_mx(mx)
+        K.gemm_nt_fp8(a8, rs, b8, sb, out, bias=bias, act=act, preact=pre)
+
     fns = {"bf16": lambda: K.gemm_nt(a, b, out, bias=bias, act=act, preact=pre),
-           "fp8": lambda: K.gemm_nt_fp8(a8, rs, b8, sb, out, bias=bias, act=act, preact=pre)}
+           "fp8 16x16x32": lambda: fp8(False), "fp8 mx 16x16x128": lambda: fp8(True)}
+    fp8(False); o0 = out.clone(); fp8(True)
+    assert torch.equal(o0, out) or float((o0.float() - out.float()).abs().max()) <= 2e-2 * float(o0.float().abs().max()), "mx != 16x16x32"
     res = {name: [] for name in fns}
     for rnd in range(7):
         for name in res:

@@ -1773,6 +1773,287 @@ __global__ __launch_bounds__(256) void attn_fwd_time_fused_kernel(AttnGeom g, co
     }
 }
 
+// ================================================================================================
+// FUSED short-sequence FULL attention (S <= 32: the CLIP text tower's 32-token captions, v2/CLIP/clip/model.py:185-187 with
+// the causal mask of :330-336).  The (sequence, head) groups are tiny and many -- 6 144 groups of 32 x 64 at 192 pairs -- and
+// the streaming kernels spend a block, two of its four waves idle, and one round trip per 64-key tile on each.  Here a WAVE
+// owns a group, like in the TIME geometry: every key of a query lives in the group, so the forward softmax is one pass over
+// register-resident score tiles, the backward gets D = sum_k P * dP in registers (no delta pass over dO and O) and does dQ
+// (phase A) and dK / dV (phase B) from wave-private LDS tiles that are staged once; the next group's rows are in flight in
+// registers while the current one is computed; no block-level synchronisation at all.  Waves walk the groups with a grid
+// stride (head index fastest: the waves of a block read neighbouring 128-byte head slices of the same token rows).
+// ================================================================================================
+template <int MT, bool TR>
+__global__ __launch_bounds__(256) void attn_fwd_seq_fused_kernel(AttnGeom g, const bf16* __restrict__ qkv,
+                                                                 bf16* __restrict__ out, int ldo, float* __restrict__ lse2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // per wave: V tile | output-staging patch
+    constexpr int RA = MT * 16, TB = RA * VSTRIDE, NU = (MT + 1) / 2;
+    constexpr int WB = TB + 1024;
+    constexpr int PT = (RA * NCH + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* Vs = smem + wave * WB;
+    char* opatch = Vs + TB;
+    const int gq = lane >> 4, li = lane & 15;
+    const int m = g.S, groups = g.B * g.heads, stride = gridDim.x * 4;
+    const bool causal = g.causal != 0;
+
+    bf16x8 qf[MT][KS], kf[MT][KS], vst[PT];
+    auto issue = [&](int gid) {
+        const bf16* base = qkv + (size_t)(gid / g.heads) * g.S * g.ld + (gid % g.heads) * DH;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int j = t * 16 + li;
+            const bf16* rowp = base + (size_t)(j < m ? j : m - 1) * g.ld;
+            ld_frags(rowp, gq, qf[t]);
+            ld_frags(rowp + g.W, gq, kf[t]);
+        }
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int cc = lane + 64 * i, row = cc / NCH, ch = cc % NCH;
+            vst[i] = row < m ? ldg8(base + (size_t)row * g.ld + 2 * g.W + ch * 8) : zero8();
+        }
+    };
+    int gid = blockIdx.x * 4 + wave;
+    if (gid < groups) issue(gid);
+    for (; gid < groups; gid += stride) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int cc = lane + 64 * i, row = cc / NCH, ch = cc % NCH;
+            if (row < RA) *(bf16x8*)(Vs + row * VSTRIDE + ch * 16) = vst[i];
+        }
+        bf16x8 qc[MT][KS], kc[MT][KS];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { qc[t][ks] = qf[t][ks]; kc[t][ks] = kf[t][ks]; }
+        if (gid + stride < groups) issue(gid + stride);
+        const int h = gid % g.heads;
+        const size_t row0 = (size_t)(gid / g.heads) * g.S;
+        const int hcol = h * DH;
+#pragma unroll
+        for (int qt = 0; qt < MT; ++qt) {
+            const int qj = qt * 16 + li;
+            f32x4 st[2 * NU];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2 * NU; ++t) {
+                st[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                if (t < MT) {
+                    f32x4 sc = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[t][ks], qc[qt][ks], sc, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = t * 16 + gq * 4 + e;
+                        const bool ok = key < m && !(causal && key > qj);
+                        const float v = ok ? sc[e] * g.scale2 : -INFINITY;
+                        st[t][e] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                }
+            }
+            mx = group_max(mx);
+            float rs = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2 * NU; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pp = __builtin_amdgcn_exp2f(st[t][e] - mx);
+                    st[t][e] = pp;
+                    rs += pp;
+                }
+            const float l = group_sum(rs);
+            f32x4 o[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Vs, u, dt, lane, RA), pf, o[dt], 0, 0, 0);
+            }
+            {
+                const float inv = 1.0f / l;
+                f32x4 on[DT];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) on[dt] = o[dt] * inv;
+                store_tile_rows(opatch, on, lane, [&](int rr) -> bf16* {
+                    const int j = qt * 16 + rr;
+                    return j < m ? out + (row0 + j) * ldo + hcol : nullptr; });
+            }
+            if (qj < m && gq == 0) lse2[(row0 + qj) * g.heads + h] = mx + log2f(l);
+        }
+    }
+}
+
+#define SEQ_BWD_WAVES 2  // 21 KiB of tiles per wave (S = 32): two-wave blocks, three of them per CU
+template <int MT, bool TR>
+__global__ __launch_bounds__(64 * SEQ_BWD_WAVES) void attn_bwd_seq_fused_kernel(AttnGeom g, const bf16* __restrict__ qkv,
+                                                                               const bf16* __restrict__ dO, int lddo,
+                                                                               const float* __restrict__ lse2,
+                                                                               bf16* __restrict__ dqkv, int lddq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RA = MT * 16, TB = RA * VSTRIDE, NU = (MT + 1) / 2;
+    constexpr int WB = 4 * TB + 2 * RA * 4 + 1024;  // one wave's region: Q | K | V | dO tiles, lse and D of the query rows, output patch
+    constexpr int PT = (RA * NCH + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* base = smem + wave * WB;
+    char* Qs = base;
+    char* Ks = Qs + TB;
+    char* Vs = Ks + TB;
+    char* Ds = Vs + TB;
+    float* st_lse = (float*)(Ds + TB);
+    float* st_dl = st_lse + RA;
+    char* opatch = (char*)(st_dl + RA);
+    const int gq = lane >> 4, li = lane & 15;
+    const int m = g.S, groups = g.B * g.heads, stride = gridDim.x * SEQ_BWD_WAVES;
+    const bool causal = g.causal != 0;
+
+    bf16x8 stg[4][PT];
+    float lse_pf = 0.f;
+    auto issue = [&](int gid) {
+        const int h = gid % g.heads;
+        const size_t row0 = (size_t)(gid / g.heads) * g.S;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16* src = t == 3 ? dO + h * DH : qkv + t * g.W + h * DH;
+            const int ld = t == 3 ? lddo : g.ld;
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int cc = lane + 64 * i, row = cc / NCH, ch = cc % NCH;
+                stg[t][i] = row < m ? ldg8(src + (row0 + row) * ld + ch * 8) : zero8();
+            }
+        }
+        if (lane < m) lse_pf = lse2[(row0 + lane) * g.heads + h];
+    };
+    int gid = blockIdx.x * SEQ_BWD_WAVES + wave;
+    if (gid < groups) issue(gid);
+    for (; gid < groups; gid += stride) {
+        // registers -> this wave's LDS tiles (rows m..RA-1 arrive as zeros)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int cc = lane + 64 * i, row = cc / NCH, ch = cc % NCH;
+                if (row < RA) *(bf16x8*)(base + t * TB + row * VSTRIDE + ch * 16) = stg[t][i];
+            }
+        if (lane < RA) st_lse[lane] = lane < m ? lse_pf : 0.f;
+        if (gid + stride < groups) issue(gid + stride);
+        const int hcol = (gid % g.heads) * DH;
+        const size_t row0 = (size_t)(gid / g.heads) * g.S;
+
+        // ---- phase A: dQ (+ D_q = sum_k P * dP, exact: every key of the query is in this group)
+#pragma unroll
+        for (int qt = 0; qt < MT; ++qt) {
+            const int qj = qt * 16 + li;
+            bf16x8 qf[KS], dof[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { qf[ks] = frag_row(Qs, qj, ks, gq); dof[ks] = frag_row(Ds, qj, ks, gq); }
+            const float lse = st_lse[qj];
+            f32x4 P[2 * NU], dP[2 * NU];
+            float part = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2 * NU; ++t) {
+                P[t] = (f32x4){0, 0, 0, 0};
+                dP[t] = (f32x4){0, 0, 0, 0};
+                if (t < MT) {
+                    f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, t * 16 + li, ks, gq), qf[ks], sc, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Vs, t * 16 + li, ks, gq), dof[ks], dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = t * 16 + gq * 4 + e;
+                        const bool ok = key < m && !(causal && key > qj);
+                        const float pp = ok ? __builtin_amdgcn_exp2f(sc[e] * g.scale2 - lse) : 0.f;
+                        P[t][e] = pp;
+                        dP[t][e] = dp[e];
+                        part += pp * dp[e];
+                    }
+                }
+            }
+            const float dlt = group_sum(part);
+            f32x4 acc[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                bf16x8 dsf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = 2 * u + (j >> 2), e = j & 3;
+                    dsf[j] = (bf16)(P[t][e] * (dP[t][e] - dlt) * g.scale);
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ks, u, dt, lane, RA), dsf, acc[dt], 0, 0, 0);
+            }
+            store_tile_rows(opatch, acc, lane, [&](int rr) -> bf16* {
+                const int j = qt * 16 + rr;
+                return j < m ? dqkv + (row0 + j) * lddq + hcol : nullptr; });
+            if (gq == 0) st_dl[qj] = dlt;
+        }
+
+        // ---- phase B: dK / dV
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+            const int kj = kt * 16 + li;
+            bf16x8 kb[KS], vb[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { kb[ks] = frag_row(Ks, kj, ks, gq); vb[ks] = frag_row(Vs, kj, ks, gq); }
+            f32x4 dv[DT], dk[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                bf16x8 pf, dsf;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int tile = 2 * u + t;
+                    if (tile < MT) {
+                        f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, tile * 16 + li, ks, gq), kb[ks], sc, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ds, tile * 16 + li, ks, gq), vb[ks], dp, 0, 0, 0);
+                        }
+                        const f32x4 l4 = *(const f32x4*)(st_lse + tile * 16 + gq * 4);
+                        const f32x4 d4 = *(const f32x4*)(st_dl + tile * 16 + gq * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int qi = tile * 16 + gq * 4 + e;
+                            const bool ok = qi < m && kj < m && !(causal && kj > qi);
+                            const float pp = ok ? __builtin_amdgcn_exp2f(sc[e] * g.scale2 - l4[e]) : 0.f;
+                            pf[t * 4 + e] = (bf16)pp;
+                            dsf[t * 4 + e] = (bf16)(pp * (dp[e] - d4[e]) * g.scale);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { pf[t * 4 + e] = (bf16)0.f; dsf[t * 4 + e] = (bf16)0.f; }
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ds, u, dt, lane, RA), pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Qs, u, dt, lane, RA), dsf, dk[dt], 0, 0, 0);
+                }
+            }
+            auto krowp = [&](int third) {
+                return [&, third](int rr) -> bf16* {
+                    const int j = kt * 16 + rr;
+                    return j < m ? dqkv + (row0 + j) * lddq + third * g.W + hcol : nullptr; };
+            };
+            store_tile_rows(opatch, dk, lane, krowp(1));
+            store_tile_rows(opatch, dv, lane, krowp(2));
+        }
+    }
+}
+
 // CLS output row = merge of the G partial softmax states of (b, h)
 __global__ void attn_cls_merge_kernel(const float* __restrict__ cls_part, int G, int heads, int S, bf16* __restrict__ out,
                                       int ldo, float* __restrict__ lse2) {
@@ -1811,6 +2092,7 @@ using namespace NS_DH;
 // ------------------------------------------------------------------------------------------------ C ABI
 static int g_use_tr = 1;
 static int g_shared = 1;  // block-shared K/V (Q/dO) staging for FULL and SPACE geometry
+static int g_fused = 1;   // single-launch kernels for the geometries whose groups fit one block / one wave
 extern "C" void ABI(set_shared)(int on) { g_shared = on ? 1 : 0; }
 extern "C" void ABI(set_transpose_read)(int on) { g_use_tr = on ? 1 : 0; }
 
@@ -1867,6 +2149,15 @@ static int fwd_impl(int mode, const void* qkv, int ld, int B, int heads, int S, 
     if (rc) return rc;
     if (ldo % 4 || (kv_len && mode != MODE_FULL)) return TVTS_EINVAL;
     g.kv_len = kv_len;
+    if (g_fused && g_use_tr && mode == MODE_FULL && !kv_len && S <= 32) {  // short sequences (text tower): a wave per (sequence, head)
+        const int MT = ceil_div(S, 16), groups = B * heads;
+        const int lds_bytes = 4 * (MT * 16 * VSTRIDE + 1024);
+        const int blocks = ceil_div(groups, 4) < 1536 ? ceil_div(groups, 4) : 1536;
+        if (MT == 1) hipLaunchKernelGGL((attn_fwd_seq_fused_kernel<1, true>), dim3(blocks), dim3(256), lds_bytes, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
+        else hipLaunchKernelGGL((attn_fwd_seq_fused_kernel<2, true>), dim3(blocks), dim3(256), lds_bytes, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
     if (g_shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
         const int nq = mode == MODE_SPACE ? g.n : g.S;
         const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : g.B * g.heads;
@@ -2097,7 +2388,6 @@ static __global__ void zero_f32_kernel(float* __restrict__ p, int n) {
 
 // Whole backward of one attention site: D = rowsum(dO*O), dQ, dK, dV (and, for the divided space / time geometries,
 // the CLS query and the CLS key/value reduction).  SPACE groups that fit 112 rows take the fused single-launch kernel.
-static int g_fused = 1;
 extern "C" void ABI(set_fused)(int on) { g_fused = on ? 1 : 0; }
 extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
                         const void* dO, int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv,
@@ -2108,6 +2398,16 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
     if (rc) return rc;
     if (lddo % 8 || ldo % 8 || lddq % 4) return TVTS_EINVAL;
     const bool divided = mode == MODE_SPACE || mode == MODE_TIME;
+    if (g_fused && g_use_tr && mode == MODE_FULL && S <= 32) {  // short sequences (text tower): one launch, D in registers
+        const int MT = ceil_div(S, 16), groups = B * heads;
+        const int lds_bytes = SEQ_BWD_WAVES * (4 * MT * 16 * VSTRIDE + 2 * MT * 16 * 4 + 1024);
+        const int want = ceil_div(groups, SEQ_BWD_WAVES);
+        const int blocks = want < 768 ? want : 768;
+        if (MT == 1) hipLaunchKernelGGL((attn_bwd_seq_fused_kernel<1, true>), dim3(blocks), dim3(64 * SEQ_BWD_WAVES), lds_bytes, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo, lse2, (bf16*)dqkv, lddq);
+        else hipLaunchKernelGGL((attn_bwd_seq_fused_kernel<2, true>), dim3(blocks), dim3(64 * SEQ_BWD_WAVES), lds_bytes, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo, lse2, (bf16*)dqkv, lddq);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
     if (divided) {
         if (!cls_acc) return TVTS_EINVAL;
         // a kernel, not hipMemsetAsync: captured memset nodes did not reliably zero this buffer on hipGraph replay (ROCm 7.x:

@@ -157,6 +157,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNT g) {
 static const int NT_MIN_TILES_256 = 150;
 static int g_nt_tile = 0;
 extern "C" void tvts_gemm_set_nt_tile(int t) { g_nt_tile = (t == 128 || t == 256) ? t : 0; }
+static int g_fp8_mx = 1;
+extern "C" void tvts_gemm_set_fp8_mx(int on) { g_fp8_mx = on ? 1 : 0; }
 
 static bool nt_use_256(int M, int N) {
     if (g_nt_tile == 128) return false;
@@ -193,11 +195,19 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_
     } else {
         kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, FP8, SD> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, FP8, SD>
              : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, FP8, SD> : nullptr;
+        if constexpr (FP8) {  // the K = 128 scaled-MFMA main loop (the fp8 issue rate); tvts_gemm_set_fp8_mx(0) restores the 16x16x32 form
+            constexpr int MX = SD | 65536;
+            if (g_fp8_mx) kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, true, MX> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, true, MX>
+                               : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, true, MX> : nullptr;
+        }
     }
     // fp32 residual in the epilogue, no activation: the instantiation that requests the residual of slab i + 1 as soon as slab i
     // has consumed its registers (ABL 256: proj + residual 334 -> 294 us, fc2 + residual 749 -> 713 us at M = 150 720; it costs the
     // plain / activation / gate kernels 1-12 %, so they keep the in-place loads)
     if (!gated && act == ACT_NONE && g.residual) kern = gemm_nt256p_kernel<0, 0, FP8, 256 | SD>;
+    if constexpr (FP8) {
+        if (g_fp8_mx && act == ACT_NONE && g.residual) kern = gemm_nt256p_kernel<0, 0, true, 256 | SD | 65536>;
+    }
     // The hand-scheduled patch epilogue (ABL 8192: bias added inside the K loop, stores by inline asm from scalar bases, side
     // inputs by inline asm two row-tiles ahead of their use and ahead of the stores, hand-counted vmcnt) where tools/gemm_ab.py
     // measures a gain at M = 150 720: QuickGELU gate 927 -> 817 us (fc2 dgrad), QuickGELU + pre-activation 908 -> 880 us (fc1),

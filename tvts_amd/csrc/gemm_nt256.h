@@ -683,6 +683,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         stage_offsets256(oa, g.lda, i_m0, g.M - 1, wave, lane);
         stage_offsets256(ob, g.ldb, i_n0, g.N - 1, wave, lane);
     }
+    constexpr bool MX = FP8 && (ABL & 65536) != 0;  // the K = 128 scaled-MFMA main loop below
+    // MX: the lane id the once-per-tile code needs is re-read (mbcnt) instead of kept: lane-derived constants that stay live across
+    // the K loop are the first thing the allocator spills in this 256-register kernel, and their reload sits behind an
+    // s_waitcnt vmcnt(0) that waits for the LDS-DMA just issued
+    auto fresh_lane = [&]() -> int {
+        if constexpr (MX) {
+            int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(l));
+            return l;
+        } else {
+            return lane;
+        }
+    };
     auto issue = [&]() {
         char* dst = smem + (i_st & 1) * 65536;
         stage_issue256<0>(oa, g.A + (size_t)i_m0 * g.lda + i_kt * BK, dst, wave);
@@ -691,8 +704,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         if (++i_kt == nk) {
             i_kt = 0; ++i_tl;
             tile_origin256(g, range_lo + slot + i_tl * per_xcd, gc, i_m0, i_n0);
-            stage_offsets256(oa, g.lda, i_m0, g.M - 1, wave, lane);
-            stage_offsets256(ob, g.ldb, i_n0, g.N - 1, wave, lane);
+            const int ln = fresh_lane();
+            stage_offsets256(oa, g.lda, i_m0, g.M - 1, wave, ln);
+            stage_offsets256(ob, g.ldb, i_n0, g.N - 1, wave, ln);
         }
     };
     issue();
@@ -733,12 +747,86 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                 acc[j][(h) * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[j], av[i], acc[j][(h) * 4 + i], 0, 0, 0); \
             }                                                                                          \
         }
-    LOAD_B(bF[0], smem, 0);
-    LOAD_A(aF[0], smem, 0, 0);
+    // FP8 at the fp8 rate (ABL & 65536): v_mfma_scale_f32_16x16x128_f8f6f4 with unit E8M0 scales -- the only fp8 MFMA form of
+    // gfx950 that issues at twice the bf16 rate.  A lane's operand is 32 bytes of K: exactly the two 16-byte pieces of its row
+    // that the two k-steps of a 128-byte stage read (A and B take the same two pieces, so every k meets its partner).  One MFMA
+    // then covers a whole stage for a (row-tile, column-tile) pair: 32 MFMAs per stage in four chunks of 2 row-tiles x 4
+    // column-tiles; the A pairs are double-buffered across chunks, the four B operands are re-read IN PLACE for the next stage
+    // behind the last MFMAs that use them (column-tile-major order in the last chunk) -- 64 fragment registers like the bf16 loop.
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    i32x8 aQ[2][2], bQ[4];
+#define LDQ(buf, row)                                                                                   \
+    __builtin_shufflevector(__builtin_bit_cast(i32x4, frag_rows128(buf, row, gq)),                      \
+                            __builtin_bit_cast(i32x4, frag_rows128(buf, row, 4 + gq)), 0, 1, 2, 3, 4, 5, 6, 7)
+#define LOAD_A2(dst, buf, p)                                                                            \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) dst[t] = LDQ(buf, arow + ((p) * 2 + t) * 16)
+    // the MFMA as volatile inline asm: left to the compiler (the builtin), every MFMA of the stage is sunk behind the stage's last
+    // branch -- their results are only read by the epilogue -- which makes all eight A operands live at once (189 spilled
+    // registers).  cbsz = blgp = 0: both operands e4m3; the scale register holds E8M0 127 (= 1.0) in every byte.  The compiler
+    // does not know these are MFMAs: the wait between the tile's last MFMA and the epilogue's reads is explicit below.
+    int mx_one = 0x7F7F7F7F;
+    asm volatile("" : "+v"(mx_one));
+#define MXMFMA(bv, av, c)                                                                               \
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(bv), "v"(av), "v"(mx_one))
+#define MFMA8(av, p)                                                                                    \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) MXMFMA(bQ[j], av[t], acc[j][(p) * 2 + t])
+    if constexpr (MX) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bQ[j] = LDQ(smem + 32768, brow + j * 16);
+        LOAD_A2(aQ[0], smem, 0);
+    } else {
+        LOAD_B(bF[0], smem, 0);
+        LOAD_A(aF[0], smem, 0, 0);
+    }
 
     for (int st = 0; st < total_st; ++st) {
         const char* cur = smem + (st & 1) * 65536;
         const char* nxt = smem + ((st + 1) & 1) * 65536;
+        if constexpr (MX) {
+            LOAD_A2(aQ[1], cur, 1);
+            MFMA8(aQ[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            LOAD_A2(aQ[0], cur, 2);
+            MFMA8(aQ[1], 1);
+            __builtin_amdgcn_sched_barrier(0);
+            LOAD_A2(aQ[1], cur, 3);
+            MFMA8(aQ[0], 2);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            RAW_BARRIER_P();
+            const bool do_issue = i_st < total_st;
+            if (do_issue && wave < 4) issue();
+            // the next stage's first fragments: under this stage's last MFMAs, or -- across a tile boundary -- behind the epilogue
+            // (48 registers that would otherwise stay live across it)
+            const bool more = st + 1 < total_st;
+            const bool pre = more && kt + 1 != nk;
+            if (pre) LOAD_A2(aQ[0], nxt, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                MXMFMA(bQ[j], aQ[1][0], acc[j][6]);
+                MXMFMA(bQ[j], aQ[1][1], acc[j][7]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pre) bQ[j] = LDQ(nxt + 32768, brow + j * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_issue && wave >= 4) issue();
+            if (++kt == nk) {
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results (16 passes) before the epilogue reads them
+                const int le = fresh_lane();
+                if (g.sa_rows) epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, le, patch, g.sb[0], g.sa);
+                else epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, le, patch, g.sa[0] * g.sb[0]);
+                kt = 0; ++tl;
+                tile_origin256(g, range_lo + slot + tl * per_xcd, gc, m0, n0);
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bQ[j] = LDQ(nxt + 32768, brow + j * 16);
+                    LOAD_A2(aQ[0], nxt, 0);
+                }
+            }
+            continue;
+        }
         LOAD_A(aF[1], cur, 0, 1);
         MFMA16(aF[0], bF[0], 0);
         LOAD_B(bF[1], cur, 1);
@@ -854,4 +942,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
 #undef LOAD_A
 #undef LOAD_B
 #undef MFMA16
+#undef LDQ
+#undef LOAD_A2
+#undef MXMFMA
+#undef MFMA8
 }

@@ -93,6 +93,11 @@ def quantize_fp8_rows(x, q=None, row_scale=None):
     return q, row_scale
 
 
+def gemm_set_fp8_mx(on: bool):
+    """main loop of gemm_nt_fp8: True (default) the K = 128 scaled MFMA (fp8 issue rate), False the 16x16x32 fp8 form"""
+    _lib.load().tvts_gemm_set_fp8_mx(int(on))
+
+
 def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, preact=None):
     """out[M,N] = act(sa*sb * (a8[M,K] @ b8[N,K]^T) + bias) [+ residual]; a8 / b8 uint8 e4m3 bit patterns; sb float32[1]; sa
     float32[1] (one scale for the tensor) or float32[>= M] (one per row, quantize_fp8_rows); preact receives the bf16
