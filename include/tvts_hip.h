@@ -47,6 +47,12 @@ int tvts_gemm_tn_select(int M, int Na, int Nb);
 int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
                      int scale_a_rows, const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact, int ldp,
                      void* out, int ldc, int out_f32, hipStream_t stream);
+/* input gradient of such a layer (autograd of nn.Linear + the GELU of video_encoder_ViT_H_14.py's Mlp): out[M,N] (bf16) =
+ * gate_act'(gate_h[M,N]) * (scale_a[m] * scale_b * (A[M,K] B[N,K]^T)), A = e4m3 copy of the output gradient (per-token scales),
+ * B = e4m3 copy of the transposed weight; the un-gated input gradients take tvts_gemm_nt_fp8 itself */
+int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
+                          int scale_a_rows, const float* scale_b, const void* gate_h, int ldh, int gate_act, void* out, int ldc,
+                          hipStream_t stream);
 /* main loop of tvts_gemm_nt_fp8: 1 (default) v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (the fp8 issue rate of gfx950),
  * 0 the 16x16x32 fp8 form (bf16 issue rate); both accumulate the same products in fp32 -- for benches and parity tests */
 void tvts_gemm_set_fp8_mx(int on);

@@ -404,6 +404,30 @@ def test_fp8_forward_path_h14_structure(gpu):
     assert min_cos(ve, fve) > 0.995 and abs(l1 - f1) < 5e-2 and abs(l2 - f2) < 5e-2, (min_cos(ve, fve), l1, f1, l2, f2)
 
 
+@pytest.mark.parametrize("h14", [False, True])
+def test_fp8_dgrad_path(gpu, h14):
+    """arch["fp8_dgrad"]: the input-gradient GEMMs of the ViT blocks' six linear layers on e4m3 operands too (output gradient one
+    scale per token, the transposed weight's e4m3 copy, the MLP's activation-gradient gate in the fp8 kernel's epilogue); the
+    weight gradients keep their bf16 operands.  Forward results are those of the forward-only fp8 path bit for bit; gradients
+    are held to the fp8 tolerance against the oracle's emulation and stay aligned with the bf16-backward ones."""
+    from tvts_amd import arch as A
+    mk = (lambda **kw: A.small_arch_h(width=640, heads=8, **kw)) if h14 else A.small_arch
+    m0, oarch, P = build(arch=mk(fp8=True), seed=4)
+    batch = O.synth_batch(oarch, B=4, T=3, seed=6, caption_len=11)
+    r1, r2, rte, rve, rpred, grads = oracle_step(P, batch, oarch)
+    l1, l2, te, ve, pred, store0 = engine_step(m0, batch)
+    g0 = store0.grad.clone()
+    m1, _, _ = build(arch=mk(fp8=True, fp8_dgrad=True), seed=4)
+    k1, k2, te1, ve1, pred1, store = engine_step(m1, batch)
+    assert len(store.w8t) == len(store.w8) == 6 * oarch["layers"]
+    assert torch.equal(ve1, ve) and torch.equal(te1, te) and k1 == l1 and k2 == l2   # same forward
+    check_grads(store, grads, gn_tol=0.05, cos_tol=0.9)
+    g1 = store.grad
+    cos = float(torch.nn.functional.cosine_similarity(g0.double().flatten(), g1.double().flatten(), dim=0))
+    assert cos > 0.995 and abs(float(g1.double().norm()) / float(g0.double().norm()) - 1) < 0.02, cos
+    assert not torch.equal(g0, g1)   # the e4m3 path did run
+
+
 def test_b16_config2_against_reference_golden(gpu, golden):
     """The headline architecture (BASELINE config 2's model): the real TVTSv2_B_16 class ran in the build container at
     B=2, T=4 with tube mask 0.5 (98 of 196 patches kept: the fused SPACE / TIME attention kernels' shapes)."""

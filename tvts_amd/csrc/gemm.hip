@@ -190,8 +190,11 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_
     constexpr int SD = 32768;
     void (*kern)(GemmNT) = nullptr;
     if (gated) {
-        if (act != ACT_NONE || FP8) return TVTS_EINVAL;
-        kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, SD> : gate_act == ACT_GELU_ERF ? gemm_nt256p_kernel<0, 2, false, SD> : nullptr;
+        if (act != ACT_NONE) return TVTS_EINVAL;
+        if constexpr (FP8)  // e4m3 dgrad with the activation-gradient gate (tvts_gemm_nt_fp8_gate): the scaled-MFMA main loop only
+            kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, true, SD | 65536> : gate_act == ACT_GELU_ERF ? gemm_nt256p_kernel<0, 2, true, SD | 65536> : nullptr;
+        else
+            kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, SD> : gate_act == ACT_GELU_ERF ? gemm_nt256p_kernel<0, 2, false, SD> : nullptr;
     } else {
         kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, FP8, SD> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, FP8, SD>
              : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, FP8, SD> : nullptr;
@@ -293,6 +296,22 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = nullptr; g.ldh = 0; g.gate_act = ACT_NONE;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
     return launch_nt256<true>(g, act, ACT_NONE, false, stream);
+}
+
+// the input-gradient form of the fp8 linear layer: out[M,N] (bf16) = gate'(h[M,N]) * (scale_a[m] * scale_b * (A[M,K] B[N,K]^T)) with
+// A the e4m3 copy of the OUTPUT gradient (one scale per token, tvts_quant_fp8_rows), B the e4m3 copy of the TRANSPOSED weight
+// and, optionally, the activation-gradient gate of the MLP's first layer (gate_h = its saved pre-activation)
+extern "C" int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
+                                     int scale_a_rows, const float* scale_b, const void* gate_h, int ldh, int gate_act, void* out,
+                                     int ldc, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b || !gate_h) return TVTS_EINVAL;
+    if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || ldh % 8) return TVTS_EINVAL;
+    GemmNT g;
+    g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;
+    g.M = M; g.N = N; g.K = K / 2; g.bias = nullptr; g.residual = nullptr; g.ldr = 0; g.act = ACT_NONE;
+    g.preact = nullptr; g.ldp = 0; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
+    g.out = out; g.ldc = ldc; g.out_f32 = 0; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
+    return launch_nt256<true>(g, ACT_NONE, gate_act, true, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -74,6 +74,7 @@ class ParamStore:
         self.conv_pad = (torch.zeros(arch["width"], self.conv_kpad, dtype=torch.bfloat16, device=device)
                          if self.conv_kpad != kc else None)
         self.w8: Dict[str, tuple] = {}
+        self.w8t: Dict[str, tuple] = {}
         self.fp8_names = [n for n in self.shapes if n.startswith("video_model.transformer.resblocks.") and
                           n.endswith(("qkv.weight", "proj.weight", "c_fc.weight", "c_proj.weight"))]
         self.m: Optional[torch.Tensor] = None
@@ -131,6 +132,13 @@ class ParamStore:
                                      torch.empty(1, dtype=torch.float32, device=self.device))
                 q, sc, am = self.w8[name]
                 K.quantize_fp8(self.p(name).view(q.shape), q=q, scale=sc, amax=am)
+                if self.arch.get("fp8_dgrad"):  # ... and of their transposes (the input-gradient GEMMs), same scale: the bf16
+                    # transposed shadow under the amax of the master weight (a bf16 rounding past it saturates at +-448)
+                    if name not in self.w8t:
+                        self.w8t[name] = (torch.empty(q.shape[1], q.shape[0], dtype=torch.uint8, device=self.device),
+                                          torch.empty(1, dtype=torch.float32, device=self.device))
+                    qt, sct = self.w8t[name]
+                    K.quantize_fp8(self.wt(name), q=qt, scale=sct, amax=am, amax_given=True)
 
     def w_conv(self) -> torch.Tensor:
         """bf16 patch-embedding weight [W, K padded to 64]."""
@@ -239,6 +247,12 @@ class Engine:
         elif want_b:
             K.colsum(dy, self.P.g(bname), M=M)
         if d_in is not None:
+            if wname in self.P.w8t:  # e4m3 input gradient (arch["fp8_dgrad"]): dy one scale per token, the transposed weight's e4m3 copy
+                d8 = self._fp8_bufs(M, dy.shape[1])
+                K.quantize_fp8_rows(dy[:M], q=d8[0], row_scale=d8[1])
+                w8t, wst = self.P.w8t[wname]
+                K.gemm_nt_fp8(d8[0], d8[1], w8t, wst, d_in[:M], **epi)
+                return
             K.gemm_nt(dy, self.P.wt(wname), d_in, M=M, **epi)
 
     def _fp8_bufs(self, M, W):

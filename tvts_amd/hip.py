@@ -65,16 +65,18 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
         GEMM_PROFILE.append(("gemm_nt", 2.0 * M * N * K, ev0, ev1, (M, N, K, "f32" if out.dtype == torch.float32 else "bf16", "res" if residual is not None else "", str(act or ""), "gate" if gate_h is not None else "")))
 
 
-def quantize_fp8(x, q=None, scale=None, amax=None):
+def quantize_fp8(x, q=None, scale=None, amax=None, amax_given=False):
     """per-tensor e4m3 quantisation of a bf16 / fp32 matrix -> (q uint8 [rows, cols], scale float32[1]); x ~ q * scale.
     q / scale / amax may be preallocated (the engine's workspace)."""
     lib = _lib.load()
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.bfloat16, torch.float32)
+    assert not (amax_given and amax is None)
     amax = torch.empty(1, dtype=torch.float32, device=x.device) if amax is None else amax
     scale = torch.empty(1, dtype=torch.float32, device=x.device) if scale is None else scale
     q = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if q is None else q
     f32 = 1 if x.dtype == torch.float32 else 0
-    _chk(lib.tvts_amax(_p(x), f32, x.stride(0), x.shape[0], x.shape[1], _p(amax), _stream()), "tvts_amax")
+    if not amax_given:  # amax_given: `amax` already holds max |x| (values beyond it saturate at +-448)
+        _chk(lib.tvts_amax(_p(x), f32, x.stride(0), x.shape[0], x.shape[1], _p(amax), _stream()), "tvts_amax")
     _chk(lib.tvts_quant_fp8(_p(x), f32, x.stride(0), x.shape[0], x.shape[1], _p(amax), _p(q), q.stride(0), _p(scale), _stream()),
          "tvts_quant_fp8")
     return q, scale
@@ -98,10 +100,10 @@ def gemm_set_fp8_mx(on: bool):
     _lib.load().tvts_gemm_set_fp8_mx(int(on))
 
 
-def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, preact=None):
+def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None):
     """out[M,N] = act(sa*sb * (a8[M,K] @ b8[N,K]^T) + bias) [+ residual]; a8 / b8 uint8 e4m3 bit patterns; sb float32[1]; sa
     float32[1] (one scale for the tensor) or float32[>= M] (one per row, quantize_fp8_rows); preact receives the bf16
-    pre-activation like gemm_nt."""
+    pre-activation like gemm_nt.  gate_h / gate_act: the input-gradient form, out = gate_act'(gate_h) * (sa*sb * (a8 @ b8^T))."""
     lib = _lib.load()
     M, Kd = a8.shape
     N = b8.shape[0]
@@ -111,6 +113,15 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
     if GEMM_PROFILE is not None:
         ev0, ev1 = Event(), Event()
         ev0.record()
+    if gate_h is not None:
+        assert bias is None and residual is None and act is None and preact is None and out.dtype == torch.bfloat16
+        rc = lib.tvts_gemm_nt_fp8_gate(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(gate_h),
+                                       _ld(gate_h), ACT[gate_act], _p(out), _ld(out), _stream())
+        _chk(rc, "tvts_gemm_nt_fp8_gate")
+        if GEMM_PROFILE is not None:
+            ev1.record()
+            GEMM_PROFILE.append(("gemm_nt_fp8", 2.0 * M * N * Kd, ev0, ev1, (M, N, Kd, "fp8", "", "", "gate")))
+        return
     rc = lib.tvts_gemm_nt_fp8(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(bias), _p(residual),
                               _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
                               _ld(preact) if preact is not None else 0, _p(out), _ld(out),
