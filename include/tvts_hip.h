@@ -60,6 +60,11 @@ void tvts_gemm_set_fp8_mx(int on);
 int tvts_amax(const void* x, int is_f32, long ld, int rows, int cols, float* amax, hipStream_t stream);
 int tvts_quant_fp8(const void* x, int is_f32, long ld, int rows, int cols, const float* amax, void* out, long ldo,
                    float* scale_out, hipStream_t stream);
+/* the same for MANY weights in three launches (every fp8 weight of the model, once per optimizer step).  table: n device records
+ *   struct { const float* w; uint8_t* q; const bf16* wt; uint8_t* qt; float* amax; float* scale; float* scale_t; int rows, cols; }
+ * w = fp32 master [rows, cols] contiguous, q its e4m3 copy; wt (optional) the bf16 transposed copy [cols, rows] and qt its e4m3
+ * copy under the SAME scale (amax of the master); rows * cols % 4 == 0 */
+int tvts_quant_fp8_multi(const void* table, int n, hipStream_t stream);
 /* per-row (per-token) quantisation of a bf16 activation in one pass: row_scale[r] = amax(x[r,:]) / 448 (1 for an all-zero
  * row), out[r,:] = e4m3(x[r,:] / row_scale[r]); cols % 8 == 0 */
 int tvts_quant_fp8_rows(const void* x, long ld, int rows, int cols, void* out, long ldo, float* row_scale,

@@ -774,6 +774,36 @@ def test_gemm_nt_fp8(K, M, N, K_):
     assert rel(out, ref + res.cpu().double()) < 5e-5
 
 
+def test_fp8_multi_tensor_quantisation(K):
+    """all fp8 weights in three launches: the same bytes and scales as tvts_amax + tvts_quant_fp8 tensor by tensor; the e4m3 copy of
+    the bf16 transposed shadow under the master's scale."""
+    shapes = [(256, 128), (1280, 3840), (5120, 1280), (12, 8), (768, 768)]
+    ws = [(rnd(r, c, seed=70 + i) * (0.02 + 0.3 * i)).to(DEV) for i, (r, c) in enumerate(shapes)]
+    ws[3].zero_()                                            # an all-zero weight: scale 1, zero bytes
+    scal = torch.full((3 * len(ws),), float("nan"), device=DEV)
+    ents, qs, qts = [], [], []
+    for i, w in enumerate(ws):
+        wt = w.t().contiguous().bfloat16() if i % 2 == 0 else None
+        q = torch.full(w.shape, 7, dtype=torch.uint8, device=DEV)
+        qt = torch.full((w.shape[1], w.shape[0]), 7, dtype=torch.uint8, device=DEV) if wt is not None else None
+        ents.append((w, q, wt, qt, scal[3 * i:3 * i + 1], scal[3 * i + 1:3 * i + 2], scal[3 * i + 2:3 * i + 3] if wt is not None else None))
+        qs.append(q); qts.append((wt, qt))
+    table, n = K.quantize_fp8_multi_table(ents, DEV)
+    for _ in range(2):                                       # a second call starts from stale amax values
+        K.quantize_fp8_multi(table, n)
+    for i, w in enumerate(ws):
+        q1, s1 = K.quantize_fp8(w)
+        assert torch.equal(qs[i], q1) and float(scal[3 * i + 1]) == float(s1) and float(scal[3 * i]) == float(w.abs().max())
+        wt, qt = qts[i]
+        if wt is not None:
+            am = scal[3 * i:3 * i + 1].clone()
+            q2, s2 = K.quantize_fp8(wt, amax=am, amax_given=True)
+            assert torch.equal(qt, q2) and float(scal[3 * i + 2]) == float(s1)
+            deq = qt.cpu().view(torch.float8_e4m3fn).float() * float(s1)
+            assert rel(deq, w.t().float()) < 0.05
+    assert float(scal[3 * 3 + 1]) == 1.0 and int(qs[3].max()) == 0
+
+
 @pytest.mark.parametrize("rows,cols", [(300, 256), (1233, 1280), (77, 5120), (9, 5128), (5, 8)])
 def test_fp8_row_quantisation(K, rows, cols):
     """per-row (token) e4m3 quantisation in one pass: row_scale = amax(row) / 448, bit patterns of torch.float8_e4m3fn on

@@ -236,6 +236,64 @@ extern "C" int tvts_quant_fp8(const void* x, int is_f32, long ld, int rows, int 
     return TVTS_OK;
 }
 
+// ---- all weights of the fp8 path in three launches (was 3-4 launches per weight, 224 weights on ViT-H/14): one table entry per
+//      weight -- fp32 master [rows, cols] (contiguous), its e4m3 copy, optionally the bf16 TRANSPOSED shadow [cols, rows] and its
+//      e4m3 copy (the input-gradient operand), amax / scale scalars.  Pass 1 zeroes the amax scalars, pass 2 takes max |w| of the
+//      master (blocks x tensors, one atomicMax per block), pass 3 converts both copies under the one scale (a bf16 rounding past
+//      the master's amax saturates at +-448).  Same bit patterns as tvts_amax + tvts_quant_fp8 per tensor.
+struct Q8Desc {
+    const float* w; unsigned char* q; const bf16* wt; unsigned char* qt; float* amax; float* scale; float* scale_t;
+    int rows, cols;
+};
+__global__ void q8_multi_zero_kernel(const Q8Desc* __restrict__ tab, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) *tab[i].amax = 0.f;
+}
+__global__ __launch_bounds__(256) void q8_multi_amax_kernel(const Q8Desc* __restrict__ tab) {
+    const Q8Desc d = tab[blockIdx.y];
+    const long n4 = (long)d.rows * d.cols / 4;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(d.w + i * 4);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    m = wave_max(m);
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax((unsigned*)d.amax, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+__device__ __forceinline__ int pack4_e4m3(float a, float b, float c, float e, float inv) {
+    int p = 0;
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(a * inv, -448.0f), 448.0f), fminf(fmaxf(b * inv, -448.0f), 448.0f), p, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(c * inv, -448.0f), 448.0f), fminf(fmaxf(e * inv, -448.0f), 448.0f), p, true);
+    return p;
+}
+__global__ __launch_bounds__(256) void q8_multi_quant_kernel(const Q8Desc* __restrict__ tab) {
+    const Q8Desc d = tab[blockIdx.y];
+    const float am = *d.amax;
+    const float scale = am > 0.f ? am / 448.0f : 1.0f;
+    const float inv = 1.0f / scale;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *d.scale = scale; if (d.scale_t) *d.scale_t = scale; }
+    const long n4 = (long)d.rows * d.cols / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(d.w + i * 4);
+        *(int*)(d.q + i * 4) = pack4_e4m3(v[0], v[1], v[2], v[3], inv);
+        if (d.wt) {
+            const bf16x4 t = *(const bf16x4*)(d.wt + i * 4);
+            *(int*)(d.qt + i * 4) = pack4_e4m3((float)t[0], (float)t[1], (float)t[2], (float)t[3], inv);
+        }
+    }
+}
+extern "C" int tvts_quant_fp8_multi(const void* table, int n, hipStream_t stream) {
+    if (!table || n <= 0) return TVTS_EINVAL;
+    hipLaunchKernelGGL(q8_multi_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const Q8Desc*)table, n);
+    hipLaunchKernelGGL(q8_multi_amax_kernel, dim3(32, n), dim3(256), 0, stream, (const Q8Desc*)table);
+    hipLaunchKernelGGL(q8_multi_quant_kernel, dim3(32, n), dim3(256), 0, stream, (const Q8Desc*)table);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
 // ---- activations: ONE scale per row (token), amax and conversion in a single pass.  A wave owns a row: it is read once into
 //      registers (rows up to 5120 columns; wider rows are read a second time, from cache), reduced to its amax with wave
 //      shuffles, scaled by 448 / amax and written as e4m3 bytes + the row's scale.  3 bytes of traffic per element instead of

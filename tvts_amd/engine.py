@@ -75,6 +75,7 @@ class ParamStore:
                          if self.conv_kpad != kc else None)
         self.w8: Dict[str, tuple] = {}
         self.w8t: Dict[str, tuple] = {}
+        self._q8_table = None
         self.fp8_names = [n for n in self.shapes if n.startswith("video_model.transformer.resblocks.") and
                           n.endswith(("qkv.weight", "proj.weight", "c_fc.weight", "c_proj.weight"))]
         self.m: Optional[torch.Tensor] = None
@@ -124,21 +125,26 @@ class ParamStore:
         if self.conv_pad is not None:
             K.pad_rows_bf16(self.w(self.conv_name), self.conv_pad)
         if self.arch.get("fp8"):  # BASELINE config 4: e4m3 copies (+ per-tensor scales) of the ViT blocks' linear weights
-            for name in self.fp8_names:
-                if name not in self.w8:
+            # ... and (fp8_dgrad) of their transposes, the input-gradient operands: the bf16 transposed shadow under the scale of the
+            # master weight (a bf16 rounding past its amax saturates at +-448).  One table, three launches for all of them.
+            if self._q8_table is None:
+                dg = bool(self.arch.get("fp8_dgrad"))
+                nw = len(self.fp8_names)
+                scal = torch.zeros(3 * nw, dtype=torch.float32, device=self.device)  # amax | scale | scale_t per weight
+                ents = []
+                for i, name in enumerate(self.fp8_names):
                     s0 = self.shapes[name]
-                    self.w8[name] = (torch.empty(s0[0], int(np.prod(s0[1:])), dtype=torch.uint8, device=self.device),
-                                     torch.empty(1, dtype=torch.float32, device=self.device),
-                                     torch.empty(1, dtype=torch.float32, device=self.device))
-                q, sc, am = self.w8[name]
-                K.quantize_fp8(self.p(name).view(q.shape), q=q, scale=sc, amax=am)
-                if self.arch.get("fp8_dgrad"):  # ... and of their transposes (the input-gradient GEMMs), same scale: the bf16
-                    # transposed shadow under the amax of the master weight (a bf16 rounding past it saturates at +-448)
-                    if name not in self.w8t:
-                        self.w8t[name] = (torch.empty(q.shape[1], q.shape[0], dtype=torch.uint8, device=self.device),
-                                          torch.empty(1, dtype=torch.float32, device=self.device))
-                    qt, sct = self.w8t[name]
-                    K.quantize_fp8(self.wt(name), q=qt, scale=sct, amax=am, amax_given=True)
+                    rows, cols = s0[0], int(np.prod(s0[1:]))
+                    q = torch.empty(rows, cols, dtype=torch.uint8, device=self.device)
+                    am, sc, sct = scal[3 * i:3 * i + 1], scal[3 * i + 1:3 * i + 2], scal[3 * i + 2:3 * i + 3]
+                    self.w8[name] = (q, sc, am)
+                    qt = None
+                    if dg:
+                        qt = torch.empty(cols, rows, dtype=torch.uint8, device=self.device)
+                        self.w8t[name] = (qt, sct)
+                    ents.append((self.p(name).view(rows, cols), q, self.wt(name) if dg else None, qt, am, sc, sct if dg else None))
+                self._q8_table = K.quantize_fp8_multi_table(ents, self.device)
+            K.quantize_fp8_multi(*self._q8_table)
 
     def w_conv(self) -> torch.Tensor:
         """bf16 patch-embedding weight [W, K padded to 64]."""

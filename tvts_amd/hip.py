@@ -82,6 +82,26 @@ def quantize_fp8(x, q=None, scale=None, amax=None, amax_given=False):
     return q, scale
 
 
+def quantize_fp8_multi_table(entries, device):
+    """device table for quantize_fp8_multi.  entries: (w fp32 [rows, cols] contiguous, q uint8, wt bf16 [cols, rows] or None,
+    qt uint8 or None, amax float32[1], scale float32[1], scale_t float32[1] or None)"""
+    import numpy as np
+    rec = np.zeros(len(entries), dtype=[("w", "<u8"), ("q", "<u8"), ("wt", "<u8"), ("qt", "<u8"), ("amax", "<u8"), ("scale", "<u8"),
+                                        ("scale_t", "<u8"), ("rows", "<i4"), ("cols", "<i4")])
+    for i, (w, q, wt, qt, am, sc, sct) in enumerate(entries):
+        assert w.dtype == torch.float32 and w.is_contiguous() and q.is_contiguous() and w.numel() % 4 == 0
+        assert wt is None or (wt.dtype == torch.bfloat16 and wt.is_contiguous() and qt.is_contiguous() and wt.numel() == w.numel())
+        rows, cols = w.shape[0], w.numel() // w.shape[0]
+        rec[i] = (w.data_ptr(), q.data_ptr(), 0 if wt is None else wt.data_ptr(), 0 if qt is None else qt.data_ptr(), am.data_ptr(),
+                  sc.data_ptr(), 0 if sct is None else sct.data_ptr(), rows, cols)
+    return torch.from_numpy(rec.view(np.uint8).copy()).to(device), len(entries)
+
+
+def quantize_fp8_multi(table, n):
+    """per-tensor e4m3 copies of all the weights of the table (and of their transposed shadows) in three launches"""
+    _chk(_lib.load().tvts_quant_fp8_multi(_p(table), n, _stream()), "tvts_quant_fp8_multi")
+
+
 def quantize_fp8_rows(x, q=None, row_scale=None):
     """per-row (per-token) e4m3 quantisation of a bf16 matrix in one pass -> (q uint8 [rows, cols], row_scale float32[rows]);
     x[r] ~ q[r] * row_scale[r]."""
