@@ -24,6 +24,9 @@ int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int
                       int gate_act, void* out, int ldc, int out_f32, hipStream_t stream);
 /* tile selection override for benches and tests: 0 auto, 128 (persistent 128x128 kernel), 256 (pipelined 256x256 kernel) */
 void tvts_gemm_set_nt_tile(int t);
+/* persistent grid of the 256x256 kernels (bf16 and fp8): at most n blocks, one per CU (8 .. 256, multiple of 8; default 256 = the
+ * whole chip) -- leaves CUs to kernels of other streams, and a measurement hook (tools/gemm_cus.py) */
+void tvts_gemm_set_nt_cus(int n);
 /* the output tile (128 or 256) tvts_gemm_nt_bf16 picks for an [M, N] result under the current override: lets a parity
  * test assert that the kernel it means to exercise is the one that ran */
 int tvts_gemm_nt_select(int M, int N);

@@ -159,6 +159,11 @@ static int g_nt_tile = 0;
 extern "C" void tvts_gemm_set_nt_tile(int t) { g_nt_tile = (t == 128 || t == 256) ? t : 0; }
 static int g_fp8_mx = 1;
 extern "C" void tvts_gemm_set_fp8_mx(int on) { g_fp8_mx = on ? 1 : 0; }
+// persistent grid of the 256x256 NT kernel: at most this many blocks (one per CU; a multiple of 8, one share per XCD).  256 = the
+// whole chip; fewer leaves CUs to kernels of other streams (a 160 KiB block shares its CU with nothing), and is how
+// tools/gemm_cus.py measures what a CU's K loop waits for (per-CU rate against the number of CUs streaming)
+static int g_nt_cus = 256;
+extern "C" void tvts_gemm_set_nt_cus(int n) { g_nt_cus = n < 8 ? 8 : n > 256 ? 256 : (n / 8) * 8; }
 
 static bool nt_use_256(int M, int N) {
     if (g_nt_tile == 128) return false;
@@ -184,7 +189,7 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_
     g.tiles_m = ceil_div(g.M, 256);
     g.gc = nt_column_group(g.N);
     const int total_tiles = g.tiles_m * g.tiles_n;
-    const int grid = total_tiles < 256 ? ((total_tiles + 7) / 8) * 8 : 256;  // persistent: one block per CU, multiple of 8 (XCDs)
+    const int grid = total_tiles < g_nt_cus ? ((total_tiles + 7) / 8) * 8 : g_nt_cus;  // persistent: one block per CU, multiple of 8 (XCDs)
     // every production instantiation staggers the LDS-DMA issue of the two waves of a SIMD (ABL 32768: +1-3 % on every shape of
     // the step, tools/gemm_ab.py; the same change is worth 6-10 % on the weight-gradient kernel)
     constexpr int SD = 32768;
