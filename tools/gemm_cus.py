@@ -10,6 +10,9 @@ import torch  # noqa: E402
 
 from tvts_amd import _lib, hip as K  # noqa: E402
 
+if os.environ.get("TVTS_LIB"):  # dev: an experiment build of the kernel library (e.g. -DTVTS_LOOP_ABL=n timing ablations)
+    _lib.LIB_PATH = os.path.abspath(os.environ["TVTS_LIB"])
+
 dev = "cuda:0"
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2304
 Kd = int(sys.argv[2]) if len(sys.argv) > 2 else 768
@@ -30,7 +33,7 @@ def timeit(fn, iters=6):
 
 lib = _lib.load()
 print(f"N={N} K={Kd}, {TILES_PER_CU} tiles per CU; TF per CU (bf16 | fp8 scaled MFMA), stage period from the K loop only is not separated")
-for cus in (8, 32, 64, 128, 192, 256):
+for cus in [int(c) for c in os.environ.get("CUS", "8,32,64,128,192,256").split(",")]:
     tiles_m = cus * TILES_PER_CU // (N // 256)
     M = tiles_m * 256
     a = torch.randn(M, Kd, device=dev).bfloat16()

@@ -641,10 +641,15 @@ __device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&a
     slab(IC<4>{}); slab(IC<5>{}); slab(IC<6>{}); slab(IC<7>{});
 }
 
+// timing ablations of the K loop for tools/gemm_cus.py (experiment builds only, -DTVTS_LOOP_ABL=n; results are wrong by construction):
+// 1 no LDS-DMA behind the prologue, 2 no fragment reads behind the first stage, 4 no MFMAs (and with them no reads), 8 no barriers
+#ifndef TVTS_LOOP_ABL
+#define TVTS_LOOP_ABL 0
+#endif
 #define RAW_BARRIER_P()                       \
     do {                                      \
         asm volatile("" ::: "memory");        \
-        __builtin_amdgcn_s_barrier();         \
+        if (!(TVTS_LOOP_ABL & 8)) __builtin_amdgcn_s_barrier(); \
         asm volatile("" ::: "memory");        \
     } while (0)
 
@@ -728,16 +733,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     // fragment registers: two A half-sets (4 MFMA row-tiles each) and two B sets, refilled while the matrix pipe
     // works on the other one
     bf16x8 aF[2][4], bF[2][4];
+    bool frag_rd = true;  // TVTS_LOOP_ABL & 2: fragment reads only up to the first stage
 #define LOAD_A(dst, buf, ks, h)                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) dst[i] = frag_rows128(buf, arow + ((h) * 4 + i) * 16, (ks) * 4 + gq)
+    if (frag_rd) _Pragma("unroll") for (int i = 0; i < 4; ++i) dst[i] = frag_rows128(buf, arow + ((h) * 4 + i) * 16, (ks) * 4 + gq)
 #define LOAD_B(dst, buf, ks)                                                                           \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) dst[j] = frag_rows128((buf) + 32768, brow + j * 16, (ks) * 4 + gq)
+    if (frag_rd) _Pragma("unroll") for (int j = 0; j < 4; ++j) dst[j] = frag_rows128((buf) + 32768, brow + j * 16, (ks) * 4 + gq)
     // FP8: the operands are e4m3 matrices addressed as bf16 matrices of half the width (the staging and the LDS image are
     // byte-identical); a 16-byte fragment then holds 16 k-values of its row and feeds two 16x16x32 fp8 MFMAs (its low and
     // its high 8 bytes -- A and B use the same split, so every k meets its partner).
     typedef __attribute__((ext_vector_type(2))) long i64x2;
 #define MFMA16(av, bv, h)                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+    if (!(TVTS_LOOP_ABL & 4)) _Pragma("unroll") for (int i = 0; i < 4; ++i)                            \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
             if (FP8) {                                                                                 \
                 const i64x2 a8 = __builtin_bit_cast(i64x2, av[i]), b8 = __builtin_bit_cast(i64x2, bv[j]); \
@@ -760,7 +766,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     __builtin_shufflevector(__builtin_bit_cast(i32x4, frag_rows128(buf, row, gq)),                      \
                             __builtin_bit_cast(i32x4, frag_rows128(buf, row, 4 + gq)), 0, 1, 2, 3, 4, 5, 6, 7)
 #define LOAD_A2(dst, buf, p)                                                                            \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t) dst[t] = LDQ(buf, arow + ((p) * 2 + t) * 16)
+    if (frag_rd) _Pragma("unroll") for (int t = 0; t < 2; ++t) dst[t] = LDQ(buf, arow + ((p) * 2 + t) * 16)
     // the MFMA as volatile inline asm: left to the compiler (the builtin), every MFMA of the stage is sunk behind the stage's last
     // branch -- their results are only read by the epilogue -- which makes all eight A operands live at once (189 spilled
     // registers).  cbsz = blgp = 0: both operands e4m3; the scale register holds E8M0 127 (= 1.0) in every byte.  The compiler
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     int mx_one = 0x7F7F7F7F;
     asm volatile("" : "+v"(mx_one));
 #define MXMFMA(bv, av, c)                                                                               \
-    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(bv), "v"(av), "v"(mx_one))
+    if (!(TVTS_LOOP_ABL & 4)) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(bv), "v"(av), "v"(mx_one))
 #define MFMA8(av, p)                                                                                    \
     _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                       \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) MXMFMA(bQ[j], av[t], acc[j][(p) * 2 + t])
@@ -782,6 +788,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     }
 
     for (int st = 0; st < total_st; ++st) {
+        if ((TVTS_LOOP_ABL & 2) && st == 1) frag_rd = false;
         const char* cur = smem + (st & 1) * 65536;
         const char* nxt = smem + ((st + 1) & 1) * 65536;
         if constexpr (MX) {
@@ -796,7 +803,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             RAW_BARRIER_P();
-            const bool do_issue = i_st < total_st;
+            const bool do_issue = i_st < total_st && !(TVTS_LOOP_ABL & 1);
             if (do_issue && wave < 4) issue();
             // the next stage's first fragments: under this stage's last MFMAs, or -- across a tile boundary -- behind the epilogue
             // (48 registers that would otherwise stay live across it)
@@ -808,7 +815,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                 MXMFMA(bQ[j], aQ[1][0], acc[j][6]);
                 MXMFMA(bQ[j], aQ[1][1], acc[j][7]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (pre) bQ[j] = LDQ(nxt + 32768, brow + j * 16);
+                if (pre && frag_rd) bQ[j] = LDQ(nxt + 32768, brow + j * 16);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (do_issue && wave >= 4) issue();
@@ -821,7 +828,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                 tile_origin256(g, range_lo + slot + tl * per_xcd, gc, m0, n0);
                 if (more) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bQ[j] = LDQ(nxt + 32768, brow + j * 16);
+                    for (int j = 0; j < 4; ++j) if (frag_rd) bQ[j] = LDQ(nxt + 32768, brow + j * 16);
                     LOAD_A2(aQ[0], nxt, 0);
                 }
             }
@@ -885,7 +892,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         // stage st+2 goes into the buffer every wave has just finished reading.  ABL & 32768: the two waves of a SIMD (w, w + 4) do
         // not issue their 8 LDS-DMA pieces at the same time (both would sit in ~100 cycles of VMEM issue per piece with the matrix
         // pipe idle): waves 0..3 issue here, waves 4..7 behind the stage's last MFMA group
-        const bool do_issue = i_st < total_st;
+        const bool do_issue = i_st < total_st && !(TVTS_LOOP_ABL & 1);
         if (do_issue && ((ABL & 32768) == 0 || wave < 4)) issue();
         // register-path epilogue: the next tile's first fragments are read behind the epilogue instead of across it (32 registers)
         const bool defer_frag = (ABL & (1024 | 8192)) != 0 && kt + 1 == nk;
