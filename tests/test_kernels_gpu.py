@@ -774,6 +774,56 @@ def test_gemm_nt_fp8(K, M, N, K_):
     assert rel(out, ref + res.cpu().double()) < 5e-5
 
 
+def test_gemm_nt_fp8_main_loops_agree_and_grid_limit(K):
+    """the K = 128 scaled-MFMA main loop and the 16x16x32 fp8 loop accumulate the same e4m3 products in fp32: identical bits on a
+    shape with ragged row tiles, every epilogue form; a persistent grid limited to 64 CUs (tvts_gemm_set_nt_cus) changes nothing, for
+    the fp8 and for the bf16 256x256 kernel."""
+    from tvts_amd import _lib
+    lib = _lib.load()
+    M, N, K_ = 9000, 1280, 640
+    a, b = rnd(M, K_, seed=81), rnd(N, K_, seed=82) * K_ ** -0.5
+    a8, rs = K.quantize_fp8_rows(a.bfloat16().to(DEV))
+    b8, sb = K.quantize_fp8(b.to(DEV))
+    bias, res = rnd(N, seed=83).to(DEV), rnd(M, N, seed=84).to(DEV)
+    h = rnd(M, N, seed=85).bfloat16().to(DEV)
+
+    def run():
+        o1 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); pre = torch.empty_like(o1)
+        K.gemm_nt_fp8(a8, rs, b8, sb, o1, bias=bias, act="gelu", preact=pre)
+        o2 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        K.gemm_nt_fp8(a8, rs, b8, sb, o2, bias=bias, residual=res)
+        o3 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt_fp8(a8, rs, b8, sb, o3, gate_h=h, gate_act="gelu")
+        return o1, pre, o2, o3
+
+    try:
+        ref = run()
+        K.gemm_set_fp8_mx(False)
+        old = run()[:3]            # the 16x16x32 loop has no gated form
+        K.gemm_set_fp8_mx(True)
+        for x, y in zip(ref[:3], old):
+            assert torch.equal(x, y)
+        lib.tvts_gemm_set_nt_cus(64)
+        for x, y in zip(ref, run()):
+            assert torch.equal(x, y)
+        ab, bb = a.bfloat16().to(DEV), b.bfloat16().to(DEV)
+        lib.tvts_gemm_set_nt_tile(256)
+        o64 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); K.gemm_nt(ab, bb, o64, bias=bias)
+        lib.tvts_gemm_set_nt_cus(256)
+        o256 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); K.gemm_nt(ab, bb, o256, bias=bias)
+        assert torch.equal(o64, o256)
+        # the gated fp8 form against its definition
+        ad, bd = a8.cpu().view(torch.float8_e4m3fn).float(), b8.cpu().view(torch.float8_e4m3fn).float()
+        z = (ad.double() @ bd.double().t()) * rs.cpu().double()[:M, None] * float(sb)
+        hf = h.float().cpu().double()
+        gate = 0.5 * (1 + torch.erf(hf / 2 ** 0.5)) + hf * torch.exp(-0.5 * hf * hf) / (2 * torch.pi) ** 0.5
+        assert rel(ref[3].float(), z * gate) < 4e-3
+    finally:
+        K.gemm_set_fp8_mx(True)
+        lib.tvts_gemm_set_nt_cus(256)
+        lib.tvts_gemm_set_nt_tile(0)
+
+
 def test_fp8_multi_tensor_quantisation(K):
     """all fp8 weights in three launches: the same bytes and scales as tvts_amax + tvts_quant_fp8 tensor by tensor; the e4m3 copy of
     the bf16 transposed shadow under the master's scale."""
