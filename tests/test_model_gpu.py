@@ -408,6 +408,38 @@ def test_sort_head_used_rows_only(gpu, h14):
     check_grads(store, grads)
 
 
+def test_h14_full_size_fp8_against_reference_golden(gpu, golden):
+    """BASELINE config 4 on its own architecture: the full-size TVTSv2 ViT-H/14 (32 layers, width 1280, head dim 80, 1.22 G
+    parameters) with the e4m3 forward and input-gradient GEMMs against the REFERENCE's fp32 outputs of the same parameters and
+    batch (the golden of test_h14_full_size_against_reference_golden) at the fp8 tolerance: video embeddings cosine >= 0.995,
+    losses within 5e-2, total gradient norm within 5 %, per-tensor gradient norms of every sizeable tensor within 15 %."""
+    from tvts_amd import arch as A
+    from tvts_amd.model._common import TVTSv2Base
+    f = golden("model_h14_cfg3")
+    a = dict(A.ARCHS["H_14"], fp8=True, fp8_dgrad=True)
+    oarch = O.ARCHS["H_14"]
+    P = O.synth_params(oarch, seed=0)
+    m = TVTSv2Base(ARGS, arch=a)
+    m.load_state_dict(P, strict=True)
+    del P
+    batch = O.synth_batch(oarch, B=2, T=4, seed=0)
+    l1, l2, te, ve, pred, store = engine_step(m, batch)
+    assert len(store.w8) == len(store.w8t) == 6 * a["layers"]
+    rte, rve, rpred = torch.tensor(f["te"]), torch.tensor(f["ve"]), torch.tensor(f["pred"])
+    assert min_cos(te, rte) > 0.9995                                  # the text tower is not quantised
+    assert min_cos(ve, rve) > 0.995 and rel(ve, rve) < 0.1, (min_cos(ve, rve), rel(ve, rve))
+    assert abs(l1 - float(f["loss1"])) < 5e-2 and abs(l2 - float(f["loss2"])) < 5e-2, (l1, l2)
+    gn = float(store.grad.double().norm())
+    assert abs(gn - float(f["grad_norm"])) < 0.05 * float(f["grad_norm"]), (gn, float(f["grad_norm"]))
+    ref = dict(zip([str(s) for s in f["gn_names"]], f["gn_vals"]))
+    bad = []
+    for k, v in ref.items():
+        mine = float(store.g(k).double().norm())
+        if float(v) > 1e-3 * float(f["grad_norm"]) and abs(mine - float(v)) > 0.15 * float(v):
+            bad.append((k, mine, float(v)))
+    assert not bad, bad[:10]
+
+
 def test_fp8_forward_path(gpu):
     """BASELINE config 4's weight / activation format on a small model: the six linear layers of every ViT block run their
     FORWARD product on per-tensor-scaled e4m3 copies (tvts_gemm_nt_fp8), the backward keeps the bf16 operands.  Checked
