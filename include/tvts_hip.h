@@ -92,6 +92,13 @@ int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const void* x, int 
                        const float* rstd, const float* gamma, const float* res1, int ldr, const void* res2_bf16, int ldr2,
                        int M, int W, float* dx, int lddx, void* dx_bf16, int lddxb, float* dgamma, float* dbeta,
                        float* workspace, long workspace_elems, hipStream_t stream);
+/* the same with the e4m3 copy of dx_bf16 (one scale per row, the bytes tvts_quant_fp8_rows would write): the output gradient of the
+ * e4m3 input-gradient GEMM that consumes dx_bf16.  bf16 dy, every row, dx_bf16 required; x fp32 with res1 / res1 + res2 / no
+ * residual, or x bf16 without residuals */
+int tvts_layernorm_bwd_fp8(const void* dy, int lddy, const void* x, int ldx, int x_bf16, const float* mean, const float* rstd,
+                           const float* gamma, const float* res1, int ldr, const void* res2_bf16, int ldr2, int M, int W, float* dx,
+                           int lddx, void* dx_bf16, int lddxb, void* q8, int ldq, float* row_scale, float* dgamma, float* dbeta,
+                           float* workspace, long workspace_elems, hipStream_t stream);
 
 /* ---- attention (attention.hip), head dim 64, packed qkv [rows, 3*heads*64]:
  *      divided space-time attention video_encoder_ViT_B_16.py:11-15,38-76; causal text attention

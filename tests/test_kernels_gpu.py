@@ -824,6 +824,45 @@ def test_gemm_nt_fp8_main_loops_agree_and_grid_limit(K):
         lib.tvts_gemm_set_nt_tile(0)
 
 
+@pytest.mark.parametrize("W,form", [(768, "res1"), (768, "res12"), (1280, "res1"), (1280, "res12"), (1280, "xbf16"), (640, "plain"), (256, "xbf16")])
+def test_layernorm_bwd_fp8_output(K, W, form):
+    """LayerNorm backward with the fused e4m3 copy of dx_bf16: dx / dx_bf16 / dgamma / dbeta identical to the plain kernel, the fp8
+    bytes and per-row scales identical to quantize_fp8_rows(dx_bf16)."""
+    M = 517
+    xdt = torch.bfloat16 if form == "xbf16" else torch.float32
+    x = (rnd(M, W, seed=90) * 2 + 0.3).to(xdt).to(DEV)
+    g = (1 + 0.1 * rnd(W, seed=91)).to(DEV)
+    b = (0.1 * rnd(W, seed=92)).to(DEV)
+    dy = (rnd(M, W, seed=93) * torch.logspace(-4, 1, M)[:, None]).bfloat16().to(DEV)
+    dy[3] = 0
+    res1 = rnd(M, W, seed=94).to(DEV) * 0.01 if form in ("res1", "res12") else None
+    res2 = (rnd(M, W, seed=95) * 0.01).bfloat16().to(DEV) if form == "res12" else None
+    if form in ("res1", "res12"):
+        res1[3] = 0
+        if res2 is not None:
+            res2[3] = 0
+    y = torch.empty(M, W, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    K.layernorm_fwd(x, g, b, 1e-5, y, mean, rstd)
+
+    def run(q8):
+        dx = None if form == "xbf16" else torch.full((M, W), float("nan"), device=DEV)
+        dxb = torch.full((M, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        dg, db = torch.zeros(W, device=DEV), torch.zeros(W, device=DEV)
+        q = torch.full((M, W), 7, dtype=torch.uint8, device=DEV) if q8 else None
+        rs = torch.full((M + 1,), float("nan"), device=DEV) if q8 else None
+        K.layernorm_bwd(dy, x, mean, rstd, g, dx, dx_bf16=dxb, res1=res1, res2=res2, dgamma=dg, dbeta=db, q8=q, row_scale=rs)
+        return dx, dxb, dg, db, q, rs
+
+    dx0, dxb0, dg0, db0, _, _ = run(False)
+    dx1, dxb1, dg1, db1, q, rs = run(True)
+    assert torch.equal(dxb0, dxb1) and (dx0 is None or torch.equal(dx0, dx1))
+    assert torch.allclose(dg0, dg1, rtol=1e-5, atol=1e-6) and torch.allclose(db0, db1, rtol=1e-5, atol=1e-6)
+    q_ref, rs_ref = K.quantize_fp8_rows(dxb1)
+    assert torch.equal(q, q_ref) and torch.equal(rs[:M], rs_ref)
+    assert float(rs[3]) == 1.0 and int(q[3].max()) == 0 and torch.isnan(rs[M])
+
+
 def test_fp8_multi_tensor_quantisation(K):
     """all fp8 weights in three launches: the same bytes and scales as tvts_amax + tvts_quant_fp8 tensor by tensor; the e4m3 copy of
     the bf16 transposed shadow under the master's scale."""

@@ -184,7 +184,9 @@ template <> struct RawDy<bf16> { typedef bf16x4 T; };
 __device__ __forceinline__ f32x4 widen(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 widen(bf16x4 v) { return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 
-template <typename TDY, int IT, bool R1, bool R2, typename TX = float>
+// Q8: additionally write the bf16 copy of dx as OCP e4m3 bytes with one scale per row (amax of the bf16-rounded values / 448) -- the
+// output gradient of the e4m3 input-gradient GEMM that consumes dx_bf16 (same bytes as tvts_quant_fp8_rows of dx_bf16)
+template <typename TDY, int IT, bool R1, bool R2, typename TX = float, bool Q8 = false>
 __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3)) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const TX* __restrict__ x,
                                                         int ldx, const int* __restrict__ rows,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -192,7 +194,9 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
                                                         const bf16* __restrict__ res2, int ldr2, int ldr, int M, int W,
                                                         float* __restrict__ dx, int lddx, bf16* __restrict__ dx_bf16,
                                                         int lddxb, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                        float* __restrict__ partial) {
+                                                        float* __restrict__ partial,
+                                                        unsigned char* __restrict__ q8 = nullptr, int ldq = 0,
+                                                        float* __restrict__ row_scale = nullptr) {
     typedef typename RawDy<TDY>::T DyV;
     __shared__ float red[2][4][IT * 256];  // [gamma|beta][wave][column slot]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -249,18 +253,58 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
             }
         }
         const float c1 = wave_sum(s1) * invW, c2 = wave_sum(s2) * invW;
+        // Q8: the row's outputs are needed twice (amax, then conversion).  The residual forms keep a copy (their launch bound leaves the
+        // registers; recomputing keeps the residual registers live through the second sweep: 246 -> 316 us at W = 1280), the
+        // residual-free forms recompute (a copy spills at their tighter bound: 130 -> 200 us)
+        constexpr bool KEEP = Q8 && (R1 || R2);
+        f32x4 ob[KEEP ? IT : 1];
+        float am = 0.f;
+        auto out_of = [&](int it) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = cur.rs * (g[it][e] - c1 - xh[it][e] * c2);
+            if (R1) o += cur.r1[it];
+            if (R2) o += widen(cur.r2[it]);
+            return o;
+        };
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int c = lane * 4 + it * 256;
             if (c < W) {
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = cur.rs * (g[it][e] - c1 - xh[it][e] * c2);
-                if (R1) o += cur.r1[it];
-                if (R2) o += widen(cur.r2[it]);
+                const f32x4 o = out_of(it);
                 if (dx) store4(dx + (size_t)cur.xr * lddx + c, o);
                 if (dx_bf16) store4(dx_bf16 + (size_t)cur.xr * lddxb + c, o);
+                if (Q8) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = (float)(bf16)o[e];  // the value the bf16 consumers see
+                        if (KEEP) ob[it][e] = v;
+                        am = fmaxf(am, fabsf(v));
+                    }
+                }
             }
+        }
+        if (Q8) {  // second sweep over the kept copy or the recomputed outputs
+            am = wave_max(am);
+            const float scale = am > 0.f ? am / 448.0f : 1.0f;
+            const float inv = 1.0f / scale;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = lane * 4 + it * 256;
+                if (c < W) {
+                    f32x4 o;
+                    if (KEEP) o = ob[it];
+                    else o = out_of(it);
+                    float f[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = fminf(fmaxf((float)(bf16)o[e] * inv, -448.0f), 448.0f);
+                    int pk = 0;
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+                    *(int*)(q8 + (size_t)cur.xr * ldq + c) = pk;
+                }
+            }
+            if (lane == 0) row_scale[cur.xr] = scale;
         }
         if (more) cur = nxt;
     }
@@ -318,18 +362,18 @@ __global__ __launch_bounds__(1024) void ln_dgamma_reduce_kernel(const float* __r
     }
 }
 
-template <typename TDY, bool R1, bool R2, typename TX = float>
+template <typename TDY, bool R1, bool R2, typename TX = float, bool Q8 = false>
 static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int lddy, const TX* x, int ldx, const int* rows,
                           const float* mean, const float* rstd, const float* gamma, const float* res1, const bf16* res2,
                           int ldr2, int ldr, int W, float* dx, int lddx, bf16* dxb, int lddxb, float* dgamma, float* dbeta,
-                          float* ws, long ws_elems) {
+                          float* ws, long ws_elems, unsigned char* q8 = nullptr, int ldq = 0, float* row_scale = nullptr) {
     // persistent grid: as many blocks per CU as the variant's registers allow (see __launch_bounds__ above)
     const int per_cu = it <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3);
     int blocks = ceil_div(M, 4);
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     const dim3 grid(blocks);
     float* partial = (dgamma && ws && ws_elems >= (long)blocks * 2 * W) ? ws : nullptr;
-#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N, R1, R2, TX>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta, partial); break;
+#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N, R1, R2, TX, Q8>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta, partial, q8, ldq, row_scale); break;
     switch (it) { LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) default: LN_BWD_CASE(5) }
 #undef LN_BWD_CASE
     if (partial)
@@ -374,6 +418,36 @@ extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const vo
     else
         launch_ln_bwd_res<bf16>(it, M, stream, (const bf16*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, W,
                                 dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// LayerNorm backward that also emits the e4m3 copy of its bf16 output with per-row scales (Q8 above): the forms of the space-time
+// block's backward -- bf16 dy with (ln_2) fp32 residual, (ln_3) fp32 + bf16 residuals, (ln_1) bf16 x and no residual, (ln_post) fp32 x
+// and no residual.  Every row (no row list), dx_bf16 required.
+extern "C" int tvts_layernorm_bwd_fp8(const void* dy, int lddy, const void* x_, int ldx, int x_bf16, const float* mean,
+                                      const float* rstd, const float* gamma, const float* res1, int ldr, const void* res2_bf16,
+                                      int ldr2, int M, int W, float* dx, int lddx, void* dx_bf16, int lddxb, void* q8, int ldq,
+                                      float* row_scale, float* dgamma, float* dbeta, float* workspace, long workspace_elems,
+                                      hipStream_t stream) {
+    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || lddy % 4 || !dx_bf16 || lddxb % 4 || !q8 || ldq % 4 || !row_scale)
+        return TVTS_EINVAL;
+    if ((dx && lddx % 4) || (res1 && ldr % 4) || (res2_bf16 && ldr2 % 4)) return TVTS_EINVAL;
+    const bf16* res2 = (const bf16*)res2_bf16;
+    const int it = ceil_div(W, 256);
+#define Q8_ARGS it, M, stream, (const bf16*)dy, lddy, x, ldx, (const int*)nullptr, mean, rstd, gamma, res1, res2, ldr2, ldr, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems, (unsigned char*)q8, ldq, row_scale
+    if (x_bf16) {
+        if (res1 || res2) return TVTS_EINVAL;
+        const bf16* x = (const bf16*)x_;
+        launch_ln_bwd<bf16, false, false, bf16, true>(Q8_ARGS);
+    } else {
+        const float* x = (const float*)x_;
+        if (res1 && res2) launch_ln_bwd<bf16, true, true, float, true>(Q8_ARGS);
+        else if (res1) launch_ln_bwd<bf16, true, false, float, true>(Q8_ARGS);
+        else if (res2) return TVTS_EINVAL;
+        else launch_ln_bwd<bf16, false, false, float, true>(Q8_ARGS);
+    }
+#undef Q8_ARGS
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

@@ -245,8 +245,9 @@ class Engine:
             return
         K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
 
-    def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, **epi):
-        """dW += dy^T a_in, db += colsum(dy) (if trainable); d_in = dy W (optional, with epilogue)."""
+    def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, dy8=None, **epi):
+        """dW += dy^T a_in, db += colsum(dy) (if trainable); d_in = dy W (optional, with epilogue).  dy8: the e4m3 copy of dy
+        (bytes, per-token scales) when its producer already wrote one (_ln_bwd with fp8_for)."""
         want_b = bool(bname) and self.requires_grad[bname]
         if self.requires_grad[wname]:  # bias gradient (column sums of dy) rides along in the same kernel
             K.gemm_tn(dy, a_in, self.P.g2d(wname), M=M, accumulate=True, colsum=self.P.g(bname) if want_b else None)
@@ -254,8 +255,10 @@ class Engine:
             K.colsum(dy, self.P.g(bname), M=M)
         if d_in is not None:
             if wname in self.P.w8t:  # e4m3 input gradient (arch["fp8_dgrad"]): dy one scale per token, the transposed weight's e4m3 copy
-                d8 = self._fp8_bufs(M, dy.shape[1])
-                K.quantize_fp8_rows(dy[:M], q=d8[0], row_scale=d8[1])
+                d8 = dy8
+                if d8 is None:
+                    d8 = self._fp8_bufs(M, dy.shape[1])
+                    K.quantize_fp8_rows(dy[:M], q=d8[0], row_scale=d8[1])
                 w8t, wst = self.P.w8t[wname]
                 K.gemm_nt_fp8(d8[0], d8[1], w8t, wst, d_in[:M], **epi)
                 return
@@ -276,11 +279,19 @@ class Engine:
                         q8=a8[0] if a8 else None, row_scale=a8[1] if a8 else None)
         return a8
 
-    def _ln_bwd(self, dy, x, name, tag, dx, dx_bf16=None, res1=None, res2=None, rows=None, M=None):
+    def _ln_bwd(self, dy, x, name, tag, dx, dx_bf16=None, res1=None, res2=None, rows=None, M=None, fp8_for=None):
+        """fp8_for: name of the weight whose input-gradient GEMM consumes dx_bf16; when that GEMM runs on e4m3 operands the
+        LayerNorm backward also emits the e4m3 copy (returned, to be handed to _lin_bwd as dy8)."""
         tr = self.requires_grad[name + ".weight"]
+        d8 = None
+        if (fp8_for is not None and fp8_for in self.P.w8t and rows is None and dx_bf16 is not None and dy.dtype == torch.bfloat16
+                and not (res2 is not None and res1 is None)):
+            d8 = self._fp8_bufs(dx_bf16.shape[0] if M is None else M, dx_bf16.shape[1])
         K.layernorm_bwd(dy, x, self.buf[tag + ".mean"], self.buf[tag + ".rstd"], self.P.p(name + ".weight"), dx,
                         dx_bf16=dx_bf16, res1=res1, res2=res2, dgamma=self.P.g(name + ".weight") if tr else None,
-                        dbeta=self.P.g(name + ".bias") if tr else None, rows=rows, M=M)
+                        dbeta=self.P.g(name + ".bias") if tr else None, rows=rows, M=M,
+                        q8=d8[0] if d8 else None, row_scale=d8[1] if d8 else None)
+        return d8
 
     # ------------------------------------------------------------------ generic pre-LN block (text tower, sort head)
     def _block_fwd(self, pre, nm, x_in, x_out, tag, M, Wd, heads, Bn, S, causal, act, eps):
@@ -485,8 +496,10 @@ class Engine:
             if rg["video_model.proj"]:  # dproj[W,E] += lnpost^T dout
                 K.gemm_tn(B_["vit.lnpost"], dout_b, self.P.g("video_model.proj"), M=M, accumulate=True)
             K.gemm_nt(dout_b, self.P.w("video_model.proj"), dln, M=M)
-            self._ln_bwd(dln, B_[f"vit.x{a['layers']}"], "video_model.ln_post", "vit.lnpost", dx, dx_bf16=dxb)
+            dxb8 = self._ln_bwd(dln, B_[f"vit.x{a['layers']}"], "video_model.ln_post", "vit.lnpost", dx, dx_bf16=dxb,
+                                fp8_for=f"video_model.transformer.resblocks.{a['layers'] - 1}.mlp.c_proj.weight")
         else:
+            dxb8 = None
             # patch-token branch (no LN): dproj += x^T dout, dx = dout proj^T (CLS rows of dout are zero)
             if dout_b is not None:
                 if rg["video_model.proj"]:
@@ -511,25 +524,29 @@ class Engine:
         for l in reversed(range(a["layers"])):
             pre, tg = f"video_model.transformer.resblocks.{l}.", f"vit{l}"
             x_in = B_[f"vit.x{l}"]
-            self._lin_bwd(dxb, B_[tg + ".a"], pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dh, M,
+            # (e4m3 input gradients: the LayerNorm backward that produces an output gradient also writes its e4m3 copy, d*8)
+            self._lin_bwd(dxb, B_[tg + ".a"], pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dh, M, dy8=dxb8,
                           gate_h=B_[tg + ".h"], gate_act=a["act"])
             self._lin_bwd(dh, B_[tg + ".ln2"], pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", dln, M)
-            self._ln_bwd(dln, B_[tg + ".s_res"], pre + "ln_2", tg + ".ln2", dsr, dx_bf16=dsrb, res1=dx)
+            dsrb8 = self._ln_bwd(dln, B_[tg + ".s_res"], pre + "ln_2", tg + ".ln2", dsr, dx_bf16=dsrb, res1=dx,
+                                 fp8_for=pre + "attn.proj.weight")
             # spatial attention branch
-            self._lin_bwd(dsrb, B_[tg + ".att_s"], pre + "attn.proj.weight", pre + "attn.proj.bias", datt, M)
+            self._lin_bwd(dsrb, B_[tg + ".att_s"], pre + "attn.proj.weight", pre + "attn.proj.bias", datt, M, dy8=dsrb8)
             self._st_attention_bwd(B_[tg + ".qkv_s"], B_[tg + ".att_s"], datt, B_[tg + ".lse_s"], dqkv, "space", B, T, n, "vit.s")
             self._lin_bwd(dqkv, B_[tg + ".ln1"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", dln, M)
             # the time-residual gradient is a side branch (t_res only feeds ln_1): it lives in bf16 only -- as the operand of
             # the timeattn.proj GEMMs and as the bf16 residual term of the ln_3 backward
-            self._ln_bwd(dln, B_[tg + ".t_res"], pre + "ln_1", tg + ".ln1", None, dx_bf16=dtrb)
+            dtrb8 = self._ln_bwd(dln, B_[tg + ".t_res"], pre + "ln_1", tg + ".ln1", None, dx_bf16=dtrb,
+                                 fp8_for=pre + "timeattn.proj.weight")
             # temporal attention branch
-            self._lin_bwd(dtrb, B_[tg + ".att_t"], pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", datt, M)
+            self._lin_bwd(dtrb, B_[tg + ".att_t"], pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", datt, M, dy8=dtrb8)
             self._st_attention_bwd(B_[tg + ".qkv_t"], B_[tg + ".att_t"], datt, B_[tg + ".lse_t"], dqkv, "time", B, T, n, "vit.s")
             self._lin_bwd(dqkv, B_[tg + ".ln3"], pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", dln, M)
             nx = "B" if (a["layers"] - l) % 2 == 1 else "A"
             dxi, dxbi = self._f("vit.dx" + nx, (M, W)), self._b("vit.dxb" + nx, (M, W))
             # x feeds ln_3, the time residual and the space residual
-            self._ln_bwd(dln, x_in, pre + "ln_3", tg + ".ln3", dxi, dx_bf16=dxbi, res1=dsr, res2=dtrb)
+            dxb8 = self._ln_bwd(dln, x_in, pre + "ln_3", tg + ".ln3", dxi, dx_bf16=dxbi, res1=dsr, res2=dtrb,
+                                fp8_for=f"video_model.transformer.resblocks.{l - 1}.mlp.c_proj.weight" if l > 0 else None)
             dx, dxb = dxi, dxbi
             self._ready(pre)
         dtok = self._f("vit.dtok", (M, W))
