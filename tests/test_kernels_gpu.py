@@ -863,6 +863,33 @@ def test_layernorm_bwd_fp8_output(K, W, form):
     assert float(rs[3]) == 1.0 and int(q[3].max()) == 0 and torch.isnan(rs[M])
 
 
+def test_transpose_batched(K):
+    """the batched bf16 transpose behind the transposed weight shadows: 16-byte path (dimensions multiples of 8) and the element
+    path (ragged shapes), one launch over a tile table."""
+    import numpy as np
+    shapes = [(768, 2304), (1280, 640), (64, 64), (200, 136), (300, 75), (8, 1000)]
+    CH = 1024
+    offs, toffs, so, to = [], [], 0, 0
+    for r, c in shapes:
+        offs.append(so); toffs.append(to)
+        so += -(-r * c // CH) * CH; to += -(-r * c // CH) * CH
+    src = torch.zeros(so, dtype=torch.bfloat16, device=DEV)
+    dst = torch.full((to,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    tiles = []
+    for (r, c), o, t in zip(shapes, offs, toffs):
+        src[o:o + r * c] = rnd(r, c, seed=100 + r).bfloat16().to(DEV).reshape(-1)
+        for tr in range(-(-r // 64)):
+            for tc in range(-(-c // 64)):
+                tiles.append((o, t, r, c, tr, tc))
+    rec = np.zeros(len(tiles), dtype=[("s", "<i8"), ("d", "<i8"), ("R", "<i4"), ("C", "<i4"), ("tr", "<i4"), ("tc", "<i4")])
+    for i, tt in enumerate(tiles):
+        rec[i] = tt
+    table = torch.from_numpy(rec.view(np.uint8).copy()).to(DEV)
+    K.transpose_batched(src, dst, table, len(tiles))
+    for (r, c), o, t in zip(shapes, offs, toffs):
+        assert torch.equal(dst[t:t + r * c].view(c, r), src[o:o + r * c].view(r, c).t()), (r, c)
+
+
 def test_fp8_multi_tensor_quantisation(K):
     """all fp8 weights in three launches: the same bytes and scales as tvts_amax + tvts_quant_fp8 tensor by tensor; the e4m3 copy of
     the bf16 transposed shadow under the master's scale."""

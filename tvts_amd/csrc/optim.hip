@@ -107,11 +107,32 @@ struct TrTile { long long src_off, dst_off; int R, C, tr, tc; };
 
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
                                                                 const TrTile* __restrict__ tiles) {
-    __shared__ bf16 t[64][66];
+    __shared__ __attribute__((aligned(16))) bf16 t[64][72];  // 144-byte rows: 16-byte stores stay aligned, column reads spread over the banks
     const TrTile e = tiles[blockIdx.x];
     const bf16* s = src + e.src_off;
     bf16* d = dst + e.dst_off;
     const int r0 = e.tr * 64, c0 = e.tc * 64;
+    if (e.R % 8 == 0 && e.C % 8 == 0 && e.src_off % 8 == 0 && e.dst_off % 8 == 0) {
+        // 16 bytes per lane on both sides (2-byte accesses ran this kernel at a third of the HBM rate: 1.8 ms for the 0.63 G bf16
+        // weights of ViT-H/14): a lane loads 8 consecutive columns of a row, and stores 8 consecutive rows of a column
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = threadIdx.x + 256 * k, r = i >> 3, c8 = (i & 7) * 8;
+            if (r0 + r < e.R && c0 + c8 < e.C) *(bf16x8*)&t[r][c8] = *(const bf16x8*)(s + (size_t)(r0 + r) * e.C + c0 + c8);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = threadIdx.x + 256 * k, c = i >> 3, r8 = (i & 7) * 8;
+            if (c0 + c < e.C && r0 + r8 < e.R) {
+                bf16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = t[r8 + j][c];
+                *(bf16x8*)(d + (size_t)(c0 + c) * e.R + r0 + r8) = v;
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
         if (r0 + r < e.R && c0 + c < e.C) t[r][c] = s[(size_t)(r0 + r) * e.C + c0 + c];
