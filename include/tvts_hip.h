@@ -39,6 +39,8 @@ int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int
 /* test hook: force the weight-gradient kernel's LDS-DMA issue path (early_dma 0 = builtin path, the one operands past 4 GiB
  * take) and its tile walk (a_fast 0 / 1); -1 = automatic */
 void tvts_gemm_set_tn_mode(int early_dma, int a_fast);
+/* bench hook: number of contraction ranges of the weight-gradient kernel (0 = automatic: the smallest count that fills >= 93 % of a round) */
+void tvts_gemm_set_tn_splits(int splits);
 /* weight-gradient tile override for benches and tests: 0 auto, 128 (128x128 kernel, two blocks per CU), 256 (pipelined 256x256
  * kernel); tvts_gemm_tn_select returns the tile tvts_gemm_tn_bf16 picks for M rows into an [Na, Nb] output under the current
  * override */

@@ -538,8 +538,9 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 #include "gemm_tn256.h"
 
 // test / bench hook (no environment reads on the launch path): -1 = automatic choice
-static int g_tn_early = -1, g_tn_afast = -1;
+static int g_tn_early = -1, g_tn_afast = -1, g_tn_splits = 0;
 extern "C" void tvts_gemm_set_tn_mode(int early_dma, int a_fast) { g_tn_early = early_dma; g_tn_afast = a_fast; }
+extern "C" void tvts_gemm_set_tn_splits(int splits) { g_tn_splits = splits > 0 ? splits : 0; }  // bench hook: 0 = automatic
 // tile selection: the pipelined 256x256 kernel for long contractions -- M >= 32 768 rows, at least 0.5 M output elements, at
 // most 15 % of the 256-tiling's area wasted: every weight gradient of the ViT blocks (tools/tn_ab.py, M = 150 720: qkv 934 ->
 // 1109, fc1 955 -> 1131, fc2 984 -> 1134, proj 905 -> 925 TF) -- else the 128x128 kernel, which is the faster one on the text
@@ -586,6 +587,7 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
             if (eff >= 0.93) { splits = sp; break; }
         }
     }
+    if (g_tn_splits > 0) splits = g_tn_splits;
     // the partials must fit the caller's workspace: fewer, longer ranges beat the atomic fallback
     if (workspace != nullptr && splits > 1 && (long)splits * Na * Nb > workspace_elems) {
         const int fit = (int)(workspace_elems / ((long)Na * Nb));
