@@ -863,6 +863,29 @@ def test_layernorm_bwd_fp8_output(K, W, form):
     assert float(rs[3]) == 1.0 and int(q[3].max()) == 0 and torch.isnan(rs[M])
 
 
+def test_gemm_tn_split_counts_agree(K):
+    """the weight-gradient kernel under forced contraction-range counts (tvts_gemm_set_tn_splits): every count gives the fp32 product
+    (different summation trees: equal within fp32 accumulation error), the column sums ride along unchanged."""
+    from tvts_amd import _lib
+    lib = _lib.load()
+    M, Na, Nb = 40000, 768, 512
+    p, q = bf(rnd(M, Na, seed=110)).to(DEV), bf(rnd(M, Nb, seed=111)).to(DEV)
+    ref = p.float().t().double().cpu() @ q.float().double().cpu()
+    outs = []
+    try:
+        for sp in (0, 1, 5, 8, 24):
+            lib.tvts_gemm_set_tn_splits(sp)
+            out = torch.zeros(Na, Nb, device=DEV)
+            cs = torch.zeros(Na, device=DEV)
+            K.gemm_tn(p, q, out, accumulate=False, colsum=cs)
+            assert rel(out, ref) < 2e-6, (sp, rel(out, ref))
+            assert rel(cs, p.float().sum(0).double().cpu()) < 1e-5, sp
+            outs.append(out)
+    finally:
+        lib.tvts_gemm_set_tn_splits(0)
+    assert rel(outs[1], outs[4]) < 2e-6
+
+
 def test_transpose_batched(K):
     """the batched bf16 transpose behind the transposed weight shadows: 16-byte path (dimensions multiples of 8) and the element
     path (ragged shapes), one launch over a tile table."""
