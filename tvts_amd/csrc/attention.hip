@@ -837,11 +837,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
                                                                   const bf16* __restrict__ dO, int lddo,
                                                                   const float* __restrict__ lse2, const float* __restrict__ delta,
                                                                   bf16* __restrict__ dqkv, int lddq, float* __restrict__ cls_acc) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * 32 * VSTRIDE];  // [buf][Q | dO] of 32 rows
-    __shared__ float stat[2][2][32];                                      // [buf][lse2 | delta][query]
+    // 64 queries per stage (was 32): half the block barriers per key tile -- this kernel ran at half the rate of its dQ twin
+    constexpr int QT = 64;
+    __shared__ __attribute__((aligned(16))) char smem[4 * QT * VSTRIDE];  // [buf][Q | dO] of QT rows
+    __shared__ float stat[2][2][QT];                                      // [buf][lse2 | delta][query]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr bool EXT = (MODE == MODE_SPACE);
-    constexpr int HT = 32 * VSTRIDE;
+    constexpr int HT = QT * VSTRIDE;
     const int nk_max = (MODE == MODE_SPACE) ? g.n + 1 : g.S;
     const int kblocks = (((nk_max + 15) >> 4) + 3) >> 2;
     const Grp r = decode<MODE>(g, blockIdx.x / kblocks);
@@ -863,78 +865,85 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
     const bool causal = (MODE == MODE_FULL) && g.causal;
-    const int q_begin = causal ? ((kb_ * 64) & ~31) : 0;  // queries before the block's first key see none of its keys
+    const int q_begin = causal ? ((kb_ * 64) & ~(QT - 1)) : 0;  // queries before the block's first key see none of its keys
     auto qrowf = [&](int qt0) { return [&, qt0](int rr) { return qx_row<MODE>(g, r, qt0 + rr); }; };
-    Stage1 sq, sd;
+    Stage2 sq, sd;
     {
-        const int rows = (nqx - q_begin) < 32 ? (nqx - q_begin) : 32;
-        sq = stage_load32(rows, tid, qkv, g.ld, hcol, qrowf(q_begin));
-        sd = stage_load32(rows, tid, dO, lddo, hcol, qrowf(q_begin));
-        stage_store32(sq, smem, tid);
-        stage_store32(sd, smem + HT, tid);
-        if (tid < 64) {
-            const int qi = q_begin + (tid & 31);
+        const int rows = (nqx - q_begin) < QT ? (nqx - q_begin) : QT;
+        stage_load64(sq, rows, tid, qkv, g.ld, hcol, qrowf(q_begin));
+        stage_load64(sd, rows, tid, dO, lddo, hcol, qrowf(q_begin));
+        stage_store64(sq, smem, tid);
+        stage_store64(sd, smem + HT, tid);
+        if (tid < 2 * QT) {
+            const int qi = q_begin + (tid % QT);
             const size_t o = (size_t)qx_row<MODE>(g, r, qi < nqx ? qi : nqx - 1) * g.heads + r.h;
-            stat[0][tid >> 5][tid & 31] = (tid < 32) ? lse2[o] : delta[o];
+            stat[0][tid / QT][tid % QT] = (tid < QT) ? lse2[o] : delta[o];
         }
     }
     float sstat = 0.f;
     int buf = 0;
-    for (int qt0 = q_begin; qt0 < nqx; qt0 += 32, buf ^= 1) {
+    for (int qt0 = q_begin; qt0 < nqx; qt0 += QT, buf ^= 1) {
         __syncthreads();
         const char* q_lds = smem + buf * 2 * HT;
         const char* do_lds = q_lds + HT;
-        const bool more = qt0 + 32 < nqx;
+        const bool more = qt0 + QT < nqx;
         if (more) {
-            const int rows = (nqx - qt0 - 32) < 32 ? (nqx - qt0 - 32) : 32;
-            sq = stage_load32(rows, tid, qkv, g.ld, hcol, qrowf(qt0 + 32));
-            sd = stage_load32(rows, tid, dO, lddo, hcol, qrowf(qt0 + 32));
-            if (tid < 64) {
-                const int qi = qt0 + 32 + (tid & 31);
+            const int rows = (nqx - qt0 - QT) < QT ? (nqx - qt0 - QT) : QT;
+            stage_load64(sq, rows, tid, qkv, g.ld, hcol, qrowf(qt0 + QT));
+            stage_load64(sd, rows, tid, dO, lddo, hcol, qrowf(qt0 + QT));
+            if (tid < 2 * QT) {
+                const int qi = qt0 + QT + (tid % QT);
                 const size_t o = (size_t)qx_row<MODE>(g, r, qi < nqx ? qi : nqx - 1) * g.heads + r.h;
-                sstat = (tid < 32) ? lse2[o] : delta[o];
+                sstat = (tid < QT) ? lse2[o] : delta[o];
             }
         }
-        if (active && !(causal && qt0 + 32 <= k0)) {
-            const int qrows = (nqx - qt0) > 16 ? 32 : 16;
-            bf16x8 pf, dsf;
+        if (active && !(causal && qt0 + QT <= k0)) {
+            const int left = nqx - qt0;
+            const int qrows = left >= QT ? QT : ((left + 15) & ~15);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
-                if (t * 16 < qrows) {
+            for (int u = 0; u < QT / 32; ++u) {
+                if (u * 32 < qrows) {
+                    bf16x8 pf, dsf;
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, t * 16 + li, ks, gq), kb[ks], s, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, t * 16 + li, ks, gq), vb[ks], dp, 0, 0, 0);
+                    for (int t = 0; t < 2; ++t) {
+                        const int tile = 2 * u + t;
+                        f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+                        if (tile * 16 < qrows) {
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) {
+                                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(q_lds, tile * 16 + li, ks, gq), kb[ks], s, 0, 0, 0);
+                                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, tile * 16 + li, ks, gq), vb[ks], dp, 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int ql = tile * 16 + gq * 4 + e;
+                            const int qi = qt0 + ql;
+                            bool ok = qi < nqx && kj < r.nk;
+                            if (causal) ok = ok && kj <= qi;
+                            if (EXT) ok = ok && !(qi == 0 && kj == 0 && r.sub != 0);
+                            float p = 0.f, d = 0.f;
+                            if (ok) {
+                                p = __builtin_amdgcn_exp2f(s[e] * g.scale2 - stat[buf][0][ql]);
+                                d = p * (dp[e] - stat[buf][1][ql]) * g.scale;
+                            }
+                            pf[t * 4 + e] = (bf16)p;
+                            dsf[t * 4 + e] = (bf16)d;
+                        }
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(do_lds, u, dt, lane), pf, dv[dt], 0, 0, 0);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(q_lds, u, dt, lane), dsf, dk[dt], 0, 0, 0);
                     }
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int qi = qt0 + t * 16 + gq * 4 + e;
-                    bool ok = qi < nqx && kj < r.nk;
-                    if (causal) ok = ok && kj <= qi;
-                    if (EXT) ok = ok && !(qi == 0 && kj == 0 && r.sub != 0);
-                    float p = 0.f, d = 0.f;
-                    if (ok) {
-                        const int ql = t * 16 + gq * 4 + e;
-                        p = __builtin_amdgcn_exp2f(s[e] * g.scale2 - stat[buf][0][ql]);
-                        d = p * (dp[e] - stat[buf][1][ql]) * g.scale;
-                    }
-                    pf[t * 4 + e] = (bf16)p;
-                    dsf[t * 4 + e] = (bf16)d;
-                }
-            }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(do_lds, 0, dt, lane), pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(q_lds, 0, dt, lane), dsf, dk[dt], 0, 0, 0);
             }
         }
         if (more) {
             char* nb = smem + (buf ^ 1) * 2 * HT;
-            stage_store32(sq, nb, tid);
-            stage_store32(sd, nb + HT, tid);
-            if (tid < 64) stat[buf ^ 1][tid >> 5][tid & 31] = sstat;
+            stage_store64(sq, nb, tid);
+            stage_store64(sd, nb + HT, tid);
+            if (tid < 2 * QT) stat[buf ^ 1][tid / QT][tid % QT] = sstat;
         }
     }
     if (active && kj < r.nk && EXT && kj == 0) {
