@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
     // 64 queries per stage (was 32): half the block barriers per key tile -- this kernel ran at half the rate of its dQ twin
     constexpr int QT = 64;
     __shared__ __attribute__((aligned(16))) char smem[4 * QT * VSTRIDE];  // [buf][Q | dO] of QT rows
-    __shared__ float stat[2][2][QT];                                      // [buf][lse2 | delta][query]
+    __shared__ __attribute__((aligned(16))) float stat[2][2][QT];         // [buf][lse2 | delta][query]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr bool EXT = (MODE == MODE_SPACE);
     constexpr int HT = QT * VSTRIDE;
@@ -915,20 +915,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
                                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(do_lds, tile * 16 + li, ks, gq), vb[ks], dp, 0, 0, 0);
                             }
                         }
+                        // the lane's 4 consecutive queries: their stats in two 16-byte LDS reads (were 8 scalar ones)
+                        const f32x4 l4 = *(const f32x4*)&stat[buf][0][tile * 16 + gq * 4];
+                        const f32x4 d4 = *(const f32x4*)&stat[buf][1][tile * 16 + gq * 4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const int ql = tile * 16 + gq * 4 + e;
-                            const int qi = qt0 + ql;
+                            const int qi = qt0 + tile * 16 + gq * 4 + e;
                             bool ok = qi < nqx && kj < r.nk;
                             if (causal) ok = ok && kj <= qi;
                             if (EXT) ok = ok && !(qi == 0 && kj == 0 && r.sub != 0);
-                            float p = 0.f, d = 0.f;
-                            if (ok) {
-                                p = __builtin_amdgcn_exp2f(s[e] * g.scale2 - stat[buf][0][ql]);
-                                d = p * (dp[e] - stat[buf][1][ql]) * g.scale;
-                            }
+                            const float p = ok ? __builtin_amdgcn_exp2f(s[e] * g.scale2 - l4[e]) : 0.f;
                             pf[t * 4 + e] = (bf16)p;
-                            dsf[t * 4 + e] = (bf16)d;
+                            dsf[t * 4 + e] = (bf16)(p * (dp[e] - d4[e]) * g.scale);
                         }
                     }
 #pragma unroll
