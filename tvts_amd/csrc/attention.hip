@@ -673,16 +673,26 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const 
                 }
             }
             float mx = -INFINITY;
+            if (!causal && kt0 + 64 <= r.nk) {  // interior tile (wave-uniform): every key is valid, no mask arithmetic
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = kt0 + t * 16 + gq * 4 + e;
-                    const bool ok = key < r.nk && !(causal && key > qi);
-                    const float sv_ = ok ? st[t][e] * g.scale2 : -INFINITY;
-                    st[t][e] = sv_;
-                    mx = fmaxf(mx, sv_);
-                }
+                    for (int e = 0; e < 4; ++e) {
+                        st[t][e] *= g.scale2;
+                        mx = fmaxf(mx, st[t][e]);
+                    }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = kt0 + t * 16 + gq * 4 + e;
+                        const bool ok = key < r.nk && !(causal && key > qi);
+                        const float sv_ = ok ? st[t][e] * g.scale2 : -INFINITY;
+                        st[t][e] = sv_;
+                        mx = fmaxf(mx, sv_);
+                    }
+            }
             mx = group_max(mx);
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -799,12 +809,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_shared_kernel(AttnGeom g, con
                         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, ks, gq), qf[ks], s, 0, 0, 0);
                         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(vt, t * 16 + li, ks, gq), dof[ks], dp, 0, 0, 0);
                     }
+                    if (!causal && kt0 + 64 <= r.nk) {  // interior tile (wave-uniform): no mask arithmetic
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int key = kt0 + t * 16 + gq * 4 + e;
-                        const bool ok = key < r.nk && !(causal && key > qi);
-                        const float p = ok ? __builtin_amdgcn_exp2f(s[e] * g.scale2 - lse) : 0.f;
-                        ds[t][e] = p * (dp[e] - dlt) * g.scale;
+                        for (int e = 0; e < 4; ++e) ds[t][e] = __builtin_amdgcn_exp2f(s[e] * g.scale2 - lse) * (dp[e] - dlt) * g.scale;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int key = kt0 + t * 16 + gq * 4 + e;
+                            const bool ok = key < r.nk && !(causal && key > qi);
+                            const float p = ok ? __builtin_amdgcn_exp2f(s[e] * g.scale2 - lse) : 0.f;
+                            ds[t][e] = p * (dp[e] - dlt) * g.scale;
+                        }
                     }
                 }
             }
@@ -918,15 +933,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
                         // the lane's 4 consecutive queries: their stats in two 16-byte LDS reads (were 8 scalar ones)
                         const f32x4 l4 = *(const f32x4*)&stat[buf][0][tile * 16 + gq * 4];
                         const f32x4 d4 = *(const f32x4*)&stat[buf][1][tile * 16 + gq * 4];
+                        if (!EXT && !causal && qt0 + QT <= nqx && k0 + 16 <= r.nk) {  // interior (wave-uniform): no mask arithmetic
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int qi = qt0 + tile * 16 + gq * 4 + e;
-                            bool ok = qi < nqx && kj < r.nk;
-                            if (causal) ok = ok && kj <= qi;
-                            if (EXT) ok = ok && !(qi == 0 && kj == 0 && r.sub != 0);
-                            const float p = ok ? __builtin_amdgcn_exp2f(s[e] * g.scale2 - l4[e]) : 0.f;
-                            pf[t * 4 + e] = (bf16)p;
-                            dsf[t * 4 + e] = (bf16)(p * (dp[e] - d4[e]) * g.scale);
+                            for (int e = 0; e < 4; ++e) {
+                                const float p = __builtin_amdgcn_exp2f(s[e] * g.scale2 - l4[e]);
+                                pf[t * 4 + e] = (bf16)p;
+                                dsf[t * 4 + e] = (bf16)(p * (dp[e] - d4[e]) * g.scale);
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int qi = qt0 + tile * 16 + gq * 4 + e;
+                                bool ok = qi < nqx && kj < r.nk;
+                                if (causal) ok = ok && kj <= qi;
+                                if (EXT) ok = ok && !(qi == 0 && kj == 0 && r.sub != 0);
+                                const float p = ok ? __builtin_amdgcn_exp2f(s[e] * g.scale2 - l4[e]) : 0.f;
+                                pf[t * 4 + e] = (bf16)p;
+                                dsf[t * 4 + e] = (bf16)(p * (dp[e] - d4[e]) * g.scale);
+                            }
                         }
                     }
 #pragma unroll
