@@ -119,10 +119,13 @@ void tvts_attn_set_transpose_read(int on);
 void tvts_attn_set_shared(int on);
 /* whole backward of one attention site (D = rowsum(dO*O), dQ, dK, dV, CLS query + CLS key/value reduction of the divided
  * geometries) = the autograd of VarAttention.forward video_encoder_ViT_B_16.py:38-76; delta [rows, heads] and
- * cls_acc [B, heads, 3, dh] are scratch.  SPACE groups of <= 112 tokens run as ONE fused launch. */
+ * cls_acc (cls_acc_elems fp32 elements) are scratch.  SPACE groups of <= 112 tokens run as ONE fused launch.  cls_acc holds the
+ * CLS token's dK / dV / dQ shares: with >= B * heads * max(T, ceil(n / 28)) * 3 * dh elements every block of the fused kernels
+ * stores its share and they are added in a fixed order (run-to-run reproducible); with B * heads * 3 * dh elements (the
+ * minimum) the shares are accumulated with fp32 atomics. */
 int tvts_attn_bwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
               int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float* cls_acc,
-              hipStream_t stream);
+              long cls_acc_elems, hipStream_t stream);
 void tvts_attn_set_fused(int on);
 /* forward of one divided-attention site including the CLS row (VarAttention.forward video_encoder_ViT_B_16.py:38-76);
  * cls_ws: fp32 scratch of >= B * heads * max(T, ceil(n / 28)) * (dh + 2) elements (partial softmax states of the CLS query) */
@@ -180,10 +183,13 @@ void tvts_attn80_set_transpose_read(int on);
 void tvts_attn80_set_shared(int on);
 /* whole backward of one attention site (D = rowsum(dO*O), dQ, dK, dV, CLS query + CLS key/value reduction of the divided
  * geometries) = the autograd of VarAttention.forward video_encoder_ViT_B_16.py:38-76; delta [rows, heads] and
- * cls_acc [B, heads, 3, dh] are scratch.  SPACE groups of <= 112 tokens run as ONE fused launch. */
+ * cls_acc (cls_acc_elems fp32 elements) are scratch.  SPACE groups of <= 112 tokens run as ONE fused launch.  cls_acc holds the
+ * CLS token's dK / dV / dQ shares: with >= B * heads * max(T, ceil(n / 28)) * 3 * dh elements every block of the fused kernels
+ * stores its share and they are added in a fixed order (run-to-run reproducible); with B * heads * 3 * dh elements (the
+ * minimum) the shares are accumulated with fp32 atomics. */
 int tvts_attn80_bwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
               int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float* cls_acc,
-              hipStream_t stream);
+              long cls_acc_elems, hipStream_t stream);
 void tvts_attn80_set_fused(int on);
 /* forward of one divided-attention site including the CLS row (VarAttention.forward video_encoder_ViT_B_16.py:38-76);
  * cls_ws: fp32 scratch of >= B * heads * max(T, ceil(n / 28)) * (dh + 2) elements (partial softmax states of the CLS query) */

@@ -107,6 +107,13 @@ def test_gemm_tn(K, M, Na, Nb):
     K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True, colsum=cs)
     assert rel(out, 2 * ref) < 3e-5
     assert rel(cs, 1 + p.float().sum(0)) < 1e-5, rel(cs, 1 + p.float().sum(0))
+    cs2 = torch.ones(Na, device=DEV)  # the bias gradient is an ordered sum of per-range partials: bit-reproducible
+    K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True, colsum=cs2)
+    assert torch.equal(cs, cs2)
+    cs3 = torch.ones(Na, device=DEV)
+    K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=False, colsum=cs3, workspace=False)  # fallback: atomics (or the one range's owner)
+    assert rel(cs3, 1 + p.float().sum(0)) < 1e-5
+    out.copy_(2 * ref)
     K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True, workspace=False)  # fp32-atomic fallback (no workspace)
     assert rel(out, 3 * ref) < 3e-5
     K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=False, workspace=False)
@@ -136,6 +143,12 @@ def test_gemm_tn_256_tile(K, M, Na, Nb):
         K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True, colsum=cs)
         assert rel(out, 2 * ref) < 3e-5
         assert rel(cs, 1 + p.float().sum(0)) < 2e-5, rel(cs, 1 + p.float().sum(0))
+        cs2 = torch.ones(Na, device=DEV)
+        K.gemm_tn(p.to(DEV), q.to(DEV), out2, accumulate=False, colsum=cs2)
+        assert torch.equal(cs, cs2)  # ordered per-range partials of the bias gradient
+        cs3 = torch.ones(Na, device=DEV)
+        K.gemm_tn(p.to(DEV), q.to(DEV), out2, accumulate=False, colsum=cs3, workspace=False)
+        assert rel(cs3, 1 + p.float().sum(0)) < 2e-5
         K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=True, workspace=False)  # fp32-atomic fallback (no workspace)
         assert rel(out, 3 * ref) < 3e-5
         K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=False, workspace=False)
@@ -299,15 +312,19 @@ def test_divided_attention(K, mode, B, heads, T, n, tr, dh):
         K.attn_set_transpose_read(True)
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "atomic"])
 @pytest.mark.parametrize("dh", [64, 80])
 @pytest.mark.parametrize("mode,B,heads,T,n", [("space", 2, 2, 3, 21), ("space", 1, 3, 2, 98), ("space", 2, 2, 4, 111),
                                               ("space", 1, 2, 2, 15), ("space", 1, 2, 2, 16), ("space", 1, 1, 2, 196),
                                               ("space", 2, 4, 3, 76), ("time", 2, 2, 8, 5), ("time", 1, 2, 16, 7),
-                                              ("time", 2, 3, 12, 4)])
+                                              ("time", 2, 3, 12, 4), ("time", 2, 2, 8, 61)])
 def test_attention_site_backward(K, mode, B, heads, T, n, dh, fused):
     """tvts_attn_bwd: the whole backward of one divided-attention site in one call (fused single-launch kernels where
-    the group fits; the split delta / dQ / dK,dV passes otherwise), against autograd of the reference formulation."""
+    the group fits; the split delta / dQ / dK,dV passes otherwise), against autograd of the reference formulation.
+    The CLS token's dK / dV / dQ shares: one partial per block added in order when the scratch has room for them (what the
+    engine passes: two calls give bit-identical outputs), fp32 atomics with the minimal scratch ("atomic")."""
+    parts = 1 if fused == "atomic" else max(T, -(-n // 28))
+    fused = bool(fused)
     K.attn_set_fused(fused)
     try:
         S, W = 1 + T * n, heads * dh
@@ -322,10 +339,15 @@ def test_attention_site_backward(K, mode, B, heads, T, n, dh, fused):
         dOd = dO.reshape(B * S, W).to(DEV)
         delta = torch.full((B * S, heads), float("nan"), device=DEV)
         dqkv = torch.full((B * S, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
-        acc = torch.full((B, heads, 3, dh), float("nan"), device=DEV)
+        acc = torch.full((B, heads, parts, 3, dh), float("nan"), device=DEV)
         K.attn_bwd(mode, qd, dOd, out, lse, delta, dqkv, B=B, heads=heads, S=S, T=T, n=n, cls_acc=acc, head_dim=dh)
         got = dqkv.float().view(B, S, 3 * W).cpu()
         assert torch.isfinite(got).all()
+        if fused and parts > 1:  # ordered partials: a second call reproduces every bit
+            dqkv2 = torch.full_like(dqkv, float("nan"))
+            acc.fill_(float("nan"))
+            K.attn_bwd(mode, qd, dOd, out, lse, delta, dqkv2, B=B, heads=heads, S=S, T=T, n=n, cls_acc=acc, head_dim=dh)
+            assert torch.equal(dqkv2.view(torch.int16), dqkv.view(torch.int16))
         for nm, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
             assert rel(got[..., sl], ref_dqkv[..., sl]) < 2e-2, (nm, rel(got[..., sl], ref_dqkv[..., sl]))
             assert rel(got[:, 0, sl], ref_dqkv[:, 0, sl]) < 2e-2, (nm + "_cls", rel(got[:, 0, sl], ref_dqkv[:, 0, sl]))

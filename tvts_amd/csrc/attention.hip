@@ -59,6 +59,7 @@ struct AttnGeom {
     const int* kv_len;      // FULL only, optional: valid keys per sequence (keys >= kv_len[b] are padding and masked)
     int cls_nq, cls_q0;     // CLS geometry generalised: cls_nq (<= 16) queries at tokens cls_q0 .. of the sequence (1, 0 = the CLS token)
     const int* cls_qpos;    // ... or ONE query per sequence at token cls_qpos[b] that sees the keys 0 .. cls_qpos[b] (causal)
+    int cls_parts;          // fused backward: > 0 = cls_acc holds one partial per block ([B, heads, cls_parts, 3, dh]); 0 = atomics
 };
 
 struct Grp { int b, h, sub, nq, nk; };
@@ -1251,11 +1252,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void attn_bwd_space_fused_kernel(
             const int j = qt * 16 + rr;
             return (j >= 1 && j < m) ? dqkv + (size_t)k_row<MODE_SPACE>(g, r, j) * lddq + hcol : nullptr; });
         if (qj == 0) {  // this frame's share of the CLS query gradient
-            float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3 + 2) * DH;
+            if (g.cls_parts) {  // its own slot of the per-frame partials (plain stores; summed in frame order by the finalize kernel)
+                float* a = cls_acc + (((size_t)(r.b * g.heads + r.h) * g.cls_parts + r.sub) * 3 + 2) * DH;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int dt = 0; dt < DT; ++dt) *(f32x4*)(a + dt * 16 + gq * 4) = acc[dt];
+            } else {
+                float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3 + 2) * DH;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(a + dt * 16 + gq * 4 + e, acc[dt][e]);
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(a + dt * 16 + gq * 4 + e, acc[dt][e]);
+            }
         }
         if (gq == 0 && qj >= 1) st_dl[qj] = dlt;
     }
@@ -1308,14 +1315,23 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void attn_bwd_space_fused_kernel(
             }
         }
         if (kj == 0) {  // CLS key/value: summed over the frames of (b,h)
-            float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH;
+            if (g.cls_parts) {
+                float* a = cls_acc + (((size_t)(r.b * g.heads + r.h) * g.cls_parts + r.sub) * 3) * DH;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    atomicAdd(a + dt * 16 + gq * 4 + e, dk[dt][e]);
-                    atomicAdd(a + DH + dt * 16 + gq * 4 + e, dv[dt][e]);
+                for (int dt = 0; dt < DT; ++dt) {
+                    *(f32x4*)(a + dt * 16 + gq * 4) = dk[dt];
+                    *(f32x4*)(a + DH + dt * 16 + gq * 4) = dv[dt];
                 }
+            } else {
+                float* a = cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        atomicAdd(a + dt * 16 + gq * 4 + e, dk[dt][e]);
+                        atomicAdd(a + DH + dt * 16 + gq * 4 + e, dv[dt][e]);
+                    }
+            }
         }
         auto krowp = [&](int third) {
             return [&, third](int rr) -> bf16* {
@@ -1525,13 +1541,14 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
             store_tile_rows(opatch, dv, lane, krowp(2));
         }
     }
-    // combine the four waves' CLS sums: one set of atomics per block
+    // combine the four waves' CLS sums: one partial per block
     __syncthreads();
     if (threadIdx.x < 3 * DH) {
         const int i = threadIdx.x;
         const float v = *(const float*)(smem + 0 * WB + 4 * TB + 2 * RA * 4 + i * 4) + *(const float*)(smem + 1 * WB + 4 * TB + 2 * RA * 4 + i * 4) +
                         *(const float*)(smem + 2 * WB + 4 * TB + 2 * RA * 4 + i * 4) + *(const float*)(smem + 3 * WB + 4 * TB + 2 * RA * 4 + i * 4);
-        atomicAdd(cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH + i, v);
+        if (g.cls_parts) cls_acc[(((size_t)(r.b * g.heads + r.h) * g.cls_parts + c) * 3) * DH + i] = v;  // this chunk's slot
+        else atomicAdd(cls_acc + ((size_t)(r.b * g.heads + r.h) * 3) * DH + i, v);
     }
 }
 
@@ -2105,16 +2122,21 @@ __global__ void attn_cls_merge_kernel(const float* __restrict__ cls_part, int G,
     if (d == 0) lse2[row * heads + h] = M + log2f(L);
 }
 
-// cls_acc [B, heads, 3, DH] = fp32 sums of (dK, dV, dQ) of the CLS token -> bf16 into the CLS row of dqkv; the dQ slot is
-// only used by the fused kernels (the split path writes the CLS dQ from its own CLS-query pass).
+// cls_acc [B, heads, parts, 3, DH] = fp32 partial sums of (dK, dV, dQ) of the CLS token (parts = 1: the atomically accumulated
+// sums of the streaming path; parts = T / the number of TIME chunks: one partial per block of the fused kernels, added here in
+// slot order -> run-to-run reproducible) -> bf16 into the CLS row of dqkv; the dQ slot is only used by the fused kernels (the
+// split path writes the CLS dQ from its own CLS-query pass).
 __global__ void attn_cls_finalize_kernel(const float* __restrict__ cls_acc, int B, int heads, int S, int W, int with_q,
-                                         bf16* __restrict__ dqkv, int lddq) {
+                                         bf16* __restrict__ dqkv, int lddq, int parts) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b, h, slot, d)
     if (idx >= B * heads * 3 * DH) return;
     const int d = idx % DH, slot = (idx / DH) % 3, h = (idx / (3 * DH)) % heads, b = idx / (3 * DH * heads);
     if (slot == 2 && !with_q) return;
     const int third = slot == 2 ? 0 : 1 + slot;
-    dqkv[(size_t)(b * S) * lddq + third * W + h * DH + d] = (bf16)cls_acc[idx];
+    const float* src = cls_acc + ((size_t)(b * heads + h) * parts * 3 + slot) * DH + d;
+    float v = 0.f;
+    for (int pidx = 0; pidx < parts; ++pidx) v += src[(size_t)pidx * 3 * DH];
+    dqkv[(size_t)(b * S) * lddq + third * W + h * DH + d] = (bf16)v;
 }
 
 }  // namespace NS_DH
@@ -2132,7 +2154,7 @@ static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int 
     if ((mode == MODE_SPACE || mode == MODE_TIME) && (T <= 0 || n <= 0 || S != 1 + T * n)) return TVTS_EINVAL;
     if (mode < MODE_FULL || mode > MODE_CLS) return TVTS_EINVAL;
     g.B = B; g.heads = heads; g.S = S; g.T = T; g.n = n; g.causal = causal; g.ld = ld; g.W = heads * DH; g.kv_len = nullptr;
-    g.cls_nq = 1; g.cls_q0 = 0; g.cls_qpos = nullptr;
+    g.cls_nq = 1; g.cls_q0 = 0; g.cls_qpos = nullptr; g.cls_parts = 0;
     g.scale = 1.0f / sqrtf((float)DH);
     g.scale2 = g.scale * 1.4426950408889634f;
     static int abl = -1;
@@ -2407,7 +2429,7 @@ extern "C" int ABI(cls_finalize)(const float* cls_acc, int B, int heads, int S, 
                                       hipStream_t stream) {
     const int total = B * heads * 3 * DH;
     hipLaunchKernelGGL(attn_cls_finalize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, cls_acc, B, heads, S,
-                       heads * DH, 0, (bf16*)dqkv, lddq);
+                       heads * DH, 0, (bf16*)dqkv, lddq, 1);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
@@ -2422,7 +2444,7 @@ static __global__ void zero_f32_kernel(float* __restrict__ p, int n) {
 extern "C" void ABI(set_fused)(int on) { g_fused = on ? 1 : 0; }
 extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
                         const void* dO, int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv,
-                        int lddq, float* cls_acc, hipStream_t stream) {
+                        int lddq, float* cls_acc, long cls_acc_elems, hipStream_t stream) {
     if (mode == MODE_CLS) return TVTS_EINVAL;
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
@@ -2439,15 +2461,22 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }
-    if (divided) {
-        if (!cls_acc) return TVTS_EINVAL;
+    const bool fused_space = g_fused && g_use_tr && mode == MODE_SPACE && n + 1 <= FUSED_MAX_TILES * 16;
+    const bool fused_time = g_fused && g_use_tr && mode == MODE_TIME && T + 1 <= 32;
+    // cls_acc: fp32 scratch for the CLS token's dK / dV / dQ sums.  With room for one partial per block of the fused kernels
+    // (B * heads * parts * 3 * dh elements, parts = T for SPACE, ceil(n / TIME_CHUNK) for TIME) the blocks store their shares and
+    // the finalize kernel adds them in order (no atomics: reproducible); with B * heads * 3 * dh elements only, or on the streaming
+    // path, the shares are accumulated with fp32 atomics.
+    const int want_parts = fused_space ? T : fused_time ? ceil_div(n, TIME_CHUNK) : 0;
+    const bool parts_ok = want_parts > 0 && cls_acc && cls_acc_elems >= (long)B * heads * want_parts * 3 * DH;
+    g.cls_parts = parts_ok ? want_parts : 0;
+    if (divided && !parts_ok) {
+        if (!cls_acc || cls_acc_elems < (long)B * heads * 3 * DH) return TVTS_EINVAL;
         // a kernel, not hipMemsetAsync: captured memset nodes did not reliably zero this buffer on hipGraph replay (ROCm 7.x:
         // the second and later replays of the captured training step produced garbage CLS gradients, tools/dbg/graph_vs_eager.py)
         const int nz = B * heads * 3 * DH;
         hipLaunchKernelGGL(zero_f32_kernel, dim3(ceil_div(nz, 256)), dim3(256), 0, stream, cls_acc, nz);
     }
-    const bool fused_space = g_fused && g_use_tr && mode == MODE_SPACE && n + 1 <= FUSED_MAX_TILES * 16;
-    const bool fused_time = g_fused && g_use_tr && mode == MODE_TIME && T + 1 <= 32;
     typedef void (*FusedKern)(AttnGeom, const bf16*, const bf16*, int, const float*, const float*, bf16*, int, float*);
     if (fused_space || fused_time) {
         // D for the CLS rows only (the patch rows get theirs inside the fused kernels)
@@ -2485,7 +2514,7 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
         TVTS_LAUNCH_CHECK();
         const int total = B * heads * 3 * DH;  // CLS row of dqkv: dK, dV and dQ all come from the accumulators
         hipLaunchKernelGGL(attn_cls_finalize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, cls_acc, B, heads, S,
-                           heads * DH, 1, (bf16*)dqkv, lddq);
+                           heads * DH, 1, (bf16*)dqkv, lddq, g.cls_parts ? g.cls_parts : 1);
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }

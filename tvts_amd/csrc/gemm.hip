@@ -337,7 +337,18 @@ struct GemmTN {
     int atomic;
     float* ws;      // split partials [splits][Na][Nb] (plain stores, reduced by tn_reduce_kernel) or nullptr -> fp32 atomics
     float* colsum;  // optional: colsum[a] += sum_m P[m,a]  (bias gradient fused into the weight gradient)
+    float* cs_ws;   // split partials of the column sums [splits][Na] (plain stores, added in split order by tn_reduce_kernel);
+                    // nullptr with one m-range: the single owner of a column adds its sum itself.  (fp32 atomics only remain
+                    // for several m-ranges WITHOUT a workspace -- the engine always passes one: bias gradients are
+                    // run-to-run reproducible.)
+    int splits;
 };
+// column-sum partial of (m-range split, column a): exactly one wave of one block owns it
+__device__ __forceinline__ void tn_colsum_out(const GemmTN& g, int split, int a, float v) {
+    if (g.cs_ws) g.cs_ws[(size_t)split * g.Na + a] = v;
+    else if (g.splits == 1) g.colsum[a] += v;
+    else atomicAdd(g.colsum + a, v);
+}
 
 __device__ __forceinline__ void stage_cols128(const bf16* __restrict__ base, int ld, int m0, int m_max, int c0,
                                               int c_max, char* lds_tile, int wave, int lane) {
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int a = a0 + wa * 64 + i * 16 + lane;
-            if (a < g.Na) atomicAdd(g.colsum + a, cs[i][0]);
+            if (a < g.Na) tn_colsum_out(g, split, a, cs[i][0]);
         }
     }
     // acc[i][j]: MFMA A-operand = Q (rows = b within tile j), B-operand = P (cols = a within tile i)
@@ -522,9 +533,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
     }
 }
 
-// out[a,b] = (accumulate ? out[a,b] : 0) + sum_s ws[s][a][b]
+// out[a,b] = (accumulate ? out[a,b] : 0) + sum_s ws[s][a][b];  colsum[a] += sum_s cs_ws[s][a]  (both in split order)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, int Na, int Nb,
-                                                        float* __restrict__ out, int ldo, int accumulate) {
+                                                        float* __restrict__ out, int ldo, int accumulate,
+                                                        const float* __restrict__ cs_ws, float* __restrict__ colsum) {
+    if (cs_ws) {
+        for (int a = blockIdx.x * 256 + threadIdx.x; a < Na; a += gridDim.x * 256) {
+            float s = colsum[a];
+            for (int k = 0; k < splits; ++k) s += cs_ws[(size_t)k * Na + a];
+            colsum[a] = s;
+        }
+    }
     const size_t n4 = (size_t)Na * Nb / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const size_t e = i * 4;
@@ -560,7 +579,7 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     if (M <= 0 || Na <= 0 || Nb <= 0) return TVTS_EINVAL;
     if (Na % 8 || Nb % 8 || ldp % 8 || ldq % 8 || ldo % 4) return TVTS_EINVAL;
     GemmTN g;
-    g.ws = nullptr; g.early_dma = 0; g.tiles_a = 0; g.a_fast = 0;
+    g.ws = nullptr; g.cs_ws = nullptr; g.splits = 1; g.early_dma = 0; g.tiles_a = 0; g.a_fast = 0;
     g.P = (const bf16*)P; g.ldp = ldp; g.Q = (const bf16*)Q; g.ldq = ldq; g.M = M; g.Na = Na; g.Nb = Nb;
     g.out = out; g.ldo = ldo; g.colsum = colsum;
     const bool t256 = tn_use_256(M, Na, Nb);
@@ -599,6 +618,9 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     // ~190 us per launch whatever M is: 16 M scattered L2 atomics); atomics remain the fallback without workspace
     const bool use_ws = workspace != nullptr && splits > 1 && (long)splits * Na * Nb <= workspace_elems && Nb % 4 == 0;
     if (use_ws) g.ws = workspace;
+    if (use_ws && colsum != nullptr && (long)splits * Na * Nb + (long)splits * Na <= workspace_elems)
+        g.cs_ws = workspace + (size_t)splits * Na * Nb;
+    g.splits = splits;
     if (!use_ws && !accumulate && splits > 1) {
         hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)Nb * 4, Na, stream);
         if (e != hipSuccess) return (int)e;
@@ -619,7 +641,8 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
         const long n4 = (long)Na * Nb / 4;
         int rb = (int)((n4 + 255) / 256);
         if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(rb), dim3(256), 0, stream, workspace, splits, Na, Nb, out, ldo, accumulate);
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(rb), dim3(256), 0, stream, workspace, splits, Na, Nb, out, ldo, accumulate,
+                           g.cs_ws, colsum);
     }
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
@@ -781,30 +804,36 @@ extern "C" int tvts_gemm_small_f32(const float* A, long sai, long sak, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// bias gradient: out[n] += sum_m X[m,n]  (bf16 in, fp32 atomics; 8 columns per lane, rows strided by blocks)
+// bias gradient: out[n] += sum_m X[m,n]  (bf16 in).  A block owns 64 columns for ALL rows: 8 column threads (8 columns each)
+// x 32 row lanes striding the rows, merged through LDS in row-lane order -- no atomics, run-to-run reproducible.  (Only used
+// where a bias trains under a frozen weight; the trained layers get their bias gradient inside the weight-gradient kernel.)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, int ld, int M, int N,
-                                                     float* __restrict__ out, int rows_per_block) {
-    const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
-    if (col >= N) return;
-    const int r0 = blockIdx.y * rows_per_block;
-    int r1 = r0 + rows_per_block;
-    r1 = r1 < M ? r1 : M;
+                                                     float* __restrict__ out) {
+    __shared__ float part[32][65];
+    const int ct = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int col = blockIdx.x * 64 + ct * 8;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = r0; r < r1; ++r) {
-        const bf16x8 v = *(const bf16x8*)(X + (size_t)r * ld + col);
+    if (col < N) {
+        for (int r = rl; r < M; r += 32) {
+            const bf16x8 v = *(const bf16x8*)(X + (size_t)r * ld + col);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+            for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+        }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + col + e, s[e]);
+    for (int e = 0; e < 8; ++e) part[rl][ct * 8 + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < N) {
+        float t = 0.f;
+        for (int r = 0; r < 32; ++r) t += part[r][threadIdx.x];
+        out[blockIdx.x * 64 + threadIdx.x] += t;
+    }
 }
 
 extern "C" int tvts_colsum_bf16(const void* X, int ld, int M, int N, float* out, hipStream_t stream) {
     if (M <= 0 || N <= 0 || N % 8 || ld % 8) return TVTS_EINVAL;
-    const int rows_per_block = 64;
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 2048), ceil_div(M, rows_per_block)), dim3(256), 0, stream,
-                       (const bf16*)X, ld, M, N, out, rows_per_block);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, stream, (const bf16*)X, ld, M, N, out);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

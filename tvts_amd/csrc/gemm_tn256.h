@@ -247,8 +247,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmTN g) {
         cs1 += __shfl_xor(cs1, 16, 64); cs1 += __shfl_xor(cs1, 32, 64);
         if (lane < 16) {
             const int a = a0 + wa * 128 + 2 * wb * 16 + lane;
-            if (a < g.Na) atomicAdd(g.colsum + a, cs0);
-            if (a + 16 < g.Na) atomicAdd(g.colsum + a + 16, cs1);
+            if (a < g.Na) tn_colsum_out(g, split, a, cs0);
+            if (a + 16 < g.Na) tn_colsum_out(g, split, a + 16, cs1);
         }
     }
     // acc[i][j]: lane holds a = a-tile i column (lane & 15), b = b-tile j rows (lane >> 4) * 4 .. + 3 -> one 16-B fp32 access

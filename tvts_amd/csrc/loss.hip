@@ -85,50 +85,71 @@ __global__ __launch_bounds__(256) void infonce_col_lse_kernel(const float* __res
         lse[G + col] = mm + __logf(tot);
     }
 }
-// loss += -(1/G) sum_i [(x_ii - rowlse_i) + (x_ii - collse_i)];  dx_ij = (e^{x_ij-rowlse_i} + e^{x_ij-collse_j} - 2 d_ij)/G
+// dx_ij = (e^{x_ij-rowlse_i} + e^{x_ij-collse_j} - 2 d_ij)/G
 __global__ __launch_bounds__(256) void infonce_grad_kernel(const float* __restrict__ x, const float* __restrict__ lse, int G,
-                                                           float* __restrict__ dx, float* __restrict__ loss) {
+                                                           float* __restrict__ dx) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)G * G) return;
     const int i = (int)(idx / G), j = (int)(idx % G);
     const float v = x[idx];
     float d = __expf(v - lse[i]) + __expf(v - lse[G + j]);
-    if (i == j) {
-        d -= 2.f;
-        atomicAdd(loss, -(2.f * v - lse[i] - lse[G + j]) / (float)G);
-    }
-    if (dx) dx[idx] = d / (float)G;
+    if (i == j) d -= 2.f;
+    dx[idx] = d / (float)G;
+}
+// A block's 256 partial sums -> one value, always in the same order (lane butterfly, then the four waves left to right): the
+// loss scalars are run-to-run reproducible (they were fp32 atomics up to round 2).
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+}
+// loss += -(1/G) sum_i [(x_ii - rowlse_i) + (x_ii - collse_i)]: ONE block, thread t takes i = t, t + 256, ... in order
+__global__ __launch_bounds__(256) void infonce_loss_kernel(const float* __restrict__ x, const float* __restrict__ lse, int G,
+                                                           float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < G; i += 256) s += 2.f * x[(size_t)i * G + i] - lse[i] - lse[G + i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) loss[0] += -s / (float)G;
 }
 extern "C" int tvts_infonce(const float* x, int G, float* lse, float* dx, float* loss, hipStream_t stream) {
     if (G <= 0) return TVTS_EINVAL;
     hipLaunchKernelGGL(infonce_row_lse_kernel, dim3(ceil_div(G, 4)), dim3(256), 0, stream, x, G, lse);
     hipLaunchKernelGGL(infonce_col_lse_kernel, dim3(ceil_div(G, 64)), dim3(256), 0, stream, x, G, lse);
-    hipLaunchKernelGGL(infonce_grad_kernel, dim3((unsigned)(((long)G * G + 255) / 256)), dim3(256), 0, stream, x, lse, G, dx,
-                       loss);
+    if (dx)
+        hipLaunchKernelGGL(infonce_grad_kernel, dim3((unsigned)(((long)G * G + 255) / 256)), dim3(256), 0, stream, x, lse, G, dx);
+    hipLaunchKernelGGL(infonce_loss_kernel, dim3(1), dim3(256), 0, stream, x, lse, G, loss);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
 
-// loss += scale * mean_r (lse_r - x[r,label_r]);  dlogits = scale * (softmax - onehot) / R
-__global__ void ce_kernel(const float* __restrict__ logits, const int* __restrict__ labels, int R, int C, float scale,
-                          float* __restrict__ dlogits, float* __restrict__ loss) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    const float* p = logits + (size_t)r * C;
-    float m = -INFINITY;
-    for (int c = 0; c < C; ++c) m = fmaxf(m, p[c]);
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s += __expf(p[c] - m);
-    const float lse = m + __logf(s);
-    const int lb = labels[r];
-    atomicAdd(loss, scale * (lse - p[lb]) / (float)R);
-    if (dlogits)
-        for (int c = 0; c < C; ++c) dlogits[(size_t)r * C + c] = scale * (__expf(p[c] - lse) - (c == lb ? 1.f : 0.f)) / (float)R;
+// loss += scale * mean_r (lse_r - x[r,label_r]);  dlogits = scale * (softmax - onehot) / R.  ONE block walks the rows (R = B * NT,
+// a few thousand at most, C = 4) so that the loss sum has a fixed order.
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int* __restrict__ labels, int R, int C,
+                                                 float scale, float* __restrict__ dlogits, float* __restrict__ loss) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const float* p = logits + (size_t)r * C;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, p[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += __expf(p[c] - m);
+        const float lse = m + __logf(s);
+        const int lb = labels[r];
+        acc += lse - p[lb];
+        if (dlogits)
+            for (int c = 0; c < C; ++c)
+                dlogits[(size_t)r * C + c] = scale * (__expf(p[c] - lse) - (c == lb ? 1.f : 0.f)) / (float)R;
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) loss[0] += scale * acc / (float)R;
 }
 extern "C" int tvts_cross_entropy(const float* logits, const int* labels, int R, int C, float scale, float* dlogits,
                                   float* loss, hipStream_t stream) {
     if (R <= 0 || C <= 0) return TVTS_EINVAL;
-    hipLaunchKernelGGL(ce_kernel, dim3(ceil_div(R, 64)), dim3(64), 0, stream, logits, labels, R, C, scale, dlogits, loss);
+    hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, stream, logits, labels, R, C, scale, dlogits, loss);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

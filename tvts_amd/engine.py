@@ -333,15 +333,16 @@ class Engine:
         self._ln_bwd(dln, x_in, pre + nm["ln1"], tag + ".ln1", dx_in, dx_bf16=dxb_in, res1=dmid)
 
     # ------------------------------------------------------------------ text tower
-    def _eot_index(self, eot_rows, L):
-        """(int64 copy of the EOT rows, int32 position of the EOT token inside its caption): made once per eot_rows tensor (plumbing)"""
-        c = getattr(self, "_eot_cache", None)
-        if c is None or c[0] is not eot_rows or c[1] != L:
-            pos = (eot_rows - torch.arange(eot_rows.numel(), device=eot_rows.device, dtype=torch.int32) * L).contiguous()
-            c = self._eot_cache = (eot_rows, L, eot_rows.long(), pos)
-        return c[2], c[3]
+    @staticmethod
+    def eot_index(eot_rows, L):
+        """(int64 copy of the EOT rows, int32 position of the EOT token inside its caption).  prepare_batch makes them once and
+        keeps them in the batch dict, so that their lifetime is the batch's -- and that of a hipGraph captured over it (an
+        identity-keyed cache on the engine handed a captured graph tensors that the next capture freed)."""
+        pos = (eot_rows - torch.arange(eot_rows.numel(), device=eot_rows.device, dtype=torch.int32) * L).contiguous()
+        return eot_rows.long(), pos
 
-    def text_forward(self, ids_dev, eot_rows, N, L):
+    def text_forward(self, ids_dev, eot_rows, N, L, eot_index=None):
+        """eot_index: Engine.eot_index(eot_rows, L) kept by the caller (prepare_batch); made here when absent (eager use only)."""
         a = self.arch
         Wt, M = a["text_width"], N * L
         x = self._f("txt.x0", (M, Wt))
@@ -352,7 +353,7 @@ class Engine:
             if l == last and self.text_used_rows_only:
                 # the model reads the last block's output at the EOT token of every caption only (CLIP/clip/model.py:343-354)
                 ht, hd = a["text_heads"], Wt // a["text_heads"]
-                rows64, pos = self._eot_index(eot_rows, L)
+                rows64, pos = self._text_eot = eot_index if eot_index is not None else self.eot_index(eot_rows, L)
                 xr = self._used_rows_fwd(f"text_model.resblocks.{l}.", _TEXT_NAMES, x, f"txt{l}", M, Wt, ht, rows64, a["act"], 1e-5,
                                          lambda qkv, att, lse: K.attn_fwd_rowq(qkv, pos, att, lse, B=N, heads=ht, S=L, head_dim=hd))
                 self._ln(xr, "text_ln_final", 1e-5, lnf, "txt.lnf")
@@ -389,7 +390,7 @@ class Engine:
             dxbi = self._b("txt.dxb" + nx, (M, Wt))
             if pruned and l == a["text_layers"] - 1:
                 ht, hd = a["text_heads"], Wt // a["text_heads"]
-                rows64, pos = self._eot_index(eot_rows, L)
+                rows64, pos = self._text_eot  # the forward's tensors (the batch's when it came through prepare_batch)
                 self._used_rows_bwd(f"text_model.resblocks.{l}.", _TEXT_NAMES, self.buf[f"txt.x{l}"], dx, dxb, dxi, dxbi, f"txt{l}",
                                     "txt.s", M, Wt, ht, rows64, a["act"],
                                     lambda qkv, datt, att, lse, delta, dqkv: K.attn_bwd_rowq(
@@ -414,7 +415,8 @@ class Engine:
         M = B * S
         delta = self._f(scr + ".delta", (M, h))
         hd = self.dh
-        cls_acc = self._f(scr + ".clsacc", (B, h, 3, hd))
+        # one partial of the CLS token's dK / dV / dQ per block of the fused kernels, added in order (no atomics)
+        cls_acc = self._f(scr + ".clsacc", (B, h, max(T, -(-n // 28)), 3, hd))
         K.attn_bwd(mode, qkv, datt, att, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, cls_acc=cls_acc, head_dim=hd)
 
     def video_forward(self, video, keep_dev, B, T, vid_rows=None):
@@ -751,7 +753,8 @@ class Engine:
         So = Sv + NT
         sort_rows = (torch.arange(B)[:, None] * So + Sv + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev)
         vid_rows = (torch.arange(B) * S).to(torch.int32).to(self.dev)
-        return dict(video=video, crop=crop, resize=resize, ids=ids_dev, eot_rows=eot_rows, keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
+        return dict(video=video, crop=crop, resize=resize, ids=ids_dev, eot_rows=eot_rows, eot_index=self.eot_index(eot_rows, L),
+                    keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
                     sort_rows=sort_rows, sort_rows64=sort_rows.long(), vid_rows=vid_rows)
 
     def forward(self, pb: dict):
@@ -759,7 +762,7 @@ class Engine:
         a = self.arch
         self.ctx = pb
         B, T, N, NT, L, S, E = pb["B"], pb["T"], pb["N"], pb["NT"], pb["L"], pb["S"], a["embed"]
-        t = self.text_forward(pb["ids"], pb["eot_rows"], N, L)
+        t = self.text_forward(pb["ids"], pb["eot_rows"], N, L, eot_index=pb.get("eot_index"))
         text_emb = self._f("mdl.text_emb", (B, E))
         text_before = self._f("mdl.text_before", (B, NT, E))
         K.text_mean(t, text_emb, text_before, NT=NT, B=B)

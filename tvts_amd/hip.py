@@ -339,7 +339,8 @@ def attn_bwd(mode, qkv, dO, O, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, caus
     """Whole backward of one attention site into dqkv (delta / cls_acc are scratch)."""
     lib = _lib.load()
     rc = _attn_fn(lib, "bwd", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO), _p(O),
-                                        _ld(O), _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc), _stream())
+                                        _ld(O), _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc),
+                                        cls_acc.numel() if cls_acc is not None else 0, _stream())
     _chk(rc, "tvts_attn_bwd")
 
 
