@@ -5,6 +5,11 @@
  * ctypes binding a maintainer adds.  Conventions: raw device pointers, explicit sizes / leading
  * dimensions in ELEMENTS, asynchronous on `stream`, no allocation inside, re-entrant, return 0 or a
  * hipError_t (> 0) / -22 for an invalid argument.  bf16 = 16-bit brain float, row-major everywhere.
+ *
+ * The library keeps NO mutable process state: entry points are called from the main thread, from PyTorch's autograd worker
+ * thread and from communication hooks.  Where a kernel family has alternative dispatch paths (tile sizes, split
+ * counts, fused / split passes) the entry point takes a per-call `opts` word -- 0 is the automatic choice the training step
+ * uses, the TVTS_*  bits below select the alternatives for parity tests and benches (tests/test_abi.py::test_two_threads).
  */
 #ifndef TVTS_HIP_H
 #define TVTS_HIP_H
@@ -15,52 +20,62 @@ extern "C" {
 
 enum { TVTS_ACT_NONE = 0, TVTS_ACT_QUICK_GELU = 1, TVTS_ACT_GELU_ERF = 2 };
 enum { TVTS_ATTN_FULL = 0, TVTS_ATTN_SPACE = 1, TVTS_ATTN_TIME = 2, TVTS_ATTN_CLS = 3 };
+/* `opts` of the GEMM entry points (OR them; 0 = automatic) */
+enum {
+    TVTS_GEMM_TILE_128 = 1,     /* force the persistent 128x128 kernel */
+    TVTS_GEMM_TILE_256 = 2,     /* force the pipelined 256x256 kernel (-22 if the shape cannot take it) */
+    TVTS_GEMM_FP8_K32 = 4,      /* tvts_gemm_nt_fp8*: the 16x16x32 fp8 MFMA main loop (bf16 issue rate) instead of the K = 128 scaled
+                                   MFMA; both accumulate the same products in fp32 */
+    TVTS_TN_NO_EARLY_DMA = 4,   /* tvts_gemm_tn_bf16: LDS-DMA through the builtin path (the one operands past 4 GiB take) */
+    TVTS_TN_AFAST_0 = 8,        /* tvts_gemm_tn_bf16: tile walk of an m-range, b-dimension fastest ... */
+    TVTS_TN_AFAST_1 = 16        /* ... or a-dimension fastest (default: the shorter one) */
+};
+/* persistent grid of the 256x256 NT kernels (bf16 and fp8): at most n blocks, one per CU (8 .. 256, multiple of 8; 0 = the whole
+ * chip) -- leaves CUs to kernels of other streams (the RCCL kernels of the side stream when world > 1), and a measurement
+ * hook (tools/gemm_cus.py) */
+#define TVTS_GEMM_CUS(n) ((((n) / 8) & 63) << 8)
+/* tvts_gemm_tn_bf16: number of contraction ranges (0 = automatic: the smallest count that fills >= 93 % of a round) */
+#define TVTS_TN_SPLITS(s) ((s) << 8)
+/* `opts` of the attention entry points */
+enum {
+    TVTS_ATTN_NO_TR = 1,        /* scalar LDS reads instead of ds_read_b64_tr_b16 fragments */
+    TVTS_ATTN_NO_SHARED = 2,    /* per-wave instead of block-shared K / V (Q / dO) staging */
+    TVTS_ATTN_NO_FUSED = 4      /* the split passes instead of the fused single-launch kernels */
+    /* bits 4..6 (tvts_attn_bwd only): timing ablations of the fused backward, results wrong by construction */
+};
 
 /* ---- GEMM (gemm.hip).  nn.Linear forward / dgrad: v2/model/video_encoder_ViT_B_16.py:26-27,41,74,105-109;
  *      v2/CLIP/clip/model.py:175-181; v2/model/sort_transformer.py:21-23,41-42.  K % 64 == 0, N % 4 == 0.
  *      out = [gate'(gate_h) *] act(A.B^T + bias) [+ residual]; preact (bf16) receives A.B^T + bias when act != 0. */
 int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                       const float* residual, int ldr, int act, void* preact, int ldp, const void* gate_h, int ldh,
-                      int gate_act, void* out, int ldc, int out_f32, hipStream_t stream);
-/* tile selection override for benches and tests: 0 auto, 128 (persistent 128x128 kernel), 256 (pipelined 256x256 kernel) */
-void tvts_gemm_set_nt_tile(int t);
-/* persistent grid of the 256x256 kernels (bf16 and fp8): at most n blocks, one per CU (8 .. 256, multiple of 8; default 256 = the
- * whole chip) -- leaves CUs to kernels of other streams, and a measurement hook (tools/gemm_cus.py) */
-void tvts_gemm_set_nt_cus(int n);
-/* the output tile (128 or 256) tvts_gemm_nt_bf16 picks for an [M, N] result under the current override: lets a parity
- * test assert that the kernel it means to exercise is the one that ran */
-int tvts_gemm_nt_select(int M, int N);
+                      int gate_act, void* out, int ldc, int out_f32, int opts, hipStream_t stream);
+/* the output tile (128 or 256) tvts_gemm_nt_bf16 picks for an [M, N] result under `opts`: lets a parity test assert that the
+ * kernel it means to exercise is the one that ran */
+int tvts_gemm_nt_select(int M, int N, int opts);
 /* weight gradient: out[Na,Nb] (+)= P[M,Na]^T . Q[M,Nb], bf16 in, fp32 out (autograd of the Linear sites above) */
 /* colsum (optional): colsum[a] += sum_m P[m,a] -- the bias gradient, fused into the same pass.
  * workspace (optional, workspace_elems floats): scratch for the split-M partials; with it the kernel stores
  * partials and a reduce pass combines them (deterministic), without it the partials meet through fp32 atomics. */
 int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb, float* out, int ldo,
-                      int accumulate, float* colsum, float* workspace, long workspace_elems, hipStream_t stream);
-/* test hook: force the weight-gradient kernel's LDS-DMA issue path (early_dma 0 = builtin path, the one operands past 4 GiB
- * take) and its tile walk (a_fast 0 / 1); -1 = automatic */
-void tvts_gemm_set_tn_mode(int early_dma, int a_fast);
-/* bench hook: number of contraction ranges of the weight-gradient kernel (0 = automatic: the smallest count that fills >= 93 % of a round) */
-void tvts_gemm_set_tn_splits(int splits);
-/* weight-gradient tile override for benches and tests: 0 auto, 128 (128x128 kernel, two blocks per CU), 256 (pipelined 256x256
- * kernel); tvts_gemm_tn_select returns the tile tvts_gemm_tn_bf16 picks for M rows into an [Na, Nb] output under the current
- * override */
-void tvts_gemm_set_tn_tile(int t);
-int tvts_gemm_tn_select(int M, int Na, int Nb);
+                      int accumulate, float* colsum, float* workspace, long workspace_elems, int opts, hipStream_t stream);
+/* the tile (128: 128x128 kernel, two blocks per CU; 256: pipelined 256x256 kernel) tvts_gemm_tn_bf16 picks for M rows into an
+ * [Na, Nb] output under `opts` */
+int tvts_gemm_tn_select(int M, int Na, int Nb, int opts);
 /* fp8 (OCP e4m3) operands with scales in device memory, fp32 accumulate: the GEMM of BASELINE config 4's weight / activation
  * path (nn.Linear sites of video_encoder_ViT_H_14.py); K % 128 == 0, lda / ldb % 16 == 0 (bytes).  scale_b: one scale for the
  * weight; scale_a: one scale for the tensor, or (scale_a_rows != 0) M per-row scales as written by tvts_quant_fp8_rows */
 int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
                      int scale_a_rows, const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact, int ldp,
-                     void* out, int ldc, int out_f32, hipStream_t stream);
+                     void* out, int ldc, int out_f32, int opts, hipStream_t stream);
 /* input gradient of such a layer (autograd of nn.Linear + the GELU of video_encoder_ViT_H_14.py's Mlp): out[M,N] (bf16) =
  * gate_act'(gate_h[M,N]) * (scale_a[m] * scale_b * (A[M,K] B[N,K]^T)), A = e4m3 copy of the output gradient (per-token scales),
  * B = e4m3 copy of the transposed weight; the un-gated input gradients take tvts_gemm_nt_fp8 itself */
 int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
                           int scale_a_rows, const float* scale_b, const void* gate_h, int ldh, int gate_act, void* out, int ldc,
-                          hipStream_t stream);
-/* main loop of tvts_gemm_nt_fp8: 1 (default) v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (the fp8 issue rate of gfx950),
- * 0 the 16x16x32 fp8 form (bf16 issue rate); both accumulate the same products in fp32 -- for benches and parity tests */
-void tvts_gemm_set_fp8_mx(int on);
+                          int opts, hipStream_t stream);
+/* (main loop of tvts_gemm_nt_fp8*: v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales, the fp8 issue rate of gfx950;
+ * TVTS_GEMM_FP8_K32 selects the 16x16x32 fp8 form) */
 /* per-tensor fp8 quantisation: amax[0] = max |x| ; q = rne(x * 448 / amax) as e4m3, scale_out[0] = amax / 448 */
 int tvts_amax(const void* x, int is_f32, long ld, int rows, int cols, float* amax, hipStream_t stream);
 int tvts_quant_fp8(const void* x, int is_f32, long ld, int rows, int cols, const float* amax, void* out, long ldo,
@@ -106,17 +121,15 @@ int tvts_layernorm_bwd_fp8(const void* dy, int lddy, const void* x, int ldx, int
  *      divided space-time attention video_encoder_ViT_B_16.py:11-15,38-76; causal text attention
  *      CLIP/clip/model.py:185-187,330-336; sort-head attention sort_transformer.py:45-53 */
 int tvts_attn_fwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, void* out, int ldo,
-                  float* lse2, hipStream_t stream);
+                  float* lse2, int opts, hipStream_t stream);
 int tvts_attn_delta(const void* dO, int lddo, const void* O, int ldo, int rows, int heads, float* delta,
                     hipStream_t stream);
 int tvts_attn_bwd_dq(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
-                     int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, hipStream_t stream);
+                     int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, int opts, hipStream_t stream);
 int tvts_attn_bwd_dkv(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
-                      int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, float* cls_acc,
+                      int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, float* cls_acc, int opts,
                       hipStream_t stream);
 int tvts_attn_cls_finalize(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq, hipStream_t stream);
-void tvts_attn_set_transpose_read(int on);
-void tvts_attn_set_shared(int on);
 /* whole backward of one attention site (D = rowsum(dO*O), dQ, dK, dV, CLS query + CLS key/value reduction of the divided
  * geometries) = the autograd of VarAttention.forward video_encoder_ViT_B_16.py:38-76; delta [rows, heads] and
  * cls_acc (cls_acc_elems fp32 elements) are scratch.  SPACE groups of <= 112 tokens run as ONE fused launch.  cls_acc holds the
@@ -125,12 +138,11 @@ void tvts_attn_set_shared(int on);
  * minimum) the shares are accumulated with fp32 atomics. */
 int tvts_attn_bwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
               int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float* cls_acc,
-              long cls_acc_elems, hipStream_t stream);
-void tvts_attn_set_fused(int on);
+              long cls_acc_elems, int opts, hipStream_t stream);
 /* forward of one divided-attention site including the CLS row (VarAttention.forward video_encoder_ViT_B_16.py:38-76);
  * cls_ws: fp32 scratch of >= B * heads * max(T, ceil(n / 28)) * (dh + 2) elements (partial softmax states of the CLS query) */
 int tvts_attn_fwd_divided(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
-                      float* lse2, float* cls_ws, long cls_ws_elems, hipStream_t stream);
+                      float* lse2, float* cls_ws, long cls_ws_elems, int opts, hipStream_t stream);
 
 /* the same entry points for head dim 80 (ViT-H/14, 1280 / 16 heads); qkv is [rows, 3*heads*80] */
 /* FULL attention over sequences padded to S with the padded keys masked: keys at positions >= kv_len[b] (device int32[B]) get
@@ -170,17 +182,15 @@ int tvts_attn80_fwd_len(const void* qkv, int ld, int B, int heads, int S, const 
 int tvts_attn80_bwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,
                         const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream);
 int tvts_attn80_fwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, void* out, int ldo,
-                  float* lse2, hipStream_t stream);
+                  float* lse2, int opts, hipStream_t stream);
 int tvts_attn80_delta(const void* dO, int lddo, const void* O, int ldo, int rows, int heads, float* delta,
                     hipStream_t stream);
 int tvts_attn80_bwd_dq(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
-                     int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, hipStream_t stream);
+                     int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, int opts, hipStream_t stream);
 int tvts_attn80_bwd_dkv(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
-                      int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, float* cls_acc,
+                      int lddo, const float* lse2, const float* delta, void* dqkv, int lddq, float* cls_acc, int opts,
                       hipStream_t stream);
 int tvts_attn80_cls_finalize(const float* cls_acc, int B, int heads, int S, void* dqkv, int lddq, hipStream_t stream);
-void tvts_attn80_set_transpose_read(int on);
-void tvts_attn80_set_shared(int on);
 /* whole backward of one attention site (D = rowsum(dO*O), dQ, dK, dV, CLS query + CLS key/value reduction of the divided
  * geometries) = the autograd of VarAttention.forward video_encoder_ViT_B_16.py:38-76; delta [rows, heads] and
  * cls_acc (cls_acc_elems fp32 elements) are scratch.  SPACE groups of <= 112 tokens run as ONE fused launch.  cls_acc holds the
@@ -189,12 +199,11 @@ void tvts_attn80_set_shared(int on);
  * minimum) the shares are accumulated with fp32 atomics. */
 int tvts_attn80_bwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
               int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float* cls_acc,
-              long cls_acc_elems, hipStream_t stream);
-void tvts_attn80_set_fused(int on);
+              long cls_acc_elems, int opts, hipStream_t stream);
 /* forward of one divided-attention site including the CLS row (VarAttention.forward video_encoder_ViT_B_16.py:38-76);
  * cls_ws: fp32 scratch of >= B * heads * max(T, ceil(n / 28)) * (dh + 2) elements (partial softmax states of the CLS query) */
 int tvts_attn80_fwd_divided(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
-                      float* lse2, float* cls_ws, long cls_ws_elems, hipStream_t stream);
+                      float* lse2, float* cls_ws, long cls_ws_elems, int opts, hipStream_t stream);
 
 /* ---- token assembly (embed.hip): video_encoder_ViT_B_16.py:176-216; model_dist..B_16.py:69-76,98-100;
  *      sort_transformer.py:124-128 */
@@ -219,8 +228,12 @@ int tvts_tube_mask(long seed, long first_sample, int B, int ppf, int n_keep, int
 /* keep_per_frame 0: keep[B, n], one tube mask for all frames of a clip (v2); 1: keep[B, T, n], one per frame / tubelet (v1) */
 int tvts_vit_assemble(const float* patch, int ldp, const float* cls, const float* pos, const float* temporal,
                       const int* keep, int keep_per_frame, int B, int T, int n, int W, float* tok, int ldt, hipStream_t stream);
+/* workspace (optional, fp32 scratch): with >= B * ceil(n / 14) * T * W + B * W elements (tube masks) the temporal-embedding and
+ * class-embedding sums are ordered per-block partials (run-to-run reproducible); the positional-embedding ROWS stay a scatter of
+ * fp32 atomics -- an embedding-table gradient, as in the reference's nn.Embedding backward */
 int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int keep_per_frame, int B, int T, int n, int W,
-                          void* dpatch, int ldp, float* dcls, float* dpos, float* dtemporal, hipStream_t stream);
+                          void* dpatch, int ldp, float* dcls, float* dpos, float* dtemporal, float* workspace,
+                          long workspace_elems, hipStream_t stream);
 /* v1 (TVTS) Conv3d tubelet embedding as im2col over the kept patches of every tube (v1/model/video_encoder.py:78-99,199-206):
  * video fp32 [B, tubes * tubelet, 3, img, img], keep int32 [B, tubes, n] -> bf16 rows [B * tubes * n, 3 * tubelet * patch^2]
  * in the Conv3d weight's (c, t, py, px) column order; patch % 8 == 0 */
@@ -234,8 +247,9 @@ int tvts_text_mean(const float* t, int NT, int B, int E, float* mean, float* bef
 int tvts_text_mean_bwd(const float* dmean, int NT, int B, int E, float* dt, hipStream_t stream);
 int tvts_sort_assemble(const float* tok, int ldt, int B, int S, int off, int Sv, const float* text, int NT,
                        const float* type, int E, float* xs, int ldx, hipStream_t stream);
+/* workspace (optional, >= B * (ceil(S / 32) + 1) * E fp32 elements): the type-embedding gradient as ordered partials (no atomics) */
 int tvts_sort_assemble_bwd(const float* dxs, int ldx, int B, int S, int off, int Sv, int NT, const float* dvid, int E,
-                           void* dout, int ldo, float* dtype, hipStream_t stream);
+                           void* dout, int ldo, float* dtype, float* workspace, long workspace_elems, hipStream_t stream);
 /* out = relu(x) (dy NULL) or out = dy * (x > 0) (its backward): the nn.ReLU of v1's txt_proj (v1/model/model_dist_TVTS.py:65-68) */
 int tvts_relu(const float* x, const float* dy, float* out, long n, hipStream_t stream);
 int tvts_rows_gather(const float* src, int ld_src, const int* rows, int R, int W, float* dst, int ld_dst, int scatter_add,

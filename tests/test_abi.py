@@ -24,6 +24,25 @@ def test_library_exports_every_declared_symbol():
     _lib.load()  # binds argtypes; raises on any mismatch between header and library
 
 
+def test_kernel_library_has_no_process_global_switches():
+    """the entry points are re-entrant (autograd worker thread + communication hooks).  Dispatch alternatives are
+    per-call `opts` words; neither the header nor the built library offers a setter."""
+    import subprocess
+    protos = _lib.parse_header()
+    assert not [n for n in protos if "_set_" in n]
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = [ln.split()[-1] for ln in syms.splitlines() if ln.strip()]
+    assert not [n for n in exported if n.startswith("tvts_") and "_set_" in n]
+    # no host-side variable in .data / .bss: what is left there are the kernel launch stubs, the HIP fat-binary registration and
+    # the C runtime's own init / fini flags
+    host_state = [ln for ln in subprocess.run(["nm", "-C", _lib.LIB_PATH], capture_output=True, text=True).stdout.splitlines()
+                  if len(ln.split()) >= 3 and ln.split()[1] in ("b", "B", "d", "D") and "(" not in ln and
+                  not any(t in ln for t in ("__hip", "__dso_handle", "_DYNAMIC", "_GLOBAL_OFFSET_TABLE_", "__do_init", "__do_fini",
+                                            "__fini", "__init", "__TMC_END__", "completed", "_edata", "__bss_start", "_end",
+                                            "__data_start"))]
+    assert not host_state, host_state
+
+
 def test_comm_library_exports_every_declared_symbol():
     protos = _lib.parse_header(_lib.COMM_HEADER_PATH)
     assert set(protos) == {"tvts_comm_unique_id", "tvts_comm_create", "tvts_comm_destroy", "tvts_comm_world",

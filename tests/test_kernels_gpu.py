@@ -126,13 +126,10 @@ def test_gemm_tn_256_tile(K, M, Na, Nb):
     """The pipelined 256x256 weight-gradient kernel (forced; the dispatcher picks it for M >= 32768 and >= 1.5 M outputs): whole
     and ragged tiles, m-ranges that end inside a stage, the fused bias gradient, workspace and fp32-atomic partials, and bit
     equality of the workspace path with itself across two launches (deterministic reduce)."""
-    from tvts_amd import _lib
-    lib = _lib.load()
     p, q = bf(rnd(M, Na, seed=19)), bf(rnd(M, Nb, seed=20))
     ref = p.float().t().double() @ q.float().double()
-    try:
-        lib.tvts_gemm_set_tn_tile(256)
-        assert lib.tvts_gemm_tn_select(M, Na, Nb) == 256
+    with K.options(tn_tile=256):
+        assert K.gemm_tn_select(M, Na, Nb) == 256
         out = torch.full((Na, Nb), float("nan"), dtype=torch.float32, device=DEV)
         K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=False)
         assert rel(out, ref) < 3e-5, rel(out, ref)
@@ -153,19 +150,16 @@ def test_gemm_tn_256_tile(K, M, Na, Nb):
         assert rel(out, 3 * ref) < 3e-5
         K.gemm_tn(p.to(DEV), q.to(DEV), out, accumulate=False, workspace=False)
         assert rel(out, ref) < 3e-5
-    finally:
-        lib.tvts_gemm_set_tn_tile(0)
 
 
 def test_gemm_tn_tile_selection(K):
     """The ViT blocks' weight gradients take the 256x256 kernel, the text tower and small outputs the 128x128 one."""
-    from tvts_amd import _lib
-    lib = _lib.load()
     M = 192 * 785
-    assert lib.tvts_gemm_tn_select(M, 2304, 768) == 256 and lib.tvts_gemm_tn_select(M, 768, 3072) == 256
-    assert lib.tvts_gemm_tn_select(M, 768, 768) == 256 and lib.tvts_gemm_tn_select(24576, 2048, 512) == 128
-    assert lib.tvts_gemm_tn_select(M, 512, 512) == 128
-    assert lib.tvts_gemm_tn_select(12 * 785, 2304, 768) == 128
+    assert K.gemm_tn_select(M, 2304, 768) == 256 and K.gemm_tn_select(M, 768, 3072) == 256
+    assert K.gemm_tn_select(M, 768, 768) == 256 and K.gemm_tn_select(24576, 2048, 512) == 128
+    assert K.gemm_tn_select(M, 512, 512) == 128
+    assert K.gemm_tn_select(12 * 785, 2304, 768) == 128
+    assert K.gemm_tn_select(12 * 785, 2304, 768, tile=256) == 256 and K.gemm_tn_select(M, 2304, 768, tile=128) == 128
 
 
 def test_gemm_tn_views(K):
@@ -281,8 +275,7 @@ def _ref_divided(qkv, heads, mode, T, n, dO):
                                               ("time", 1, 4, 12, 3), ("space", 2, 1, 8, 49), ("time", 1, 2, 16, 4),
                                               ("space", 1, 2, 2, 76)])
 def test_divided_attention(K, mode, B, heads, T, n, tr, dh):
-    K.attn_set_transpose_read(tr)
-    try:
+    with K.options(attn_tr=tr):
         S, W = 1 + T * n, heads * dh
         qkv = bf(rnd(B, S, 3 * W, seed=25))
         dO = bf(rnd(B, S, W, seed=26))
@@ -308,8 +301,6 @@ def test_divided_attention(K, mode, B, heads, T, n, tr, dh):
             assert rel(got[..., sl], ref_dqkv[..., sl]) < 2e-2, (nm, rel(got[..., sl], ref_dqkv[..., sl]))
             # CLS rows separately: they are the cross-group sums
             assert rel(got[:, 0, sl], ref_dqkv[:, 0, sl]) < 2e-2, (nm + "_cls", rel(got[:, 0, sl], ref_dqkv[:, 0, sl]))
-    finally:
-        K.attn_set_transpose_read(True)
 
 
 @pytest.mark.parametrize("fused", [True, False, "atomic"])
@@ -325,8 +316,7 @@ def test_attention_site_backward(K, mode, B, heads, T, n, dh, fused):
     engine passes: two calls give bit-identical outputs), fp32 atomics with the minimal scratch ("atomic")."""
     parts = 1 if fused == "atomic" else max(T, -(-n // 28))
     fused = bool(fused)
-    K.attn_set_fused(fused)
-    try:
+    with K.options(attn_fused=fused):
         S, W = 1 + T * n, heads * dh
         qkv = bf(rnd(B, S, 3 * W, seed=35))
         dO = bf(rnd(B, S, W, seed=36))
@@ -351,8 +341,6 @@ def test_attention_site_backward(K, mode, B, heads, T, n, dh, fused):
         for nm, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
             assert rel(got[..., sl], ref_dqkv[..., sl]) < 2e-2, (nm, rel(got[..., sl], ref_dqkv[..., sl]))
             assert rel(got[:, 0, sl], ref_dqkv[:, 0, sl]) < 2e-2, (nm + "_cls", rel(got[:, 0, sl], ref_dqkv[:, 0, sl]))
-    finally:
-        K.attn_set_fused(True)
 
 
 @pytest.mark.parametrize("fused", [True, False])
@@ -363,8 +351,7 @@ def test_attention_site_backward(K, mode, B, heads, T, n, dh, fused):
                                               ("time", 1, 2, 8, 98)])
 def test_attention_site_forward(K, mode, B, heads, T, n, dh, fused):
     """tvts_attn_fwd_divided: patch rows and the CLS row (merged from per-group partial softmax states) in one call."""
-    K.attn_set_fused(fused)
-    try:
+    with K.options(attn_fused=fused):
         S, W = 1 + T * n, heads * dh
         qkv = bf(rnd(B, S, 3 * W, seed=37))
         ref_out = O.divided_attention_core(qkv.float(), heads, mode, T, n)
@@ -378,13 +365,10 @@ def test_attention_site_forward(K, mode, B, heads, T, n, dh, fused):
         assert rel(got, ref_out) < 8e-3, rel(got, ref_out)
         assert rel(got[:, 0], ref_out[:, 0]) < 8e-3, rel(got[:, 0], ref_out[:, 0])
         # lse (log2 domain) against the streaming kernels
-        K.attn_set_fused(False)
         out2 = torch.empty_like(out)
         lse2 = torch.empty_like(lse)
-        K.attn_fwd_divided(mode, qd, out2, lse2, ws, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh)
+        K.attn_fwd_divided(mode, qd, out2, lse2, ws, B=B, heads=heads, S=S, T=T, n=n, head_dim=dh, fused=False)
         assert float((lse - lse2).abs().max()) < 2e-3
-    finally:
-        K.attn_set_fused(True)
 
 
 def _ref_full(qkv, heads, causal, dO):
@@ -407,8 +391,7 @@ def _ref_full(qkv, heads, causal, dO):
 @pytest.mark.parametrize("B,heads,S,causal", [(3, 2, 32, True), (2, 2, 77, True), (2, 2, 197, False), (1, 8, 789, False),
                                               (4, 1, 9, True)])
 def test_full_attention(K, B, heads, S, causal, tr, dh):
-    K.attn_set_transpose_read(tr)
-    try:
+    with K.options(attn_tr=tr):
         W = heads * dh
         qkv, dO = bf(rnd(B, S, 3 * W, seed=27)), bf(rnd(B, S, W, seed=28))
         ref_out, ref_d = _ref_full(qkv.float(), heads, causal, dO.float())
@@ -425,8 +408,6 @@ def test_full_attention(K, B, heads, S, causal, tr, dh):
         assert torch.isfinite(got).all()
         for nm, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
             assert rel(got[..., sl], ref_d[..., sl]) < 2e-2, (nm, rel(got[..., sl], ref_d[..., sl]))
-    finally:
-        K.attn_set_transpose_read(True)
 
 
 @pytest.mark.parametrize("dh", [64, 80])
@@ -449,11 +430,8 @@ def test_short_sequence_attention(K, B, heads, S, causal, dh):
         return out.float().cpu(), lse.cpu(), dqkv.float().cpu()
 
     out, lse, got = run()
-    K.attn_set_fused(False)
-    try:
+    with K.options(attn_fused=False):
         out_s, lse_s, got_s = run()
-    finally:
-        K.attn_set_fused(True)
     assert torch.isfinite(out).all() and torch.isfinite(lse).all() and torch.isfinite(got).all()
     assert rel(out, out_s) < 4e-3 and (lse - lse_s).abs().max() < 1e-3 and rel(got, got_s) < 8e-3
     if B <= 16:
@@ -798,10 +776,8 @@ def test_gemm_nt_fp8(K, M, N, K_):
 
 def test_gemm_nt_fp8_main_loops_agree_and_grid_limit(K):
     """the K = 128 scaled-MFMA main loop and the 16x16x32 fp8 loop accumulate the same e4m3 products in fp32: identical bits on a
-    shape with ragged row tiles, every epilogue form; a persistent grid limited to 64 CUs (tvts_gemm_set_nt_cus) changes nothing, for
-    the fp8 and for the bf16 256x256 kernel."""
-    from tvts_amd import _lib
-    lib = _lib.load()
+    shape with ragged row tiles, every epilogue form; a persistent grid limited to 64 CUs (TVTS_GEMM_CUS in the call's opts) changes
+    nothing, for the fp8 and for the bf16 256x256 kernel."""
     M, N, K_ = 9000, 1280, 640
     a, b = rnd(M, K_, seed=81), rnd(N, K_, seed=82) * K_ ** -0.5
     a8, rs = K.quantize_fp8_rows(a.bfloat16().to(DEV))
@@ -818,21 +794,18 @@ def test_gemm_nt_fp8_main_loops_agree_and_grid_limit(K):
         K.gemm_nt_fp8(a8, rs, b8, sb, o3, gate_h=h, gate_act="gelu")
         return o1, pre, o2, o3
 
-    try:
+    if True:
         ref = run()
-        K.gemm_set_fp8_mx(False)
-        old = run()[:3]            # the 16x16x32 loop has no gated form
-        K.gemm_set_fp8_mx(True)
+        with K.options(fp8_k32=True):
+            old = run()[:3]            # the 16x16x32 loop has no gated form
         for x, y in zip(ref[:3], old):
             assert torch.equal(x, y)
-        lib.tvts_gemm_set_nt_cus(64)
-        for x, y in zip(ref, run()):
-            assert torch.equal(x, y)
+        with K.options(nt_cus=64):
+            for x, y in zip(ref, run()):
+                assert torch.equal(x, y)
         ab, bb = a.bfloat16().to(DEV), b.bfloat16().to(DEV)
-        lib.tvts_gemm_set_nt_tile(256)
-        o64 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); K.gemm_nt(ab, bb, o64, bias=bias)
-        lib.tvts_gemm_set_nt_cus(256)
-        o256 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); K.gemm_nt(ab, bb, o256, bias=bias)
+        o64 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); K.gemm_nt(ab, bb, o64, bias=bias, tile=256, cus=64)
+        o256 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); K.gemm_nt(ab, bb, o256, bias=bias, tile=256)
         assert torch.equal(o64, o256)
         # the gated fp8 form against its definition
         ad, bd = a8.cpu().view(torch.float8_e4m3fn).float(), b8.cpu().view(torch.float8_e4m3fn).float()
@@ -840,10 +813,6 @@ def test_gemm_nt_fp8_main_loops_agree_and_grid_limit(K):
         hf = h.float().cpu().double()
         gate = 0.5 * (1 + torch.erf(hf / 2 ** 0.5)) + hf * torch.exp(-0.5 * hf * hf) / (2 * torch.pi) ** 0.5
         assert rel(ref[3].float(), z * gate) < 4e-3
-    finally:
-        K.gemm_set_fp8_mx(True)
-        lib.tvts_gemm_set_nt_cus(256)
-        lib.tvts_gemm_set_nt_tile(0)
 
 
 @pytest.mark.parametrize("W,form", [(768, "res1"), (768, "res12"), (1280, "res1"), (1280, "res12"), (1280, "xbf16"), (640, "plain"), (256, "xbf16")])
@@ -886,25 +855,19 @@ def test_layernorm_bwd_fp8_output(K, W, form):
 
 
 def test_gemm_tn_split_counts_agree(K):
-    """the weight-gradient kernel under forced contraction-range counts (tvts_gemm_set_tn_splits): every count gives the fp32 product
+    """the weight-gradient kernel under forced contraction-range counts (TVTS_TN_SPLITS in the call's opts): every count gives the fp32 product
     (different summation trees: equal within fp32 accumulation error), the column sums ride along unchanged."""
-    from tvts_amd import _lib
-    lib = _lib.load()
     M, Na, Nb = 40000, 768, 512
     p, q = bf(rnd(M, Na, seed=110)).to(DEV), bf(rnd(M, Nb, seed=111)).to(DEV)
     ref = p.float().t().double().cpu() @ q.float().double().cpu()
     outs = []
-    try:
-        for sp in (0, 1, 5, 8, 24):
-            lib.tvts_gemm_set_tn_splits(sp)
-            out = torch.zeros(Na, Nb, device=DEV)
-            cs = torch.zeros(Na, device=DEV)
-            K.gemm_tn(p, q, out, accumulate=False, colsum=cs)
-            assert rel(out, ref) < 2e-6, (sp, rel(out, ref))
-            assert rel(cs, p.float().sum(0).double().cpu()) < 1e-5, sp
-            outs.append(out)
-    finally:
-        lib.tvts_gemm_set_tn_splits(0)
+    for sp in (0, 1, 5, 8, 24):
+        out = torch.zeros(Na, Nb, device=DEV)
+        cs = torch.zeros(Na, device=DEV)
+        K.gemm_tn(p, q, out, accumulate=False, colsum=cs, splits=sp)
+        assert rel(out, ref) < 2e-6, (sp, rel(out, ref))
+        assert rel(cs, p.float().sum(0).double().cpu()) < 1e-5, sp
+        outs.append(out)
     assert rel(outs[1], outs[4]) < 2e-6
 
 
@@ -1049,22 +1012,80 @@ def test_layernorm_fwd_fp8_output(K, W, xdt):
 def test_gemm_tn_dma_paths_agree(K, M, Na, Nb):
     """The weight-gradient kernel issues its LDS-DMA from inline asm ahead of the fragment reads (32-bit offsets from a
     uniform base); operands past 4 GiB take the builtin path.  Both paths and both tile walks must give identical bits."""
-    from tvts_amd import _lib
-    lib = _lib.load()
     p, q = rnd(M, Na, seed=70).bfloat16().to(DEV), rnd(M, Nb, seed=71).bfloat16().to(DEV)
     outs = []
-    try:
-        for early, afast in ((-1, -1), (0, -1), (-1, 0), (-1, 1)):
-            lib.tvts_gemm_set_tn_mode(early, afast)
-            out = torch.full((Na, Nb), float("nan"), device=DEV)
-            cs = torch.zeros(Na, device=DEV)
-            K.gemm_tn(p, q, out, accumulate=False, colsum=cs)
-            outs.append((out, cs))
-    finally:
-        lib.tvts_gemm_set_tn_mode(-1, -1)
+    for early, afast in ((None, None), (False, None), (None, False), (None, True)):
+        out = torch.full((Na, Nb), float("nan"), device=DEV)
+        cs = torch.zeros(Na, device=DEV)
+        K.gemm_tn(p, q, out, accumulate=False, colsum=cs, early_dma=early, a_fast=afast)
+        outs.append((out, cs))
     ref = p.float().t().double() @ q.float().double()
     assert rel(outs[0][0], ref.cpu()) < 2e-5
     for o, c in outs[1:]:
         assert torch.equal(o, outs[0][0])
-        assert torch.allclose(c, outs[0][1], rtol=1e-5, atol=1e-3)   # column sums meet through fp32 atomics
+        assert torch.equal(c, outs[0][1])   # column sums: ordered per-range partials, whatever the DMA path / tile walk
     assert torch.allclose(outs[0][1].cpu(), p.float().sum(0).cpu(), rtol=1e-3, atol=2e-2)
+
+
+def test_two_threads_call_different_shapes_and_options_concurrently(K):
+    """backward kernels are launched from PyTorch's autograd worker thread (and communication hooks fire there)
+    while the main thread runs forward / optimizer.  Two host threads, each on its own stream, hammer the GEMM, LayerNorm and
+    attention entry points with DIFFERENT shapes and different per-call dispatch options (forced tiles, split counts, fused /
+    split attention) -- ctypes drops the GIL inside the calls, so the dispatch code really runs concurrently.  Every result must
+    be bit-identical to the same call made alone: the library keeps no state one caller could change under the other."""
+    import threading
+
+    def work(seed, M, N, Kd, tile, tn_tile, splits, fused, reps, streams, out):
+        try:
+            torch.cuda.set_device(0)
+            s = streams[seed]
+            with torch.cuda.stream(s):
+                g = torch.Generator(device=DEV).manual_seed(seed)
+                a = torch.randn(M, Kd, generator=g, device=DEV).bfloat16()
+                b = (torch.randn(N, Kd, generator=g, device=DEV) * Kd ** -0.5).bfloat16()
+                bias = torch.randn(N, generator=g, device=DEV)
+                B_, h, T, n = 2, 2, 3, 21 + seed
+                S, W = 1 + T * n, h * 64
+                qkv = torch.randn(B_ * S, 3 * W, generator=g, device=DEV).bfloat16()
+                dO = torch.randn(B_ * S, W, generator=g, device=DEV).bfloat16()
+                res = []
+                for _ in range(reps):
+                    o = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+                    K.gemm_nt(a, b, o, bias=bias, act="quick_gelu", preact=torch.empty_like(o), tile=tile)
+                    w = torch.zeros(N, Kd, device=DEV)
+                    cs = torch.zeros(N, device=DEV)
+                    K.gemm_tn(o, a, w, accumulate=False, colsum=cs, tile=tn_tile, splits=splits, workspace=False)
+                    att = torch.empty(B_ * S, W, dtype=torch.bfloat16, device=DEV)
+                    lse = torch.empty(B_ * S, h, device=DEV)
+                    ws = torch.empty(B_ * h * max(T, -(-n // 28)) * 66, device=DEV)
+                    K.attn_fwd_divided("space", qkv, att, lse, ws, B=B_, heads=h, S=S, T=T, n=n, fused=fused)
+                    dqkv = torch.empty_like(qkv)
+                    delta = torch.empty(B_ * S, h, device=DEV)
+                    acc = torch.empty(B_, h, T, 3, 64, device=DEV)
+                    K.attn_bwd("space", qkv, dO, att, lse, delta, dqkv, B=B_, heads=h, S=S, T=T, n=n, cls_acc=acc, fused=fused)
+                    res.append((o, w, cs, att, dqkv))
+                s.synchronize()
+            out[seed] = res
+        except Exception as e:  # surfaced by the main thread
+            out[seed] = e
+
+    # the TN calls run with splits = 1 and no workspace: the shared module-level workspace tensor of hip.gemm_tn is the caller's
+    # buffer (one per stream in a multi-stream caller), not library state
+    cfg = {0: (3000, 768, 256, 128, 128, 1, True), 1: (5000, 512, 192, 256, 256, 1, False)}
+    streams = {0: torch.cuda.Stream(), 1: torch.cuda.Stream()}
+    alone = {}
+    for sd, c in cfg.items():
+        work(sd, *c, 1, streams, alone)
+        assert not isinstance(alone[sd], Exception), alone[sd]
+    both = {}
+    th = [threading.Thread(target=work, args=(sd, *c, 20, streams, both)) for sd, c in cfg.items()]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    for sd in cfg:
+        assert not isinstance(both[sd], Exception), both[sd]
+        for r in both[sd]:
+            for x, y in zip(r, alone[sd][0]):
+                assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y)

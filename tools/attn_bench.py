@@ -32,7 +32,7 @@ def run(mode, Bn, heads, S, T=0, n=0, causal=False):
     out = torch.empty(M, W, dtype=torch.bfloat16, device=dev)
     lse, delta = torch.empty(M, heads, device=dev), torch.empty(M, heads, device=dev)
     dqkv = torch.empty(M, 3 * W, dtype=torch.bfloat16, device=dev)
-    acc = torch.zeros(Bn, heads, 3, 64, device=dev)
+    acc = torch.zeros(Bn, heads, max(T, -(-n // 28), 1), 3, 64, device=dev)
     kw = dict(B=Bn, heads=heads, S=S, T=T, n=n)
     if mode == "full":
         kw["causal"] = causal
@@ -48,23 +48,17 @@ def run(mode, Bn, heads, S, T=0, n=0, causal=False):
         ws = torch.empty(Bn * heads * max(T, -(-n // 28)) * 66, device=dev)
         tf = []
         for fused in (True, False):
-            K.attn_set_fused(fused)
-            tf.append(timeit(lambda: K.attn_fwd_divided(mode, qkv, out, lse, ws, B=Bn, heads=heads, S=S, T=T, n=n)))
-        K.attn_set_fused(True)
+            tf.append(timeit(lambda: K.attn_fwd_divided(mode, qkv, out, lse, ws, B=Bn, heads=heads, S=S, T=T, n=n, fused=fused)))
         site = f"  site-fwd fused {tf[0]:7.1f} us / split {tf[1]:7.1f} us\n"
     if mode == "full" and S <= 32:  # short sequences: wave-per-group kernels vs the streaming ones
-        K.attn_set_fused(False)
-        fs = timeit(lambda: K.attn_fwd(mode, qkv, out, lse, **kw))
-        K.attn_set_fused(True)
+        fs = timeit(lambda: K.attn_fwd(mode, qkv, out, lse, fused=False, **kw))
         site = f"  fwd fused {f:7.1f} us / streaming {fs:7.1f} us\n"
     if mode != "cls":
         extra = dict(cls_acc=acc) if mode in ("space", "time") else {}
         K.attn_fwd(mode, qkv, out, lse, **kw)
         ts = []
         for fused in (True, False):
-            K.attn_set_fused(fused)
-            ts.append(timeit(lambda: K.attn_bwd(mode, qkv, dO, out, lse, delta, dqkv, **kw, **extra)))
-        K.attn_set_fused(True)
+            ts.append(timeit(lambda: K.attn_bwd(mode, qkv, dO, out, lse, delta, dqkv, fused=fused, **kw, **extra)))
         site += f"  site-bwd fused {ts[0]:7.1f} us / split {ts[1]:7.1f} us\n"
     gb = M * 3 * W * 2 / 1e9
     print(site, end="")

@@ -17,7 +17,8 @@ a = A.ARCHS[name] if name in A.ARCHS else A.small_arch()
 oarch = O.ARCHS[name] if name in A.ARCHS else O.tiny_arch(**a)
 P = O.synth_params(oarch, seed=21)
 batch = O.synth_batch(oarch, B=4, T=8 if name in A.ARCHS else 2, seed=22, caption_len=32 if name in A.ARCHS else 9)
-_lib.load().tvts_gemm_set_nt_tile(force)
+from tvts_amd import hip as _K
+_K.set_default(nt_tile=force)
 
 
 def runner():

@@ -1,0 +1,60 @@
+"""Bit-reproducibility hunt: every epilogue form of the NT kernels, the same call repeated on the same inputs; any call whose
+output differs from the first one is reported (a race in the kernel, not fp32 reordering: each output element has one owner)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tvts_amd import hip as K  # noqa: E402
+
+dev = "cuda:0"
+TILE = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+shapes = [(3140, 768, 768), (3140, 2304, 768), (3140, 3072, 768), (3140, 768, 3072), (3140, 512, 768), (3156, 512, 512),
+          (3156, 1536, 512), (3156, 2048, 512), (3156, 512, 2048), (512, 512, 512), (512, 2048, 512), (18840, 2304, 768)]
+forms = ["bf16", "f32res", "bf16res", "act", "gate"]
+g = torch.Generator(device=dev).manual_seed(0)
+# a second stream keeps the memory system busy (as the step's other kernels do)
+noise = torch.empty(64 * 1024 * 1024, device=dev)
+for (M, N, Kd) in shapes:
+    a = torch.randn(M, Kd, generator=g, device=dev).bfloat16()
+    b = (torch.randn(N, Kd, generator=g, device=dev) * Kd ** -0.5).bfloat16()
+    bias = torch.randn(N, generator=g, device=dev)
+    res = torch.randn(M, N, generator=g, device=dev)
+    h = torch.randn(M, N, generator=g, device=dev).bfloat16()
+    for form in forms:
+        def call():
+            odt = torch.float32 if form == "f32res" else torch.bfloat16
+            out = torch.full((M, N), float("nan"), dtype=odt, device=dev)
+            pre = None
+            if form == "bf16":
+                K.gemm_nt(a, b, out, bias=bias, tile=TILE)
+            elif form in ("f32res", "bf16res"):
+                K.gemm_nt(a, b, out, bias=bias, residual=res, tile=TILE)
+            elif form == "act":
+                pre = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+                K.gemm_nt(a, b, out, bias=bias, act="quick_gelu", preact=pre, tile=TILE)
+            else:
+                K.gemm_nt(a, b, out, gate_h=h, gate_act="quick_gelu", tile=TILE)
+            return out, pre
+        ref, refp = call()
+        torch.cuda.synchronize()
+        assert torch.isfinite(ref.float()).all(), (M, N, Kd, form, "non-finite")
+        bad = 0
+        first = None
+        for i in range(REPS):
+            if i % 3 == 0:
+                noise.add_(1.0)
+            o, p = call()
+            same = torch.equal(o.view(torch.int32 if o.dtype == torch.float32 else torch.int16), ref.view(torch.int32 if o.dtype == torch.float32 else torch.int16))
+            if p is not None:
+                same = same and torch.equal(p.view(torch.int16), refp.view(torch.int16))
+            if not same:
+                bad += 1
+                if first is None:
+                    d = (o.float() - ref.float())
+                    idx = d.nonzero()
+                    first = (i, int(idx.shape[0]), idx[:4].tolist(), float(d.abs().max()))
+        print(f"tile {TILE} {M}x{N}x{Kd} {form:8s}: {bad}/{REPS} differ", first or "", flush=True)

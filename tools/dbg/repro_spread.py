@@ -17,7 +17,11 @@ a, oarch = A.ARCHS["B_16"], O.ARCHS["B_16"]
 P = O.synth_params(oarch, seed=21)
 batch = O.synth_batch(oarch, B=4, T=8, seed=22, caption_len=32)
 runs = []
-for mode in ("eager", "eager", "eager", "graph"):
+TILE = int(sys.argv[1]) if len(sys.argv) > 1 else 0   # 256: force the pipelined 256x256 NT kernel (what the test does)
+MODES = sys.argv[2].split(",") if len(sys.argv) > 2 else ("eager", "eager", "eager", "graph")
+from tvts_amd import hip as K  # noqa: E402
+K.set_default(nt_tile=TILE)
+for mode in MODES:
     m, _, l, g = T._three_steps(a, P, batch, mode)
     runs.append((mode, l, g, m.store.flat.clone()))
     print(mode, ["%.9g" % x for x in l], ["%.9g" % x for x in g], flush=True)

@@ -11,11 +11,9 @@ for (M, N) in ((64, 256), (200, 512)):
     for probe in (0, 1, 16, 63, 70):
         pp = torch.zeros(M, N, device=dev); pp[probe, :] = 1
         qq = torch.zeros(M, N, device=dev); qq[probe, :] = torch.arange(N, device=dev).float() % 64 + 1
-        lib.tvts_gemm_set_tn_tile(256)
         o2 = torch.full((N, N), float("nan"), device=dev)
-        K.gemm_tn(pp.bfloat16(), qq.bfloat16(), o2, accumulate=False)
+        K.gemm_tn(pp.bfloat16(), qq.bfloat16(), o2, accumulate=False, tile=256)
         torch.cuda.synchronize()
-        lib.tvts_gemm_set_tn_tile(0)
         exp = (torch.arange(N, device=dev).float() % 64 + 1)[None, :].expand(N, N)
         bad = ~(o2 == exp)
         n16 = (N + 15) // 16

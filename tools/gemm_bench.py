@@ -31,10 +31,10 @@ def main():
     dev = "cuda:0"
     from tvts_amd import _lib
     for tile in [int(x) for x in os.environ.get('TILES', '0,128,256').split(',')]:
-        _lib.load().tvts_gemm_set_nt_tile(tile)
         print(f"--- NT tile {tile}")
-        nt(dev)
-    _lib.load().tvts_gemm_set_nt_tile(0)
+        from tvts_amd import hip
+        with hip.options(nt_tile=tile):
+            nt(dev)
     tn(dev)
 
 

@@ -39,15 +39,11 @@ for cus in [int(c) for c in os.environ.get("CUS", "8,32,64,128,192,256").split("
     a = torch.randn(M, Kd, device=dev).bfloat16()
     b = (torch.randn(N, Kd, device=dev) * Kd ** -0.5).bfloat16()
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    lib.tvts_gemm_set_nt_tile(256)
-    lib.tvts_gemm_set_nt_cus(cus)
-    t_bf = timeit(lambda: K.gemm_nt(a, b, out))
+    t_bf = timeit(lambda: K.gemm_nt(a, b, out, tile=256, cus=cus))
     line = f"CUs {cus:3d}  M {M:6d}  bf16 {t_bf * 1e3:7.1f} us {2.0 * M * N * Kd / t_bf / 1e9 / cus:6.2f} TF/CU"
     if Kd % 128 == 0:
         a8, rs = K.quantize_fp8_rows(a)
         b8, sb = K.quantize_fp8(b)
-        t_f8 = timeit(lambda: K.gemm_nt_fp8(a8, rs, b8, sb, out))
+        t_f8 = timeit(lambda: K.gemm_nt_fp8(a8, rs, b8, sb, out, cus=cus))
         line += f" | fp8 {t_f8 * 1e3:7.1f} us {2.0 * M * N * Kd / t_f8 / 1e9 / cus:6.2f} TF/CU"
     print(line, flush=True)
-lib.tvts_gemm_set_nt_cus(256)
-lib.tvts_gemm_set_nt_tile(0)

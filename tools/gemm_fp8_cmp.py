@@ -33,8 +33,7 @@ for n, k, act in ((3840, 1280, None), (5120, 1280, "gelu"), (1280, 5120, None), 
     out = torch.empty(M, n, dtype=torch.bfloat16, device=dev)
     pre = torch.empty(M, n, dtype=torch.bfloat16, device=dev) if act else None
     def fp8(mx):
-        K.gemm_set_fp8_mx(mx)
-        K.gemm_nt_fp8(a8, rs, b8, sb, out, bias=bias, act=act, preact=pre)
+        K.gemm_nt_fp8(a8, rs, b8, sb, out, bias=bias, act=act, preact=pre, k32=not mx)
 
     fns = {"bf16": lambda: K.gemm_nt(a, b, out, bias=bias, act=act, preact=pre),
            "fp8 16x16x32": lambda: fp8(False), "fp8 mx 16x16x128": lambda: fp8(True)}

@@ -10,7 +10,7 @@ from tvts_amd import hip as K  # noqa: E402
 
 M, N, Kd = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-K.gemm_set_fp8_mx(bool(int(sys.argv[5])) if len(sys.argv) > 5 else True)
+K.set_default(fp8_k32=not (bool(int(sys.argv[5])) if len(sys.argv) > 5 else True))
 dev = "cuda:0"
 a = torch.randn(M, Kd, device=dev).bfloat16()
 b = (torch.randn(N, Kd, device=dev) * Kd ** -0.5).bfloat16()

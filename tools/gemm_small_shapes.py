@@ -17,12 +17,10 @@ for (m,n,k) in shapes:
     As=[a.clone() for _ in range(4)]; Os=[out.clone() for _ in range(4)]
     line=f"{m}x{n}x{k}:"
     for tile in (128,256):
-        _lib.load().tvts_gemm_set_nt_tile(tile)
         i=[0]
         def f():
             i[0]=(i[0]+1)%4
-            K.gemm_nt(As[i[0]], b, Os[i[0]])
+            K.gemm_nt(As[i[0]], b, Os[i[0]], tile=tile)
         ms=timeit(f)
         line+=f"  tile{tile} {ms*1e3:6.1f}us {2.0*m*n*k/ms/1e9:6.0f}TF"
     print(line, flush=True)
-_lib.load().tvts_gemm_set_nt_tile(0)

@@ -40,10 +40,9 @@ def main():
         line = f"{name:11s} {m}x{na}x{nb}:"
         ts = {128: [], 256: []}
         for tile in (128, 256):
-            lib.tvts_gemm_set_tn_tile(tile)
             out = torch.full((na, nb), float("nan"), device=dev)
             cs = torch.zeros(na, device=dev)
-            K.gemm_tn(p, q, out, accumulate=False, colsum=cs)
+            K.gemm_tn(p, q, out, accumulate=False, colsum=cs, tile=tile)
             err = float((out - ref).norm() / ref.norm())
             amax = float((out - ref).abs().max() / ref.abs().max())
             cerr = float((cs - csr).abs().max() / csr.abs().max())
@@ -53,17 +52,15 @@ def main():
         css = torch.zeros(na, device=dev)
         for _ in range(rounds):
             for tile in (128, 256):
-                lib.tvts_gemm_set_tn_tile(tile)
-                def run():
+                def run(tile=tile):
                     for (pp, qq), oo in zip(sets, outs):
-                        K.gemm_tn(pp, qq, oo, accumulate=False, colsum=css)
+                        K.gemm_tn(pp, qq, oo, accumulate=False, colsum=css, tile=tile)
                 ts[tile].append(timeit(run) / len(sets))
-        lib.tvts_gemm_set_tn_tile(0)
         for tile in (128, 256):
             med = sorted(ts[tile])[len(ts[tile]) // 2]
             tot[tile] += med
             line += f" | {tile} {med * 1e3:7.1f}us {2.0 * m * na * nb / med / 1e9:5.0f}TF"
-        line += f" | auto picks {lib.tvts_gemm_tn_select(m, na, nb)}"
+        line += f" | auto picks {K.gemm_tn_select(m, na, nb)}"
         print(line, flush=True)
     print("sum of medians (ms):", {k: round(v, 3) for k, v in tot.items()})
 

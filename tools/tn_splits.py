@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The weight-gradient kernel against the number of contraction ranges (tvts_gemm_set_tn_splits): round efficiency vs L2 locality
+"""The weight-gradient kernel against the number of contraction ranges (TVTS_TN_SPLITS in the call's opts): round efficiency vs L2 locality
 (with 8 ranges every XCD owns exactly one; the automatic choice fills the round).  GPU only.  usage: tn_splits.py [PAIRS]"""
 import os
 import sys
@@ -33,13 +33,11 @@ for na, nb in ((2304, 768), (3072, 768), (768, 3072), (768, 768)):
     cs = torch.zeros(na, device=dev)
     line = f"TN {M} x {na} x {nb}:"
     for sp in (0, 8, 16, 24, 32):
-        lib.tvts_gemm_set_tn_splits(sp)
         i = [0]
 
         def f():
             i[0] = (i[0] + 1) % 3
-            K.gemm_tn(ps[i[0]], qs[i[0]], out, accumulate=True, colsum=cs)
+            K.gemm_tn(ps[i[0]], qs[i[0]], out, accumulate=True, colsum=cs, splits=sp)
         ms = timeit(f)
         line += f"  s{sp}: {ms * 1e3:6.1f}us {2.0 * M * na * nb / ms / 1e9:5.0f}TF"
     print(line, flush=True)
-lib.tvts_gemm_set_tn_splits(0)

@@ -55,7 +55,7 @@ struct AttnGeom {
     int W;                  // heads * 64
     float scale2;           // dh^-0.5 * log2(e)
     float scale;            // dh^-0.5
-    int ablate;             // dev knob (TVTS_ATTN_ABLATE): 1 skip phase A, 2 skip phase B, 4 skip global loads
+    int ablate;             // dev knob (opts bits 4..6 of tvts_attn_bwd): 1 skip phase A, 2 skip phase B, 4 skip global loads
     const int* kv_len;      // FULL only, optional: valid keys per sequence (keys >= kv_len[b] are padding and masked)
     int cls_nq, cls_q0;     // CLS geometry generalised: cls_nq (<= 16) queries at tokens cls_q0 .. of the sequence (1, 0 = the CLS token)
     const int* cls_qpos;    // ... or ONE query per sequence at token cls_qpos[b] that sees the keys 0 .. cls_qpos[b] (causal)
@@ -2143,11 +2143,13 @@ __global__ void attn_cls_finalize_kernel(const float* __restrict__ cls_acc, int 
 using namespace NS_DH;
 
 // ------------------------------------------------------------------------------------------------ C ABI
-static int g_use_tr = 1;
-static int g_shared = 1;  // block-shared K/V (Q/dO) staging for FULL and SPACE geometry
-static int g_fused = 1;   // single-launch kernels for the geometries whose groups fit one block / one wave
-extern "C" void ABI(set_shared)(int on) { g_shared = on ? 1 : 0; }
-extern "C" void ABI(set_transpose_read)(int on) { g_use_tr = on ? 1 : 0; }
+// Per-call dispatch options (include/tvts_hip.h: TVTS_ATTN_NO_TR / _NO_SHARED / _NO_FUSED; 0 = what the step uses).  The library
+// keeps no mutable process state: the alternative kernel paths (scalar LDS reads instead of ds_read_tr, per-wave instead of
+// block-shared staging, the split passes instead of the fused single-launch kernels) are reachable per call, for parity tests and
+// benches, and cannot leak from one caller or thread into another.
+#define ATTN_OPTS(opts)                                                                      \
+    const bool use_tr = !((opts) & 1), shared = !((opts) & 2), fused = !((opts) & 4);        \
+    (void)use_tr; (void)shared; (void)fused
 
 static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int n, int causal, int ld) {
     if (B <= 0 || heads <= 0 || S <= 0 || ld % 8) return TVTS_EINVAL;
@@ -2157,9 +2159,7 @@ static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int 
     g.cls_nq = 1; g.cls_q0 = 0; g.cls_qpos = nullptr; g.cls_parts = 0;
     g.scale = 1.0f / sqrtf((float)DH);
     g.scale2 = g.scale * 1.4426950408889634f;
-    static int abl = -1;
-    if (abl < 0) { const char* e = getenv("TVTS_ATTN_ABLATE"); abl = e ? atoi(e) : 0; }
-    g.ablate = abl;
+    g.ablate = 0;  // timing-ablation bits of the fused backward (opts bits 4..6 of tvts_attn_bwd; results are wrong by construction)
     return TVTS_OK;
 }
 static int items_q(const AttnGeom& g, int mode) {
@@ -2175,7 +2175,7 @@ static int items_k(const AttnGeom& g, int mode) {
 
 #define DISPATCH_MODE(KERNEL, mode, ...)                                                        \
     do {                                                                                        \
-        if (g_use_tr) {                                                                         \
+        if (use_tr) {                                                                         \
             switch (mode) {                                                                     \
                 case MODE_FULL: hipLaunchKernelGGL((KERNEL<MODE_FULL, true>), __VA_ARGS__); break;   \
                 case MODE_SPACE: hipLaunchKernelGGL((KERNEL<MODE_SPACE, true>), __VA_ARGS__); break; \
@@ -2196,13 +2196,14 @@ static int items_k(const AttnGeom& g, int mode) {
 
 // out[rows, ldo] (heads merged, the layout the output projection consumes), lse2[rows, heads]
 static int fwd_impl(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const int* kv_len,
-                    void* out, int ldo, float* lse2, hipStream_t stream) {
+                    void* out, int ldo, float* lse2, int opts, hipStream_t stream) {
+    ATTN_OPTS(opts);
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     if (ldo % 4 || (kv_len && mode != MODE_FULL)) return TVTS_EINVAL;
     g.kv_len = kv_len;
-    if (g_fused && g_use_tr && mode == MODE_FULL && !kv_len && S <= 32) {  // short sequences (text tower): a wave per (sequence, head)
+    if (fused && use_tr && mode == MODE_FULL && !kv_len && S <= 32) {  // short sequences (text tower): a wave per (sequence, head)
         const int MT = ceil_div(S, 16), groups = B * heads;
         const int lds_bytes = 4 * (MT * 16 * VSTRIDE + 1024);
         const int blocks = ceil_div(groups, 4) < 1536 ? ceil_div(groups, 4) : 1536;
@@ -2211,13 +2212,13 @@ static int fwd_impl(int mode, const void* qkv, int ld, int B, int heads, int S, 
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }
-    if (g_shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
+    if (shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
         const int nq = mode == MODE_SPACE ? g.n : g.S;
         const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : g.B * g.heads;
         const int nb = groups * ceil_div(ceil_div(nq, 16), 4);
-        if (mode == MODE_FULL) { if (g_use_tr) hipLaunchKernelGGL((attn_fwd_shared_kernel<MODE_FULL, true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
+        if (mode == MODE_FULL) { if (use_tr) hipLaunchKernelGGL((attn_fwd_shared_kernel<MODE_FULL, true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
                                  else hipLaunchKernelGGL((attn_fwd_shared_kernel<MODE_FULL, false>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2); }
-        else { if (g_use_tr) hipLaunchKernelGGL((attn_fwd_shared_kernel<MODE_SPACE, true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
+        else { if (use_tr) hipLaunchKernelGGL((attn_fwd_shared_kernel<MODE_SPACE, true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
                else hipLaunchKernelGGL((attn_fwd_shared_kernel<MODE_SPACE, false>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2); }
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
@@ -2229,15 +2230,15 @@ static int fwd_impl(int mode, const void* qkv, int ld, int B, int heads, int S, 
 }
 
 extern "C" int ABI(fwd)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
-                             void* out, int ldo, float* lse2, hipStream_t stream) {
-    return fwd_impl(mode, qkv, ld, B, heads, S, T, n, causal, nullptr, out, ldo, lse2, stream);
+                             void* out, int ldo, float* lse2, int opts, hipStream_t stream) {
+    return fwd_impl(mode, qkv, ld, B, heads, S, T, n, causal, nullptr, out, ldo, lse2, opts, stream);
 }
 // FULL attention over sequences padded to S: keys at positions >= kv_len[b] are masked out (the attention_mask of the v1
 // text tower, transformers DistilBERT MultiHeadSelfAttention); kv_len is a device int32[B]
 extern "C" int ABI(fwd_len)(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, void* out, int ldo,
                                  float* lse2, hipStream_t stream) {
     if (!kv_len) return TVTS_EINVAL;
-    return fwd_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, out, ldo, lse2, stream);
+    return fwd_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, out, ldo, lse2, 0, stream);
 }
 
 extern "C" int ABI(delta)(const void* dO, int lddo, const void* O, int ldo, int rows, int heads, float* delta,
@@ -2252,20 +2253,21 @@ extern "C" int ABI(delta)(const void* dO, int lddo, const void* O, int ldo, int 
 
 static int bwd_dq_impl(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const int* kv_len,
                        const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
-                       hipStream_t stream) {
+                       int opts, hipStream_t stream) {
+    ATTN_OPTS(opts);
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     if (lddo % 8 || lddq % 4) return TVTS_EINVAL;
     g.kv_len = kv_len;
-    if (g_shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
+    if (shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
         const int nq = mode == MODE_SPACE ? g.n : g.S;
         const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : g.B * g.heads;
         const int nb = groups * ceil_div(ceil_div(nq, 16), 4);
 #define DQ_ARGS dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo, lse2, delta, (bf16*)dqkv, lddq
-        if (mode == MODE_FULL) { if (g_use_tr) hipLaunchKernelGGL((attn_bwd_dq_shared_kernel<MODE_FULL, true>), DQ_ARGS);
+        if (mode == MODE_FULL) { if (use_tr) hipLaunchKernelGGL((attn_bwd_dq_shared_kernel<MODE_FULL, true>), DQ_ARGS);
                                  else hipLaunchKernelGGL((attn_bwd_dq_shared_kernel<MODE_FULL, false>), DQ_ARGS); }
-        else { if (g_use_tr) hipLaunchKernelGGL((attn_bwd_dq_shared_kernel<MODE_SPACE, true>), DQ_ARGS);
+        else { if (use_tr) hipLaunchKernelGGL((attn_bwd_dq_shared_kernel<MODE_SPACE, true>), DQ_ARGS);
                else hipLaunchKernelGGL((attn_bwd_dq_shared_kernel<MODE_SPACE, false>), DQ_ARGS); }
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
@@ -2279,15 +2281,16 @@ static int bwd_dq_impl(int mode, const void* qkv, int ld, int B, int heads, int 
 
 extern "C" int ABI(bwd_dq)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
                                 const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
-                                hipStream_t stream) {
-    return bwd_dq_impl(mode, qkv, ld, B, heads, S, T, n, causal, nullptr, dO, lddo, lse2, delta, dqkv, lddq, stream);
+                                int opts, hipStream_t stream) {
+    return bwd_dq_impl(mode, qkv, ld, B, heads, S, T, n, causal, nullptr, dO, lddo, lse2, delta, dqkv, lddq, opts, stream);
 }
 
 // cls_acc: fp32 [B, heads, 3, dh] (dK | dV | dQ of the CLS token), zeroed by the caller before the SPACE/TIME pass, consumed by
 // tvts_attn_cls_finalize afterwards (unused for FULL).
 static int bwd_dkv_impl(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const int* kv_len,
                         const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
-                        float* cls_acc, hipStream_t stream) {
+                        float* cls_acc, int opts, hipStream_t stream) {
+    ATTN_OPTS(opts);
     AttnGeom g;
     if (mode == MODE_CLS) return TVTS_EINVAL;  // the CLS query is folded into the SPACE/TIME pass
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
@@ -2295,21 +2298,21 @@ static int bwd_dkv_impl(int mode, const void* qkv, int ld, int B, int heads, int
     g.kv_len = kv_len;
     if (lddo % 8 || lddq % 4) return TVTS_EINVAL;
     if ((mode == MODE_SPACE || mode == MODE_TIME) && !cls_acc) return TVTS_EINVAL;
-    if (g_shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
+    if (shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
         const int nk = mode == MODE_SPACE ? g.n + 1 : g.S;
         const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : g.B * g.heads;
         const int nb = groups * ceil_div(ceil_div(nk, 16), 4);
 #define DKV_ARGS dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo, lse2, delta, (bf16*)dqkv, lddq, cls_acc
-        if (mode == MODE_FULL) { if (g_use_tr) hipLaunchKernelGGL((attn_bwd_dkv_shared_kernel<MODE_FULL, true>), DKV_ARGS);
+        if (mode == MODE_FULL) { if (use_tr) hipLaunchKernelGGL((attn_bwd_dkv_shared_kernel<MODE_FULL, true>), DKV_ARGS);
                                  else hipLaunchKernelGGL((attn_bwd_dkv_shared_kernel<MODE_FULL, false>), DKV_ARGS); }
-        else { if (g_use_tr) hipLaunchKernelGGL((attn_bwd_dkv_shared_kernel<MODE_SPACE, true>), DKV_ARGS);
+        else { if (use_tr) hipLaunchKernelGGL((attn_bwd_dkv_shared_kernel<MODE_SPACE, true>), DKV_ARGS);
                else hipLaunchKernelGGL((attn_bwd_dkv_shared_kernel<MODE_SPACE, false>), DKV_ARGS); }
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }
-    if (g_shared && mode == MODE_TIME) {
+    if (shared && mode == MODE_TIME) {
         const int nb = g.B * g.heads * ceil_div(g.n, TIME_CHUNK);
-        if (g_use_tr) hipLaunchKernelGGL((attn_bwd_dkv_time_kernel<true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo, lse2, delta, (bf16*)dqkv, lddq, cls_acc);
+        if (use_tr) hipLaunchKernelGGL((attn_bwd_dkv_time_kernel<true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo, lse2, delta, (bf16*)dqkv, lddq, cls_acc);
         else hipLaunchKernelGGL((attn_bwd_dkv_time_kernel<false>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo, lse2, delta, (bf16*)dqkv, lddq, cls_acc);
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
@@ -2323,8 +2326,8 @@ static int bwd_dkv_impl(int mode, const void* qkv, int ld, int B, int heads, int
 
 extern "C" int ABI(bwd_dkv)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
                                  const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
-                                 float* cls_acc, hipStream_t stream) {
-    return bwd_dkv_impl(mode, qkv, ld, B, heads, S, T, n, causal, nullptr, dO, lddo, lse2, delta, dqkv, lddq, cls_acc, stream);
+                                 float* cls_acc, int opts, hipStream_t stream) {
+    return bwd_dkv_impl(mode, qkv, ld, B, heads, S, T, n, causal, nullptr, dO, lddo, lse2, delta, dqkv, lddq, cls_acc, opts, stream);
 }
 // whole backward of FULL attention with padded keys masked (see fwd_len).  The dK / dV rows of the padded positions are not
 // written: the caller zeroes dqkv beforehand (their true gradient is zero).
@@ -2334,9 +2337,9 @@ extern "C" int ABI(bwd_len)(const void* qkv, int ld, int B, int heads, int S, co
     if (!kv_len || lddo % 8 || ldo % 8 || lddq % 4) return TVTS_EINVAL;
     int rc = ABI(delta)(dO, lddo, O, ldo, B * S, heads, delta, stream);
     if (rc) return rc;
-    rc = bwd_dq_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, dO, lddo, lse2, delta, dqkv, lddq, stream);
+    rc = bwd_dq_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, dO, lddo, lse2, delta, dqkv, lddq, 0, stream);
     if (rc) return rc;
-    return bwd_dkv_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, dO, lddo, lse2, delta, dqkv, lddq, nullptr, stream);
+    return bwd_dkv_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, dO, lddo, lse2, delta, dqkv, lddq, nullptr, 0, stream);
 }
 
 // ---- TAIL queries: FULL geometry (no mask) in which only the LAST nq (<= 16) tokens of every sequence are queries, all S tokens
@@ -2364,6 +2367,7 @@ static __global__ __launch_bounds__(256) void attn_delta_tail_kernel(const bf16*
 }
 extern "C" int ABI(fwd_tail)(const void* qkv, int ld, int B, int heads, int S, int nq, void* out, int ldo, float* lse2,
                              hipStream_t stream) {
+    ATTN_OPTS(0);
     AttnGeom g;
     int rc = make_geom(g, MODE_CLS, B, heads, S, 0, 0, 0, ld);
     if (rc) return rc;
@@ -2375,6 +2379,7 @@ extern "C" int ABI(fwd_tail)(const void* qkv, int ld, int B, int heads, int S, i
 }
 extern "C" int ABI(bwd_tail)(const void* qkv, int ld, int B, int heads, int S, int nq, const void* dO, int lddo, const void* O,
                              int ldo, const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream) {
+    ATTN_OPTS(0);
     AttnGeom g;
     int rc = make_geom(g, MODE_CLS, B, heads, S, 0, 0, 0, ld);
     if (rc) return rc;
@@ -2397,6 +2402,7 @@ extern "C" int ABI(bwd_tail)(const void* qkv, int ld, int B, int heads, int S, i
 // conventions as the tail form; dK / dV of the keys behind the query are not written (their gradient is zero): zero dqkv first.
 extern "C" int ABI(fwd_rowq)(const void* qkv, int ld, int B, int heads, int S, const int* qpos, void* out, int ldo, float* lse2,
                              hipStream_t stream) {
+    ATTN_OPTS(0);
     AttnGeom g;
     int rc = make_geom(g, MODE_CLS, B, heads, S, 0, 0, 0, ld);
     if (rc) return rc;
@@ -2408,6 +2414,7 @@ extern "C" int ABI(fwd_rowq)(const void* qkv, int ld, int B, int heads, int S, c
 }
 extern "C" int ABI(bwd_rowq)(const void* qkv, int ld, int B, int heads, int S, const int* qpos, const void* dO, int lddo,
                              const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream) {
+    ATTN_OPTS(0);
     AttnGeom g;
     int rc = make_geom(g, MODE_CLS, B, heads, S, 0, 0, 0, ld);
     if (rc) return rc;
@@ -2441,17 +2448,17 @@ static __global__ void zero_f32_kernel(float* __restrict__ p, int n) {
 
 // Whole backward of one attention site: D = rowsum(dO*O), dQ, dK, dV (and, for the divided space / time geometries,
 // the CLS query and the CLS key/value reduction).  SPACE groups that fit 112 rows take the fused single-launch kernel.
-extern "C" void ABI(set_fused)(int on) { g_fused = on ? 1 : 0; }
 extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
                         const void* dO, int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv,
-                        int lddq, float* cls_acc, long cls_acc_elems, hipStream_t stream) {
+                        int lddq, float* cls_acc, long cls_acc_elems, int opts, hipStream_t stream) {
     if (mode == MODE_CLS) return TVTS_EINVAL;
+    ATTN_OPTS(opts);
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     if (lddo % 8 || ldo % 8 || lddq % 4) return TVTS_EINVAL;
     const bool divided = mode == MODE_SPACE || mode == MODE_TIME;
-    if (g_fused && g_use_tr && mode == MODE_FULL && S <= 32) {  // short sequences (text tower): one launch, D in registers
+    if (fused && use_tr && mode == MODE_FULL && S <= 32) {  // short sequences (text tower): one launch, D in registers
         const int MT = ceil_div(S, 16), groups = B * heads;
         const int lds_bytes = SEQ_BWD_WAVES * (4 * MT * 16 * VSTRIDE + 2 * MT * 16 * 4 + 1024);
         const int want = ceil_div(groups, SEQ_BWD_WAVES);
@@ -2461,8 +2468,8 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }
-    const bool fused_space = g_fused && g_use_tr && mode == MODE_SPACE && n + 1 <= FUSED_MAX_TILES * 16;
-    const bool fused_time = g_fused && g_use_tr && mode == MODE_TIME && T + 1 <= 32;
+    const bool fused_space = fused && use_tr && mode == MODE_SPACE && n + 1 <= FUSED_MAX_TILES * 16;
+    const bool fused_time = fused && use_tr && mode == MODE_TIME && T + 1 <= 32;
     // cls_acc: fp32 scratch for the CLS token's dK / dV / dQ sums.  With room for one partial per block of the fused kernels
     // (B * heads * parts * 3 * dh elements, parts = T for SPACE, ceil(n / TIME_CHUNK) for TIME) the blocks store their shares and
     // the finalize kernel adds them in order (no atomics: reproducible); with B * heads * 3 * dh elements only, or on the streaming
@@ -2470,6 +2477,7 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
     const int want_parts = fused_space ? T : fused_time ? ceil_div(n, TIME_CHUNK) : 0;
     const bool parts_ok = want_parts > 0 && cls_acc && cls_acc_elems >= (long)B * heads * want_parts * 3 * DH;
     g.cls_parts = parts_ok ? want_parts : 0;
+    g.ablate = (opts >> 4) & 7;
     if (divided && !parts_ok) {
         if (!cls_acc || cls_acc_elems < (long)B * heads * 3 * DH) return TVTS_EINVAL;
         // a kernel, not hipMemsetAsync: captured memset nodes did not reliably zero this buffer on hipGraph replay (ROCm 7.x:
@@ -2503,12 +2511,9 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
             kern = MT == 1 ? attn_bwd_time_fused_kernel<1, true> : attn_bwd_time_fused_kernel<2, true>;
             blocks = B * heads * ceil_div(n, TIME_CHUNK); threads = 256; slot = FUSED_MAX_TILES + MT;
         }
-        static bool attr_set[FUSED_MAX_TILES + 3] = {};
-        if (!attr_set[slot]) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
-                return TVTS_EINVAL;
-            attr_set[slot] = true;
-        }
+        (void)slot;  // (no memo of the attribute call: the library keeps no mutable state; the call is a host-side table write)
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return TVTS_EINVAL;
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, stream, g, (const bf16*)qkv, (const bf16*)dO, lddo,
                            lse2, delta, (bf16*)dqkv, lddq, cls_acc);
         TVTS_LAUNCH_CHECK();
@@ -2520,12 +2525,12 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
     }
     rc = ABI(delta)(dO, lddo, O, ldo, B * S, heads, delta, stream);
     if (rc) return rc;
-    rc = ABI(bwd_dq)(mode, qkv, ld, B, heads, S, T, n, causal, dO, lddo, lse2, delta, dqkv, lddq, stream);
+    rc = ABI(bwd_dq)(mode, qkv, ld, B, heads, S, T, n, causal, dO, lddo, lse2, delta, dqkv, lddq, opts, stream);
     if (rc) return rc;
-    rc = ABI(bwd_dkv)(mode, qkv, ld, B, heads, S, T, n, causal, dO, lddo, lse2, delta, dqkv, lddq, cls_acc, stream);
+    rc = ABI(bwd_dkv)(mode, qkv, ld, B, heads, S, T, n, causal, dO, lddo, lse2, delta, dqkv, lddq, cls_acc, opts, stream);
     if (rc) return rc;
     if (divided) {
-        rc = ABI(bwd_dq)(MODE_CLS, qkv, ld, B, heads, S, T, n, 0, dO, lddo, lse2, delta, dqkv, lddq, stream);
+        rc = ABI(bwd_dq)(MODE_CLS, qkv, ld, B, heads, S, T, n, 0, dO, lddo, lse2, delta, dqkv, lddq, opts, stream);
         if (rc) return rc;
         rc = ABI(cls_finalize)(cls_acc, B, heads, S, dqkv, lddq, stream);
     }
@@ -2536,14 +2541,15 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
 // groups fit (SPACE n + 1 <= 112, TIME T + 1 <= 32), the streaming kernels + the CLS-query kernel otherwise.
 // cls_ws: fp32 scratch, at least B * heads * max(T, ceil(n / 28)) * (dh + 2) elements.
 extern "C" int ABI(fwd_divided)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
-                                float* lse2, float* cls_ws, long cls_ws_elems, hipStream_t stream) {
+                                float* lse2, float* cls_ws, long cls_ws_elems, int opts, hipStream_t stream) {
     if (mode != MODE_SPACE && mode != MODE_TIME) return TVTS_EINVAL;
+    ATTN_OPTS(opts);
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, 0, ld);
     if (rc) return rc;
     if (ldo % 4) return TVTS_EINVAL;
-    const bool fs = g_fused && g_use_tr && mode == MODE_SPACE && n + 1 <= FUSED_MAX_TILES * 16;
-    const bool ft = g_fused && g_use_tr && mode == MODE_TIME && T + 1 <= 32;
+    const bool fs = fused && use_tr && mode == MODE_SPACE && n + 1 <= FUSED_MAX_TILES * 16;
+    const bool ft = fused && use_tr && mode == MODE_TIME && T + 1 <= 32;
     const int G = mode == MODE_SPACE ? T : ceil_div(n, TIME_CHUNK);
     if ((fs || ft) && cls_ws && cls_ws_elems >= (long)B * heads * G * (DH + 2)) {
         typedef void (*Kern)(AttnGeom, const bf16*, bf16*, int, float*, float*);
@@ -2575,7 +2581,7 @@ extern "C" int ABI(fwd_divided)(int mode, const void* qkv, int ld, int B, int he
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }
-    rc = ABI(fwd)(mode, qkv, ld, B, heads, S, T, n, 0, out, ldo, lse2, stream);
+    rc = ABI(fwd)(mode, qkv, ld, B, heads, S, T, n, 0, out, ldo, lse2, opts, stream);
     if (rc) return rc;
-    return ABI(fwd)(MODE_CLS, qkv, ld, B, heads, S, T, n, 0, out, ldo, lse2, stream);
+    return ABI(fwd)(MODE_CLS, qkv, ld, B, heads, S, T, n, 0, out, ldo, lse2, opts, stream);
 }

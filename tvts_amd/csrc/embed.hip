@@ -221,10 +221,14 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __re
 // clips x 8 frames x 98 patches x 768 columns: the atomics were the kernel's run time, 465 us); 16-byte loads, 8-byte stores.
 #define ASM_SLOTS 14
 #define ASM_MAXT 16
+// part_t / part_c (optional): per-block partials [B * groups][T][W] of the temporal-embedding sums and [B][W] of the CLS rows,
+// added in block order by colsum_partials_kernel (no atomics: the sums are run-to-run reproducible); the positional-embedding
+// rows stay a scatter of fp32 atomics (an embedding-table gradient, like the reference's nn.Embedding backward).
 __global__ __launch_bounds__(256) void vit_assemble_bwd_tube_kernel(const float* __restrict__ dtok, int ldt,
                                                                     const int* __restrict__ keep, int B, int T, int n, int W,
                                                                     bf16* __restrict__ dpatch, int ldp, float* __restrict__ dcls,
-                                                                    float* __restrict__ dpos, float* __restrict__ dtemporal) {
+                                                                    float* __restrict__ dpos, float* __restrict__ dtemporal,
+                                                                    float* __restrict__ part_t, float* __restrict__ part_c) {
     const int S = 1 + T * n;
     const int groups = (n + ASM_SLOTS - 1) / ASM_SLOTS;
     const int b = blockIdx.x / groups, grp = blockIdx.x % groups;
@@ -251,24 +255,59 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_tube_kernel(const float*
 #pragma unroll
         for (int f = 0; f < ASM_MAXT; ++f) {
             if (f < T) {
+                if (part_t) *(f32x4*)(part_t + ((size_t)blockIdx.x * T + f) * W + c) = ts[f];
+                else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(dtemporal + (size_t)f * W + c + e, ts[f][e]);
+                    for (int e = 0; e < 4; ++e) atomicAdd(dtemporal + (size_t)f * W + c + e, ts[f][e]);
+                }
             }
         }
         if (grp == 0) {
             const f32x4 v0 = *(const f32x4*)(dtok + (size_t)(b * S) * ldt + c);
+            if (part_c) *(f32x4*)(part_c + (size_t)b * W + c) = v0;
+            else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { atomicAdd(dcls + c + e, v0[e]); atomicAdd(dpos + c + e, v0[e]); }
+                for (int e = 0; e < 4; ++e) { atomicAdd(dcls + c + e, v0[e]); atomicAdd(dpos + c + e, v0[e]); }
+            }
         }
     }
 }
 
+// out[c] (and out2[c]) += sum_p part[p][c] for c < W: 64 columns x 16 partial-groups per block, every thread adds its partials
+// in order, the 16 groups are combined in order
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ part, int nparts, int W,
+                                                               float* __restrict__ out, float* __restrict__ out2) {
+    __shared__ float acc[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < W)
+        for (int p = grp; p < nparts; p += 16) s += part[(size_t)p * W + c];
+    acc[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && c < W) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += acc[g][threadIdx.x];
+        out[c] += t;
+        if (out2) out2[c] += t;
+    }
+}
+
 extern "C" int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int keep_per_frame, int B, int T, int n, int W,
-                                     void* dpatch, int ldp, float* dcls, float* dpos, float* dtemporal, hipStream_t stream) {
+                                     void* dpatch, int ldp, float* dcls, float* dpos, float* dtemporal, float* workspace,
+                                     long workspace_elems, hipStream_t stream) {
     if (!keep_per_frame && T <= ASM_MAXT && W % 4 == 0 && ldt % 4 == 0 && ldp % 4 == 0) {
         const int groups = (n + ASM_SLOTS - 1) / ASM_SLOTS;
+        const long need = (long)B * groups * T * W + (long)B * W;
+        float* part_t = (workspace && workspace_elems >= need) ? workspace : nullptr;
+        float* part_c = part_t ? workspace + (size_t)B * groups * T * W : nullptr;
         hipLaunchKernelGGL(vit_assemble_bwd_tube_kernel, dim3(B * groups), dim3(256), 0, stream, dtok, ldt, keep, B, T, n, W,
-                           (bf16*)dpatch, ldp, dcls, dpos, dtemporal);
+                           (bf16*)dpatch, ldp, dcls, dpos, dtemporal, part_t, part_c);
+        if (part_t) {
+            hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div(T * W, 64)), dim3(1024), 0, stream, part_t, B * groups, T * W,
+                               dtemporal, (float*)nullptr);
+            hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div(W, 64)), dim3(1024), 0, stream, part_c, B, W, dcls, dpos);
+        }
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }
@@ -374,7 +413,8 @@ extern "C" int tvts_sort_assemble(const float* tok, int ldt, int B, int S, int o
 // grid (B, row chunks of 32): each block converts its rows and adds its partial column sums with atomics.
 __global__ __launch_bounds__(256) void sort_assemble_bwd_kernel(const float* __restrict__ dxs, int ldx, int S, int off, int Sv,
                                                                 int NT, const float* __restrict__ dvid, int E,
-                                                                bf16* __restrict__ dout, int ldo, float* __restrict__ dtype) {
+                                                                bf16* __restrict__ dout, int ldo, float* __restrict__ dtype,
+                                                                float* __restrict__ part0, float* __restrict__ part1) {
     const int So = Sv + NT;
     const int b = blockIdx.x;
     const int r0 = blockIdx.y * 32;
@@ -394,15 +434,33 @@ __global__ __launch_bounds__(256) void sort_assemble_bwd_kernel(const float* __r
         if (dxs) {
             if (blockIdx.y == 0)
                 for (int i = 0; i < NT; ++i) s1 += dxs[(size_t)(b * So + Sv + i) * ldx + c];
-            atomicAdd(dtype + c, s0);
-            if (blockIdx.y == 0) atomicAdd(dtype + E + c, s1);
+            if (part0) {  // per-block partials, added in block order by colsum_partials_kernel
+                part0[((size_t)b * gridDim.y + blockIdx.y) * E + c] = s0;
+                if (blockIdx.y == 0) part1[(size_t)b * E + c] = s1;
+            } else {
+                atomicAdd(dtype + c, s0);
+                if (blockIdx.y == 0) atomicAdd(dtype + E + c, s1);
+            }
         }
     }
 }
+// workspace (optional, >= B * (ceil(S / 32) + 1) * E floats): the type-embedding gradient (a plain sum over token rows, one of the
+// lr 1e-4 parameters: its noise is what Adam amplifies) as ordered per-block partials instead of fp32 atomics
 extern "C" int tvts_sort_assemble_bwd(const float* dxs, int ldx, int B, int S, int off, int Sv, int NT, const float* dvid,
-                                      int E, void* dout, int ldo, float* dtype, hipStream_t stream) {
-    hipLaunchKernelGGL(sort_assemble_bwd_kernel, dim3(B, ceil_div(S, 32)), dim3(256), 0, stream, dxs, ldx, S, off, Sv, NT, dvid,
-                       E, (bf16*)dout, ldo, dtype);
+                                      int E, void* dout, int ldo, float* dtype, float* workspace, long workspace_elems,
+                                      hipStream_t stream) {
+    const int chunks = ceil_div(S, 32);
+    const bool parts = dxs && dtype && workspace && workspace_elems >= (long)B * (chunks + 1) * E;
+    float* part0 = parts ? workspace : nullptr;
+    float* part1 = parts ? workspace + (size_t)B * chunks * E : nullptr;
+    hipLaunchKernelGGL(sort_assemble_bwd_kernel, dim3(B, chunks), dim3(256), 0, stream, dxs, ldx, S, off, Sv, NT, dvid,
+                       E, (bf16*)dout, ldo, dtype, part0, part1);
+    if (parts) {
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div(E, 64)), dim3(1024), 0, stream, part0, B * chunks, E, dtype,
+                           (float*)nullptr);
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div(E, 64)), dim3(1024), 0, stream, part1, B, E, dtype + E,
+                           (float*)nullptr);
+    }
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

@@ -153,25 +153,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNT g) {
 
 // ---- dispatch.  Tile choice: the pipelined 256x256 kernel when N is a multiple of 256 and the output has at least
 // NT_MIN_TILES_256 of its tiles (the text tower of a 192-pair step has 192 of them, M = 24 576, N = 512, and runs ~10 % faster
-// on it), else the persistent 128x128 kernel.  tvts_gemm_set_nt_tile overrides (0 auto, 128, 256) for benches and tests.
+// on it), else the persistent 128x128 kernel.  The per-call `opts` word (include/tvts_hip.h, TVTS_GEMM_*) overrides for benches and
+// tests: the library keeps NO mutable process state (the entry points are called from the autograd worker thread and from
+// communication hooks as well as from the main thread).
 static const int NT_MIN_TILES_256 = 150;
-static int g_nt_tile = 0;
-extern "C" void tvts_gemm_set_nt_tile(int t) { g_nt_tile = (t == 128 || t == 256) ? t : 0; }
-static int g_fp8_mx = 1;
-extern "C" void tvts_gemm_set_fp8_mx(int on) { g_fp8_mx = on ? 1 : 0; }
+static inline int opt_tile(int opts) { return (opts & 1) ? 128 : (opts & 2) ? 256 : 0; }
 // persistent grid of the 256x256 NT kernel: at most this many blocks (one per CU; a multiple of 8, one share per XCD).  256 = the
 // whole chip; fewer leaves CUs to kernels of other streams (a 160 KiB block shares its CU with nothing), and is how
 // tools/gemm_cus.py measures what a CU's K loop waits for (per-CU rate against the number of CUs streaming)
-static int g_nt_cus = 256;
-extern "C" void tvts_gemm_set_nt_cus(int n) { g_nt_cus = n < 8 ? 8 : n > 256 ? 256 : (n / 8) * 8; }
+static inline int opt_cus(int opts) {
+    const int n = ((opts >> 8) & 63) * 8;
+    return n == 0 ? 256 : n > 256 ? 256 : n;
+}
 
-static bool nt_use_256(int M, int N) {
-    if (g_nt_tile == 128) return false;
+static bool nt_use_256(int M, int N, int opts) {
+    const int forced = opt_tile(opts);
+    if (forced == 128) return false;
     if (N % 8) return false;
-    if (g_nt_tile == 256) return true;
+    if (forced == 256) return true;
     return N % 256 == 0 && (long)ceil_div(M, 256) * (N / 256) >= NT_MIN_TILES_256;
 }
-extern "C" int tvts_gemm_nt_select(int M, int N) { return nt_use_256(M, N) ? 256 : 128; }
+extern "C" int tvts_gemm_nt_select(int M, int N, int opts) { return nt_use_256(M, N, opts) ? 256 : 128; }
 
 // Wide outputs (>= 10 tile columns: the MLP's 4x expansion): walk the tiles in column groups of 6 or 5.  An XCD's 32
 // co-resident tiles then span 5-6 weight panels x 5-6 row panels instead of all 12-20 weight panels x 2-3 row panels
@@ -184,12 +186,14 @@ static int nt_column_group(int N) {
 }
 
 template <bool FP8>
-static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_t stream) {
+static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, hipStream_t stream) {
+    const int nt_cus = opt_cus(opts);
+    const bool fp8_mx = !(opts & 4);
     g.tiles_n = ceil_div(g.N, 256);
     g.tiles_m = ceil_div(g.M, 256);
     g.gc = nt_column_group(g.N);
     const int total_tiles = g.tiles_m * g.tiles_n;
-    const int grid = total_tiles < g_nt_cus ? ((total_tiles + 7) / 8) * 8 : g_nt_cus;  // persistent: one block per CU, multiple of 8 (XCDs)
+    const int grid = total_tiles < nt_cus ? ((total_tiles + 7) / 8) * 8 : nt_cus;  // persistent: one block per CU, multiple of 8 (XCDs)
     // every production instantiation staggers the LDS-DMA issue of the two waves of a SIMD (ABL 32768: +1-3 % on every shape of
     // the step, tools/gemm_ab.py; the same change is worth 6-10 % on the weight-gradient kernel)
     constexpr int SD = 32768;
@@ -203,9 +207,9 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_
     } else {
         kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, FP8, SD> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, FP8, SD>
              : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, FP8, SD> : nullptr;
-        if constexpr (FP8) {  // the K = 128 scaled-MFMA main loop (the fp8 issue rate); tvts_gemm_set_fp8_mx(0) restores the 16x16x32 form
+        if constexpr (FP8) {  // the K = 128 scaled-MFMA main loop (the fp8 issue rate); TVTS_GEMM_FP8_K32 selects the 16x16x32 form
             constexpr int MX = SD | 65536;
-            if (g_fp8_mx) kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, true, MX> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, true, MX>
+            if (fp8_mx) kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, true, MX> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, true, MX>
                                : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, true, MX> : nullptr;
         }
     }
@@ -214,7 +218,7 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_
     // plain / activation / gate kernels 1-12 %, so they keep the in-place loads)
     if (!gated && act == ACT_NONE && g.residual) kern = gemm_nt256p_kernel<0, 0, FP8, 256 | SD>;
     if constexpr (FP8) {
-        if (g_fp8_mx && act == ACT_NONE && g.residual) kern = gemm_nt256p_kernel<0, 0, true, 256 | SD | 65536>;
+        if (fp8_mx && act == ACT_NONE && g.residual) kern = gemm_nt256p_kernel<0, 0, true, 256 | SD | 65536>;
     }
     // The hand-scheduled patch epilogue (ABL 8192: bias added inside the K loop, stores by inline asm from scalar bases, side
     // inputs by inline asm two row-tiles ahead of their use and ahead of the stores, hand-counted vmcnt) where tools/gemm_ab.py
@@ -251,7 +255,7 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, hipStream_
 extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                                  const float* bias, const float* residual, int ldr, int act, void* preact,
                                  int ldp, const void* gate_h, int ldh, int gate_act, void* out, int ldc,
-                                 int out_f32, hipStream_t stream) {
+                                 int out_f32, int opts, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return TVTS_EINVAL;
     if (K % BK != 0 || N % 4 != 0 || lda % 8 != 0 || ldb % 8 != 0) return TVTS_EINVAL;
     if ((ldc % 4) || (residual && (ldr % 4)) || (preact && (ldp % 4)) || (gate_h && (ldh % 4))) return TVTS_EINVAL;
@@ -260,11 +264,11 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.sa = nullptr; g.sb = nullptr; g.sa_rows = 0; g.gc = 0;
-    if (nt_use_256(M, N)) {
+    if (nt_use_256(M, N, opts)) {
         if (ldc % 8 || (preact && ldp % 8) || (gate_h && ldh % 8)) {
-            if (g_nt_tile == 256) return TVTS_EINVAL;  // forced, but the 16-byte epilogue accesses do not fit
+            if (opt_tile(opts) == 256) return TVTS_EINVAL;  // forced, but the 16-byte epilogue accesses do not fit
         } else {
-            return launch_nt256<false>(g, act, gate_act, gate_h != nullptr, stream);
+            return launch_nt256<false>(g, act, gate_act, gate_h != nullptr, opts, stream);
         }
     }
     g.tiles_n = ceil_div(N, BN);
@@ -292,7 +296,7 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
 // of tvts_quant_fp8_rows (BASELINE config 4's weight/activation path).  Same pipelined 256x256 kernel: K % 128 == 0, lda / ldb % 16 == 0.
 extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
                                 int scale_a_rows, const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact,
-                                int ldp, void* out, int ldc, int out_f32, hipStream_t stream) {
+                                int ldp, void* out, int ldc, int out_f32, int opts, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b) return TVTS_EINVAL;
     if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || (residual && ldr % 4) || (preact && ldp % 8)) return TVTS_EINVAL;
     GemmNT g;
@@ -300,7 +304,7 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
     g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = nullptr; g.ldh = 0; g.gate_act = ACT_NONE;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
-    return launch_nt256<true>(g, act, ACT_NONE, false, stream);
+    return launch_nt256<true>(g, act, ACT_NONE, false, opts, stream);
 }
 
 // the input-gradient form of the fp8 linear layer: out[M,N] (bf16) = gate'(h[M,N]) * (scale_a[m] * scale_b * (A[M,K] B[N,K]^T)) with
@@ -308,7 +312,7 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
 // and, optionally, the activation-gradient gate of the MLP's first layer (gate_h = its saved pre-activation)
 extern "C" int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
                                      int scale_a_rows, const float* scale_b, const void* gate_h, int ldh, int gate_act, void* out,
-                                     int ldc, hipStream_t stream) {
+                                     int ldc, int opts, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b || !gate_h) return TVTS_EINVAL;
     if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || ldh % 8) return TVTS_EINVAL;
     GemmNT g;
@@ -316,7 +320,7 @@ extern "C" int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int 
     g.M = M; g.N = N; g.K = K / 2; g.bias = nullptr; g.residual = nullptr; g.ldr = 0; g.act = ACT_NONE;
     g.preact = nullptr; g.ldp = 0; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
     g.out = out; g.ldc = ldc; g.out_f32 = 0; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
-    return launch_nt256<true>(g, ACT_NONE, gate_act, true, stream);
+    return launch_nt256<true>(g, ACT_NONE, gate_act, true, opts, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -556,42 +560,38 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 
 #include "gemm_tn256.h"
 
-// test / bench hook (no environment reads on the launch path): -1 = automatic choice
-static int g_tn_early = -1, g_tn_afast = -1, g_tn_splits = 0;
-extern "C" void tvts_gemm_set_tn_mode(int early_dma, int a_fast) { g_tn_early = early_dma; g_tn_afast = a_fast; }
-extern "C" void tvts_gemm_set_tn_splits(int splits) { g_tn_splits = splits > 0 ? splits : 0; }  // bench hook: 0 = automatic
+// per-call options of the weight-gradient entry point (TVTS_GEMM_TILE_*, TVTS_TN_*, TVTS_TN_SPLITS in include/tvts_hip.h): test /
+// bench hooks, 0 = automatic choice; no process state, no environment reads on the launch path
 // tile selection: the pipelined 256x256 kernel for long contractions -- M >= 32 768 rows, at least 0.5 M output elements, at
 // most 15 % of the 256-tiling's area wasted: every weight gradient of the ViT blocks (tools/tn_ab.py, M = 150 720: qkv 934 ->
 // 1109, fc1 955 -> 1131, fc2 984 -> 1134, proj 905 -> 925 TF) -- else the 128x128 kernel, which is the faster one on the text
 // tower's M = 24 576 (819 vs 757 TF).  0 auto, 128 / 256 force.
-static int g_tn_tile = 0;
-extern "C" void tvts_gemm_set_tn_tile(int t) { g_tn_tile = (t == 128 || t == 256) ? t : 0; }
-static bool tn_use_256(int M, int Na, int Nb) {
-    if (g_tn_tile) return g_tn_tile == 256;
+static bool tn_use_256(int M, int Na, int Nb, int opts) {
+    if (opt_tile(opts)) return opt_tile(opts) == 256;
     const double area = 65536.0 * ceil_div(Na, 256) * ceil_div(Nb, 256), elems = (double)Na * (double)Nb;
     return M >= 32768 && elems >= 0.5e6 && area <= 1.15 * elems;
 }
-extern "C" int tvts_gemm_tn_select(int M, int Na, int Nb) { return tn_use_256(M, Na, Nb) ? 256 : 128; }
+extern "C" int tvts_gemm_tn_select(int M, int Na, int Nb, int opts) { return tn_use_256(M, Na, Nb, opts) ? 256 : 128; }
 
 extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb,
                                  float* out, int ldo, int accumulate, float* colsum, float* workspace,
-                                 long workspace_elems, hipStream_t stream) {
+                                 long workspace_elems, int opts, hipStream_t stream) {
     if (M <= 0 || Na <= 0 || Nb <= 0) return TVTS_EINVAL;
     if (Na % 8 || Nb % 8 || ldp % 8 || ldq % 8 || ldo % 4) return TVTS_EINVAL;
     GemmTN g;
     g.ws = nullptr; g.cs_ws = nullptr; g.splits = 1; g.early_dma = 0; g.tiles_a = 0; g.a_fast = 0;
     g.P = (const bf16*)P; g.ldp = ldp; g.Q = (const bf16*)Q; g.ldq = ldq; g.M = M; g.Na = Na; g.Nb = Nb;
     g.out = out; g.ldo = ldo; g.colsum = colsum;
-    const bool t256 = tn_use_256(M, Na, Nb);
+    const bool t256 = tn_use_256(M, Na, Nb, opts);
     const int tile = t256 ? 256 : 128;
     const int tiles_a = ceil_div(Na, tile);
     g.tiles_b = ceil_div(Nb, tile);
     g.tiles_ab = tiles_a * g.tiles_b;
     g.tiles_a = tiles_a;
-    g.a_fast = g_tn_afast >= 0 ? g_tn_afast : (tiles_a < g.tiles_b ? 1 : 0);  // walk the tiles of an m-range with the SHORTER tile dimension fastest
+    g.a_fast = (opts & 8) ? 0 : (opts & 16) ? 1 : (tiles_a < g.tiles_b ? 1 : 0);  // walk the tiles of an m-range with the SHORTER tile dimension fastest
     // the early LDS-DMA issue addresses its operand with 32-bit offsets from a wave-uniform base: the operand must fit 4 GiB
     g.early_dma = ((unsigned long long)M * (unsigned long long)(ldp > ldq ? ldp : ldq) * 2ull < (1ull << 32)) ? 1 : 0;
-    if (g_tn_early == 0) g.early_dma = 0;
+    if (opts & 4) g.early_dma = 0;
     // split the contraction over M into S ranges (range s lives on XCD s % 8, see the kernel).  S is chosen for
     // whole rounds of 2 blocks x 256 CUs: the smallest S reaching >= 93 % round efficiency, else the best one.
     int splits = 1;
@@ -606,7 +606,7 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
             if (eff >= 0.93) { splits = sp; break; }
         }
     }
-    if (g_tn_splits > 0) splits = g_tn_splits;
+    if ((opts >> 8) > 0) splits = opts >> 8;
     // the partials must fit the caller's workspace: fewer, longer ranges beat the atomic fallback
     if (workspace != nullptr && splits > 1 && (long)splits * Na * Nb > workspace_elems) {
         const int fit = (int)(workspace_elems / ((long)Na * Nb));

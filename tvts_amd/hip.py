@@ -44,7 +44,84 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
-def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None):
+# ---- per-call dispatch options.  The C library keeps no state: every alternative kernel path is selected by the `opts` word of
+# the call (include/tvts_hip.h, TVTS_GEMM_* / TVTS_TN_* / TVTS_ATTN_*).  Tests and benches that want a whole engine step on an
+# alternative path wrap it in `with hip.options(nt_tile=256): ...`; the defaults below are what every call uses otherwise.
+# The one product use: `nt_cus` -- the CU reservation of the persistent GEMM grid when world > 1 (tvts_amd/dist.py).
+_DEFAULTS = dict(nt_tile=0, nt_cus=0, fp8_k32=False, tn_tile=0, tn_splits=0, tn_early_dma=None, tn_a_fast=None,
+                 attn_tr=True, attn_shared=True, attn_fused=True, attn_ablate=0)
+_OPTS = dict(_DEFAULTS)
+
+
+class options:
+    """Context manager: dispatch options of every call made inside the block (restored on exit, also on an exception)."""
+
+    def __init__(self, **kw):
+        bad = set(kw) - set(_DEFAULTS)
+        if bad:
+            raise KeyError(f"unknown dispatch option(s) {sorted(bad)}")
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = dict(_OPTS)
+        _OPTS.update(self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        _OPTS.clear()
+        _OPTS.update(self.saved)
+        return False
+
+
+def set_default(**kw):
+    """Process-wide default of a dispatch option (Python side only; dist.py reserves CUs for the RCCL kernels with nt_cus)."""
+    bad = set(kw) - set(_DEFAULTS)
+    if bad:
+        raise KeyError(f"unknown dispatch option(s) {sorted(bad)}")
+    _OPTS.update(kw)
+
+
+def _tile_bits(t):
+    return {0: 0, None: 0, 128: 1, 256: 2}[t]
+
+
+def nt_opts(tile=None, cus=None, fp8_k32=None):
+    tile = _OPTS["nt_tile"] if tile is None else tile
+    cus = _OPTS["nt_cus"] if cus is None else cus
+    k32 = _OPTS["fp8_k32"] if fp8_k32 is None else fp8_k32
+    return _tile_bits(tile) | (4 if k32 else 0) | (((int(cus) // 8) & 63) << 8)
+
+
+def tn_opts(tile=None, splits=None, early_dma=None, a_fast=None):
+    tile = _OPTS["tn_tile"] if tile is None else tile
+    splits = _OPTS["tn_splits"] if splits is None else splits
+    early_dma = _OPTS["tn_early_dma"] if early_dma is None else early_dma
+    a_fast = _OPTS["tn_a_fast"] if a_fast is None else a_fast
+    o = _tile_bits(tile) | (int(splits) << 8)
+    if early_dma is not None and not early_dma:
+        o |= 4
+    if a_fast is not None:
+        o |= 16 if a_fast else 8
+    return o
+
+
+def attn_opts(tr=None, shared=None, fused=None, ablate=None):
+    tr = _OPTS["attn_tr"] if tr is None else tr
+    shared = _OPTS["attn_shared"] if shared is None else shared
+    fused = _OPTS["attn_fused"] if fused is None else fused
+    ablate = _OPTS["attn_ablate"] if ablate is None else ablate
+    return (0 if tr else 1) | (0 if shared else 2) | (0 if fused else 4) | ((int(ablate) & 7) << 4)
+
+
+def gemm_nt_select(M, N, tile=None):
+    return _lib.load().tvts_gemm_nt_select(M, N, nt_opts(tile=tile))
+
+
+def gemm_tn_select(M, Na, Nb, tile=None):
+    return _lib.load().tvts_gemm_tn_select(M, Na, Nb, tn_opts(tile=tile))
+
+
+def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None, tile=None, cus=None):
     """out[M,N] = [act'(gate_h) *] act(a[M,K] @ b[N,K]^T + bias) [+ residual]; a, b bf16; out bf16 or fp32."""
     lib = _lib.load()
     M = a.shape[0] if M is None else M
@@ -58,7 +135,7 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
                                _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
                                _ld(preact) if preact is not None else 0, _p(gate_h),
                                _ld(gate_h) if gate_h is not None else 0, ACT[gate_act], _p(out), _ld(out),
-                               1 if out.dtype == torch.float32 else 0, _stream())
+                               1 if out.dtype == torch.float32 else 0, nt_opts(tile, cus), _stream())
     _chk(rc, "tvts_gemm_nt_bf16")
     if GEMM_PROFILE is not None:
         ev1.record()
@@ -115,15 +192,12 @@ def quantize_fp8_rows(x, q=None, row_scale=None):
     return q, row_scale
 
 
-def gemm_set_fp8_mx(on: bool):
-    """main loop of gemm_nt_fp8: True (default) the K = 128 scaled MFMA (fp8 issue rate), False the 16x16x32 fp8 form"""
-    _lib.load().tvts_gemm_set_fp8_mx(int(on))
-
-
-def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None):
+def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None, k32=None,
+                cus=None):
     """out[M,N] = act(sa*sb * (a8[M,K] @ b8[N,K]^T) + bias) [+ residual]; a8 / b8 uint8 e4m3 bit patterns; sb float32[1]; sa
     float32[1] (one scale for the tensor) or float32[>= M] (one per row, quantize_fp8_rows); preact receives the bf16
-    pre-activation like gemm_nt.  gate_h / gate_act: the input-gradient form, out = gate_act'(gate_h) * (sa*sb * (a8 @ b8^T))."""
+    pre-activation like gemm_nt.  gate_h / gate_act: the input-gradient form, out = gate_act'(gate_h) * (sa*sb * (a8 @ b8^T)).
+    k32: the 16x16x32 fp8 main loop instead of the K = 128 scaled MFMA (same products, same fp32 accumulation)."""
     lib = _lib.load()
     M, Kd = a8.shape
     N = b8.shape[0]
@@ -136,7 +210,7 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
     if gate_h is not None:
         assert bias is None and residual is None and act is None and preact is None and out.dtype == torch.bfloat16
         rc = lib.tvts_gemm_nt_fp8_gate(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(gate_h),
-                                       _ld(gate_h), ACT[gate_act], _p(out), _ld(out), _stream())
+                                       _ld(gate_h), ACT[gate_act], _p(out), _ld(out), nt_opts(None, cus, k32), _stream())
         _chk(rc, "tvts_gemm_nt_fp8_gate")
         if GEMM_PROFILE is not None:
             ev1.record()
@@ -145,7 +219,7 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
     rc = lib.tvts_gemm_nt_fp8(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(bias), _p(residual),
                               _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
                               _ld(preact) if preact is not None else 0, _p(out), _ld(out),
-                              1 if out.dtype == torch.float32 else 0, _stream())
+                              1 if out.dtype == torch.float32 else 0, nt_opts(None, cus, k32), _stream())
     _chk(rc, "tvts_gemm_nt_fp8")
     if GEMM_PROFILE is not None:
         ev1.record()
@@ -162,7 +236,7 @@ def _tn_workspace(dev):
     return TN_WORKSPACE
 
 
-def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True):
+def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True, tile=None, splits=None, early_dma=None, a_fast=None):
     """out[Na,Nb] (+)= p[M,Na]^T @ q[M,Nb]; p, q bf16; out fp32."""
     lib = _lib.load()
     M = p.shape[0] if M is None else M
@@ -172,7 +246,8 @@ def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True):
         ev0, ev1 = Event(), Event()
         ev0.record()
     rc = lib.tvts_gemm_tn_bf16(_p(p), _ld(p), _p(q), _ld(q), M, p.shape[1], q.shape[1], _p(out), _ld(out),
-                               1 if accumulate else 0, _p(colsum), _p(ws), ws.numel() if ws is not None else 0, _stream())
+                               1 if accumulate else 0, _p(colsum), _p(ws), ws.numel() if ws is not None else 0,
+                               tn_opts(tile, splits, early_dma, a_fast), _stream())
     _chk(rc, "tvts_gemm_tn_bf16")
     if GEMM_PROFILE is not None:
         ev1.record()
@@ -254,10 +329,10 @@ def _attn_fn(lib, name, head_dim):
     raise HipError(f"attention kernels are built for head dim 64 and 80, not {head_dim}")
 
 
-def attn_fwd(mode, qkv, out, lse2, *, B, heads, S, T=0, n=0, causal=False, head_dim=64):
+def attn_fwd(mode, qkv, out, lse2, *, B, heads, S, T=0, n=0, causal=False, head_dim=64, **opt):
     lib = _lib.load()
     rc = _attn_fn(lib, "fwd", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(out), _ld(out), _p(lse2),
-                           _stream())
+                           attn_opts(**opt), _stream())
     _chk(rc, "tvts_attn_fwd")
 
 
@@ -313,50 +388,40 @@ def attn_delta(dO, O, delta, *, rows, heads, head_dim=64):
     _chk(_attn_fn(lib, "delta", head_dim)(_p(dO), _ld(dO), _p(O), _ld(O), rows, heads, _p(delta), _stream()), "tvts_attn_delta")
 
 
-def attn_bwd_dq(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, head_dim=64):
+def attn_bwd_dq(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, head_dim=64, **opt):
     lib = _lib.load()
     rc = _attn_fn(lib, "bwd_dq", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO), _p(lse2),
-                              _p(delta), _p(dqkv), _ld(dqkv), _stream())
+                              _p(delta), _p(dqkv), _ld(dqkv), attn_opts(**opt), _stream())
     _chk(rc, "tvts_attn_bwd_dq")
 
 
-def attn_bwd_dkv(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None, head_dim=64):
+def attn_bwd_dkv(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None, head_dim=64, **opt):
     lib = _lib.load()
     rc = _attn_fn(lib, "bwd_dkv", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO),
-                               _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc), _stream())
+                               _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc), attn_opts(**opt), _stream())
     _chk(rc, "tvts_attn_bwd_dkv")
 
 
-def attn_fwd_divided(mode, qkv, out, lse2, cls_ws, *, B, heads, S, T, n, head_dim=64):
+def attn_fwd_divided(mode, qkv, out, lse2, cls_ws, *, B, heads, S, T, n, head_dim=64, **opt):
     """Forward of one divided-attention site (patch rows + CLS row); cls_ws is fp32 scratch."""
     lib = _lib.load()
     rc = _attn_fn(lib, "fwd_divided", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, _p(out), _ld(out), _p(lse2),
-                                                _p(cls_ws), cls_ws.numel(), _stream())
+                                                _p(cls_ws), cls_ws.numel(), attn_opts(**opt), _stream())
     _chk(rc, "tvts_attn_fwd_divided")
 
 
-def attn_bwd(mode, qkv, dO, O, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None, head_dim=64):
+def attn_bwd(mode, qkv, dO, O, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None, head_dim=64, **opt):
     """Whole backward of one attention site into dqkv (delta / cls_acc are scratch)."""
     lib = _lib.load()
     rc = _attn_fn(lib, "bwd", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO), _p(O),
                                         _ld(O), _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc),
-                                        cls_acc.numel() if cls_acc is not None else 0, _stream())
+                                        cls_acc.numel() if cls_acc is not None else 0, attn_opts(**opt), _stream())
     _chk(rc, "tvts_attn_bwd")
-
-
-def attn_set_fused(on: bool):
-    _lib.load().tvts_attn_set_fused(int(on))
-    _lib.load().tvts_attn80_set_fused(int(on))
 
 
 def attn_cls_finalize(cls_acc, dqkv, *, B, heads, S, head_dim=64):
     lib = _lib.load()
     _chk(_attn_fn(lib, "cls_finalize", head_dim)(_p(cls_acc), B, heads, S, _p(dqkv), _ld(dqkv), _stream()), "tvts_attn_cls_finalize")
-
-
-def attn_set_transpose_read(on: bool):
-    _lib.load().tvts_attn_set_transpose_read(int(on))
-    _lib.load().tvts_attn80_set_transpose_read(int(on))
 
 
 def patch_gather(video, keep, out, *, B, T, n, img, patch):
@@ -408,8 +473,10 @@ def vit_assemble(patch, cls, pos, temporal, keep, tok, *, B, T, n):
 
 def vit_assemble_bwd(dtok, keep, dpatch, dcls, dpos, dtemporal, *, B, T, n):
     lib = _lib.load()
+    ws = _tn_workspace(dtok.device)  # ordered partials of the temporal / class embedding sums (shared fp32 scratch of this stream)
     _chk(lib.tvts_vit_assemble_bwd(_p(dtok), _ld(dtok), _p(keep), 1 if keep.dim() == 3 else 0, B, T, n, dtok.shape[1],
-                                   _p(dpatch), _ld(dpatch), _p(dcls), _p(dpos), _p(dtemporal), _stream()), "tvts_vit_assemble_bwd")
+                                   _p(dpatch), _ld(dpatch), _p(dcls), _p(dpos), _p(dtemporal), _p(ws), ws.numel(), _stream()),
+         "tvts_vit_assemble_bwd")
 
 
 def patch_gather_tube(video, keep, out, *, B, tubes, tubelet, n, img, patch):
@@ -452,8 +519,9 @@ def sort_assemble(tok, text, type_embed, xs, *, B, S, off, Sv, NT):
 def sort_assemble_bwd(dxs, dvid, dout, dtype, *, B, S, off, Sv, NT):
     lib = _lib.load()
     E = dout.shape[1]
+    ws = _tn_workspace(dout.device)  # ordered partials of the type-embedding gradient
     _chk(lib.tvts_sort_assemble_bwd(_p(dxs), _ld(dxs) if dxs is not None else 0, B, S, off, Sv, NT, _p(dvid), E,
-                                    _p(dout), _ld(dout), _p(dtype), _stream()), "tvts_sort_assemble_bwd")
+                                    _p(dout), _ld(dout), _p(dtype), _p(ws), ws.numel(), _stream()), "tvts_sort_assemble_bwd")
 
 
 def relu(x, out, dy=None):
