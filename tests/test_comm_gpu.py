@@ -100,3 +100,68 @@ def test_training_step_through_the_native_transport(comm):
     l2, p2, sent2, _ = _step(True, "bf16")
     assert sent2 * 2 == sent1
     assert l2[0] == pytest.approx(l0[0], rel=1e-6, abs=1e-6) and l2[-1] == pytest.approx(l0[-1], rel=5e-3, abs=5e-3)
+
+
+def test_captured_step_through_the_native_transport(comm):
+    """The step with its exchange steps on the library's side stream, captured into ONE hipGraph (the fork / join events pull
+    the side stream into the capture; RCCL launches are capturable) and replayed: the same losses and parameters as eager
+    launches of the same step.  What bench.py does under TVTS_BENCH_GRAPH_DDP=1 for world > 1."""
+    from tvts_amd import arch as A
+    from tvts_amd import dist as D
+    from tvts_amd.model._common import TVTSv2Base
+    from tvts_amd.optim import FusedHFAdamW
+    from tvts_amd.step import StepRunner
+    a = A.small_arch()
+    oarch = O.tiny_arch(**a)
+    batch = O.synth_batch(oarch, B=4, T=2, seed=2, caption_len=9)
+
+    def make():
+        m = TVTSv2Base(types.SimpleNamespace(local_rank=0, rank=0, world_size=1), arch=a)
+        m.load_state_dict(O.synth_params(oarch, seed=1), strict=True)
+        groups = [[], [], [], []]
+        for name, p in m.named_parameters():
+            gi = A.param_group_of(name, a)
+            if gi < 0:
+                p.requires_grad = False
+            else:
+                groups[gi].append(p)
+        opt = FusedHFAdamW([dict(params=groups[i], lr=A.GROUP_HPARAMS[i][0] * 30, weight_decay=A.GROUP_HPARAMS[i][1])
+                            for i in range(4)], m.store, model=m)
+        run = StepRunner(m, opt)
+        run.sync = D.GradSync(m.store.grad, native=True)
+        run.gather = D.EmbedGather(native=True)
+        m.engine.grad_ready = run.sync.reduce_range
+        pb = m.engine.prepare_batch(batch)
+        lab = batch["label"].reshape(-1).to(torch.int32).to(DEV)
+        m._fresh_shadows(); m._sync_requires_grad()
+        return m, opt, run, pb, lab
+
+    m, opt, run, pb, lab = make()
+    eager = []
+    for _ in range(3):
+        out = run.run(pb, lab, device_step=True)
+        torch.cuda.synchronize()
+        eager.append(float(out["loss1"]) + float(out["loss2"]))
+    p_eager = m.store.flat.clone()
+
+    m, opt, run, pb, lab = make()
+    snap = {k: t.clone() for k, t in (("flat", m.store.flat), ("m", m.store.m), ("v", m.store.v))}
+    run.run(pb, lab, device_step=True)  # warm-up: workspaces, communicator, hyper-parameter table
+    torch.cuda.synchronize()
+    m.store.flat.copy_(snap["flat"]); m.store.m.copy_(snap["m"]); m.store.v.copy_(snap["v"])
+    opt.step_dev.zero_(); opt.global_step = 0
+    m.store.refresh_shadows()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = run.run(pb, lab, device_step=True)
+    torch.cuda.synchronize()
+    assert torch.equal(m.store.flat, snap["flat"])  # capture does not execute
+    replayed = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        replayed.append(float(out["loss1"]) + float(out["loss2"]))
+    assert run.sync.bytes_sent > 0
+    assert replayed == eager, (replayed, eager)
+    assert float((m.store.flat - p_eager).abs().max()) < 1e-7

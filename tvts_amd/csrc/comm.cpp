@@ -35,19 +35,34 @@ extern "C" int tvts_comm_unique_id(void* id128) {
     return 0;
 }
 
+static void comm_free(TvtsComm* c) {
+    if (c->fork) hipEventDestroy(c->fork);
+    if (c->join) hipEventDestroy(c->join);
+    if (c->side) hipStreamDestroy(c->side);
+    if (c->nccl) ncclCommDestroy(c->nccl);
+    delete c;
+}
+
 extern "C" int tvts_comm_create(const void* id128, int rank, int world, void** comm_out) {
     if (!id128 || !comm_out || world < 1 || rank < 0 || rank >= world) return TVTS_EINVAL;
+    *comm_out = nullptr;
     TvtsComm* c = new TvtsComm();
+    c->nccl = nullptr; c->side = nullptr; c->fork = nullptr; c->join = nullptr;
     c->rank = rank; c->world = world;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
-    NCCL_TRY(ncclCommInitRank(&c->nccl, world, id, rank));
+    // every early return releases what exists so far (communicator, stream, events) and leaves *comm_out NULL
+#define CREATE_TRY_NCCL(x) do { ncclResult_t r__ = (x); if (r__ != ncclSuccess) { comm_free(c); return -(1000 + (int)r__); } } while (0)
+#define CREATE_TRY_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { comm_free(c); return (int)e__; } } while (0)
+    CREATE_TRY_NCCL(ncclCommInitRank(&c->nccl, world, id, rank));
     // a high-priority side stream: its (few, short) kernels should not queue behind the persistent GEMM blocks
     int lo = 0, hi = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIP_TRY(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
-    HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->join, hipEventDisableTiming));
+    CREATE_TRY_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CREATE_TRY_HIP(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
+    CREATE_TRY_HIP(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+    CREATE_TRY_HIP(hipEventCreateWithFlags(&c->join, hipEventDisableTiming));
+#undef CREATE_TRY_NCCL
+#undef CREATE_TRY_HIP
     *comm_out = c;
     return 0;
 }
@@ -55,13 +70,18 @@ extern "C" int tvts_comm_create(const void* id128, int rank, int world, void** c
 extern "C" int tvts_comm_destroy(void* comm) {
     if (!comm) return TVTS_EINVAL;
     TvtsComm* c = (TvtsComm*)comm;
-    hipStreamSynchronize(c->side);
-    ncclCommDestroy(c->nccl);
-    hipEventDestroy(c->fork);
-    hipEventDestroy(c->join);
-    hipStreamDestroy(c->side);
+    // the first failure is reported, everything is released regardless
+    int rc = 0;
+    hipError_t e = hipStreamSynchronize(c->side);
+    if (e != hipSuccess) rc = (int)e;
+    ncclResult_t r = ncclCommDestroy(c->nccl);
+    if (r != ncclSuccess && !rc) rc = -(1000 + (int)r);
+    c->nccl = nullptr;
+    e = hipEventDestroy(c->fork); if (e != hipSuccess && !rc) rc = (int)e;
+    e = hipEventDestroy(c->join); if (e != hipSuccess && !rc) rc = (int)e;
+    e = hipStreamDestroy(c->side); if (e != hipSuccess && !rc) rc = (int)e;
     delete c;
-    return 0;
+    return rc;
 }
 
 extern "C" int tvts_comm_world(void* comm, int* rank, int* world) {

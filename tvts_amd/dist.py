@@ -11,9 +11,18 @@
   ``TVTS_GRAD_PAYLOAD=bf16``).
 
 Two transports, same semantics:
-  ``torch``  (default)  torch.distributed collectives (backend nccl = RCCL on the GPUs, gloo on CPU tensors in the tests);
-  ``native`` (``TVTS_COMM=native``)  the C ABI of include/tvts_comm.h: RCCL calls on a side HIP stream the library owns,
-             fork / join by events against the compute stream, no host synchronisation anywhere in the step.
+  ``native`` the C ABI of include/tvts_comm.h: RCCL calls on a side HIP stream the library owns, fork / join by events against
+             the compute stream, no host synchronisation anywhere in the step.  The DEFAULT whenever world > 1 on the RCCL
+             backend and libtvts_comm.so loads (``TVTS_COMM=torch`` switches it off);
+  ``torch``  torch.distributed collectives (backend nccl = RCCL on the GPUs, gloo on CPU tensors in the tests): the default at
+             world 1 and on non-RCCL backends, the fallback when the library cannot be loaded.
+
+CU reservation (``TVTS_NT_CUS``, default none): the persistent 256x256 GEMM blocks fill a CU completely, so an RCCL kernel only
+gets CUs at a GEMM kernel boundary or on CUs the persistent grid leaves free.  tools/overlap_probe.py (profiles/r03_overlap_probe.txt)
+measures both on one GPU: a side-stream kernel forked under the dgrad chain starts within one GEMM launch (<= 0.5 ms) either way;
+on 8 reserved CUs it streams at ~0.27 TB/s (128 MB in 480 us), on 32 at ~1.3 TB/s -- and reserving 8 / 16 CUs costs the GEMM chain
+4.3 % / 8.7 %.  At the bench's 192 pairs per GPU the whole gradient all-reduce (624 MB fp32) is ~5 ms of a 150 ms step, less
+than what a reservation costs, so none is made by default; at small per-GPU batches set TVTS_NT_CUS=248.
 """
 from __future__ import annotations
 
@@ -74,6 +83,20 @@ class NativeComm:
         h = ctypes.c_void_p()
         self._chk(self.lib.tvts_comm_create(ctypes.cast(raw, ctypes.c_void_p), r, W, ctypes.byref(h)), "tvts_comm_create")
         self.h, self.W, self.rank = h, W, r
+        import atexit
+        atexit.register(self.close)  # before torch.distributed tears its own RCCL communicators down at interpreter exit
+
+    def close(self):
+        """Destroys the communicator, the side stream and its events (idempotent)."""
+        h, self.h = self.h, None
+        if h is not None:
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            self.lib.tvts_comm_destroy(h)
+            if NativeComm._inst is self:
+                NativeComm._inst = None
 
     @staticmethod
     def _chk(rc, name):
@@ -106,11 +129,34 @@ class NativeComm:
         self._chk(self.lib.tvts_comm_wait(self.h, self._stream()), "tvts_comm_wait")
 
 
+_TRANSPORT: Optional[str] = None
+
+
 def transport() -> str:
-    t = os.environ.get("TVTS_COMM", "torch")
-    if t not in ("torch", "native"):
-        raise ValueError(f"TVTS_COMM={t!r}: expected 'torch' or 'native'")
-    return t
+    """'native' or 'torch' (see the module docstring); decided once per process."""
+    global _TRANSPORT
+    t = os.environ.get("TVTS_COMM")
+    if t is not None:
+        if t not in ("torch", "native"):
+            raise ValueError(f"TVTS_COMM={t!r}: expected 'torch' or 'native'")
+        return t
+    if _TRANSPORT is None:
+        _TRANSPORT = "torch"
+        W, _ = world()
+        if W > 1 and torch.cuda.is_available() and dist.get_backend() == "nccl":
+            try:
+                from . import _lib
+                _lib.load_comm()
+                _TRANSPORT = "native"
+            except Exception as e:  # the library is optional: torch.distributed carries the same exchange steps
+                import warnings
+                warnings.warn(f"libtvts_comm.so not usable ({type(e).__name__}: {e}); exchange steps go through torch.distributed")
+        if _TRANSPORT == "native":
+            cus = int(os.environ.get("TVTS_NT_CUS", "0"))
+            if cus:
+                from . import hip as K
+                K.set_default(nt_cus=cus)
+    return _TRANSPORT
 
 
 # ------------------------------------------------------------------------------------------------ embedding all-gather
