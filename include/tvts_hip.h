@@ -153,6 +153,17 @@ int tvts_attn_fwd_len(const void* qkv, int ld, int B, int heads, int S, const in
                       hipStream_t stream);
 int tvts_attn_bwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,
                       const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream);
+/* the same pair with DROPOUT on the attention probabilities -- transformers' DistilBERT MultiHeadSelfAttention in training mode
+ * (weights = dropout(softmax(scores)), attention_dropout 0.1), which the v1 model runs in every pretraining step
+ * (v1/model/model_dist_TVTS.py:33-34 text_model.train(), :131-141).  Counter-based mask: probability (b, h, q, k) is kept iff the
+ * upper 32 bits of splitmix64(seed_dev[0] + site + index * 0x9E3779B97F4A7C15) are >= p * 2^32, kept values are scaled by
+ * 1 / (1 - p); seed_dev is DEVICE memory (a replayed hipGraph draws new masks when the caller advances it), the backward
+ * regenerates the forward's mask from the same (seed, site).  p = 0: the plain pair. */
+int tvts_attn_fwd_len_drop(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, void* out, int ldo, float* lse2,
+                    float p, const long* seed_dev, long site, hipStream_t stream);
+int tvts_attn_bwd_len_drop(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,
+                    const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float p,
+                    const long* seed_dev, long site, hipStream_t stream);
 /* FULL attention (no mask) whose only QUERIES are the last nq (<= 16) tokens of every sequence, all S tokens keys: the last block
  * of the transcript-sorting head -- SortTransformer.forward_features reads its output at the transcript positions only
  * (v2/model/sort_transformer.py:131-141: x = self.norm(x[:, x_len:])), so the other rows of that block's attention output, MLP and
@@ -181,6 +192,17 @@ int tvts_attn80_fwd_len(const void* qkv, int ld, int B, int heads, int S, const 
                         hipStream_t stream);
 int tvts_attn80_bwd_len(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,
                         const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, hipStream_t stream);
+/* the same pair with DROPOUT on the attention probabilities -- transformers' DistilBERT MultiHeadSelfAttention in training mode
+ * (weights = dropout(softmax(scores)), attention_dropout 0.1), which the v1 model runs in every pretraining step
+ * (v1/model/model_dist_TVTS.py:33-34 text_model.train(), :131-141).  Counter-based mask: probability (b, h, q, k) is kept iff the
+ * upper 32 bits of splitmix64(seed_dev[0] + site + index * 0x9E3779B97F4A7C15) are >= p * 2^32, kept values are scaled by
+ * 1 / (1 - p); seed_dev is DEVICE memory (a replayed hipGraph draws new masks when the caller advances it), the backward
+ * regenerates the forward's mask from the same (seed, site).  p = 0: the plain pair. */
+int tvts_attn80_fwd_len_drop(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, void* out, int ldo, float* lse2,
+                    float p, const long* seed_dev, long site, hipStream_t stream);
+int tvts_attn80_bwd_len_drop(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,
+                    const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float p,
+                    const long* seed_dev, long site, hipStream_t stream);
 int tvts_attn80_fwd(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, void* out, int ldo,
                   float* lse2, int opts, hipStream_t stream);
 int tvts_attn80_delta(const void* dO, int lddo, const void* O, int ldo, int rows, int heads, float* delta,
@@ -250,6 +272,12 @@ int tvts_sort_assemble(const float* tok, int ldt, int B, int S, int off, int Sv,
 /* workspace (optional, >= B * (ceil(S / 32) + 1) * E fp32 elements): the type-embedding gradient as ordered partials (no atomics) */
 int tvts_sort_assemble_bwd(const float* dxs, int ldx, int B, int S, int off, int Sv, int NT, const float* dvid, int E,
                            void* dout, int ldo, float* dtype, float* workspace, long workspace_elems, hipStream_t stream);
+/* hidden-state dropout of the v1 text tower in training mode (transformers DistilBERT: Embeddings.dropout after the embedding
+ * LayerNorm, FFN.dropout after lin2; p = 0.1; v1/model/model_dist_TVTS.py:33-34): out[r, c] = x[r, c] * m / (1 - p) (+ residual[r, c]),
+ * m from the same counter-based generator as the attention dropout with index r * cols + c; out (fp32) and / or out_bf16 may be
+ * given.  The backward is the same call on the gradient (same seed / site => same mask). */
+int tvts_dropout_rows(const float* x, int ldx, int rows, int cols, float p, const long* seed_dev, long site,
+                      const float* residual, int ldr, float* out, int ldo, void* out_bf16, int ldob, hipStream_t stream);
 /* out = relu(x) (dy NULL) or out = dy * (x > 0) (its backward): the nn.ReLU of v1's txt_proj (v1/model/model_dist_TVTS.py:65-68) */
 int tvts_relu(const float* x, const float* dy, float* out, long n, hipStream_t stream);
 int tvts_rows_gather(const float* src, int ld_src, const int* rows, int R, int W, float* dst, int ld_dst, int scatter_add,

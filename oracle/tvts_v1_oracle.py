@@ -155,15 +155,52 @@ def synth_batch(a, B: int, T: int, seed: int = 0, n_trans: Optional[int] = None,
     return batch
 
 
+# ------------------------------------------------------------------------------------------------ dropout masks
+# The build's counter-based generator, restated (tvts_amd/csrc/attention.hip::drop_keep, embed.hip::dropout_rows_kernel):
+# element i of call site k at seed s is KEPT iff the upper 32 bits of splitmix64(s + k * SITE_STRIDE + i * PHI) >= p * 2^32.
+# (transformers' nn.Dropout draws from torch's generator instead: the masks themselves are the build's own choice, what is pinned
+# against the reference is WHERE dropout acts and how it scales -- tests/golden/make_golden_v1.py runs the real DistilBertModel
+# with torch.nn.functional.dropout replaced by this very function.)
+DROP_SITE_STRIDE = 0x632BE59BD9B4E019
+DROP_STEP_STRIDE = 0x51ED270B7F4A7C15
+_M64 = (1 << 64) - 1
+
+
+def drop_mask(seed: int, site: int, shape, p: float) -> Tensor:
+    """float32 tensor of `shape`: 1 / (1 - p) where kept, 0 where dropped"""
+    import numpy as np
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        base = np.uint64((seed + site * DROP_SITE_STRIDE) & _M64)
+        z = base + np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    keep = (z >> np.uint64(32)) >= np.uint64(int(p * 4294967296.0))
+    return torch.from_numpy((keep.astype(np.float32) / np.float32(1.0 - p)).reshape(shape))
+
+
+def trim_text(text: dict) -> dict:
+    """the tokenizer's right-padded batch cut to its longest caption (what the build's prepare_batch does; the network function
+    is unchanged -- padded keys are masked -- but the dropout masks are indexed by the padded length)"""
+    L = int(text["attention_mask"].sum(-1).max())
+    return {"input_ids": text["input_ids"][:, :L], "attention_mask": text["attention_mask"][:, :L]}
+
+
 # ------------------------------------------------------------------------------------------------ text tower
-def distilbert(P: Params, ids: Tensor, mask: Tensor, a) -> Tensor:
+def distilbert(P: Params, ids: Tensor, mask: Tensor, a, drop=None) -> Tensor:
     """DistilBertModel(input_ids, attention_mask).last_hidden_state (transformers modeling_distilbert: Embeddings,
-    TransformerBlock with MultiHeadSelfAttention + FFN, POST-LayerNorm, eps 1e-12, erf-GELU; padded keys masked)."""
+    TransformerBlock with MultiHeadSelfAttention + FFN, POST-LayerNorm, eps 1e-12, erf-GELU; padded keys masked).
+    drop = dict(p=0.1, seed=int): training mode -- dropout(LayerNorm(embeddings)) [site 0], dropout(softmax(scores)) [site 1 + 2i],
+    dropout(lin2(gelu(lin1(x)))) [site 2 + 2i]; ids / mask must then be trimmed to the longest caption (trim_text)."""
     N, L = ids.shape
     h, Wt = a["text_heads"], a["text_width"]
     dh = Wt // h
+    dp = float(drop["p"]) if drop else 0.0
     x = P["text_model.embeddings.word_embeddings.weight"][ids] + P["text_model.embeddings.position_embeddings.weight"][:L]
     x = layer_norm(x, P["text_model.embeddings.LayerNorm.weight"], P["text_model.embeddings.LayerNorm.bias"], 1e-12)
+    if dp > 0:
+        x = x * drop_mask(drop["seed"], 0, (N, L, Wt), dp)
     key_mask = (mask == 0)[:, None, None, :]  # [N,1,1,L]
     for i in range(a["text_layers"]):
         p = f"text_model.transformer.layer.{i}."
@@ -172,18 +209,25 @@ def distilbert(P: Params, ids: Tensor, mask: Tensor, a) -> Tensor:
         v = linear(x, P[p + "attention.v_lin.weight"], P[p + "attention.v_lin.bias"]).reshape(N, L, h, dh).permute(0, 2, 1, 3)
         s = (q * dh ** -0.5) @ k.transpose(-1, -2)
         s = s.masked_fill(key_mask, torch.finfo(s.dtype).min)
-        o = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(N, L, Wt)
+        w = torch.softmax(s, dim=-1)
+        if dp > 0:
+            w = w * drop_mask(drop["seed"], 1 + 2 * i, (N, h, L, L), dp)
+        o = (w @ v).permute(0, 2, 1, 3).reshape(N, L, Wt)
         sa = linear(o, P[p + "attention.out_lin.weight"], P[p + "attention.out_lin.bias"])
         x = layer_norm(sa + x, P[p + "sa_layer_norm.weight"], P[p + "sa_layer_norm.bias"], 1e-12)
         f = linear(gelu_erf(linear(x, P[p + "ffn.lin1.weight"], P[p + "ffn.lin1.bias"])), P[p + "ffn.lin2.weight"],
                    P[p + "ffn.lin2.bias"])
+        if dp > 0:
+            f = f * drop_mask(drop["seed"], 2 + 2 * i, (N, L, Wt), dp)
         x = layer_norm(f + x, P[p + "output_layer_norm.weight"], P[p + "output_layer_norm.bias"], 1e-12)
     return x
 
 
-def compute_text(P: Params, text: dict, a) -> Tuple[Tensor, Tensor]:
+def compute_text(P: Params, text: dict, a, drop=None) -> Tuple[Tensor, Tensor]:
     """model_dist_TVTS.py:131-141: [CLS] row of the last hidden state, then txt_proj = Linear(ReLU(.)) (:65-68)."""
-    before = distilbert(P, text["input_ids"], text["attention_mask"], a)[:, 0, :]
+    if drop:
+        text = trim_text(text)
+    before = distilbert(P, text["input_ids"], text["attention_mask"], a, drop)[:, 0, :]
     return before, linear(torch.relu(before), P["txt_proj.1.weight"], P["txt_proj.1.bias"])
 
 
@@ -230,10 +274,11 @@ def compute_video(P: Params, video: Tensor, keep_ind: Tensor, a) -> Tuple[Tensor
     return before, linear(before[:, 0], P["vid_proj.0.weight"], P["vid_proj.0.bias"])
 
 
-def model_forward(P: Params, batch: dict, a):
-    """TVTS.forward (model_dist_TVTS.py:93-123) -> (text_emb [B,E], video_emb [B,E], pred [B,NT,4] | None)."""
+def model_forward(P: Params, batch: dict, a, drop=None):
+    """TVTS.forward (model_dist_TVTS.py:93-123) -> (text_emb [B,E], video_emb [B,E], pred [B,NT,4] | None).
+    drop: the text tower's training-mode dropout (distilbert)."""
     B = batch["video"].shape[0]
-    before, emb = compute_text(P, batch["text"], a)
+    before, emb = compute_text(P, batch["text"], a, drop)
     NT = before.shape[0] // B
     text_before = before.reshape(NT, B, -1).detach().permute(1, 0, 2)
     text_emb = emb.reshape(NT, B, -1).mean(0)
@@ -243,9 +288,9 @@ def model_forward(P: Params, batch: dict, a):
     return text_emb, video_emb, pred
 
 
-def step_losses(P: Params, batch: dict, a):
+def step_losses(P: Params, batch: dict, a, drop=None):
     """v1/trainer/trainer.py:137-152: sim_matrix(video, text) -> NormSoftmaxLoss; 2 x CE on the predicted order."""
-    te, ve, pred = model_forward(P, batch, a)
+    te, ve, pred = model_forward(P, batch, a, drop)
     loss1 = norm_softmax_loss(sim_matrix(ve, te))
     loss2 = sorting_ce(pred, batch["label"]) if pred is not None else torch.zeros(())
     return loss1, loss2, te, ve, pred

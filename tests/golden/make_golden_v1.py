@@ -7,7 +7,7 @@ random initialisation of the SAME classes -- transformers' DistilBertModel, the 
 reference file is edited or copied; only data (inputs are regenerated from seeds, expected outputs / gradients are
 stored) lands in tests/golden/v1_*.npz.
 
-    python tests/golden/make_golden_v1.py [tiny] [full]
+    python tests/golden/make_golden_v1.py [tiny] [dropout] [full]
 """
 from __future__ import annotations
 
@@ -103,13 +103,16 @@ class TinyV1(torch.nn.Module):
     """The reference's sub-modules at the tiny architecture, wired by the reference's own TVTS.forward / compute_text /
     compute_video (called as unbound functions)."""
 
-    def __init__(self, ns, a, P):
+    def __init__(self, ns, a, P, dropout=0.0):
         super().__init__()
         from functools import partial
         self.text_params = {"model": "distilbert-base-uncased"}
-        self.text_model = ns.DistilBertModel(ns.DistilBertConfig(
+        cfg = ns.DistilBertConfig(
             vocab_size=a["vocab"], max_position_embeddings=a["max_pos"], n_layers=a["text_layers"], n_heads=a["text_heads"],
-            dim=a["text_width"], hidden_dim=a["text_ffn"], dropout=0.0, attention_dropout=0.0))
+            dim=a["text_width"], hidden_dim=a["text_ffn"], dropout=dropout, attention_dropout=dropout)
+        if dropout > 0:
+            cfg._attn_implementation = "eager"  # the attention path that calls nn.functional.dropout on the probabilities
+        self.text_model = ns.DistilBertModel(cfg)
         vm = ns.ve.VisionTransformer(img_size=a["image"], patch_size=a["patch"], embed_dim=a["width"], depth=a["layers"],
                                      num_heads=a["heads"], mlp_ratio=4, qkv_bias=True,
                                      norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_frames=a["num_frames"],
@@ -176,6 +179,49 @@ def gen_tiny():
     save("v1_tiny_nt1", te=te, ve=ve, loss1=ns.loss.NormSoftmaxLoss()(ns.tvts.sim_matrix(ve, te)), seed=31, batch_seed=33)
 
 
+def gen_tiny_dropout():
+    """The reference's training-mode text tower: the REAL transformers DistilBertModel with dropout = attention_dropout = 0.1 in
+    train() mode (v1/model/model_dist_TVTS.py:33-34), wired by the reference's own TVTS.forward.  torch.nn.functional.dropout --
+    what nn.Dropout and the eager attention path call -- is replaced for the duration of the forward by the build's counter-based
+    mask generator (oracle drop_mask; call k of the forward = site k), so that the fixture pins WHERE the reference drops and how
+    it scales, independent of torch's random stream.  The captions are cut to the longest one first (the build's batch format)."""
+    ns = import_reference_v1()
+    a = V.tiny_arch()
+    P = V.synth_params(a, seed=31)
+    p_drop, seed = 0.1, 0x5EED5EED
+    m = TinyV1(ns, a, P, dropout=p_drop)
+    batch = V.synth_batch(a, B=3, T=4, seed=34, caption_len=11)
+    batch = dict(batch, text=V.trim_text(batch["text"]))
+    import torch.nn.functional as F
+    real, calls = F.dropout, []
+
+    def counter_dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        assert abs(p - p_drop) < 1e-12
+        site = len(calls)
+        calls.append(tuple(x.shape))
+        return x * V.drop_mask(seed, site, tuple(x.shape), p)
+    F.dropout = counter_dropout
+    torch.nn.functional.dropout = counter_dropout
+    try:
+        sel = {"g_word": ("text_model.embeddings.word_embeddings.weight", (slice(None),)),
+               "g_qlin0": ("text_model.transformer.layer.0.attention.q_lin.weight", (slice(None),)),
+               "g_vlin1": ("text_model.transformer.layer.1.attention.v_lin.weight", (slice(None),)),
+               "g_lin2": ("text_model.transformer.layer.1.ffn.lin2.weight", (slice(None),)),
+               "g_lin1": ("text_model.transformer.layer.0.ffn.lin1.weight", (slice(None),)),
+               "g_txtproj": ("txt_proj.1.weight", (slice(None),)),
+               "g_head": ("pred_model.head.weight", (slice(None),))}
+        _run(m, batch, ns, sel, "v1_tiny_dropout", dict(seed=31, batch_seed=34, B=3, T=4, caption_len=11, p=p_drop, drop_seed=seed,
+                                                       n_dropout_calls=1 + 2 * a["text_layers"]))
+    finally:
+        F.dropout = real
+        torch.nn.functional.dropout = real
+    N, L, h, W = batch["text"]["input_ids"].shape[0], batch["text"]["input_ids"].shape[1], a["text_heads"], a["text_width"]
+    want = [(N, L, W)] + [(N, h, L, L), (N, L, W)] * a["text_layers"]
+    assert calls == want, (calls, want)  # embeddings, then per layer: attention probabilities, FFN output
+
+
 def gen_full():
     """The real TVTS class (DistilBERT-base + ViT-B/16 with tubelets + sorting head, 170 M parameters) at B=2, 4 frames,
     mask 0.75 (the reference loader's clip shape, v1/configs/dist-yt-pt.json)."""
@@ -200,9 +246,11 @@ def gen_full():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "full"]
+    which = sys.argv[1:] or ["tiny", "dropout", "full"]
     torch.manual_seed(0)
     if "tiny" in which:
         gen_tiny()
+    if "dropout" in which:
+        gen_tiny_dropout()
     if "full" in which:
         gen_full()

@@ -101,6 +101,78 @@ def test_full_attention_with_padded_keys(K, B, h, S):
     assert float(dqkv.float()[~valid.to(DEV)][:, W:].abs().max()) == 0.0 if (~valid).any() else True
 
 
+def _seed_tensor(v):
+    return torch.tensor([v - (1 << 64) if v >= (1 << 63) else v], dtype=torch.int64, device=DEV)
+
+
+@pytest.mark.parametrize("B,h,S,p", [(5, 2, 14, 0.1), (3, 12, 50, 0.1), (4, 4, 77, 0.25), (2, 2, 130, 0.1)])
+def test_attention_probability_dropout(K, B, h, S, p):
+    """tvts_attn_fwd_len_drop / bwd_len_drop: weights = dropout(softmax(scores)) with the counter-based mask, forward and backward
+    against torch autograd with the SAME mask (oracle drop_mask), padded keys masked, several key tiles (S > 64)."""
+    dh, W = 64, h * 64
+    g = torch.Generator().manual_seed(S)
+    lens = torch.randint(1, S + 1, (B,), generator=g)
+    lens[0] = S
+    qkv = (torch.randn(B * S, 3 * W, generator=g) * 0.5).bfloat16()
+    dO = torch.randn(B * S, W, generator=g).bfloat16()
+    for b in range(B):
+        dO[b * S + int(lens[b]):(b + 1) * S] = 0
+    kv = lens.to(torch.int32).to(DEV)
+    seed, site = 0xF00DF00DF00DF00D, 3
+    sd = _seed_tensor(seed)
+    out = torch.empty(B * S, W, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B * S, h, device=DEV)
+    K.attn_fwd_len_drop(qkv.to(DEV), kv, out, lse, B=B, heads=h, S=S, p=p, seed=sd, site=site)
+    mask = V.drop_mask(seed, site, (B, h, S, S), p)
+    x = qkv.float().clone().requires_grad_(True)
+    q, k, v = (x[:, i * W:(i + 1) * W].reshape(B, S, h, dh).permute(0, 2, 1, 3) for i in range(3))
+    s = (q * dh ** -0.5) @ k.transpose(-1, -2)
+    s = s.masked_fill((torch.arange(S)[None, :] >= lens[:, None])[:, None, None, :], float("-inf"))
+    ref = ((torch.softmax(s, -1) * mask) @ v).permute(0, 2, 1, 3).reshape(B * S, W)
+    valid = (torch.arange(S)[None, :] < lens[:, None]).reshape(-1)
+    assert rel(out[valid.to(DEV)].float(), ref[valid]) < 8e-3, rel(out[valid.to(DEV)].float(), ref[valid])
+    # the log-sum-exp is of the UNdropped scores (softmax first, dropout second): equal to the plain kernel's
+    lse0, out0 = torch.empty_like(lse), torch.empty_like(out)
+    K.attn_fwd_len(qkv.to(DEV), kv, out0, lse0, B=B, heads=h, S=S)
+    assert float((lse - lse0)[valid.to(DEV)].abs().max()) < 1e-5 and rel(out0[valid.to(DEV)].float(), ref[valid]) > 0.05
+    ref.backward(dO.float())
+    dqkv = torch.full((B * S, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(B * S, h, device=DEV)
+    K.attn_bwd_len_drop(qkv.to(DEV), kv, dO.to(DEV), out, lse, delta, dqkv, B=B, heads=h, S=S, p=p, seed=sd, site=site)
+    assert torch.isfinite(dqkv.float()).all()
+    assert rel(dqkv.float(), x.grad) < 2e-2, rel(dqkv.float(), x.grad)
+    # p = 0 through the dropout entry points is the plain pair
+    out1 = torch.empty_like(out)
+    K.attn_fwd_len_drop(qkv.to(DEV), kv, out1, lse, B=B, heads=h, S=S, p=0.0, seed=sd, site=site)
+    assert torch.equal(out1[valid.to(DEV)].view(torch.int16), out0[valid.to(DEV)].view(torch.int16))
+
+
+def test_hidden_state_dropout(K):
+    """tvts_dropout_rows: x * m / (1 - p) (+ residual), fp32 and bf16 outputs, bit-exact against the oracle's restatement of the
+    generator; keep rate 1 - p; a different site or seed gives a different mask; the seed is read from device memory."""
+    M, W, p = 333, 768, 0.1
+    g = torch.Generator().manual_seed(0)
+    x, res = torch.randn(M, W, generator=g), torch.randn(M, W, generator=g)
+    seed = 0x8000000000000123
+    sd = _seed_tensor(seed)
+    out, outb = torch.empty(M, W, device=DEV), torch.empty(M, W, dtype=torch.bfloat16, device=DEV)
+    K.dropout_rows(x.to(DEV), p=p, seed=sd, site=4, residual=res.to(DEV), out=out, out_bf16=outb)
+    mask = V.drop_mask(seed, 4, (M, W), p)
+    want = x * mask + res
+    assert torch.equal(out.cpu(), want) and torch.equal(outb.float().cpu(), want.bfloat16().float())
+    ones = torch.ones(2000, 512, device=DEV)
+    kept = torch.empty_like(ones)
+    K.dropout_rows(ones, p=p, seed=sd, site=9, out=kept)
+    rate = float((kept > 0).float().mean())
+    assert abs(rate - (1 - p)) < 2e-3 and float(kept.max()) == pytest.approx(1 / (1 - p))
+    other = torch.empty_like(ones)
+    K.dropout_rows(ones, p=p, seed=sd, site=10, out=other)
+    assert 0.15 < float((other != kept).float().mean()) < 0.21  # independent masks differ on 2 p (1 - p) = 18 % of the elements
+    sd.add_(1)                                                   # a device-side seed update is seen by the next launch
+    K.dropout_rows(ones, p=p, seed=sd, site=9, out=other)
+    assert 0.15 < float((other != kept).float().mean()) < 0.21
+
+
 def test_relu(K):
     x = torch.randn(1000, generator=torch.Generator().manual_seed(0)).to(DEV)
     dy = torch.randn(1000, generator=torch.Generator().manual_seed(1)).to(DEV)
@@ -111,9 +183,11 @@ def test_relu(K):
 
 
 # ------------------------------------------------------------------------------------------------ model
-def build(a, P):
+def build(a, P, dropout=0.0):
+    """dropout 0: the p = 0 model the reference-class fixtures were made with (DistilBertConfig(dropout=0)); the training-mode
+    text tower (p = 0.1, the reference's text_model.train()) is covered by the *_dropout tests below"""
     from tvts_amd.model.model_dist_TVTS import TVTS
-    m = TVTS(ARGS, arch=dict(a))
+    m = TVTS(ARGS, arch=dict(a, text_dropout=dropout))
     m.load_state_dict(P, strict=True)
     return m
 
@@ -183,6 +257,79 @@ def test_small_v1_forward_backward(K, nt):
     vb, v = m.compute_video(batch["video"], batch["keep_ind"])
     rvb, rv = V.compute_video(P, batch["video"], batch["keep_ind"], oa)
     assert vb.shape == rvb.shape and rel(vb, rvb) < 0.02 and rel(v, rv) < 0.02
+
+
+@pytest.mark.parametrize("nt", [4, 1])
+def test_small_v1_training_mode_dropout(K, nt):
+    """The training step the reference runs: DistilBERT in train() mode (v1/model/model_dist_TVTS.py:33-34), dropout 0.1 on the
+    embedding output, the attention probabilities and the FFN output.  The engine draws counter-based masks (regenerated in the
+    backward); the oracle -- pinned to the real transformers class in this mode by tests/golden/v1_tiny_dropout.npz -- takes the
+    same seed: embeddings, losses and every gradient at the bf16 gates of the p = 0 test.  Then: a second step draws NEW masks,
+    eval mode draws none."""
+    a, oa = small()
+    P = V.synth_params(oa, seed=5)
+    batch = V.synth_batch(oa, B=4, T=6, seed=6, n_trans=nt, caption_len=13)
+    m = build(a, P, dropout=0.1)
+    eng = m.engine
+    assert eng.training and eng.text_drop_p == 0.1
+    seed0 = int(eng.drop_seed.item()) & ((1 << 64) - 1)
+    seed1 = (seed0 + eng.DROP_STEP_STRIDE) & ((1 << 64) - 1)   # the engine advances the seed at the start of a training forward
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    r1, r2, rte, rve, rpred = V.step_losses(leaves, batch, oa, drop=dict(p=0.1, seed=seed1))
+    (r1 + r2).backward()
+    grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    l1, l2, te, ve, pred = engine_step(m, batch)
+    assert (int(eng.drop_seed.item()) & ((1 << 64) - 1)) == seed1
+    assert min_cos(te, rte) > 0.9995 and rel(te, rte) < 0.02, (min_cos(te, rte), rel(te, rte))
+    assert min_cos(ve, rve) > 0.9995 and rel(ve, rve) < 0.02
+    assert abs(l1 - float(r1)) < (1e-2 if nt == 4 else 2e-2) and abs(l2 - float(r2)) < 1e-2, (l1, float(r1), l2, float(r2))
+    check_grads(m.store, grads, gn_tol=0.01 if nt == 4 else 0.03)
+    # not the p = 0 model
+    with torch.no_grad():
+        te0 = V.model_forward(P, batch, oa)[0]
+    assert rel(te, te0) > 0.02
+    # a second training forward: new masks
+    te_a = te.clone()
+    _, _, te_b, _, _ = engine_step(m, batch)
+    assert rel(te_b, te_a) > 0.02
+    # eval mode (validation, retrieval features): no dropout, the module flag is mirrored into the engine
+    m.eval()
+    with torch.no_grad():
+        te_e, ve_e, _ = m(batch)
+    assert not eng.training and rel(te_e, te0) < 0.02 and min_cos(te_e, te0) > 0.9995
+    m.train()
+    te_t, _, _ = m(batch)
+    assert eng.training and rel(te_t.detach(), te0) > 0.02
+
+
+def test_v1_training_curve_with_dropout_tracks_oracle(K):
+    """ten optimizer steps with the training-mode text tower: the engine's seed sequence handed to the oracle step by step"""
+    from tvts_amd.optim import FusedHFAdamW
+    from tvts_amd.step import StepRunner
+    a, oa = small()
+    P = V.synth_params(oa, seed=7)
+    batch = V.synth_batch(oa, B=4, T=4, seed=8, caption_len=9)
+    m = build(a, P, dropout=0.1)
+    opt = FusedHFAdamW([dict(params=list(m.parameters()), lr=3e-4, weight_decay=0.0)], m.store, model=m)
+    run = StepRunner(m, opt)
+    seed = int(m.engine.drop_seed.item()) & ((1 << 64) - 1)
+    Pr = {k: v.clone() for k, v in P.items()}
+    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in Pr.items()}
+    curve, ref = [], []
+    for step in range(1, 11):
+        seed = (seed + m.engine.DROP_STEP_STRIDE) & ((1 << 64) - 1)
+        leaves = {k: v.clone().requires_grad_(True) for k, v in Pr.items()}
+        r1, r2, *_ = V.step_losses(leaves, batch, oa, drop=dict(p=0.1, seed=seed))
+        (r1 + r2).backward()
+        ref.append(float(r1 + r2))
+        for k in Pr:
+            gk = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(Pr[k])
+            O.hf_adamw_step(Pr[k], gk, st[k][0], st[k][1], step, 3e-4, 0.0)
+        out = run.step(batch)
+        curve.append(float(out["loss1"]) + float(out["loss2"]))
+    curve, ref = np.array(curve), np.array(ref)
+    assert ref[-1] < ref[0] - 0.02, ref
+    assert np.all(np.abs(curve - ref) < 0.02 * np.abs(ref) + 1e-2), (curve, ref)
 
 
 def test_v1_full_size_against_reference_golden(K, golden):

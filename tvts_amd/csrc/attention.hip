@@ -60,7 +60,22 @@ struct AttnGeom {
     int cls_nq, cls_q0;     // CLS geometry generalised: cls_nq (<= 16) queries at tokens cls_q0 .. of the sequence (1, 0 = the CLS token)
     const int* cls_qpos;    // ... or ONE query per sequence at token cls_qpos[b] that sees the keys 0 .. cls_qpos[b] (causal)
     int cls_parts;          // fused backward: > 0 = cls_acc holds one partial per block ([B, heads, cls_parts, 3, dh]); 0 = atomics
+    // dropout on the attention probabilities (FULL geometry with kv_len: the DistilBERT text tower of v1 in training mode,
+    // transformers MultiHeadSelfAttention: weights = dropout(softmax(scores))).  Counter-based: element (b, h, q, k) is kept iff
+    // the upper 32 bits of splitmix64(seed + index) are >= drop_thr = p * 2^32; kept probabilities are scaled by drop_inv =
+    // 1 / (1 - p).  The backward regenerates the same mask from the same (seed, index).
+    unsigned drop_thr;
+    float drop_inv;
+    const unsigned long long* drop_seed;  // device memory (a captured graph draws new masks on every replay); + drop_site per call
+    unsigned long long drop_site;
 };
+__device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned long long idx, unsigned thr) {
+    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32) >= thr;
+}
 
 struct Grp { int b, h, sub, nq, nk; };
 
@@ -612,10 +627,11 @@ __device__ __forceinline__ void stage_store32(const Stage1& r, char* tile, int t
 }
 #define TILE_B (64 * VSTRIDE)
 
-template <int MODE, bool TR>
+template <int MODE, bool TR, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                               int ldo, float* __restrict__ lse2) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [buf][K | V]
+    const unsigned long long dseed = DROP ? g.drop_seed[0] + g.drop_site : 0ull;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nq_max = (MODE == MODE_SPACE) ? g.n : g.S;
     const int qblocks = (((nq_max + 15) >> 4) + 3) >> 2;
@@ -716,7 +732,15 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const 
                 if (u * 32 < rows) {
                     bf16x8 pf;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[2 * u + (j >> 2)][j & 3];
+                    for (int j = 0; j < 8; ++j) {
+                        float pv = st[2 * u + (j >> 2)][j & 3];
+                        if (DROP) {  // the row sum above is of the UNdropped probabilities (softmax first, dropout second)
+                            const int key = kt0 + (2 * u + (j >> 2)) * 16 + gq * 4 + (j & 3);
+                            const unsigned long long idx = ((unsigned long long)(r.b * g.heads + r.h) * g.S + qi) * g.S + key;
+                            pv = drop_keep(dseed, idx, g.drop_thr) ? pv * g.drop_inv : 0.f;
+                        }
+                        pf[j] = (bf16)pv;
+                    }
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt)
                         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T<TR>(vt, u, dt, lane), pf, o[dt], 0, 0, 0);
@@ -742,12 +766,13 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(AttnGeom g, const 
     if (active && qi < r.nq && gq == 0) lse2[(size_t)q_row<MODE>(g, r, qi) * g.heads + r.h] = m_run + log2f(l_run);
 }
 
-template <int MODE, bool TR>
+template <int MODE, bool TR, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_shared_kernel(AttnGeom g, const bf16* __restrict__ qkv,
                                                                  const bf16* __restrict__ dO, int lddo,
                                                                  const float* __restrict__ lse2, const float* __restrict__ delta,
                                                                  bf16* __restrict__ dqkv, int lddq) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [buf][K | V]
+    const unsigned long long dseed = DROP ? g.drop_seed[0] + g.drop_site : 0ull;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nq_max = (MODE == MODE_SPACE) ? g.n : g.S;
     const int qblocks = (((nq_max + 15) >> 4) + 3) >> 2;
@@ -810,6 +835,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_shared_kernel(AttnGeom g, con
                         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(kt_, t * 16 + li, ks, gq), qf[ks], s, 0, 0, 0);
                         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(vt, t * 16 + li, ks, gq), dof[ks], dp, 0, 0, 0);
                     }
+                    if (DROP) {  // dP of the dropped probabilities: dS = P o (m / (1 - p) o dP - D)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int key = kt0 + t * 16 + gq * 4 + e;
+                            const unsigned long long idx = ((unsigned long long)(r.b * g.heads + r.h) * g.S + qi) * g.S + key;
+                            dp[e] = drop_keep(dseed, idx, g.drop_thr) ? dp[e] * g.drop_inv : 0.f;
+                        }
+                    }
                     if (!causal && kt0 + 64 <= r.nk) {  // interior tile (wave-uniform): no mask arithmetic
 #pragma unroll
                         for (int e = 0; e < 4; ++e) ds[t][e] = __builtin_amdgcn_exp2f(s[e] * g.scale2 - lse) * (dp[e] - dlt) * g.scale;
@@ -848,7 +881,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_shared_kernel(AttnGeom g, con
         return (active && j < r.nq) ? dqkv + (size_t)q_row<MODE>(g, r, j) * lddq + hcol : nullptr; });
 }
 
-template <int MODE, bool TR>
+template <int MODE, bool TR, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, const bf16* __restrict__ qkv,
                                                                   const bf16* __restrict__ dO, int lddo,
                                                                   const float* __restrict__ lse2, const float* __restrict__ delta,
@@ -857,6 +890,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
     constexpr int QT = 64;
     __shared__ __attribute__((aligned(16))) char smem[4 * QT * VSTRIDE];  // [buf][Q | dO] of QT rows
     __shared__ __attribute__((aligned(16))) float stat[2][2][QT];         // [buf][lse2 | delta][query]
+    const unsigned long long dseed = DROP ? g.drop_seed[0] + g.drop_site : 0ull;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr bool EXT = (MODE == MODE_SPACE);
     constexpr int HT = QT * VSTRIDE;
@@ -934,12 +968,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
                         // the lane's 4 consecutive queries: their stats in two 16-byte LDS reads (were 8 scalar ones)
                         const f32x4 l4 = *(const f32x4*)&stat[buf][0][tile * 16 + gq * 4];
                         const f32x4 d4 = *(const f32x4*)&stat[buf][1][tile * 16 + gq * 4];
+                        float dm[4] = {1.f, 1.f, 1.f, 1.f};  // dropout factor m / (1 - p) of (query, key) for the lane's 4 queries
+                        if (DROP) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int qi = qt0 + tile * 16 + gq * 4 + e;
+                                const unsigned long long idx = ((unsigned long long)(r.b * g.heads + r.h) * g.S + qi) * g.S + kj;
+                                dm[e] = drop_keep(dseed, idx, g.drop_thr) ? g.drop_inv : 0.f;
+                            }
+                        }
                         if (!EXT && !causal && qt0 + QT <= nqx && k0 + 16 <= r.nk) {  // interior (wave-uniform): no mask arithmetic
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float p = __builtin_amdgcn_exp2f(s[e] * g.scale2 - l4[e]);
-                                pf[t * 4 + e] = (bf16)p;
-                                dsf[t * 4 + e] = (bf16)(p * (dp[e] - d4[e]) * g.scale);
+                                pf[t * 4 + e] = (bf16)(DROP ? p * dm[e] : p);
+                                dsf[t * 4 + e] = (bf16)(p * ((DROP ? dp[e] * dm[e] : dp[e]) - d4[e]) * g.scale);
                             }
                         } else {
 #pragma unroll
@@ -949,8 +992,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_shared_kernel(AttnGeom g, co
                                 if (causal) ok = ok && kj <= qi;
                                 if (EXT) ok = ok && !(qi == 0 && kj == 0 && r.sub != 0);
                                 const float p = ok ? __builtin_amdgcn_exp2f(s[e] * g.scale2 - l4[e]) : 0.f;
-                                pf[t * 4 + e] = (bf16)p;
-                                dsf[t * 4 + e] = (bf16)(p * (dp[e] - d4[e]) * g.scale);
+                                pf[t * 4 + e] = (bf16)(DROP ? p * dm[e] : p);
+                                dsf[t * 4 + e] = (bf16)(p * ((DROP ? dp[e] * dm[e] : dp[e]) - d4[e]) * g.scale);
                             }
                         }
                     }
@@ -2157,6 +2200,7 @@ static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int 
     if (mode < MODE_FULL || mode > MODE_CLS) return TVTS_EINVAL;
     g.B = B; g.heads = heads; g.S = S; g.T = T; g.n = n; g.causal = causal; g.ld = ld; g.W = heads * DH; g.kv_len = nullptr;
     g.cls_nq = 1; g.cls_q0 = 0; g.cls_qpos = nullptr; g.cls_parts = 0;
+    g.drop_thr = 0; g.drop_inv = 1.f; g.drop_seed = nullptr; g.drop_site = 0;
     g.scale = 1.0f / sqrtf((float)DH);
     g.scale2 = g.scale * 1.4426950408889634f;
     g.ablate = 0;  // timing-ablation bits of the fused backward (opts bits 4..6 of tvts_attn_bwd; results are wrong by construction)
@@ -2195,14 +2239,33 @@ static int items_k(const AttnGeom& g, int mode) {
     } while (0)
 
 // out[rows, ldo] (heads merged, the layout the output projection consumes), lse2[rows, heads]
+struct DropArgs { float p; const unsigned long long* seed; unsigned long long site; };
+static int set_drop(AttnGeom& g, const DropArgs* d) {
+    if (!d || d->p <= 0.f) return TVTS_OK;
+    if (d->p >= 1.f || !d->seed) return TVTS_EINVAL;
+    g.drop_thr = (unsigned)((double)d->p * 4294967296.0);
+    g.drop_inv = 1.0f / (1.0f - d->p);
+    g.drop_seed = d->seed;
+    g.drop_site = d->site;
+    return TVTS_OK;
+}
+
 static int fwd_impl(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const int* kv_len,
-                    void* out, int ldo, float* lse2, int opts, hipStream_t stream) {
+                    void* out, int ldo, float* lse2, int opts, hipStream_t stream, const DropArgs* drop = nullptr) {
     ATTN_OPTS(opts);
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     if (ldo % 4 || (kv_len && mode != MODE_FULL)) return TVTS_EINVAL;
     g.kv_len = kv_len;
+    if ((rc = set_drop(g, drop))) return rc;
+    if (g.drop_thr) {  // attention-probability dropout: the block-shared FULL kernel with ds_read_tr fragments only
+        if (mode != MODE_FULL) return TVTS_EINVAL;
+        const int nb = g.B * g.heads * ceil_div(ceil_div(g.S, 16), 4);
+        hipLaunchKernelGGL((attn_fwd_shared_kernel<MODE_FULL, true, true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
     if (fused && use_tr && mode == MODE_FULL && !kv_len && S <= 32) {  // short sequences (text tower): a wave per (sequence, head)
         const int MT = ceil_div(S, 16), groups = B * heads;
         const int lds_bytes = 4 * (MT * 16 * VSTRIDE + 1024);
@@ -2253,13 +2316,22 @@ extern "C" int ABI(delta)(const void* dO, int lddo, const void* O, int ldo, int 
 
 static int bwd_dq_impl(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const int* kv_len,
                        const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
-                       int opts, hipStream_t stream) {
+                       int opts, hipStream_t stream, const DropArgs* drop = nullptr) {
     ATTN_OPTS(opts);
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     if (lddo % 8 || lddq % 4) return TVTS_EINVAL;
     g.kv_len = kv_len;
+    if ((rc = set_drop(g, drop))) return rc;
+    if (g.drop_thr) {
+        if (mode != MODE_FULL) return TVTS_EINVAL;
+        const int nb = g.B * g.heads * ceil_div(ceil_div(g.S, 16), 4);
+        hipLaunchKernelGGL((attn_bwd_dq_shared_kernel<MODE_FULL, true, true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv,
+                           (const bf16*)dO, lddo, lse2, delta, (bf16*)dqkv, lddq);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
     if (shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
         const int nq = mode == MODE_SPACE ? g.n : g.S;
         const int groups = mode == MODE_SPACE ? g.B * g.heads * g.T : g.B * g.heads;
@@ -2289,13 +2361,22 @@ extern "C" int ABI(bwd_dq)(int mode, const void* qkv, int ld, int B, int heads, 
 // tvts_attn_cls_finalize afterwards (unused for FULL).
 static int bwd_dkv_impl(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const int* kv_len,
                         const void* dO, int lddo, const float* lse2, const float* delta, void* dqkv, int lddq,
-                        float* cls_acc, int opts, hipStream_t stream) {
+                        float* cls_acc, int opts, hipStream_t stream, const DropArgs* drop = nullptr) {
     ATTN_OPTS(opts);
     AttnGeom g;
     if (mode == MODE_CLS) return TVTS_EINVAL;  // the CLS query is folded into the SPACE/TIME pass
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     g.kv_len = kv_len;
+    if ((rc = set_drop(g, drop))) return rc;
+    if (g.drop_thr) {
+        if (mode != MODE_FULL || lddo % 8 || lddq % 4) return TVTS_EINVAL;
+        const int nb = g.B * g.heads * ceil_div(ceil_div(g.S, 16), 4);
+        hipLaunchKernelGGL((attn_bwd_dkv_shared_kernel<MODE_FULL, true, true>), dim3(nb), dim3(256), 0, stream, g, (const bf16*)qkv,
+                           (const bf16*)dO, lddo, lse2, delta, (bf16*)dqkv, lddq, cls_acc);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
     if (lddo % 8 || lddq % 4) return TVTS_EINVAL;
     if ((mode == MODE_SPACE || mode == MODE_TIME) && !cls_acc) return TVTS_EINVAL;
     if (shared && (mode == MODE_FULL || mode == MODE_SPACE)) {
@@ -2340,6 +2421,27 @@ extern "C" int ABI(bwd_len)(const void* qkv, int ld, int B, int heads, int S, co
     rc = bwd_dq_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, dO, lddo, lse2, delta, dqkv, lddq, 0, stream);
     if (rc) return rc;
     return bwd_dkv_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, dO, lddo, lse2, delta, dqkv, lddq, nullptr, 0, stream);
+}
+
+// the same pair with dropout on the attention probabilities (transformers MultiHeadSelfAttention in training mode, reached from
+// v1/model/model_dist_TVTS.py:33-34,131-141): weights = dropout_p(softmax(scores)), the mask drawn from the counter-based
+// generator of AttnGeom (seed = seed_dev[0] + site: the same call pair regenerates the same mask; p = 0 is the plain pair)
+extern "C" int ABI(fwd_len_drop)(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, void* out, int ldo,
+                                 float* lse2, float p, const long* seed_dev, long site, hipStream_t stream) {
+    if (!kv_len) return TVTS_EINVAL;
+    const DropArgs d = {p, (const unsigned long long*)seed_dev, (unsigned long long)site};
+    return fwd_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, out, ldo, lse2, 0, stream, &d);
+}
+extern "C" int ABI(bwd_len_drop)(const void* qkv, int ld, int B, int heads, int S, const int* kv_len, const void* dO, int lddo,
+                                 const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float p,
+                                 const long* seed_dev, long site, hipStream_t stream) {
+    if (!kv_len || lddo % 8 || ldo % 8 || lddq % 4) return TVTS_EINVAL;
+    const DropArgs d = {p, (const unsigned long long*)seed_dev, (unsigned long long)site};
+    int rc = ABI(delta)(dO, lddo, O, ldo, B * S, heads, delta, stream);  // D = rowsum(dO o O) with the DROPPED output: unchanged
+    if (rc) return rc;
+    rc = bwd_dq_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, dO, lddo, lse2, delta, dqkv, lddq, 0, stream, &d);
+    if (rc) return rc;
+    return bwd_dkv_impl(MODE_FULL, qkv, ld, B, heads, S, 0, 0, 0, kv_len, dO, lddo, lse2, delta, dqkv, lddq, nullptr, 0, stream, &d);
 }
 
 // ---- TAIL queries: FULL geometry (no mask) in which only the LAST nq (<= 16) tokens of every sequence are queries, all S tokens

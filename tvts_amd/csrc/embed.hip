@@ -482,6 +482,40 @@ extern "C" int tvts_rows_gather(const float* src, int ld_src, const int* rows, i
     return TVTS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- hidden-state dropout (v1 text tower)
+// out = x * m / (1 - p) (+ residual); m: element (r, c) is kept iff the upper 32 bits of splitmix64(seed + (r * cols + c) * phi)
+// are >= p * 2^32 -- the generator of the attention-probability dropout (attention.hip::drop_keep)
+__global__ __launch_bounds__(256) void dropout_rows_kernel(const float* __restrict__ x, int ldx, int rows, int cols, unsigned thr,
+                                                           float inv, const unsigned long long* __restrict__ seed_dev,
+                                                           unsigned long long site, const float* __restrict__ residual, int ldr,
+                                                           float* __restrict__ out, int ldo, bf16* __restrict__ outb, int ldob) {
+    const unsigned long long seed = seed_dev[0] + site;
+    const long n = (long)rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        unsigned long long z = seed + (unsigned long long)i * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        float v = ((unsigned)(z >> 32) >= thr) ? x[(size_t)r * ldx + c] * inv : 0.f;
+        if (residual) v += residual[(size_t)r * ldr + c];
+        if (out) out[(size_t)r * ldo + c] = v;
+        if (outb) outb[(size_t)r * ldob + c] = (bf16)v;
+    }
+}
+extern "C" int tvts_dropout_rows(const float* x, int ldx, int rows, int cols, float p, const long* seed_dev, long site,
+                                 const float* residual, int ldr, float* out, int ldo, void* out_bf16, int ldob, hipStream_t stream) {
+    if (!x || rows <= 0 || cols <= 0 || p < 0.f || p >= 1.f || !seed_dev || (!out && !out_bf16)) return TVTS_EINVAL;
+    const long n = (long)rows * cols;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dropout_rows_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, rows, cols,
+                       (unsigned)((double)p * 4294967296.0), 1.0f / (1.0f - p), (const unsigned long long*)seed_dev,
+                       (unsigned long long)site, residual, ldr, out, ldo, (bf16*)out_bf16, ldob);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- ReLU (v1 txt_proj)
 // y = max(x, 0) / dx = dy * (x > 0): the nn.ReLU in front of the v1 text projection (v1/model/model_dist_TVTS.py:65-68)
 __global__ void relu_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, long n) {

@@ -10,7 +10,14 @@ What differs from TVTSv2 (reference paths under v1/):
                                                             model/model_dist_TVTS.py:34,65-68,131-141
   sort head     the same SortTransformer, fed the un-projected normed ViT tokens (width 768) and the [CLS] text rows
                                                             model/model_dist_TVTS.py:99-116
-Dropout (0.1 inside DistilBERT while training) is not built: this engine is the p = 0 model.
+Dropout: the reference puts the text tower in training mode (model_dist_TVTS.py:33-34 ``self.text_model.train()``), so every
+pretraining step runs DistilBERT's dropouts (transformers modeling_distilbert: ``Embeddings.dropout`` behind the embedding
+LayerNorm, ``attention_dropout`` on the softmax probabilities, ``FFN.dropout`` behind lin2; all p = 0.1, config defaults).  Built
+here with a COUNTER-BASED generator (splitmix64 of seed + site + element index, tvts_attn_*_len_drop / tvts_dropout_rows): the
+attention mask lives inside the attention kernels (probabilities are never materialised), the backward regenerates every mask from
+(seed, site), the seed sits in device memory and is advanced by a device op at the start of every training forward (graph replays
+draw new masks).  ``engine.training = False`` (the module's eval mode: validation, feature extraction) or
+``arch["text_dropout"] = 0`` switch it off.
 """
 from __future__ import annotations
 
@@ -29,17 +36,34 @@ class EngineV1(Engine):
         assert self.arch.get("family") == "v1"
         if self.dh_text != 64:
             raise NotImplementedError("the masked FULL attention kernels are used at head dim 64 here")
+        self.training = True                                   # the nn.Module wrapper mirrors its own .training flag here
+        self.text_drop_p = float(self.arch.get("text_dropout", 0.1))
+        # seed of the step's dropout masks (int64 device scalar = the bits of an unsigned 64-bit counter)
+        self.drop_seed = torch.tensor([int(self.arch.get("dropout_seed", 0x1234ABCD))], dtype=torch.int64, device=self.dev)
+        self._drop_active = 0.0
+
+    DROP_STEP_STRIDE = 0x51ED270B7F4A7C15  # added to the seed (mod 2^64) once per training forward
+
+    def _advance_drop_seed(self):
+        """new masks for this step (a device op: a captured graph advances the seed on every replay)"""
+        self._drop_active = self.text_drop_p if self.training else 0.0
+        if self._drop_active > 0.0:
+            self.drop_seed.add_(self.DROP_STEP_STRIDE)
 
     # ------------------------------------------------------------------ DistilBERT text tower
-    def _pln_fwd(self, pre, x, xb, x_out, xb_out, tag, M, N, L, kv_len):
+    def _pln_fwd(self, pre, x, xb, x_out, xb_out, tag, M, N, L, kv_len, layer=0):
         """one POST-LN DistilBERT block: x (fp32) / xb (bf16 copy) -> x_out / xb_out"""
         a, P = self.arch, self.P
+        dp = self._drop_active
         Wt, h = a["text_width"], a["text_heads"]
         qkv = self._b(tag + ".qkv", (M, 3 * Wt))
         for i, lin in enumerate(("q_lin", "k_lin", "v_lin")):  # three projections into the packed [M, 3 Wt] buffer
             K.gemm_nt(xb, P.w(pre + f"attention.{lin}.weight"), qkv[:, i * Wt:(i + 1) * Wt], M=M, bias=P.p(pre + f"attention.{lin}.bias"))
         att, lse = self._b(tag + ".att", (M, Wt)), self._f(tag + ".lse", (M, h))
-        K.attn_fwd_len(qkv, kv_len, att, lse, B=N, heads=h, S=L, head_dim=self.dh_text)
+        if dp > 0.0:  # weights = dropout(softmax(scores)) inside the kernel
+            K.attn_fwd_len_drop(qkv, kv_len, att, lse, B=N, heads=h, S=L, p=dp, seed=self.drop_seed, site=1 + 2 * layer, head_dim=self.dh_text)
+        else:
+            K.attn_fwd_len(qkv, kv_len, att, lse, B=N, heads=h, S=L, head_dim=self.dh_text)
         pre1 = self._f(tag + ".pre1", (M, Wt))
         self._lin(att, pre + "attention.out_lin.weight", pre + "attention.out_lin.bias", pre1, M, residual=x)
         x1, x1b = self._f(tag + ".x1", (M, Wt)), self._b(tag + ".x1b", (M, Wt))
@@ -48,19 +72,29 @@ class EngineV1(Engine):
         hpre, hact = self._b(tag + ".h", (M, a["text_ffn"])), self._b(tag + ".a", (M, a["text_ffn"]))
         self._lin(x1b, pre + "ffn.lin1.weight", pre + "ffn.lin1.bias", hact, M, act="gelu", preact=hpre)
         pre2 = self._f(tag + ".pre2", (M, Wt))
-        self._lin(hact, pre + "ffn.lin2.weight", pre + "ffn.lin2.bias", pre2, M, residual=x1)
+        if dp > 0.0:  # pre2 = dropout(lin2(.)) + x1
+            y2 = self._f("txt.s.y2", (M, Wt))
+            self._lin(hact, pre + "ffn.lin2.weight", pre + "ffn.lin2.bias", y2, M)
+            K.dropout_rows(y2, p=dp, seed=self.drop_seed, site=2 + 2 * layer, residual=x1, out=pre2)
+        else:
+            self._lin(hact, pre + "ffn.lin2.weight", pre + "ffn.lin2.bias", pre2, M, residual=x1)
         self._ln(pre2, pre + "output_layer_norm", 1e-12, x_out, tag + ".ln_out")
         K.cast_f32_bf16(x_out, xb_out)
 
-    def _pln_bwd(self, pre, xb_in, dx_out, dx_in, tag, M, N, L, kv_len):
+    def _pln_bwd(self, pre, xb_in, dx_out, dx_in, tag, M, N, L, kv_len, layer=0):
         """dx_out: fp32 grad wrt the block output; writes the fp32 grad wrt the block input into dx_in."""
         a, P, B_ = self.arch, self.P, self.buf
+        dp = self._drop_active
         Wt, h, Ff = a["text_width"], a["text_heads"], a["text_ffn"]
         # output_layer_norm: y = LN(pre2), pre2 = lin2(gelu(lin1(x1))) + x1
         dpre2, dpre2b = self._f("txt.s.dpre2", (M, Wt)), self._b("txt.s.dpre2b", (M, Wt))
         self._ln_bwd(dx_out, B_[tag + ".pre2"], pre + "output_layer_norm", tag + ".ln_out", dpre2, dx_bf16=dpre2b)
         dh = self._b("txt.s.dh", (M, Ff))
-        self._lin_bwd(dpre2b, B_[tag + ".a"], pre + "ffn.lin2.weight", pre + "ffn.lin2.bias", dh, M, gate_h=B_[tag + ".h"], gate_act="gelu")
+        dy2b = dpre2b
+        if dp > 0.0:  # gradient of lin2's output: the forward's mask again (the residual path keeps the unmasked dpre2)
+            dy2b = self._b("txt.s.dy2b", (M, Wt))
+            K.dropout_rows(dpre2, p=dp, seed=self.drop_seed, site=2 + 2 * layer, out_bf16=dy2b)
+        self._lin_bwd(dy2b, B_[tag + ".a"], pre + "ffn.lin2.weight", pre + "ffn.lin2.bias", dh, M, gate_h=B_[tag + ".h"], gate_act="gelu")
         dx1 = self._f("txt.s.dx1", (M, Wt))  # = dpre2 (residual) + lin1 dgrad, fused as the GEMM's fp32 residual epilogue
         self._lin_bwd(dh, B_[tag + ".x1b"], pre + "ffn.lin1.weight", pre + "ffn.lin1.bias", dx1, M, residual=dpre2)
         # sa_layer_norm: x1 = LN(pre1), pre1 = out_lin(att) + x
@@ -69,8 +103,12 @@ class EngineV1(Engine):
         datt = self._b("txt.s.datt", (M, Wt))
         self._lin_bwd(dpre1b, B_[tag + ".att"], pre + "attention.out_lin.weight", pre + "attention.out_lin.bias", datt, M)
         dqkv, delta = self._b("txt.s.dqkv", (M, 3 * Wt)), self._f("txt.s.delta", (M, h))
-        K.attn_bwd_len(B_[tag + ".qkv"], kv_len, datt, B_[tag + ".att"], B_[tag + ".lse"], delta, dqkv, B=N, heads=h, S=L,
-                       head_dim=self.dh_text)
+        if dp > 0.0:
+            K.attn_bwd_len_drop(B_[tag + ".qkv"], kv_len, datt, B_[tag + ".att"], B_[tag + ".lse"], delta, dqkv, B=N, heads=h, S=L,
+                                p=dp, seed=self.drop_seed, site=1 + 2 * layer, head_dim=self.dh_text)
+        else:
+            K.attn_bwd_len(B_[tag + ".qkv"], kv_len, datt, B_[tag + ".att"], B_[tag + ".lse"], delta, dqkv, B=N, heads=h, S=L,
+                           head_dim=self.dh_text)
         # dx = dpre1 (residual) + dq Wq + dk Wk + dv Wv: a chain of fp32-residual epilogues over two ping-pong buffers
         acc, tmp = dpre1, self._f("txt.s.dacc", (M, Wt))
         for i, lin in enumerate(("q_lin", "k_lin", "v_lin")):
@@ -87,11 +125,17 @@ class EngineV1(Engine):
         K.text_embed(ids, P.p("text_model.embeddings.word_embeddings.weight"),
                      P.p("text_model.embeddings.position_embeddings.weight"), emb, N=N, L=L)
         x, xb = self._f("txt.x0", (M, Wt)), self._b("txt.x0b", (M, Wt))
-        self._ln(emb, "text_model.embeddings.LayerNorm", 1e-12, x, "txt.ln_emb")
-        K.cast_f32_bf16(x, xb)
+        self._advance_drop_seed()
+        if self._drop_active > 0.0:  # Embeddings: dropout(LayerNorm(word + position))
+            xln = self._f("txt.xln", (M, Wt))
+            self._ln(emb, "text_model.embeddings.LayerNorm", 1e-12, xln, "txt.ln_emb")
+            K.dropout_rows(xln, p=self._drop_active, seed=self.drop_seed, site=0, out=x, out_bf16=xb)
+        else:
+            self._ln(emb, "text_model.embeddings.LayerNorm", 1e-12, x, "txt.ln_emb")
+            K.cast_f32_bf16(x, xb)
         for l in range(a["text_layers"]):
             xo, xbo = self._f(f"txt.x{l + 1}", (M, Wt)), self._b(f"txt.x{l + 1}b", (M, Wt))
-            self._pln_fwd(f"text_model.transformer.layer.{l}.", x, xb, xo, xbo, f"txt{l}", M, N, L, kv_len)
+            self._pln_fwd(f"text_model.transformer.layer.{l}.", x, xb, xo, xbo, f"txt{l}", M, N, L, kv_len, layer=l)
             x, xb = xo, xbo
         before = self._f("txt.before", (N, Wt))
         K.rows_gather(x, cls_rows, before)
@@ -117,8 +161,12 @@ class EngineV1(Engine):
         for l in reversed(range(a["text_layers"])):
             nx = "B" if (a["text_layers"] - l) % 2 == 1 else "A"
             dxi = self._f("txt.dx" + nx, (M, Wt))
-            self._pln_bwd(f"text_model.transformer.layer.{l}.", B_[f"txt.x{l}b"], dx, dxi, f"txt{l}", M, N, L, kv_len)
+            self._pln_bwd(f"text_model.transformer.layer.{l}.", B_[f"txt.x{l}b"], dx, dxi, f"txt{l}", M, N, L, kv_len, layer=l)
             dx = dxi
+        if self._drop_active > 0.0:  # through the embedding dropout
+            ddrop = self._f("txt.s.ddrop", (M, Wt))
+            K.dropout_rows(dx, p=self._drop_active, seed=self.drop_seed, site=0, out=ddrop)
+            dx = ddrop
         demb = self._f("txt.demb", (M, Wt))
         self._ln_bwd(dx, B_["txt.emb"], "text_model.embeddings.LayerNorm", "txt.ln_emb", demb)
         K.text_embed_bwd(demb, ids, P.g("text_model.embeddings.word_embeddings.weight"),

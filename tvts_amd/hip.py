@@ -352,6 +352,39 @@ def attn_bwd_len(qkv, kv_len, dO, O, lse2, delta, dqkv, *, B, heads, S, head_dim
                                             _p(delta), _p(dqkv), _ld(dqkv), _stream()), "tvts_attn_bwd_len")
 
 
+DROP_SITE_STRIDE = 0x632BE59BD9B4E019  # odd 64-bit constant: site k of a step uses seed_dev[0] + k * this (mod 2^64)
+
+
+def _site(site: int) -> int:
+    v = (site * DROP_SITE_STRIDE) & 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v  # the same bits as a C long
+
+
+def attn_fwd_len_drop(qkv, kv_len, out, lse2, *, B, heads, S, p, seed, site, head_dim=64):
+    """attn_fwd_len with dropout p on the attention probabilities; seed: int64 device tensor [1], site: small int (per call site)"""
+    lib = _lib.load()
+    assert kv_len.dtype == torch.int32 and kv_len.numel() == B and seed.dtype == torch.int64 and seed.is_cuda
+    _chk(_attn_fn(lib, "fwd_len_drop", head_dim)(_p(qkv), _ld(qkv), B, heads, S, _p(kv_len), _p(out), _ld(out), _p(lse2), float(p),
+                                                 _p(seed), _site(site), _stream()), "tvts_attn_fwd_len_drop")
+
+
+def attn_bwd_len_drop(qkv, kv_len, dO, O, lse2, delta, dqkv, *, B, heads, S, p, seed, site, head_dim=64):
+    lib = _lib.load()
+    dqkv.zero_()
+    _chk(_attn_fn(lib, "bwd_len_drop", head_dim)(_p(qkv), _ld(qkv), B, heads, S, _p(kv_len), _p(dO), _ld(dO), _p(O), _ld(O),
+                                                 _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), float(p), _p(seed), _site(site),
+                                                 _stream()), "tvts_attn_bwd_len_drop")
+
+
+def dropout_rows(x, *, p, seed, site, residual=None, out=None, out_bf16=None):
+    """out = x * mask / (1 - p) (+ residual), fp32 and / or bf16 output; the backward is the same call on the gradient."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.dim() == 2 and seed.dtype == torch.int64
+    _chk(lib.tvts_dropout_rows(_p(x), _ld(x), x.shape[0], x.shape[1], float(p), _p(seed), _site(site), _p(residual),
+                               _ld(residual) if residual is not None else 0, _p(out), _ld(out) if out is not None else 0,
+                               _p(out_bf16), _ld(out_bf16) if out_bf16 is not None else 0, _stream()), "tvts_dropout_rows")
+
+
 def attn_fwd_tail(qkv, out, lse2, *, B, heads, S, nq, head_dim=64):
     """FULL attention whose only queries are the last nq tokens of every sequence (rows b*S + S-nq .. of out / lse2 are written)."""
     lib = _lib.load()

@@ -4,8 +4,9 @@ ReLU+Linear / Linear projections, transcript-sorting head -- over the HIP step e
 ``forward(data, return_embeds=True) -> (text_embeds, video_embeds, pred_order)``, ``compute_text`` / ``compute_video``,
 state-dict names and order, ``sim_matrix`` as an importable free function.
 
-Not built: dropout inside the text tower (Hugging Face DistilBERT trains with p = 0.1, model_dist_TVTS.py:35) -- this is the
-p = 0 model; the pretrained initialisations (``AutoModel.from_pretrained``, ``./mae_pretrain_vit_base.pth``, :34,49-58) are
+The text tower's dropout (Hugging Face DistilBERT, p = 0.1, active because of ``self.text_model.train()`` at
+model_dist_TVTS.py:33-34) follows the module's training flag: ``model.train()`` steps draw counter-based masks
+(tvts_amd/engine_v1.py), ``model.eval()`` (validation, compute_text for retrieval) runs without.  The pretrained initialisations (``AutoModel.from_pretrained``, ``./mae_pretrain_vit_base.pth``, :34,49-58) are
 replaced by the same classes' random initialisers unless ``load_checkpoint`` names a checkpoint.
 """
 from __future__ import annotations
@@ -63,10 +64,15 @@ class TVTS(TVTSv2Base):
         self.video_params, self.text_params = video_params, text_params
         super().__init__(args, load_checkpoint=load_checkpoint, arch=arch, init_seed=init_seed)
 
+    def forward(self, data, return_embeds=True):
+        self.engine.training = self.training  # dropout of the text tower in training mode only
+        return super().forward(data, return_embeds)
+
     # pieces the reference exposes (model_dist_TVTS.py:131-147)
     def compute_text(self, text_data):
         self._fresh_shadows()
         eng = self.engine
+        eng.training = self.training
         ids = text_data["input_ids"].detach().to("cpu", torch.int64)
         lens = text_data["attention_mask"].detach().to("cpu", torch.int64).sum(-1)
         N, L = ids.shape[0], int(lens.max())

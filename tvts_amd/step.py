@@ -35,6 +35,8 @@ class StepRunner:
 
     def step(self, data: dict, device_step: bool = False, pb=None):
         m = self.model
+        if hasattr(self.eng, "training"):  # v1: DistilBERT's dropout follows the module's train() / eval() flag
+            self.eng.training = bool(m.training)
         m._fresh_shadows()
         m._sync_requires_grad()
         if pb is None:

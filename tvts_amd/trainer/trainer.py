@@ -10,6 +10,8 @@ AllGather / AllGather_multi are exported with the same names and semantics for c
 """
 from __future__ import annotations
 
+import collections.abc
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -255,7 +257,8 @@ class Trainer_TVTS(_TrainerBase):
             group["lr"] = lr
 
     def _tokenize(self, data):
-        if self.tokenizer is not None and not isinstance(data["text"], dict):
+        # an already tokenised batch (a dict or a Hugging Face BatchEncoding -- a UserDict, not a dict) passes through
+        if self.tokenizer is not None and not (isinstance(data["text"], collections.abc.Mapping) or hasattr(data["text"], "input_ids")):
             text_all = []
             for clip_texts in data["text"]:
                 text_all = text_all + list(clip_texts)
