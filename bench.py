@@ -141,9 +141,24 @@ def gemm_bytes(kind, shp):
     return b
 
 
+GEMM_SOURCES = ("gemm.hip", "gemm_nt256.h", "gemm_tn256.h", "common.h")
+
+
+def gemm_source_id():
+    """sha256[:16] over the GEMM kernel sources: the build id a committed PMC traffic measurement is stamped with"""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tvts_amd", "csrc")
+    for f in GEMM_SOURCES:
+        h.update(open(os.path.join(base, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(args):
     """HBM bytes of the step's GEMM launches from a committed PMC pass of this exact workload (counters cannot be read
-    live: they need rocprofv3's own passes, tools/pmc_traffic.sh).  None when no such measurement is committed."""
+    live: they need rocprofv3's own passes, tools/pmc_traffic.sh).  The file carries the id of the GEMM sources it was measured
+    on (gemm_source_id); a file measured on other sources is REFUSED (returns a dict with only "stale"), so a kernel change cannot
+    keep quoting an old number.  None when no measurement of this workload is committed."""
     import glob
     if args.fp8 or args.n_trans != 4:
         return None
@@ -154,6 +169,9 @@ def pmc_traffic(args):
         return None
     d = json.load(open(hits[-1]))
     d["source"] = "profiles/" + os.path.basename(hits[-1])
+    if d.get("gemm_source_id") != gemm_source_id():
+        return {"stale": f"{d['source']} was measured on GEMM sources {d.get('gemm_source_id', '(unstamped)')}, this build is "
+                         f"{gemm_source_id()}: re-run tools/pmc_traffic.sh"}
     return d
 
 
@@ -171,6 +189,8 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 4: e4m3 forward GEMMs in the ViT blocks")
     ap.add_argument("--fp8-dgrad", action="store_true", help="... and e4m3 input-gradient GEMMs (output gradient one scale per token, "
                     "transposed e4m3 weight copies); the weight gradients stay bf16")
+    ap.add_argument("--bf16-grad-stream", action="store_true", help="carry the residual-stream gradient of the ViT blocks in bf16 (not the "
+                    "default: +1.4 %% throughput, 2.4x the error of the embedding-side gradients; profiles/r03_bf16_grad_stream_ab.txt)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
@@ -223,6 +243,8 @@ def main():
         a["fp8"] = True
     if args.dense_sort_head:
         a["sort_used_rows_only"] = False
+    if args.bf16_grad_stream:
+        a["bf16_grad_stream"] = True
     margs = types.SimpleNamespace(local_rank=local_rank, rank=rank, world_size=world)
     v1 = a.get("family") == "v1"
     if v1:
@@ -357,12 +379,15 @@ def main():
                       open(os.environ['TVTS_BENCH_ORDER'], 'w'))
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         traffic = pmc_traffic(args)
+        stale = traffic.get("stale") if traffic else None
+        if stale:
+            traffic = None
         line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_BF16_TFLOPS,
                             "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
                             "traffic_unit": "HBM bytes per step over the same launches (rocprofv3 --pmc FETCH_SIZE x2 + "
                                             "WRITE_SIZE, tools/pmc_traffic.sh)" if traffic else None,
-                            "traffic_source": traffic["source"] if traffic else None,
+                            "traffic_source": traffic["source"] if traffic else stale,
                             "algorithmic_bytes": sum(gemm_bytes(r[0], r[4]) for r in recs),
                             "kernel": "gemm_nt_kernel + gemm_tn_kernel (all MFMA GEMM launches of one step)",
                             "launches": len(recs), "gemm_ms_per_step": tot_ms,

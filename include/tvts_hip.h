@@ -105,15 +105,17 @@ int tvts_layernorm_fwd(const void* x, int ldx, int x_bf16, const int* rows, cons
 int tvts_layernorm_fwd_fp8(const void* x, int ldx, int x_bf16, const int* rows, const float* gamma, const float* beta, float eps,
                            int M, int W, void* y, int ldy, void* q8, int ldq, float* row_scale, float* mean, float* rstd,
                            hipStream_t stream);
+/* dx = LayerNorm backward (+ res1 + res2): res1 is the residual-stream gradient, fp32 or (res1_bf16 != 0, bf16 dy only) bf16 --
+ * the space-time block's backward carries it in bf16, the precision its GEMM consumers read it in anyway; res2 a bf16 side branch */
 int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const void* x, int ldx, int x_bf16, const int* rows, const float* mean,
-                       const float* rstd, const float* gamma, const float* res1, int ldr, const void* res2_bf16, int ldr2,
+                       const float* rstd, const float* gamma, const void* res1, int res1_bf16, int ldr, const void* res2_bf16, int ldr2,
                        int M, int W, float* dx, int lddx, void* dx_bf16, int lddxb, float* dgamma, float* dbeta,
                        float* workspace, long workspace_elems, hipStream_t stream);
 /* the same with the e4m3 copy of dx_bf16 (one scale per row, the bytes tvts_quant_fp8_rows would write): the output gradient of the
  * e4m3 input-gradient GEMM that consumes dx_bf16.  bf16 dy, every row, dx_bf16 required; x fp32 with res1 / res1 + res2 / no
  * residual, or x bf16 without residuals */
 int tvts_layernorm_bwd_fp8(const void* dy, int lddy, const void* x, int ldx, int x_bf16, const float* mean, const float* rstd,
-                           const float* gamma, const float* res1, int ldr, const void* res2_bf16, int ldr2, int M, int W, float* dx,
+                           const float* gamma, const void* res1, int res1_bf16, int ldr, const void* res2_bf16, int ldr2, int M, int W, float* dx,
                            int lddx, void* dx_bf16, int lddxb, void* q8, int ldq, float* row_scale, float* dgamma, float* dbeta,
                            float* workspace, long workspace_elems, hipStream_t stream);
 

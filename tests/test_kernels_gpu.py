@@ -239,6 +239,17 @@ def test_layernorm(K, W, eps):
     dxb2 = torch.empty_like(dxb)
     K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), None, dx_bf16=dxb2)
     assert rel(dxb2.float(), xr.grad) < 4e-3
+    # the residual-stream gradient carried in bf16 (the space-time block's backward): bf16 res1, alone and with the bf16 side
+    # branch, bf16-only output, dgamma / dbeta unchanged
+    resb = bf(res)
+    for r2 in (None, res2):
+        dxb4 = torch.empty_like(dxb)
+        dg4, db4 = torch.zeros(W, device=DEV), torch.zeros(W, device=DEV)
+        K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), None, dx_bf16=dxb4, res1=resb.to(DEV),
+                        res2=r2.to(DEV) if r2 is not None else None, dgamma=dg4, dbeta=db4)
+        want4 = xr.grad + resb.float() + (r2.float() if r2 is not None else 0)
+        assert rel(dxb4.float(), want4) < 4e-3
+        assert torch.equal(dg4, dg) and torch.equal(db4, db)
 
 
 def test_layernorm_rows(K):

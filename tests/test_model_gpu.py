@@ -533,3 +533,24 @@ def test_b16_config2_against_reference_golden(gpu, golden):
                            "g_head": ("pred_model.head.weight", (slice(None), slice(None))),
                            "g_pos": ("video_model.positional_embedding", (slice(None), slice(0, 16)))}.items():
         assert rel(store.g(name)[idx], torch.tensor(f[k])) < 0.08, (k, rel(store.g(name)[idx], torch.tensor(f[k])))
+
+
+@pytest.mark.parametrize("h14", [False, True])
+def test_bf16_grad_stream_option(gpu, h14):
+    """arch["bf16_grad_stream"] (opt-in, bench.py --bf16-grad-stream): the residual-stream gradient of the ViT blocks carried in
+    bf16 -- bf16 res1 in the ln_2 / ln_3 backward, no fp32 copy of the chain.  Same forward, the SURVEY 8d gradient gates against
+    the oracle, and close to the default fp32 chain (the difference is two bf16 roundings per block)."""
+    from tvts_amd import arch as A
+    mk = (lambda **kw: A.small_arch_h(**kw)) if h14 else A.small_arch
+    m0, oarch, P = build(arch=mk(), seed=4)
+    batch = O.synth_batch(oarch, B=4, T=3, seed=6, caption_len=11)
+    r1, r2, rte, rve, rpred, grads = oracle_step(P, batch, oarch)
+    l1, l2, te, ve, pred, store0 = engine_step(m0, batch)
+    g0 = store0.grad.clone()
+    m1, _, _ = build(arch=mk(bf16_grad_stream=True), seed=4)
+    k1, k2, te1, ve1, pred1, store = engine_step(m1, batch)
+    assert "vit.s.dsres" not in m1.engine.buf and "vit.s.dsres" in m0.engine.buf  # the fp32 copies of the chain are gone
+    assert torch.equal(ve1, ve) and torch.equal(te1, te) and k1 == l1 and k2 == l2
+    check_grads(store, grads)
+    cos = float(torch.nn.functional.cosine_similarity(g0.double().flatten(), store.grad.double().flatten(), dim=0))
+    assert cos > 0.9995 and not torch.equal(g0, store.grad), cos

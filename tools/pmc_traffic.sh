@@ -31,7 +31,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if c == "FETCH_SIZE": n[fam] += 1
     tot[c] = s
 # gfx950: FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes -> doubled (guide's correction)
-out = {"flags": flags, "steps_in_process": steps,
+sys.path.insert(0, ".")
+import bench
+out = {"flags": flags, "steps_in_process": steps, "gemm_source_id": bench.gemm_source_id(),
        "fetch_bytes_per_step": 2.0 * tot["FETCH_SIZE"] / steps, "write_bytes_per_step": tot["WRITE_SIZE"] / steps,
        "hbm_bytes_per_step": (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / steps,
        "by_kernel": {k: {"fetch_bytes": 2.0 * v["FETCH_SIZE"] / steps, "write_bytes": v["WRITE_SIZE"] / steps,

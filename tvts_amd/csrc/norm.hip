@@ -3,7 +3,7 @@
 // forward : y = (x - mean) * rstd * gamma + beta, x fp32 (optionally gathered rows), y bf16 or fp32;
 //           mean / rstd are saved for the backward pass.
 // backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ res1 + res2],  g = dy * gamma
-//           res1 fp32 (the residual-stream gradient), res2 bf16 (a side-branch gradient that only exists as a GEMM
+//           res1 fp32 or bf16 (the residual-stream gradient), res2 bf16 (a side-branch gradient that only exists as a GEMM
 //           operand anyway); dx fp32 and / or a bf16 copy that feeds the next MFMA GEMM; dgamma / dbeta accumulated
 //           from per-block partial sums: written to a workspace and combined by a second tiny kernel (or, without
 //           a workspace, one fp32 atomic per column per block).
@@ -186,11 +186,11 @@ __device__ __forceinline__ f32x4 widen(bf16x4 v) { return (f32x4){(float)v[0], (
 
 // Q8: additionally write the bf16 copy of dx as OCP e4m3 bytes with one scale per row (amax of the bf16-rounded values / 448) -- the
 // output gradient of the e4m3 input-gradient GEMM that consumes dx_bf16 (same bytes as tvts_quant_fp8_rows of dx_bf16)
-template <typename TDY, int IT, bool R1, bool R2, typename TX = float, bool Q8 = false>
+template <typename TDY, int IT, bool R1, bool R2, typename TX = float, bool Q8 = false, typename TR1 = float>
 __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3)) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const TX* __restrict__ x,
                                                         int ldx, const int* __restrict__ rows,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        const float* __restrict__ gamma, const float* __restrict__ res1,
+                                                        const float* __restrict__ gamma, const TR1* __restrict__ res1,
                                                         const bf16* __restrict__ res2, int ldr2, int ldr, int M, int W,
                                                         float* __restrict__ dx, int lddx, bf16* __restrict__ dx_bf16,
                                                         int lddxb, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
             if (c < W) {
                 w.x[it] = load4<TX>(x + (size_t)w.xr * ldx + c);
                 w.d[it] = *(const DyV*)(dy + (size_t)rr * lddy + c);
-                if (R1) w.r1[it] = load4<float>(res1 + (size_t)w.xr * ldr + c);
+                if (R1) w.r1[it] = load4<TR1>(res1 + (size_t)w.xr * ldr + c);
                 if (R2) w.r2[it] = *(const bf16x4*)(res2 + (size_t)w.xr * ldr2 + c);
             }
         }
@@ -362,9 +362,9 @@ __global__ __launch_bounds__(1024) void ln_dgamma_reduce_kernel(const float* __r
     }
 }
 
-template <typename TDY, bool R1, bool R2, typename TX = float, bool Q8 = false>
+template <typename TDY, bool R1, bool R2, typename TX = float, bool Q8 = false, typename TR1 = float>
 static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int lddy, const TX* x, int ldx, const int* rows,
-                          const float* mean, const float* rstd, const float* gamma, const float* res1, const bf16* res2,
+                          const float* mean, const float* rstd, const float* gamma, const TR1* res1, const bf16* res2,
                           int ldr2, int ldr, int W, float* dx, int lddx, bf16* dxb, int lddxb, float* dgamma, float* dbeta,
                           float* ws, long ws_elems, unsigned char* q8 = nullptr, int ldq = 0, float* row_scale = nullptr) {
     // persistent grid: as many blocks per CU as the variant's registers allow (see __launch_bounds__ above)
@@ -373,51 +373,59 @@ static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int 
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     const dim3 grid(blocks);
     float* partial = (dgamma && ws && ws_elems >= (long)blocks * 2 * W) ? ws : nullptr;
-#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N, R1, R2, TX, Q8>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta, partial, q8, ldq, row_scale); break;
+#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N, R1, R2, TX, Q8, TR1>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta, partial, q8, ldq, row_scale); break;
     switch (it) { LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) default: LN_BWD_CASE(5) }
 #undef LN_BWD_CASE
     if (partial)
         hipLaunchKernelGGL(ln_dgamma_reduce_kernel, dim3(ceil_div(W, 64), 2), dim3(1024), 0, stream, partial, blocks, W, dgamma, dbeta);
 }
-template <typename TDY>
+template <typename TDY, typename TR1>
 static void launch_ln_bwd_res(int it, int M, hipStream_t stream, const TDY* dy, int lddy, const float* x, int ldx,
-                              const int* rows, const float* mean, const float* rstd, const float* gamma, const float* res1,
+                              const int* rows, const float* mean, const float* rstd, const float* gamma, const TR1* res1,
                               const bf16* res2, int ldr2, int ldr, int W, float* dx, int lddx, bf16* dxb, int lddxb,
                               float* dgamma, float* dbeta, float* ws, long ws_elems) {
 #define LN_ARGS it, M, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, W, dx, lddx, dxb, lddxb, dgamma, dbeta, ws, ws_elems
-    if (res1 && res2) launch_ln_bwd<TDY, true, true>(LN_ARGS);
-    else if (res1) launch_ln_bwd<TDY, true, false>(LN_ARGS);
-    else if (res2) launch_ln_bwd<TDY, false, true>(LN_ARGS);
-    else launch_ln_bwd<TDY, false, false>(LN_ARGS);
+    if (res1 && res2) launch_ln_bwd<TDY, true, true, float, false, TR1>(LN_ARGS);
+    else if (res1) launch_ln_bwd<TDY, true, false, float, false, TR1>(LN_ARGS);
+    else if (res2) launch_ln_bwd<TDY, false, true, float, false, TR1>(LN_ARGS);
+    else launch_ln_bwd<TDY, false, false, float, false, TR1>(LN_ARGS);
 #undef LN_ARGS
 }
 
 extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const void* x_, int ldx, int x_bf16, const int* rows,
-                                  const float* mean, const float* rstd, const float* gamma, const float* res1,
+                                  const float* mean, const float* rstd, const float* gamma, const void* res1_, int res1_bf16,
                                   int ldr, const void* res2_bf16, int ldr2, int M, int W, float* dx, int lddx,
                                   void* dx_bf16, int lddxb, float* dgamma, float* dbeta, float* workspace,
                                   long workspace_elems, hipStream_t stream) {
     if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || lddy % 4) return TVTS_EINVAL;
     if ((!dx && !dx_bf16) || (dx && lddx % 4)) return TVTS_EINVAL;
-    if ((res1 && ldr % 4) || (res2_bf16 && ldr2 % 4)) return TVTS_EINVAL;
+    if ((res1_ && ldr % 4) || (res2_bf16 && ldr2 % 4)) return TVTS_EINVAL;
     const bf16* res2 = (const bf16*)res2_bf16;
     if (dx_bf16 && lddxb % 4) return TVTS_EINVAL;
     if (x_bf16) {  // side-branch input kept in bf16: only the residual-free bf16-dy form exists (ln_1 of the space-time block)
-        if (dy_f32 || res1 || res2) return TVTS_EINVAL;
+        if (dy_f32 || res1_ || res2) return TVTS_EINVAL;
         launch_ln_bwd<bf16, false, false, bf16>(ceil_div(W, 256), M, stream, (const bf16*)dy, lddy, (const bf16*)x_, ldx, rows, mean, rstd,
-                                                gamma, res1, res2, ldr2, ldr, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta,
+                                                gamma, (const float*)nullptr, res2, ldr2, ldr, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta,
                                                 workspace, workspace_elems);
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }
     const float* x = (const float*)x_;
     const int it = ceil_div(W, 256);
+    if (res1_ && res1_bf16) {  // the residual-stream gradient carried in bf16 (the space-time block's backward): bf16 dy only
+        if (dy_f32) return TVTS_EINVAL;
+        launch_ln_bwd_res<bf16, bf16>(it, M, stream, (const bf16*)dy, lddy, x, ldx, rows, mean, rstd, gamma, (const bf16*)res1_, res2, ldr2,
+                                      ldr, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems);
+        TVTS_LAUNCH_CHECK();
+        return TVTS_OK;
+    }
+    const float* res1 = (const float*)res1_;
     if (dy_f32)
-        launch_ln_bwd_res<float>(it, M, stream, (const float*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, W,
-                                 dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems);
+        launch_ln_bwd_res<float, float>(it, M, stream, (const float*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, W,
+                                        dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems);
     else
-        launch_ln_bwd_res<bf16>(it, M, stream, (const bf16*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, W,
-                                dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems);
+        launch_ln_bwd_res<bf16, float>(it, M, stream, (const bf16*)dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, W,
+                                       dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
@@ -426,22 +434,29 @@ extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const vo
 // block's backward -- bf16 dy with (ln_2) fp32 residual, (ln_3) fp32 + bf16 residuals, (ln_1) bf16 x and no residual, (ln_post) fp32 x
 // and no residual.  Every row (no row list), dx_bf16 required.
 extern "C" int tvts_layernorm_bwd_fp8(const void* dy, int lddy, const void* x_, int ldx, int x_bf16, const float* mean,
-                                      const float* rstd, const float* gamma, const float* res1, int ldr, const void* res2_bf16,
+                                      const float* rstd, const float* gamma, const void* res1_, int res1_bf16, int ldr, const void* res2_bf16,
                                       int ldr2, int M, int W, float* dx, int lddx, void* dx_bf16, int lddxb, void* q8, int ldq,
                                       float* row_scale, float* dgamma, float* dbeta, float* workspace, long workspace_elems,
                                       hipStream_t stream) {
     if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || lddy % 4 || !dx_bf16 || lddxb % 4 || !q8 || ldq % 4 || !row_scale)
         return TVTS_EINVAL;
-    if ((dx && lddx % 4) || (res1 && ldr % 4) || (res2_bf16 && ldr2 % 4)) return TVTS_EINVAL;
+    if ((dx && lddx % 4) || (res1_ && ldr % 4) || (res2_bf16 && ldr2 % 4)) return TVTS_EINVAL;
     const bf16* res2 = (const bf16*)res2_bf16;
     const int it = ceil_div(W, 256);
 #define Q8_ARGS it, M, stream, (const bf16*)dy, lddy, x, ldx, (const int*)nullptr, mean, rstd, gamma, res1, res2, ldr2, ldr, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems, (unsigned char*)q8, ldq, row_scale
     if (x_bf16) {
-        if (res1 || res2) return TVTS_EINVAL;
+        if (res1_ || res2) return TVTS_EINVAL;
         const bf16* x = (const bf16*)x_;
+        const float* res1 = nullptr;
         launch_ln_bwd<bf16, false, false, bf16, true>(Q8_ARGS);
+    } else if (res1_ && res1_bf16) {
+        const float* x = (const float*)x_;
+        const bf16* res1 = (const bf16*)res1_;
+        if (res2) launch_ln_bwd<bf16, true, true, float, true, bf16>(Q8_ARGS);
+        else launch_ln_bwd<bf16, true, false, float, true, bf16>(Q8_ARGS);
     } else {
         const float* x = (const float*)x_;
+        const float* res1 = (const float*)res1_;
         if (res1 && res2) launch_ln_bwd<bf16, true, true, float, true>(Q8_ARGS);
         else if (res1) launch_ln_bwd<bf16, true, false, float, true>(Q8_ARGS);
         else if (res2) return TVTS_EINVAL;

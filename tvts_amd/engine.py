@@ -493,7 +493,17 @@ class Engine:
         M, Mp = B * S, B * T * n
         rg = self.requires_grad
         dln = self._b("vit.s.dln", (M, W))
-        dx, dxb = self._f("vit.dxA", (M, W)), self._b("vit.dxbA", (M, W))
+        # arch["bf16_grad_stream"] (default off): carry the residual-stream gradient of the space-time blocks in bf16.  Every
+        # consumer but the next LayerNorm backward's residual add reads its bf16 copy anyway (GEMM operands); the fp32 copy buys
+        # the exact accumulation of the chain at 463 MB written + 463 MB read per LayerNorm backward (192 pairs).  Measured (round
+        # 3, profiles/r03_bf16_grad_stream_ab.txt): the three LayerNorm backwards of a block move 3.2 instead of 4.6 GB, the step
+        # 149.3 -> 147.2 ms (+1.4 %), and the chain is rounded twice per block -- all SURVEY 8d gates hold (worst tensor cosine
+        # 0.9983, gradient norm -0.25 %), but the error of the embedding-side gradients (positional / class embedding, conv1, which
+        # sit behind ln_pre's cancellation) grows 2.4x (5.8 % instead of 2.4 % rel-L2).  Parity is the first gate: the default
+        # keeps the fp32 chain; bench.py --bf16-grad-stream measures the other.
+        lowp = bool(a.get("bf16_grad_stream", False))
+        dxb = self._b("vit.dxbA", (M, W))
+        dx = None if (lowp and not self.pooled_tail) else self._f("vit.dxA", (M, W))
         if not self.pooled_tail:
             if rg["video_model.proj"]:  # dproj[W,E] += lnpost^T dout
                 K.gemm_tn(B_["vit.lnpost"], dout_b, self.P.g("video_model.proj"), M=M, accumulate=True)
@@ -521,7 +531,8 @@ class Engine:
         dh = self._b("vit.s.dh", (M, 4 * W))
         datt = self._b("vit.s.datt", (M, W))
         dqkv = self._b("vit.s.dqkv", (M, 3 * W))
-        dsr, dsrb = self._f("vit.s.dsres", (M, W)), self._b("vit.s.dsresb", (M, W))
+        dsrb = self._b("vit.s.dsresb", (M, W))
+        dsr = None if lowp else self._f("vit.s.dsres", (M, W))
         dtrb = self._b("vit.s.dtresb", (M, W))
         for l in reversed(range(a["layers"])):
             pre, tg = f"video_model.transformer.resblocks.{l}.", f"vit{l}"
@@ -530,7 +541,7 @@ class Engine:
             self._lin_bwd(dxb, B_[tg + ".a"], pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dh, M, dy8=dxb8,
                           gate_h=B_[tg + ".h"], gate_act=a["act"])
             self._lin_bwd(dh, B_[tg + ".ln2"], pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", dln, M)
-            dsrb8 = self._ln_bwd(dln, B_[tg + ".s_res"], pre + "ln_2", tg + ".ln2", dsr, dx_bf16=dsrb, res1=dx,
+            dsrb8 = self._ln_bwd(dln, B_[tg + ".s_res"], pre + "ln_2", tg + ".ln2", dsr, dx_bf16=dsrb, res1=dxb if lowp else dx,
                                  fp8_for=pre + "attn.proj.weight")
             # spatial attention branch
             self._lin_bwd(dsrb, B_[tg + ".att_s"], pre + "attn.proj.weight", pre + "attn.proj.bias", datt, M, dy8=dsrb8)
@@ -545,14 +556,15 @@ class Engine:
             self._st_attention_bwd(B_[tg + ".qkv_t"], B_[tg + ".att_t"], datt, B_[tg + ".lse_t"], dqkv, "time", B, T, n, "vit.s")
             self._lin_bwd(dqkv, B_[tg + ".ln3"], pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", dln, M)
             nx = "B" if (a["layers"] - l) % 2 == 1 else "A"
-            dxi, dxbi = self._f("vit.dx" + nx, (M, W)), self._b("vit.dxb" + nx, (M, W))
+            dxbi = self._b("vit.dxb" + nx, (M, W))
+            dxi = None if lowp else self._f("vit.dx" + nx, (M, W))
             # x feeds ln_3, the time residual and the space residual
-            dxb8 = self._ln_bwd(dln, x_in, pre + "ln_3", tg + ".ln3", dxi, dx_bf16=dxbi, res1=dsr, res2=dtrb,
+            dxb8 = self._ln_bwd(dln, x_in, pre + "ln_3", tg + ".ln3", dxi, dx_bf16=dxbi, res1=dsrb if lowp else dsr, res2=dtrb,
                                 fp8_for=f"video_model.transformer.resblocks.{l - 1}.mlp.c_proj.weight" if l > 0 else None)
             dx, dxb = dxi, dxbi
             self._ready(pre)
         dtok = self._f("vit.dtok", (M, W))
-        self._ln_bwd(dx, B_["vit.tok"], "video_model.ln_pre", "vit.lnpre", dtok)
+        self._ln_bwd(dxb if lowp else dx, B_["vit.tok"], "video_model.ln_pre", "vit.lnpre", dtok)
         dpatch = self._b("vit.dpatch", (Mp, W))
         K.vit_assemble_bwd(dtok, keep_dev, dpatch, self.P.g("video_model.class_embedding"),
                            self.P.g("video_model.positional_embedding"), self.P.g("video_model.temporal_embedding"),

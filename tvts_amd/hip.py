@@ -296,7 +296,7 @@ def _ln_workspace(dev):
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2=None, dgamma=None, dbeta=None,
                   rows=None, M=None, workspace=True, q8=None, row_scale=None):
-    """dx (fp32, may be None when only the bf16 copy is wanted) = LN backward [+ res1 (fp32) + res2 (bf16)];
+    """dx (fp32, may be None when only the bf16 copy is wanted) = LN backward [+ res1 (fp32 or bf16) + res2 (bf16)];
     dgamma / dbeta are ACCUMULATED (+=) from per-block partials in a shared scratch buffer.  q8 / row_scale: also the e4m3
     copy of dx_bf16 with one scale per row (bf16 dy, every row)."""
     lib = _lib.load()
@@ -306,7 +306,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2
     if q8 is not None:
         assert rows is None and dx_bf16 is not None and dy.dtype == torch.bfloat16 and row_scale is not None and row_scale.numel() >= M
         rc = lib.tvts_layernorm_bwd_fp8(_p(dy), _ld(dy), _p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(mean), _p(rstd),
-                                        _p(gamma), _p(res1), _ld(res1) if res1 is not None else 0, _p(res2),
+                                        _p(gamma), _p(res1), 1 if (res1 is not None and res1.dtype == torch.bfloat16) else 0,
+                                        _ld(res1) if res1 is not None else 0, _p(res2),
                                         _ld(res2) if res2 is not None else 0, M, x.shape[1], _p(dx), _ld(dx) if dx is not None else 0,
                                         _p(dx_bf16), _ld(dx_bf16), _p(q8), q8.stride(0), _p(row_scale), _p(dgamma), _p(dbeta), _p(ws),
                                         ws.numel() if ws is not None else 0, _stream())
@@ -314,7 +315,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2
         return
     rc = lib.tvts_layernorm_bwd(_p(dy), _ld(dy), 1 if dy.dtype == torch.float32 else 0, _p(x), _ld(x),
                                 1 if x.dtype == torch.bfloat16 else 0, _p(rows),
-                                _p(mean), _p(rstd), _p(gamma), _p(res1), _ld(res1) if res1 is not None else 0, _p(res2),
+                                _p(mean), _p(rstd), _p(gamma), _p(res1), 1 if (res1 is not None and res1.dtype == torch.bfloat16) else 0,
+                                _ld(res1) if res1 is not None else 0, _p(res2),
                                 _ld(res2) if res2 is not None else 0, M, x.shape[1], _p(dx),
                                 _ld(dx) if dx is not None else 0, _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0,
                                 _p(dgamma), _p(dbeta), _p(ws), ws.numel() if ws is not None else 0, _stream())
