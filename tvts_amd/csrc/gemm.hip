@@ -196,7 +196,10 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
     const int grid = total_tiles < nt_cus ? ((total_tiles + 7) / 8) * 8 : nt_cus;  // persistent: one block per CU, multiple of 8 (XCDs)
     // every production instantiation staggers the LDS-DMA issue of the two waves of a SIMD (ABL 32768: +1-3 % on every shape of
     // the step, tools/gemm_ab.py; the same change is worth 6-10 % on the weight-gradient kernel)
-    constexpr int SD = 32768;
+    // ... and pins the written order of fragment reads and MFMA groups in the bf16 K loop (ABL 131072, round 3: hipcc otherwise
+    // sinks every ds_read_b128 in front of its consumer and waits lgkmcnt(0) there; -1.2 % over the step's shapes with their
+    // epilogues, tools/gemm_ab.py "pasm+pin" / "pin", profiles/r03_gemm_ab_pin.txt)
+    constexpr int SD = 32768 | 131072;
     void (*kern)(GemmNT) = nullptr;
     if (gated) {
         if (act != ACT_NONE) return TVTS_EINVAL;

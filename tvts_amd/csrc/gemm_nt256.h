@@ -834,13 +834,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
             }
             continue;
         }
+        // ABL & 131072: pin the written order of fragment reads and MFMA groups.  Left to itself hipcc sinks every ds_read_b128 down
+        // to just in front of the MFMA group that consumes it and waits lgkmcnt(0) there (round 3, from the ISA of the round-2 build:
+        // four read bursts + full waits per stage with the matrix pipe idle behind each) -- the fragment double-buffering written
+        // here only exists in the source.  With the order pinned the reads of group G + 1 are in flight under group G's MFMAs and
+        // the compiler's own counted lgkmcnt(4 / 8) in front of each group is all that is left.
+#define SB() do { if constexpr ((ABL & 131072) != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
         LOAD_A(aF[1], cur, 0, 1);
+        SB();
         MFMA16(aF[0], bF[0], 0);
+        SB();
         LOAD_B(bF[1], cur, 1);
         LOAD_A(aF[0], cur, 1, 0);
+        SB();
         MFMA16(aF[1], bF[0], 1);
+        SB();
         LOAD_A(aF[1], cur, 1, 1);
+        SB();
         MFMA16(aF[0], bF[1], 0);
+        SB();
         if constexpr ((ABL & 512) != 0) {
             // the stage this wait is for was requested BEFORE the previous tile's epilogue; the counter retires in order, so
             // leaving as many operations outstanding as the epilogue's tail issued stores still proves the stage has landed
@@ -900,7 +912,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
             LOAD_B(bF[0], nxt, 0);
             LOAD_A(aF[0], nxt, 0, 0);
         }
+        SB();
         MFMA16(aF[1], bF[1], 1);
+        SB();
         if (do_issue && (ABL & 32768) != 0 && wave >= 4) issue();
         if (++kt == nk) {
             if constexpr ((ABL & 2048) != 0) {  // experiment library: per-tile time stamps of wave 0 (g.sa carries the trace buffer)
@@ -946,6 +960,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
             }
         }
     }
+#undef SB
 #undef LOAD_A
 #undef LOAD_B
 #undef MFMA16
