@@ -18,7 +18,8 @@
 extern "C" {
 #endif
 
-enum { TVTS_ACT_NONE = 0, TVTS_ACT_QUICK_GELU = 1, TVTS_ACT_GELU_ERF = 2 };
+enum { TVTS_ACT_NONE = 0, TVTS_ACT_QUICK_GELU = 1, TVTS_ACT_GELU_ERF = 2,
+       TVTS_GATE_ADD_BF16 = 3 /* gate_act only: gate_h is a bf16 matrix ADDED to the result -- the bf16 residual stream */ };
 enum { TVTS_ATTN_FULL = 0, TVTS_ATTN_SPACE = 1, TVTS_ATTN_TIME = 2, TVTS_ATTN_CLS = 3 };
 /* `opts` of the GEMM entry points (OR them; 0 = automatic) */
 enum {
@@ -46,7 +47,9 @@ enum {
 
 /* ---- GEMM (gemm.hip).  nn.Linear forward / dgrad: v2/model/video_encoder_ViT_B_16.py:26-27,41,74,105-109;
  *      v2/CLIP/clip/model.py:175-181; v2/model/sort_transformer.py:21-23,41-42.  K % 64 == 0, N % 4 == 0.
- *      out = [gate'(gate_h) *] act(A.B^T + bias) [+ residual]; preact (bf16) receives A.B^T + bias when act != 0. */
+ *      out = [gate'(gate_h) *] act(A.B^T + bias) [+ residual]; preact (bf16) receives A.B^T + bias when act != 0.
+ *      gate_act = TVTS_GATE_ADD_BF16: out = A.B^T + bias + gate_h (bf16 residual: x + proj(.) / x + mlp(.) of
+ *      video_encoder_ViT_B_16.py:117-123 with the residual stream kept in bf16; `residual` is the fp32 form of the same sum) */
 int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                       const float* residual, int ldr, int act, void* preact, int ldp, const void* gate_h, int ldh,
                       int gate_act, void* out, int ldc, int out_f32, int opts, hipStream_t stream);
@@ -72,8 +75,8 @@ int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int 
  * gate_act'(gate_h[M,N]) * (scale_a[m] * scale_b * (A[M,K] B[N,K]^T)), A = e4m3 copy of the output gradient (per-token scales),
  * B = e4m3 copy of the transposed weight; the un-gated input gradients take tvts_gemm_nt_fp8 itself */
 int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
-                          int scale_a_rows, const float* scale_b, const void* gate_h, int ldh, int gate_act, void* out, int ldc,
-                          int opts, hipStream_t stream);
+                          int scale_a_rows, const float* scale_b, const float* bias, const void* gate_h, int ldh, int gate_act,
+                          void* out, int ldc, int opts, hipStream_t stream);
 /* (main loop of tvts_gemm_nt_fp8*: v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales, the fp8 issue rate of gfx950;
  * TVTS_GEMM_FP8_K32 selects the 16x16x32 fp8 form) */
 /* per-tensor fp8 quantisation: amax[0] = max |x| ; q = rne(x * 448 / amax) as e4m3, scale_out[0] = amax / 448 */

@@ -1,6 +1,6 @@
 """Margins of the parity gates on the headline architecture (B/16, T=8, mask .5, B pairs) against the fp32 CPU oracle: row cosine /
-rel-L2 of the embeddings, loss differences, gradient-norm deviation and the worst per-tensor gradient cosine -- with the
-residual-stream gradient carried in bf16 (arch["bf16_grad_stream"] = True) and in fp32 (the default)."""
+rel-L2 of the embeddings, loss differences, gradient-norm deviation and the worst per-tensor gradient cosine -- for the three
+precisions of the residual stream / its gradient (arch["bf16_residual"], arch["bf16_grad_stream"])."""
 import os
 import sys
 import types
@@ -31,8 +31,8 @@ def cosmin(x, y):
     return float(torch.nn.functional.cosine_similarity(x, y, dim=1).min())
 
 
-for lowp in (True, False):
-    a = dict(a0, bf16_grad_stream=lowp)
+for lowp in ("fp32 residual + bf16 gradient stream (default)", "bf16 residual + bf16 gradient stream (opt-in)", "fp32 streams (rounds 1-2)"):
+    a = dict(a0, bf16_residual=lowp.startswith("bf16 residual"), bf16_grad_stream=not lowp.startswith("fp32 streams"))
     m = TVTSv2Base(types.SimpleNamespace(local_rank=0, rank=0, world_size=1), arch=a)
     m.load_state_dict(P, strict=True)
     m._fresh_shadows(); m._sync_requires_grad()
@@ -51,7 +51,7 @@ for lowp in (True, False):
         if float(g.norm()) > 1e-3 * gn_ref:
             worst.append((float(torch.nn.functional.cosine_similarity(mine.double().flatten(), g.double().flatten(), dim=0)), k))
     worst.sort()
-    print(f"bf16_grad_stream={lowp}: B={B} te cos {cosmin(te, rte):.6f} ve cos {cosmin(ve, rve):.6f} d loss1 {float(l1) - float(r1):+.2e} "
+    print(f"{lowp}: B={B} te rel-L2 {float((te.cpu().double() - rte.double()).norm() / rte.double().norm()):.4f} ve rel-L2 {float((ve.cpu().double() - rve.double()).norm() / rve.double().norm()):.4f} te cos {cosmin(te, rte):.6f} ve cos {cosmin(ve, rve):.6f} d loss1 {float(l1) - float(r1):+.2e} "
           f"d loss2 {float(l2) - float(r2):+.2e} grad-norm {gn ** 0.5:.5f} vs {gn_ref:.5f} ({(gn ** 0.5 / gn_ref - 1) * 100:+.3f} %) "
           f"worst tensor cosines {[(round(c, 5), k) for c, k in worst[:4]]}", flush=True)
     del m

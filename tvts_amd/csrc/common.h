@@ -22,7 +22,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
         if (e__ != hipSuccess) return (int)e__;              \
     } while (0)
 
-enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU_ERF = 2 };
+// ACT_ADD_BF16 only exists in the GATE slot of the GEMM epilogues: the bf16 side input is ADDED (the bf16 residual stream of the
+// space-time blocks) instead of multiplying the result by an activation derivative
+enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU_ERF = 2, ACT_ADD_BF16 = 3 };
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -78,6 +80,11 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
         return cdf + x * 0.3989422804014327f * gs;
     }
     return 1.0f;
+}
+
+// the GATE slot of a GEMM epilogue: v * act'(h) (input gradient through an activation) or v + h (bf16 residual)
+__device__ __forceinline__ float gate_apply(float v, float h, int gate) {
+    return gate == ACT_ADD_BF16 ? v + h : v * act_bwd(h, gate);
 }
 
 // XCD-aware bijective remap of a 1-D block id: blocks that land on one XCD (bid % 8) get a

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNT g) {
                 if (GATE != ACT_NONE) {
                     const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
+                    for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)h[e], GATE);
                 }
                 if (g.residual) {
                     const f32x4 r = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
@@ -204,9 +204,11 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
     if (gated) {
         if (act != ACT_NONE) return TVTS_EINVAL;
         if constexpr (FP8)  // e4m3 dgrad with the activation-gradient gate (tvts_gemm_nt_fp8_gate): the scaled-MFMA main loop only
-            kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, true, SD | 65536> : gate_act == ACT_GELU_ERF ? gemm_nt256p_kernel<0, 2, true, SD | 65536> : nullptr;
+            kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, true, SD | 65536> : gate_act == ACT_GELU_ERF ? gemm_nt256p_kernel<0, 2, true, SD | 65536>
+                 : gate_act == ACT_ADD_BF16 ? gemm_nt256p_kernel<0, 3, true, SD | 65536> : nullptr;
         else
-            kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, SD> : gate_act == ACT_GELU_ERF ? gemm_nt256p_kernel<0, 2, false, SD> : nullptr;
+            kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, SD> : gate_act == ACT_GELU_ERF ? gemm_nt256p_kernel<0, 2, false, SD>
+                 : gate_act == ACT_ADD_BF16 ? gemm_nt256p_kernel<0, 3, false, SD> : nullptr;
     } else {
         kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, FP8, SD> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, FP8, SD>
              : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, FP8, SD> : nullptr;
@@ -238,6 +240,8 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
         if (fits) {
             if (gated) {
                 if (gate_act == ACT_QUICK_GELU && !g.out_f32 && !g.residual) kern = gemm_nt256p_kernel<0, 1, false, 8192 | SD, 0>;
+                // bf16 residual added to a bf16 result (the residual stream of the space-time blocks): the gate form's traffic
+                if (gate_act == ACT_ADD_BF16 && !g.out_f32 && !g.residual) kern = gemm_nt256p_kernel<0, 3, false, 8192 | SD, 0>;
             } else if (act == ACT_QUICK_GELU) {
                 if (!g.out_f32 && !g.residual) kern = gemm_nt256p_kernel<1, 0, false, 8192 | SD, 0>;
             } else if (act == ACT_NONE) {
@@ -281,7 +285,8 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     void (*kern)(GemmNT) = nullptr;
     if (gate_h) {
         if (act != ACT_NONE) return TVTS_EINVAL;
-        kern = gate_act == ACT_QUICK_GELU ? gemm_nt_kernel<0, 1> : gate_act == ACT_GELU_ERF ? gemm_nt_kernel<0, 2> : nullptr;
+        kern = gate_act == ACT_QUICK_GELU ? gemm_nt_kernel<0, 1> : gate_act == ACT_GELU_ERF ? gemm_nt_kernel<0, 2>
+             : gate_act == ACT_ADD_BF16 ? gemm_nt_kernel<0, 3> : nullptr;
     } else {
         kern = act == ACT_NONE ? gemm_nt_kernel<0, 0> : act == ACT_QUICK_GELU ? gemm_nt_kernel<1, 0>
              : act == ACT_GELU_ERF ? gemm_nt_kernel<2, 0> : nullptr;
@@ -314,13 +319,13 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
 // A the e4m3 copy of the OUTPUT gradient (one scale per token, tvts_quant_fp8_rows), B the e4m3 copy of the TRANSPOSED weight
 // and, optionally, the activation-gradient gate of the MLP's first layer (gate_h = its saved pre-activation)
 extern "C" int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
-                                     int scale_a_rows, const float* scale_b, const void* gate_h, int ldh, int gate_act, void* out,
-                                     int ldc, int opts, hipStream_t stream) {
+                                     int scale_a_rows, const float* scale_b, const float* bias, const void* gate_h, int ldh,
+                                     int gate_act, void* out, int ldc, int opts, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b || !gate_h) return TVTS_EINVAL;
     if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || ldh % 8) return TVTS_EINVAL;
     GemmNT g;
     g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;
-    g.M = M; g.N = N; g.K = K / 2; g.bias = nullptr; g.residual = nullptr; g.ldr = 0; g.act = ACT_NONE;
+    g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = nullptr; g.ldr = 0; g.act = ACT_NONE;
     g.preact = nullptr; g.ldp = 0; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
     g.out = out; g.ldc = ldc; g.out_f32 = 0; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
     return launch_nt256<true>(g, ACT_NONE, gate_act, true, opts, stream);

@@ -171,7 +171,7 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
                                : PF ? (bf16x4){side.gate[t >> 1][(t & 1) * 4], side.gate[t >> 1][(t & 1) * 4 + 1], side.gate[t >> 1][(t & 1) * 4 + 2], side.gate[t >> 1][(t & 1) * 4 + 3]}
                                     : side_load<ABL, bf16x4>(g.gate_h + (size_t)m * g.ldh + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= act_bwd((float)h[e], GATE);
+                for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)h[e], GATE);
             }
             if (g.residual && !(ABL & 2)) v += (PF && GATE == ACT_NONE) ? side.res[t] : side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
             if (!(ABL & 4) || v[0] == 1.2345e33f) store16<ABL>((float*)g.out + (size_t)m * g.ldc + n, v);
@@ -204,7 +204,7 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
                     h = PF ? side.gate[t] : side_load<ABL, bf16x8>(g.gate_h + (size_t)m * g.ldh + n);
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= act_bwd((float)h[e], GATE);
+                for (int e = 0; e < 8; ++e) v[e] = gate_apply(v[e], (float)h[e], GATE);
             }
             if (g.residual && !(ABL & 2)) {
                 const f32x4 r0 = (PF && GATE == ACT_NONE) ? side.res[2 * t] : side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
@@ -414,7 +414,7 @@ __device__ __forceinline__ void epilogue256_reg(const GemmNT& g, f32x4 (&acc)[4]
                 }
                 if (GATED) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[j][e] *= act_bwd((float)s.gate[j >> 1][(j & 1) * 4 + e], GATE);
+                    for (int e = 0; e < 4; ++e) v[j][e] = gate_apply(v[j][e], (float)s.gate[j >> 1][(j & 1) * 4 + e], GATE);
                 }
                 if (!GATED && has_res) v[j] += s.res[j];
             }
@@ -451,7 +451,7 @@ __device__ __forceinline__ void epilogue256_reg(const GemmNT& g, f32x4 (&acc)[4]
                 }
                 if (GATED) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) w[e] *= act_bwd((float)s.gate[p][e], GATE);
+                    for (int e = 0; e < 8; ++e) w[e] = gate_apply(w[e], (float)s.gate[p][e], GATE);
                 }
                 if (!GATED && has_res) {
 #pragma unroll
@@ -607,7 +607,7 @@ __device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&a
                 }
                 if constexpr (GATED) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) w[e] *= act_bwd((float)s.gate[t][e], GATE);
+                    for (int e = 0; e < 8; ++e) w[e] = gate_apply(w[e], (float)s.gate[t][e], GATE);
                 } else if constexpr (has_res) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { w[e] += s.res[2 * t][e]; w[4 + e] += s.res[2 * t + 1][e]; }

@@ -402,11 +402,18 @@ extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const vo
     if ((res1_ && ldr % 4) || (res2_bf16 && ldr2 % 4)) return TVTS_EINVAL;
     const bf16* res2 = (const bf16*)res2_bf16;
     if (dx_bf16 && lddxb % 4) return TVTS_EINVAL;
-    if (x_bf16) {  // side-branch input kept in bf16: only the residual-free bf16-dy form exists (ln_1 of the space-time block)
-        if (dy_f32 || res1_ || res2) return TVTS_EINVAL;
-        launch_ln_bwd<bf16, false, false, bf16>(ceil_div(W, 256), M, stream, (const bf16*)dy, lddy, (const bf16*)x_, ldx, rows, mean, rstd,
-                                                gamma, (const float*)nullptr, res2, ldr2, ldr, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta,
-                                                workspace, workspace_elems);
+    if (x_bf16) {  // bf16 input: a side-branch value (ln_1's time residual) or the bf16 residual stream of the space-time blocks:
+        // bf16 dy; no residual, or a bf16 res1 (+ the bf16 side branch res2)
+        if (dy_f32 || (res1_ && !res1_bf16)) return TVTS_EINVAL;
+        const bf16* xb = (const bf16*)x_;
+        const bf16* r1 = (const bf16*)res1_;
+        const int it = ceil_div(W, 256);
+#define LNB_ARGS it, M, stream, (const bf16*)dy, lddy, xb, ldx, rows, mean, rstd, gamma, r1, res2, ldr2, ldr, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems
+        if (r1 && res2) launch_ln_bwd<bf16, true, true, bf16, false, bf16>(LNB_ARGS);
+        else if (r1) launch_ln_bwd<bf16, true, false, bf16, false, bf16>(LNB_ARGS);
+        else if (res2) launch_ln_bwd<bf16, false, true, bf16, false, bf16>(LNB_ARGS);
+        else launch_ln_bwd<bf16, false, false, bf16, false, bf16>(LNB_ARGS);
+#undef LNB_ARGS
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }
@@ -445,10 +452,13 @@ extern "C" int tvts_layernorm_bwd_fp8(const void* dy, int lddy, const void* x_, 
     const int it = ceil_div(W, 256);
 #define Q8_ARGS it, M, stream, (const bf16*)dy, lddy, x, ldx, (const int*)nullptr, mean, rstd, gamma, res1, res2, ldr2, ldr, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems, (unsigned char*)q8, ldq, row_scale
     if (x_bf16) {
-        if (res1_ || res2) return TVTS_EINVAL;
         const bf16* x = (const bf16*)x_;
-        const float* res1 = nullptr;
-        launch_ln_bwd<bf16, false, false, bf16, true>(Q8_ARGS);
+        if (res1_ && !res1_bf16) return TVTS_EINVAL;
+        const bf16* res1 = (const bf16*)res1_;
+        if (res1 && res2) launch_ln_bwd<bf16, true, true, bf16, true, bf16>(Q8_ARGS);
+        else if (res1) launch_ln_bwd<bf16, true, false, bf16, true, bf16>(Q8_ARGS);
+        else if (res2) return TVTS_EINVAL;
+        else launch_ln_bwd<bf16, false, false, bf16, true, bf16>(Q8_ARGS);
     } else if (res1_ && res1_bf16) {
         const float* x = (const float*)x_;
         const bf16* res1 = (const bf16*)res1_;

@@ -178,6 +178,19 @@ class Engine:
         self.sort_used_rows_only = bool(a.get("sort_used_rows_only", True))  # last sort block on the rows the head reads (sort_forward)
         self.text_used_rows_only = bool(a.get("text_used_rows_only", a.get("sort_used_rows_only", True)))  # last text block: EOT rows
         self.has_sort_head = bool(a.get("sort_head", True))
+        # Precision of the space-time blocks' residual stream (round 3).  Every consumer but the residual adds themselves reads
+        # these tensors as bf16 anyway (LayerNorm outputs and GEMM operands are bf16): fp32 buys exact accumulation along the
+        # 12 / 32 blocks, at 2.1 GB per block of HBM traffic in the forward + saved activations and 1.4 GB in the backward chain
+        # (192 pairs).  Measured on B/16 against the fp32 oracle (tools/dbg/grad_margins.py, profiles/r03_bf16_streams_ab.txt):
+        #   gradient stream bf16 (DEFAULT, arch["bf16_grad_stream"]): +1.4 %; forward untouched; gradient norm -0.25 %, worst
+        #     tensor cosine 0.9983 (gates 1 % / 0.98) -- the embedding-side gradients behind ln_pre's cancellation carry 2.4x the
+        #     error of the fp32 chain (5.8 % rel-L2);
+        #   residual stream bf16 as well (OPT-IN, arch["bf16_residual"], bench.py --bf16-residual): +5 % in total (1354-1372
+        #     pairs/s); video embedding rel-L2 0.89 % (gate 2 %; 0.39 % in fp32), row cosine 0.99995 (gate 0.9995), but the
+        #     |d loss| <= 1e-2 gate fails on one small 3-pair NT = 1 configuration (0.0155) -- parity is the first gate, so it
+        #     is not the default.
+        self.bf16_residual = bool(a.get("bf16_residual", False)) and a.get("family") != "v1"
+        self.bf16_grad_stream = bool(a.get("bf16_grad_stream", True)) or self.bf16_residual
         self.dev = store.device
         self.buf: Dict[str, torch.Tensor] = {}
         self.requires_grad = {name: True for name in store.shapes}
@@ -436,7 +449,9 @@ class Engine:
         tok = self._f("vit.tok", (M, W))
         K.vit_assemble(pe, self.P.p("video_model.class_embedding"), self.P.p("video_model.positional_embedding"),
                        self.P.p("video_model.temporal_embedding"), keep_dev, tok, B=B, T=T, n=n)
-        x = self._f("vit.x0", (M, W))
+        lowres = self.bf16_residual
+        xbuf = self._b if lowres else self._f   # the residual stream's buffers: bf16 or fp32
+        x = xbuf("vit.x0", (M, W))
         self._ln(tok, "video_model.ln_pre", 1e-5, x, "vit.lnpre")
         for l in range(a["layers"]):
             pre, tg = f"video_model.transformer.resblocks.{l}.", f"vit{l}"
@@ -455,13 +470,13 @@ class Engine:
             self._lin(ln1, pre + "attn.qkv.weight", pre + "attn.qkv.bias", qkv_s, M, a8=a8)
             att_s, lse_s = self._b(tg + ".att_s", (M, W)), self._f(tg + ".lse_s", (M, a["heads"]))
             self._st_attention_fwd(qkv_s, att_s, lse_s, "space", B, T, n)
-            s_res = self._f(tg + ".s_res", (M, W))  # residual from the block INPUT x (video_encoder_ViT_B_16.py:121)
+            s_res = xbuf(tg + ".s_res", (M, W))  # residual from the block INPUT x (video_encoder_ViT_B_16.py:121)
             self._lin(att_s, pre + "attn.proj.weight", pre + "attn.proj.bias", s_res, M, residual=x)
             ln2 = self._b(tg + ".ln2", (M, W))
             a8 = self._ln(s_res, pre + "ln_2", 1e-5, ln2, tg + ".ln2", fp8_for=pre + "mlp.c_fc.weight")
             h, act = self._b(tg + ".h", (M, 4 * W)), self._b(tg + ".a", (M, 4 * W))
             self._lin(ln2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", act, M, act=a["act"], preact=h, a8=a8)
-            xo = self._f(f"vit.x{l + 1}", (M, W))
+            xo = xbuf(f"vit.x{l + 1}", (M, W))
             self._lin(act, pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", xo, M, residual=s_res)
             x = xo
         out = self._f("vit.out", (M, E))
@@ -472,13 +487,23 @@ class Engine:
             return out, None
         # H/14 (video_encoder_ViT_H_14.py:472-484): pooled = ln_post(CLS) @ proj in fp32; the patch tokens are projected
         # WITHOUT ln_post (row 0 of each clip is computed too but never read: sort_assemble takes rows 1..S-1)
-        xb = self._b("vit.xlast_b", (M, W))
-        K.cast_f32_bf16(x, xb)
+        if lowres:
+            xb = self.buf["vit.xlast_b"] = x  # the stream is bf16 already
+        else:
+            xb = self._b("vit.xlast_b", (M, W))
+            K.cast_f32_bf16(x, xb)
         K.gemm_nt(xb, self.P.wt("video_model.proj"), out, M=M)
         lnc = self._f("vit.lnpost_cls", (B, W))
         if vid_rows is None:
             vid_rows = (torch.arange(B, device=self.dev) * S).to(torch.int32)
-        self._ln(x, "video_model.ln_post", 1e-5, lnc, "vit.lnpost", rows=vid_rows)
+        if lowres:  # ln_post on the B CLS rows in fp32: an fp32 copy of those rows (plumbing on [B, W])
+            xc, xcb = self._f("vit.xcls32", (B, W)), self._b("vit.xcls16", (B, W))
+            vr64 = self.ctx.get("vid_rows64") if isinstance(self.ctx, dict) else None
+            torch.index_select(x, 0, vr64 if vr64 is not None else vid_rows.long(), out=xcb)
+            xc.copy_(xcb)
+            self._ln(xc, "video_model.ln_post", 1e-5, lnc, "vit.lnpost")
+        else:
+            self._ln(x, "video_model.ln_post", 1e-5, lnc, "vit.lnpost", rows=vid_rows)
         pooled = self._f("vit.pooled", (B, E))
         K.gemm_small(lnc, self.P.p("video_model.proj"), pooled, M=B, N=E, K=W, sa=(W, 1), sb=(E, 1))
         return out, pooled
@@ -493,15 +518,11 @@ class Engine:
         M, Mp = B * S, B * T * n
         rg = self.requires_grad
         dln = self._b("vit.s.dln", (M, W))
-        # arch["bf16_grad_stream"] (default off): carry the residual-stream gradient of the space-time blocks in bf16.  Every
-        # consumer but the next LayerNorm backward's residual add reads its bf16 copy anyway (GEMM operands); the fp32 copy buys
-        # the exact accumulation of the chain at 463 MB written + 463 MB read per LayerNorm backward (192 pairs).  Measured (round
-        # 3, profiles/r03_bf16_grad_stream_ab.txt): the three LayerNorm backwards of a block move 3.2 instead of 4.6 GB, the step
-        # 149.3 -> 147.2 ms (+1.4 %), and the chain is rounded twice per block -- all SURVEY 8d gates hold (worst tensor cosine
-        # 0.9983, gradient norm -0.25 %), but the error of the embedding-side gradients (positional / class embedding, conv1, which
-        # sit behind ln_pre's cancellation) grows 2.4x (5.8 % instead of 2.4 % rel-L2).  Parity is the first gate: the default
-        # keeps the fp32 chain; bench.py --bf16-grad-stream measures the other.
-        lowp = bool(a.get("bf16_grad_stream", False))
+        # the residual-stream gradient in bf16 (self.bf16_grad_stream, see __init__): measured alone +1.4 % (the three LayerNorm
+        # backwards of a block move 3.2 instead of 4.6 GB) at 2.4x the error of the embedding-side gradients, which sit behind
+        # ln_pre's cancellation (5.8 % instead of 2.4 % rel-L2; profiles/r03_bf16_streams_ab.txt)
+        lowp = self.bf16_grad_stream
+        lowres = self.bf16_residual
         dxb = self._b("vit.dxbA", (M, W))
         dx = None if (lowp and not self.pooled_tail) else self._f("vit.dxA", (M, W))
         if not self.pooled_tail:
@@ -525,8 +546,13 @@ class Engine:
                 K.gemm_small(lnc, d_pooled, self.P.g("video_model.proj"), M=W, N=E, K=B, sa=(1, W), sb=(E, 1), accumulate=True)
             dlnc = self._f("vit.s.dlnc", (B, W))
             K.gemm_small(d_pooled, self.P.p("video_model.proj"), dlnc, M=B, N=W, K=E, sa=(E, 1), sb=(1, E))
-            self._ln_bwd(dlnc, B_[f"vit.x{a['layers']}"], "video_model.ln_post", "vit.lnpost", dx, res1=dx,
-                         rows=self.ctx["vid_rows"])
+            if lowres:  # ln_post backward on the fp32 copy of the CLS rows, added into those rows of dx
+                dxc = self._f("vit.s.dxcls", (B, W))
+                self._ln_bwd(dlnc, B_["vit.xcls32"], "video_model.ln_post", "vit.lnpost", dxc)
+                dx.index_add_(0, self.ctx["vid_rows64"] if "vid_rows64" in self.ctx else self.ctx["vid_rows"].long(), dxc)
+            else:
+                self._ln_bwd(dlnc, B_[f"vit.x{a['layers']}"], "video_model.ln_post", "vit.lnpost", dx, res1=dx,
+                             rows=self.ctx["vid_rows"])
             K.cast_f32_bf16(dx, dxb)
         dh = self._b("vit.s.dh", (M, 4 * W))
         datt = self._b("vit.s.datt", (M, W))
@@ -767,7 +793,7 @@ class Engine:
         vid_rows = (torch.arange(B) * S).to(torch.int32).to(self.dev)
         return dict(video=video, crop=crop, resize=resize, ids=ids_dev, eot_rows=eot_rows, eot_index=self.eot_index(eot_rows, L),
                     keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
-                    sort_rows=sort_rows, sort_rows64=sort_rows.long(), vid_rows=vid_rows)
+                    sort_rows=sort_rows, sort_rows64=sort_rows.long(), vid_rows=vid_rows, vid_rows64=vid_rows.long())
 
     def forward(self, pb: dict):
         """-> (text_emb [B,E], video_emb [B,E], pred [B*NT, n_trans] | None); all fp32 workspace tensors."""

@@ -14,7 +14,7 @@ from . import _lib
 
 GEMM_PROFILE = None  # bench.py: list collecting (kind, flops, start_event, end_event) per MFMA GEMM launch
 
-ACT = {"none": 0, None: 0, "quick_gelu": 1, "gelu": 2}
+ACT = {"none": 0, None: 0, "quick_gelu": 1, "gelu": 2, "add": 3}  # "add": gate slot only (bf16 residual added to the result)
 MODE = {"full": 0, "space": 1, "time": 2, "cls": 3}
 
 
@@ -128,6 +128,9 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
     N, K = b.shape
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape[1] == K
     assert out.shape[1] == N and out.dtype in (torch.bfloat16, torch.float32)
+    if residual is not None and residual.dtype == torch.bfloat16:  # the bf16 residual stream: the gate slot used additively
+        assert gate_h is None and act is None
+        gate_h, gate_act, residual = residual, "add", None
     if GEMM_PROFILE is not None:
         ev0, ev1 = Event(), Event()
         ev0.record()
@@ -207,9 +210,13 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
     if GEMM_PROFILE is not None:
         ev0, ev1 = Event(), Event()
         ev0.record()
+    if residual is not None and residual.dtype == torch.bfloat16:
+        assert gate_h is None and act is None and preact is None
+        gate_h, gate_act, residual = residual, "add", None
     if gate_h is not None:
-        assert bias is None and residual is None and act is None and preact is None and out.dtype == torch.bfloat16
-        rc = lib.tvts_gemm_nt_fp8_gate(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(gate_h),
+        assert residual is None and act is None and preact is None and out.dtype == torch.bfloat16
+        assert bias is None or gate_act == "add"
+        rc = lib.tvts_gemm_nt_fp8_gate(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(bias), _p(gate_h),
                                        _ld(gate_h), ACT[gate_act], _p(out), _ld(out), nt_opts(None, cus, k32), _stream())
         _chk(rc, "tvts_gemm_nt_fp8_gate")
         if GEMM_PROFILE is not None:
