@@ -41,6 +41,12 @@ def test_native_comm_world_of_one(comm):
         assert torch.equal(x, ref)
 
 
+def test_known_answer_self_test(comm):
+    """the check `dist.transport()` runs on every rank before it settles on the native transport (a wrong or failing rank sends
+    all of them to torch.distributed instead)"""
+    comm.self_test()
+
+
 def test_side_stream_orders_against_the_compute_stream(comm):
     """producer kernel -> collective -> consumer kernel with no host synchronisation in between, many times over: the
     collective must see the producer's output (fork) and the consumer the collective's (join)."""

@@ -73,12 +73,14 @@ class NativeComm:
         idbuf = torch.zeros(128, dtype=torch.uint8)
         if r == 0:
             raw = (ctypes.c_ubyte * 128)()
-            self._chk(self.lib.tvts_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)), "tvts_comm_unique_id")
-            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-        if W > 1:
+            if self.lib.tvts_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)) == 0:
+                idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+        if W > 1:  # the broadcast runs on every rank even when rank 0 has no id to send (all zero), so that all of them fail together
             t = idbuf.to(dev) if dist.get_backend() == "nccl" else idbuf
             dist.broadcast(t, src=0)
             idbuf = t.cpu()
+        if not bool(idbuf.any()):
+            raise RuntimeError("tvts_comm_unique_id failed on rank 0")
         raw = (ctypes.c_ubyte * 128)(*idbuf.tolist())
         h = ctypes.c_void_p()
         self._chk(self.lib.tvts_comm_create(ctypes.cast(raw, ctypes.c_void_p), r, W, ctypes.byref(h)), "tvts_comm_create")
@@ -128,6 +130,22 @@ class NativeComm:
     def wait(self):
         self._chk(self.lib.tvts_comm_wait(self.h, self._stream()), "tvts_comm_wait")
 
+    def self_test(self):
+        """One small all-reduce and one all-gather with known answers (rank r contributes r + 1); raises when a result is wrong."""
+        W, r = self.W, self.rank
+        dev = torch.device("cuda", torch.cuda.current_device())
+        x = torch.full((4096,), float(r + 1), device=dev)
+        v = torch.full((2, 8), float(r + 1), device=dev)
+        t = -v
+        v_all, t_all = torch.zeros(2 * W, 8, device=dev), torch.zeros(2 * W, 8, device=dev)
+        self.allreduce(x)
+        self.allgather_embeds(v, t, v_all, t_all)
+        self.wait()
+        torch.cuda.synchronize()
+        want = torch.arange(1, W + 1, device=dev, dtype=torch.float32).repeat_interleave(2)[:, None].expand(2 * W, 8)
+        if not (bool((x == W * (W + 1) / 2).all()) and torch.equal(v_all, want) and torch.equal(t_all, -want)):
+            raise RuntimeError("native transport self-test: wrong all-reduce / all-gather result")
+
 
 _TRANSPORT: Optional[str] = None
 
@@ -144,13 +162,32 @@ def transport() -> str:
         _TRANSPORT = "torch"
         W, _ = world()
         if W > 1 and torch.cuda.is_available() and dist.get_backend() == "nccl":
+            # Every rank must end up on the same transport: each stage (the library loads; the communicator comes up and a small
+            # all-reduce / all-gather with known answers is right) is followed by an agreement over torch.distributed, and one
+            # rank's failure sends all of them to the torch transport instead of leaving the others inside a collective.
+            def agree(ok: bool) -> bool:
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return bool(flag.item())
+            err = None
             try:
                 from . import _lib
                 _lib.load_comm()
-                _TRANSPORT = "native"
             except Exception as e:  # the library is optional: torch.distributed carries the same exchange steps
+                err = e
+            if agree(err is None):
+                try:
+                    NativeComm.get().self_test()
+                except Exception as e:
+                    err = e
+                if agree(err is None):
+                    _TRANSPORT = "native"
+                elif NativeComm._inst is not None:
+                    NativeComm._inst.close()
+            if _TRANSPORT != "native":
                 import warnings
-                warnings.warn(f"libtvts_comm.so not usable ({type(e).__name__}: {e}); exchange steps go through torch.distributed")
+                why = f"{type(err).__name__}: {err}" if err is not None else "another rank failed"
+                warnings.warn(f"native transport (libtvts_comm.so) not usable ({why}); exchange steps go through torch.distributed")
         if _TRANSPORT == "native":
             cus = int(os.environ.get("TVTS_NT_CUS", "0"))
             if cus:
