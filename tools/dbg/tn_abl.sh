@@ -6,6 +6,6 @@ for fl in "" "$@"; do
   touch gemm.hip
   make FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -I../../include $fl" build/gemm.o ../libtvts_hip.so > /dev/null 2>&1
   echo "== flags: $fl"
-  (cd ../.. && python tools/tn_ab.py 192 3 2>&1 | grep -E "qkv wgrad|fc1 wgrad|fc2 wgrad|proj wgrad" | sed -E 's/\| 128: [^|]*\| 256: ([^ ]*) [^|]*/| 256 \1 /' | cut -c1-200)
+  (cd ../.. && python tools/tn_ab.py 192 3 2>&1 | grep -E "qkv wgrad|fc1 wgrad|fc2 wgrad|proj wgrad" | sed -E "s/ rel [^|]*//g" | cut -c1-220)
 done
 touch gemm.hip; make build/gemm.o ../libtvts_hip.so > /dev/null 2>&1

@@ -38,7 +38,7 @@ def main():
         ref = (p.float().t() @ q.float())
         csr = p.float().sum(0)
         line = f"{name:11s} {m}x{na}x{nb}:"
-        ts = {128: [], 256: []}
+        ts = {128: [], 256: [], "256nc": []}
         for tile in (128, 256):
             out = torch.full((na, nb), float("nan"), device=dev)
             cs = torch.zeros(na, device=dev)
@@ -56,9 +56,14 @@ def main():
                     for (pp, qq), oo in zip(sets, outs):
                         K.gemm_tn(pp, qq, oo, accumulate=False, colsum=css, tile=tile)
                 ts[tile].append(timeit(run) / len(sets))
-        for tile in (128, 256):
+
+            def run_nc():  # the 256 kernel without the bias-gradient column sums
+                for (pp, qq), oo in zip(sets, outs):
+                    K.gemm_tn(pp, qq, oo, accumulate=False, colsum=None, tile=256)
+            ts["256nc"].append(timeit(run_nc) / len(sets))
+        for tile in (128, 256, "256nc"):
             med = sorted(ts[tile])[len(ts[tile]) // 2]
-            tot[tile] += med
+            tot[tile] = tot.get(tile, 0.0) + med
             line += f" | {tile} {med * 1e3:7.1f}us {2.0 * m * na * nb / med / 1e9:5.0f}TF"
         line += f" | auto picks {K.gemm_tn_select(m, na, nb)}"
         print(line, flush=True)

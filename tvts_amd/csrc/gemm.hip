@@ -171,7 +171,10 @@ static bool nt_use_256(int M, int N, int opts) {
     if (forced == 128) return false;
     if (N % 8) return false;
     if (forced == 256) return true;
-    return N % 256 == 0 && (long)ceil_div(M, 256) * (N / 256) >= NT_MIN_TILES_256;
+    if (N % 256) return false;
+    // ... or as soon as the 128x128 kernel would need a second round of its 512 co-resident blocks (129-149 tiles of 256: the text
+    // tower at 24 pairs, M = 18 936 x N = 512: 54 vs 72 us at K = 2048, profiles/r03_gemm_tile_choice_small_m.txt)
+    return (long)ceil_div(M, 256) * (N / 256) >= NT_MIN_TILES_256 || (long)ceil_div(M, 128) * (N / 128) > 512;
 }
 extern "C" int tvts_gemm_nt_select(int M, int N, int opts) { return nt_use_256(M, N, opts) ? 256 : 128; }
 
@@ -199,7 +202,11 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
     // ... and pins the written order of fragment reads and MFMA groups in the bf16 K loop (ABL 131072, round 3: hipcc otherwise
     // sinks every ds_read_b128 in front of its consumer and waits lgkmcnt(0) there; -1.2 % over the step's shapes with their
     // epilogues, tools/gemm_ab.py "pasm+pin" / "pin", profiles/r03_gemm_ab_pin.txt)
-    constexpr int SD = 32768 | 131072;
+#ifndef TVTS_NT_SD
+#define TVTS_NT_SD (32768 | 131072)   // overridable for A/B builds (tools/dbg/ab_flags.sh), e.g. | 262144: LDS-DMA from inline asm -- exact
+                                      // lgkmcnt counts in the K loop instead of lgkmcnt(0), and no change in the step (145.5-146.0 ms either way)
+#endif
+    constexpr int SD = TVTS_NT_SD;
     void (*kern)(GemmNT) = nullptr;
     if (gated) {
         if (act != ACT_NONE) return TVTS_EINVAL;

@@ -52,6 +52,21 @@ __device__ __forceinline__ void stage_issue256(const StageOff256& o, const bf16*
         __builtin_amdgcn_global_load_lds((const GLB_PTR(void))((const char*)ubase + o.off[t]),
                                          (LDS_PTR(void))(lds_tile + (t * 8 + wave) * 1024), 16, 0, AUX);
 }
+// the same four pieces from inline asm (ABL & 262144).  The builtin is a FLAT-class instruction that writes LDS: hipcc's wait
+// bookkeeping marks it as touching both the vector-memory and the LDS counter ("pending flat"), after which every wait it
+// inserts for an LDS read is a full lgkmcnt(0) -- in the K loop two of them per stage sit right behind a burst of four fragment
+// reads whose data is only needed a whole MFMA group later.  Issued this way the compiler counts its own reads exactly
+// (lgkmcnt(4)) and the waits for the DMA itself are the explicit ones at the stage barrier.  M0 carries the LDS destination
+// (8 KiB between pieces); the offsets are 32-bit from a wave-uniform base.
+__device__ __forceinline__ void stage_issue256_asm(const StageOff256& o, const bf16* ubase_, unsigned lds_addr) {
+    const char* ubase = uniform_ptr(ubase_);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(o.off[0]), "v"(o.off[1]), "v"(o.off[2]), "v"(o.off[3]), "s"(ubase), "s"(lds_addr) : "memory", "scc");
+}
 // tile index -> tile origin.  gc == 0: row-major over (m, n).  gc > 0: column groups of gc tile columns, row-major
 // inside a group, so the tiles an XCD works on at one time span gc weight panels instead of all of them.
 __device__ __forceinline__ void tile_origin256(const GemmNT& g, int t, int gc, int& m0, int& n0) {
@@ -703,8 +718,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     };
     auto issue = [&]() {
         char* dst = smem + (i_st & 1) * 65536;
-        stage_issue256<0>(oa, g.A + (size_t)i_m0 * g.lda + i_kt * BK, dst, wave);
-        stage_issue256<0>(ob, g.B + (size_t)i_n0 * g.ldb + i_kt * BK, dst + 32768, wave);
+        if constexpr ((ABL & 262144) != 0) {
+            const unsigned d = (unsigned)(size_t)(LDS_PTR(char))smem + (unsigned)(i_st & 1) * 65536u + (unsigned)wave * 1024u;
+            stage_issue256_asm(oa, g.A + (size_t)i_m0 * g.lda + i_kt * BK, d);
+            stage_issue256_asm(ob, g.B + (size_t)i_n0 * g.ldb + i_kt * BK, d + 32768u);
+        } else {
+            stage_issue256<0>(oa, g.A + (size_t)i_m0 * g.lda + i_kt * BK, dst, wave);
+            stage_issue256<0>(ob, g.B + (size_t)i_n0 * g.ldb + i_kt * BK, dst + 32768, wave);
+        }
         ++i_st;
         if (++i_kt == nk) {
             i_kt = 0; ++i_tl;
@@ -863,7 +884,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             young_stores = 0;
         } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if constexpr ((ABL & 262144) != 0) __builtin_amdgcn_s_waitcnt(0x0070);
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
         RAW_BARRIER_P();
         if constexpr ((ABL & 2048) != 0) {  // first barrier behind an epilogue: every wave of the block has finished its stores' issue

@@ -206,14 +206,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmTN g) {
         TN_LOAD_P(pF[1], cur, 1, 1, valid);                                                            \
         TN_MFMA16(pF[0], qF[1], 0);                                                                    \
         TN_CS(pF[0], 0);                                                                               \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+        __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) lgkmcnt(0) expcnt(7); the builtin, not inline asm: the compiler's own wait */ \
+        /* bookkeeping sees it (with the asm form it re-waits for the same reads behind the barrier); +1-2 %, tools/tn_ab.py */ \
         RAW_BARRIER_P();                                                                               \
         /* stage st+2 goes into the buffer every wave has just finished reading.  The two waves of a SIMD (w, w + 4) do not issue */ \
         /* their 8 LDS-DMA pieces at the same time (a piece costs ~100+ cycles of VMEM issue and both would sit in it with the */ \
         /* matrix pipe idle): waves 0..3 issue here, waves 4..7 behind the stage's last MFMA group */ \
         const bool do_issue = i_st < nk && !(TN_ABL & 1);                                              \
         if (do_issue && (!TN_STAGGER_DMA || wave < 4)) issue();                                        \
-        if (st + 1 < nk) {                                                                             \
+        if (!TAIL || st + 1 < nk) { /* the mask-free copy only runs while a next stage exists */       \
             TN_LOAD_Q(qF[0], nxt, 0);                                                                  \
             TN_LOAD_P(pF[0], nxt, 0, 0, valid_n);                                                      \
         }                                                                                              \
