@@ -256,10 +256,11 @@ int tvts_tube_mask(long seed, long first_sample, int B, int ppf, int n_keep, int
 int tvts_vit_assemble(const float* patch, int ldp, const float* cls, const float* pos, const float* temporal,
                       const int* keep, int keep_per_frame, int B, int T, int n, int W, float* tok, int ldt, hipStream_t stream);
 /* workspace (optional, fp32 scratch): with >= B * ceil(n / 14) * T * W + B * W elements (tube masks) the temporal-embedding and
- * class-embedding sums are ordered per-block partials (run-to-run reproducible); the positional-embedding ROWS stay a scatter of
- * fp32 atomics -- an embedding-table gradient, as in the reference's nn.Embedding backward */
+ * class-embedding sums are ordered per-block partials; with B * n * W more and n_pos > 0 (the rows of dpos behind the class row:
+ * the patches per frame) the positional-embedding rows are gathered in clip order too -- every sum run-to-run reproducible.
+ * Without the room (or n_pos = 0, or one keep list per frame) they are a scatter of fp32 atomics. */
 int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int keep_per_frame, int B, int T, int n, int W,
-                          void* dpatch, int ldp, float* dcls, float* dpos, float* dtemporal, float* workspace,
+                          void* dpatch, int ldp, float* dcls, float* dpos, int n_pos, float* dtemporal, float* workspace,
                           long workspace_elems, hipStream_t stream);
 /* v1 (TVTS) Conv3d tubelet embedding as im2col over the kept patches of every tube (v1/model/video_encoder.py:78-99,199-206):
  * video fp32 [B, tubes * tubelet, 3, img, img], keep int32 [B, tubes, n] -> bf16 rows [B * tubes * n, 3 * tubelet * patch^2]
@@ -268,8 +269,11 @@ int tvts_patch_gather_tube(const float* video, const int* keep, int B, int tubes
                            void* out, int ldo, hipStream_t stream);
 int tvts_text_embed(const int* ids, int ld_ids, int N, int L, const float* emb, const float* pos, int Wt, float* x, int ldx,
                     hipStream_t stream);
+/* order / seg (optional, device int32): the rows 0 .. N * L - 1 sorted by token id (ties in row order) and the starts of the runs
+ * of equal ids in that list (N * L + 1 entries, non-decreasing, padded with N * L) -- with them both embedding gradients are
+ * ordered sums (run-to-run reproducible), without them (NULL) a scatter of fp32 atomics like nn.Embedding's backward */
 int tvts_text_embed_bwd(const float* dx, int ldx, const int* ids, int ld_ids, int N, int L, int Wt, float* demb, float* dpos,
-                        hipStream_t stream);
+                        const int* order, const int* seg, hipStream_t stream);
 int tvts_text_mean(const float* t, int NT, int B, int E, float* mean, float* before, hipStream_t stream);
 int tvts_text_mean_bwd(const float* dmean, int NT, int B, int E, float* dt, hipStream_t stream);
 int tvts_sort_assemble(const float* tok, int ldt, int B, int S, int off, int Sv, const float* text, int NT,

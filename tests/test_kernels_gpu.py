@@ -566,6 +566,10 @@ def test_patch_embed_and_assemble(K):
     assert rel(dcls, tokr["video_model.class_embedding"].grad) < 1e-5
     assert rel(dpos, pos.grad) < 1e-5
     assert rel(dtmp, tokr["video_model.temporal_embedding"].grad) < 1e-5
+    # every sum is ordered (per-block partials, positional rows gathered in clip order): the same bits on every run
+    dcls2, dpos2, dtmp2 = torch.zeros(W, device=DEV), torch.zeros(g * g + 1, W, device=DEV), torch.zeros(12, W, device=DEV)
+    K.vit_assemble_bwd(dtok.to(DEV), keep, dpatch, dcls2, dpos2, dtmp2, B=B, T=T, n=n)
+    assert torch.equal(dcls, dcls2) and torch.equal(dpos, dpos2) and torch.equal(dtmp, dtmp2)
 
 
 def test_text_embed_mean_sort_assemble(K):
@@ -582,6 +586,18 @@ def test_text_embed_mean_sort_assemble(K):
     e2 = emb.clone().requires_grad_(True); p2 = pos.clone().requires_grad_(True)
     (e2[ids[:, :L].long()] + p2[:L]).backward(dx.view(N, L, Wt))
     assert rel(demb, e2.grad) < 1e-5 and rel(dpos, p2.grad) < 1e-5
+    # ... and as ordered sums over the rows sorted by token id (what the engines pass): the same values, the same bits every time
+    order, seg = K.token_sort(ids[:, :L])
+    assert sorted(order.tolist()) == list(range(N * L)) and seg.numel() == N * L + 1 and int(seg[-1]) == N * L
+    flat = ids[:, :L].reshape(-1)
+    assert all(flat[order[i]] < flat[order[i + 1]] or (flat[order[i]] == flat[order[i + 1]] and order[i] < order[i + 1]) for i in range(N * L - 1))
+    outs = []
+    for _ in range(2):
+        demb2, dpos2 = torch.zeros(V, Wt, device=DEV), torch.zeros(ctx, Wt, device=DEV)
+        K.text_embed_bwd(dx.to(DEV), ids.to(DEV), demb2, dpos2, N=N, L=L, tok_sort=(order.to(DEV), seg.to(DEV)))
+        assert rel(demb2, e2.grad) < 1e-6 and rel(dpos2, p2.grad) < 1e-6
+        outs.append((demb2, dpos2))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     # caption mean (clip-major) and its backward
     NT, B, E = 4, 3, 128
     t = rnd(NT * B, E, seed=38)

@@ -222,13 +222,15 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __re
 #define ASM_SLOTS 14
 #define ASM_MAXT 16
 // part_t / part_c (optional): per-block partials [B * groups][T][W] of the temporal-embedding sums and [B][W] of the CLS rows,
-// added in block order by colsum_partials_kernel (no atomics: the sums are run-to-run reproducible); the positional-embedding
-// rows stay a scatter of fp32 atomics (an embedding-table gradient, like the reference's nn.Embedding backward).
+// added in block order by colsum_partials_kernel (no atomics: the sums are run-to-run reproducible).  part_p (optional): the
+// frame sums of every kept patch slot [B][n][W]; pos_rows_from_partials_kernel then adds, for every row of the positional
+// embedding, the slots that point at it in clip order.  Without part_p the rows are a scatter of fp32 atomics.
 __global__ __launch_bounds__(256) void vit_assemble_bwd_tube_kernel(const float* __restrict__ dtok, int ldt,
                                                                     const int* __restrict__ keep, int B, int T, int n, int W,
                                                                     bf16* __restrict__ dpatch, int ldp, float* __restrict__ dcls,
                                                                     float* __restrict__ dpos, float* __restrict__ dtemporal,
-                                                                    float* __restrict__ part_t, float* __restrict__ part_c) {
+                                                                    float* __restrict__ part_t, float* __restrict__ part_c,
+                                                                    float* __restrict__ part_p) {
     const int S = 1 + T * n;
     const int groups = (n + ASM_SLOTS - 1) / ASM_SLOTS;
     const int b = blockIdx.x / groups, grp = blockIdx.x % groups;
@@ -248,9 +250,13 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_tube_kernel(const float*
                     ts[f] += v;
                 }
             }
-            float* dp = dpos + (size_t)(1 + keep[b * n + i]) * W + c;
+            if (part_p) {
+                *(f32x4*)(part_p + ((size_t)b * n + i) * W + c) = ps;
+            } else {
+                float* dp = dpos + (size_t)(1 + keep[b * n + i]) * W + c;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(dp + e, ps[e]);
+                for (int e = 0; e < 4; ++e) atomicAdd(dp + e, ps[e]);
+            }
         }
 #pragma unroll
         for (int f = 0; f < ASM_MAXT; ++f) {
@@ -293,16 +299,69 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
     }
 }
 
+// dpos[1 + r] += sum over the clips b, in clip order, of the slot sums part_p[b][i] with keep[b][i] == r: a block per row r of the
+// positional embedding; a thread first looks up "its" clip's slot (256 clips at a time; a tube mask holds a position at most
+// once, further matches of a malformed one are added too), then owns four columns
+__global__ __launch_bounds__(256) void pos_rows_from_partials_kernel(const float* __restrict__ part_p, const int* __restrict__ keep,
+                                                                     int B, int n, int W, float* __restrict__ dpos) {
+    __shared__ int first[256], more[256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    f32x4 acc[4];  // columns tid * 4 + 1024 * q (W <= 4096: checked by the entry point)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        int f = -1, cnt = 0;
+        if (b0 + tid < B) {
+            const int* kp = keep + (size_t)(b0 + tid) * n;
+            for (int i = 0; i < n; ++i)
+                if (kp[i] == r) { if (f < 0) f = i; ++cnt; }
+        }
+        first[tid] = f; more[tid] = cnt > 1;
+        __syncthreads();
+        const int nb = B - b0 < 256 ? B - b0 : 256;
+        for (int k = 0; k < nb; ++k) {
+            const int fi = first[k];
+            if (fi < 0) continue;
+            const float* src = part_p + ((size_t)(b0 + k) * n + fi) * W;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = tid * 4 + 1024 * q;
+                if (c < W) acc[q] += *(const f32x4*)(src + c);
+            }
+            if (more[k]) {
+                const int* kp = keep + (size_t)(b0 + k) * n;
+                for (int i = fi + 1; i < n; ++i) {
+                    if (kp[i] != r) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = tid * 4 + 1024 * q;
+                        if (c < W) acc[q] += *(const f32x4*)(part_p + ((size_t)(b0 + k) * n + i) * W + c);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = tid * 4 + 1024 * q;
+        if (c < W) *(f32x4*)(dpos + (size_t)(1 + r) * W + c) += acc[q];
+    }
+}
+
 extern "C" int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int keep_per_frame, int B, int T, int n, int W,
-                                     void* dpatch, int ldp, float* dcls, float* dpos, float* dtemporal, float* workspace,
+                                     void* dpatch, int ldp, float* dcls, float* dpos, int n_pos, float* dtemporal, float* workspace,
                                      long workspace_elems, hipStream_t stream) {
     if (!keep_per_frame && T <= ASM_MAXT && W % 4 == 0 && ldt % 4 == 0 && ldp % 4 == 0) {
         const int groups = (n + ASM_SLOTS - 1) / ASM_SLOTS;
         const long need = (long)B * groups * T * W + (long)B * W;
         float* part_t = (workspace && workspace_elems >= need) ? workspace : nullptr;
         float* part_c = part_t ? workspace + (size_t)B * groups * T * W : nullptr;
+        float* part_p = (part_t && n_pos > 0 && W <= 4096 && workspace_elems >= need + (long)B * n * W) ? workspace + need : nullptr;
         hipLaunchKernelGGL(vit_assemble_bwd_tube_kernel, dim3(B * groups), dim3(256), 0, stream, dtok, ldt, keep, B, T, n, W,
-                           (bf16*)dpatch, ldp, dcls, dpos, dtemporal, part_t, part_c);
+                           (bf16*)dpatch, ldp, dcls, dpos, dtemporal, part_t, part_c, part_p);
+        if (part_p)
+            hipLaunchKernelGGL(pos_rows_from_partials_kernel, dim3(n_pos), dim3(256), 0, stream, part_p, keep, B, n, W, dpos);
         if (part_t) {
             hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div(T * W, 64)), dim3(1024), 0, stream, part_t, B * groups, T * W,
                                dtemporal, (float*)nullptr);
@@ -348,9 +407,60 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __rest
         }
     }
 }
+// the same sums without atomics (run-to-run reproducible).  Positions: dpos[l] += sum_n dx[n * L + l], a block per (64 columns,
+// position), 16 thread groups over the captions, each in caption order, combined in group order.
+__global__ __launch_bounds__(1024) void text_pos_bwd_kernel(const float* __restrict__ dx, int ldx, int N, int L, int Wt,
+                                                            float* __restrict__ dpos) {
+    __shared__ float acc[16][64];
+    const int l = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < Wt)
+        for (int nn = grp; nn < N; nn += 16) s += dx[((size_t)nn * L + l) * ldx + c];
+    acc[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && c < Wt) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += acc[g][threadIdx.x];
+        dpos[(size_t)l * Wt + c] += t;
+    }
+}
+// Tokens: the caller hands over the rows sorted by token id (`order`, ties in row order) and the starts of the runs of equal ids
+// (`seg`, N * L + 1 entries, padded with N * L: a fixed grid, empty runs exit).  A block per run adds its rows in order --
+// G = 256 / (Wt / 4) thread groups take every G-th row, each thread four columns, the groups are combined in group order.
+__global__ __launch_bounds__(256) void text_tok_bwd_kernel(const float* __restrict__ dx, int ldx, const int* __restrict__ ids,
+                                                           int ld_ids, int L, int Wt, const int* __restrict__ order,
+                                                           const int* __restrict__ seg, float* __restrict__ demb) {
+    __shared__ f32x4 part[256];
+    const int lo = seg[blockIdx.x], hi = seg[blockIdx.x + 1];
+    if (lo >= hi) return;
+    const int row0 = order[lo];
+    const int id = ids[(size_t)(row0 / L) * ld_ids + row0 % L];
+    const int cpt = Wt / 4 < 256 ? Wt / 4 : 256;  // column-threads per group
+    const int G = 256 / cpt, grp = threadIdx.x / cpt, ct = threadIdx.x % cpt;
+    for (int c0 = 0; c0 < Wt; c0 += cpt * 4) {
+        const int c = c0 + ct * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (grp < G && c < Wt)
+            for (int k = lo + grp; k < hi; k += G) a += *(const f32x4*)(dx + (size_t)order[k] * ldx + c);
+        part[threadIdx.x] = a;
+        __syncthreads();
+        if (grp == 0 && c < Wt) {
+            f32x4 t = part[ct];
+            for (int g = 1; g < G; ++g) t += part[g * cpt + ct];
+            *(f32x4*)(demb + (size_t)id * Wt + c) += t;
+        }
+        __syncthreads();
+    }
+}
 extern "C" int tvts_text_embed_bwd(const float* dx, int ldx, const int* ids, int ld_ids, int N, int L, int Wt, float* demb,
-                                   float* dpos, hipStream_t stream) {
-    hipLaunchKernelGGL(text_embed_bwd_kernel, dim3(N * L), dim3(256), 0, stream, dx, ldx, ids, ld_ids, N, L, Wt, demb, dpos);
+                                   float* dpos, const int* order, const int* seg, hipStream_t stream) {
+    if (order != nullptr && seg != nullptr && Wt % 4 == 0 && ldx % 4 == 0) {
+        hipLaunchKernelGGL(text_pos_bwd_kernel, dim3(ceil_div(Wt, 64), L), dim3(1024), 0, stream, dx, ldx, N, L, Wt, dpos);
+        hipLaunchKernelGGL(text_tok_bwd_kernel, dim3(N * L), dim3(256), 0, stream, dx, ldx, ids, ld_ids, L, Wt, order, seg, demb);
+    } else {
+        hipLaunchKernelGGL(text_embed_bwd_kernel, dim3(N * L), dim3(256), 0, stream, dx, ldx, ids, ld_ids, N, L, Wt, demb, dpos);
+    }
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

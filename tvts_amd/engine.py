@@ -381,7 +381,7 @@ class Engine:
         K.gemm_small(lnf, self.P.p("text_projection"), t, M=N, N=a["embed"], K=Wt, sa=(Wt, 1), sb=(a["embed"], 1))
         return t
 
-    def text_backward(self, dt, ids_dev, eot_rows, N, L):
+    def text_backward(self, dt, ids_dev, eot_rows, N, L, tok_sort=None):
         a = self.arch
         Wt, E, M = a["text_width"], a["embed"], N * L
         lnf = self.buf["txt.lnf"]
@@ -415,7 +415,7 @@ class Engine:
             dx, dxb = dxi, dxbi
         if self.requires_grad["text_token_embedding.weight"] or self.requires_grad["text_positional_embedding"]:
             K.text_embed_bwd(dx, ids_dev, self.P.g("text_token_embedding.weight"), self.P.g("text_positional_embedding"),
-                             N=N, L=L)
+                             N=N, L=L, tok_sort=tok_sort)
 
     # ------------------------------------------------------------------ video tower
     def _st_attention_fwd(self, qkv, att, lse, mode, B, T, n):
@@ -772,6 +772,8 @@ class Engine:
         NT = N // B
         eot_rows = (torch.arange(N) * L + eot).to(torch.int32).to(self.dev)
         ids_dev = ids_cpu[:, :L].to(torch.int32).contiguous().to(self.dev)
+        # rows sorted by token id: the token-embedding gradient is then an ordered sum per id instead of a scatter of atomics
+        tok_sort = tuple(t.to(self.dev) for t in K.token_sort(ids_cpu[:, :L]))
         if "keep_ind" not in data:
             # device-drawn tube mask: data["mask_seed"] + the global number of the batch's first sample
             # reproduce the draw whatever the batch split; the reference draws it in the dataset worker
@@ -791,7 +793,7 @@ class Engine:
         So = Sv + NT
         sort_rows = (torch.arange(B)[:, None] * So + Sv + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev)
         vid_rows = (torch.arange(B) * S).to(torch.int32).to(self.dev)
-        return dict(video=video, crop=crop, resize=resize, ids=ids_dev, eot_rows=eot_rows, eot_index=self.eot_index(eot_rows, L),
+        return dict(video=video, crop=crop, resize=resize, ids=ids_dev, tok_sort=tok_sort, eot_rows=eot_rows, eot_index=self.eot_index(eot_rows, L),
                     keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
                     sort_rows=sort_rows, sort_rows64=sort_rows.long(), vid_rows=vid_rows, vid_rows64=vid_rows.long())
 
@@ -825,7 +827,7 @@ class Engine:
         if d_text is not None:
             dt = self._f("mdl.dt", (N, E))
             K.text_mean_bwd(d_text, dt, NT=NT, B=B)
-            self.text_backward(dt, pb["ids"], pb["eot_rows"], N, L)
+            self.text_backward(dt, pb["ids"], pb["eot_rows"], N, L, tok_sort=pb.get("tok_sort"))
             self._ready("text_")
         dout = self._b("mdl.dout", (B * S, E))
         off = 1 if self.pooled_tail else 0

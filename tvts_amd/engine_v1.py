@@ -145,7 +145,7 @@ class EngineV1(Engine):
         K.gemm_small(act, P.p("txt_proj.1.weight"), t, M=N, N=E, K=Wt, sa=(Wt, 1), sb=(1, Wt), bias=P.p("txt_proj.1.bias"))
         return before, t
 
-    def text_backward_v1(self, dt, ids, kv_len, cls_rows, N, L):
+    def text_backward_v1(self, dt, ids, kv_len, cls_rows, N, L, tok_sort=None):
         a, P, B_ = self.arch, self.P, self.buf
         Wt, M, E = a["text_width"], N * L, a["embed"]
         K.gemm_small(dt, B_["txt.relu"], P.g("txt_proj.1.weight"), M=E, N=Wt, K=N, sa=(1, E), sb=(Wt, 1), accumulate=True)
@@ -170,7 +170,7 @@ class EngineV1(Engine):
         demb = self._f("txt.demb", (M, Wt))
         self._ln_bwd(dx, B_["txt.emb"], "text_model.embeddings.LayerNorm", "txt.ln_emb", demb)
         K.text_embed_bwd(demb, ids, P.g("text_model.embeddings.word_embeddings.weight"),
-                         P.g("text_model.embeddings.position_embeddings.weight"), N=N, L=L)
+                         P.g("text_model.embeddings.position_embeddings.weight"), N=N, L=L, tok_sort=tok_sort)
 
     # ------------------------------------------------------------------ tubelet ViT with joint attention
     def video_forward_v1(self, video, keep, B, tubes, cls_rows):
@@ -244,6 +244,7 @@ class EngineV1(Engine):
         S = 1 + tubes * n
         So = S + NT
         return dict(video=video, ids=ids[:, :L].to(torch.int32).contiguous().to(self.dev), kv_len=lens.to(torch.int32).to(self.dev),
+                    tok_sort=tuple(t.to(self.dev) for t in K.token_sort(ids[:, :L])),  # ordered word-embedding gradient sums
                     txt_cls_rows=(torch.arange(N) * L).to(torch.int32).to(self.dev), keep=keep, B=B, T=T, tubes=tubes, N=N, NT=NT, L=L,
                     n=n, S=S, vid_rows=(torch.arange(B) * S).to(torch.int32).to(self.dev),
                     sort_rows=(torch.arange(B)[:, None] * So + S + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev),
@@ -271,7 +272,7 @@ class EngineV1(Engine):
         if d_text is not None:
             dt = self._f("mdl.dt", (N, E))
             K.text_mean_bwd(d_text, dt, NT=NT, B=B)
-            self.text_backward_v1(dt, pb["ids"], pb["kv_len"], pb["txt_cls_rows"], N, L)
+            self.text_backward_v1(dt, pb["ids"], pb["kv_len"], pb["txt_cls_rows"], N, L, tok_sort=pb.get("tok_sort"))
             self._ready("text_model.")
             self._ready("txt_proj.")
         # vid_proj on the CLS token: dW += d_video^T cls, db += colsum, d_cls = d_video W

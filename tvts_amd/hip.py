@@ -517,7 +517,8 @@ def vit_assemble_bwd(dtok, keep, dpatch, dcls, dpos, dtemporal, *, B, T, n):
     lib = _lib.load()
     ws = _tn_workspace(dtok.device)  # ordered partials of the temporal / class embedding sums (shared fp32 scratch of this stream)
     _chk(lib.tvts_vit_assemble_bwd(_p(dtok), _ld(dtok), _p(keep), 1 if keep.dim() == 3 else 0, B, T, n, dtok.shape[1],
-                                   _p(dpatch), _ld(dpatch), _p(dcls), _p(dpos), _p(dtemporal), _p(ws), ws.numel(), _stream()),
+                                   _p(dpatch), _ld(dpatch), _p(dcls), _p(dpos), dpos.shape[0] - 1, _p(dtemporal), _p(ws), ws.numel(),
+                                   _stream()),
          "tvts_vit_assemble_bwd")
 
 
@@ -536,10 +537,27 @@ def text_embed(ids, emb, pos, x, *, N, L):
          "tvts_text_embed")
 
 
-def text_embed_bwd(dx, ids, demb, dpos, *, N, L):
+def token_sort(ids_cpu):
+    """(order, seg) of tvts_text_embed_bwd for the [N, L] token ids of a batch (host tensors in, int32 host tensors out): the rows
+    sorted by token id, ties in row order, and the starts of the runs of equal ids padded to N * L + 1 entries."""
+    flat = ids_cpu.reshape(-1).to(torch.int64)
+    n = flat.numel()
+    order = torch.argsort(flat, stable=True)
+    srt = flat[order]
+    starts = torch.nonzero(torch.cat([torch.ones(1, dtype=torch.bool), srt[1:] != srt[:-1]])).reshape(-1)
+    seg = torch.full((n + 1,), n, dtype=torch.int32)
+    seg[:starts.numel()] = starts.to(torch.int32)
+    return order.to(torch.int32), seg
+
+
+def text_embed_bwd(dx, ids, demb, dpos, *, N, L, tok_sort=None):
+    """tok_sort = (order, seg) device tensors of token_sort(): ordered sums; None: fp32 atomics."""
     lib = _lib.load()
+    order, seg = tok_sort if tok_sort is not None else (None, None)
+    if order is not None:
+        assert order.dtype == torch.int32 and seg.dtype == torch.int32 and order.numel() == N * L and seg.numel() == N * L + 1
     _chk(lib.tvts_text_embed_bwd(_p(dx), _ld(dx), _p(ids), ids.stride(0), N, L, dx.shape[1], _p(demb), _p(dpos),
-                                 _stream()), "tvts_text_embed_bwd")
+                                 _p(order), _p(seg), _stream()), "tvts_text_embed_bwd")
 
 
 def text_mean(t, mean, before, *, NT, B):
