@@ -299,16 +299,17 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
     }
 }
 
-// dpos[1 + r] += sum over the clips b, in clip order, of the slot sums part_p[b][i] with keep[b][i] == r: a block per row r of the
-// positional embedding; a thread first looks up "its" clip's slot (256 clips at a time; a tube mask holds a position at most
-// once, further matches of a malformed one are added too), then owns four columns
+// dpos[1 + r] += sum over the clips b of the slot sums part_p[b][i] with keep[b][i] == r, in a fixed order: a block per (row r of the
+// positional embedding, 256 columns).  Its threads first look up "their" clip's slot (256 clips at a time; a tube mask holds a
+// position at most once, further matches of a malformed one are added too); then 4 thread groups take every 4th clip, a thread
+// four columns, and the groups are combined in group order.
 __global__ __launch_bounds__(256) void pos_rows_from_partials_kernel(const float* __restrict__ part_p, const int* __restrict__ keep,
                                                                      int B, int n, int W, float* __restrict__ dpos) {
     __shared__ int first[256], more[256];
+    __shared__ f32x4 comb[256];
     const int r = blockIdx.x, tid = threadIdx.x;
-    f32x4 acc[4];  // columns tid * 4 + 1024 * q (W <= 4096: checked by the entry point)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int grp = tid >> 6, c = blockIdx.y * 256 + (tid & 63) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int b0 = 0; b0 < B; b0 += 256) {
         int f = -1, cnt = 0;
         if (b0 + tid < B) {
@@ -319,33 +320,25 @@ __global__ __launch_bounds__(256) void pos_rows_from_partials_kernel(const float
         first[tid] = f; more[tid] = cnt > 1;
         __syncthreads();
         const int nb = B - b0 < 256 ? B - b0 : 256;
-        for (int k = 0; k < nb; ++k) {
-            const int fi = first[k];
-            if (fi < 0) continue;
-            const float* src = part_p + ((size_t)(b0 + k) * n + fi) * W;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = tid * 4 + 1024 * q;
-                if (c < W) acc[q] += *(const f32x4*)(src + c);
-            }
-            if (more[k]) {
-                const int* kp = keep + (size_t)(b0 + k) * n;
-                for (int i = fi + 1; i < n; ++i) {
-                    if (kp[i] != r) continue;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = tid * 4 + 1024 * q;
-                        if (c < W) acc[q] += *(const f32x4*)(part_p + ((size_t)(b0 + k) * n + i) * W + c);
-                    }
+        if (c < W) {
+            for (int k = grp; k < nb; k += 4) {
+                const int fi = first[k];
+                if (fi < 0) continue;
+                acc += *(const f32x4*)(part_p + ((size_t)(b0 + k) * n + fi) * W + c);
+                if (more[k]) {
+                    const int* kp = keep + (size_t)(b0 + k) * n;
+                    for (int i = fi + 1; i < n; ++i)
+                        if (kp[i] == r) acc += *(const f32x4*)(part_p + ((size_t)(b0 + k) * n + i) * W + c);
                 }
             }
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c = tid * 4 + 1024 * q;
-        if (c < W) *(f32x4*)(dpos + (size_t)(1 + r) * W + c) += acc[q];
+    comb[tid] = acc;
+    __syncthreads();
+    if (grp == 0 && c < W) {
+        const f32x4 t = ((comb[tid] + comb[64 + tid]) + comb[128 + tid]) + comb[192 + tid];
+        *(f32x4*)(dpos + (size_t)(1 + r) * W + c) += t;
     }
 }
 
@@ -357,11 +350,11 @@ extern "C" int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep
         const long need = (long)B * groups * T * W + (long)B * W;
         float* part_t = (workspace && workspace_elems >= need) ? workspace : nullptr;
         float* part_c = part_t ? workspace + (size_t)B * groups * T * W : nullptr;
-        float* part_p = (part_t && n_pos > 0 && W <= 4096 && workspace_elems >= need + (long)B * n * W) ? workspace + need : nullptr;
+        float* part_p = (part_t && n_pos > 0 && workspace_elems >= need + (long)B * n * W) ? workspace + need : nullptr;
         hipLaunchKernelGGL(vit_assemble_bwd_tube_kernel, dim3(B * groups), dim3(256), 0, stream, dtok, ldt, keep, B, T, n, W,
                            (bf16*)dpatch, ldp, dcls, dpos, dtemporal, part_t, part_c, part_p);
         if (part_p)
-            hipLaunchKernelGGL(pos_rows_from_partials_kernel, dim3(n_pos), dim3(256), 0, stream, part_p, keep, B, n, W, dpos);
+            hipLaunchKernelGGL(pos_rows_from_partials_kernel, dim3(n_pos, ceil_div(W, 256)), dim3(256), 0, stream, part_p, keep, B, n, W, dpos);
         if (part_t) {
             hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div(T * W, 64)), dim3(1024), 0, stream, part_t, B * groups, T * W,
                                dtemporal, (float*)nullptr);
@@ -441,8 +434,19 @@ __global__ __launch_bounds__(256) void text_tok_bwd_kernel(const float* __restri
     for (int c0 = 0; c0 < Wt; c0 += cpt * 4) {
         const int c = c0 + ct * 4;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        if (grp < G && c < Wt)
-            for (int k = lo + grp; k < hi; k += G) a += *(const f32x4*)(dx + (size_t)order[k] * ldx + c);
+        if (grp < G && c < Wt) {
+            // eight rows in flight (the two id runs every caption shares -- start and end token -- are N rows long); added in row order
+            for (int k = lo + grp; k < hi; k += 8 * G) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = k + u * G;
+                    v[u] = kk < hi ? *(const f32x4*)(dx + (size_t)order[kk] * ldx + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u];
+            }
+        }
         part[threadIdx.x] = a;
         __syncthreads();
         if (grp == 0 && c < Wt) {
