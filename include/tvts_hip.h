@@ -258,7 +258,8 @@ int tvts_vit_assemble(const float* patch, int ldp, const float* cls, const float
 /* workspace (optional, fp32 scratch): with >= B * ceil(n / 14) * T * W + B * W elements (tube masks) the temporal-embedding and
  * class-embedding sums are ordered per-block partials; with B * n * W more and n_pos > 0 (the rows of dpos behind the class row:
  * the patches per frame) the positional-embedding rows are gathered in clip order too -- every sum run-to-run reproducible.
- * Without the room (or n_pos = 0, or one keep list per frame) they are a scatter of fp32 atomics. */
+ * One keep list per frame / tubelet (v1): B * T * W + B * W + B * T * n * W elements for the same.  Without the room (or
+ * n_pos = 0) they are a scatter of fp32 atomics. */
 int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep, int keep_per_frame, int B, int T, int n, int W,
                           void* dpatch, int ldp, float* dcls, float* dpos, int n_pos, float* dtemporal, float* workspace,
                           long workspace_elems, hipStream_t stream);

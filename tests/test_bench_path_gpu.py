@@ -299,6 +299,59 @@ def test_full_size_step_properties(K, lib):
     assert stats["g"] < 1e-2 and abs(stats["gn"]) < 1e-3, stats
 
 
+@pytest.mark.parametrize("arch_name,B,T,flags", [("B_16", 48, 8, ()), ("B_32", 48, 8, ()), ("H_14", 8, 16, ()), ("H_14", 8, 16, ("fp8", "fp8_dgrad")),
+                                                 ("B_16", 48, 8, ("bf16_residual",)), ("v1", 48, 4, ())])
+def test_every_gradient_is_bit_reproducible(K, lib, arch_name, B, T, flags):
+    """Two identical steps (the training step's parameter groups, v1 with its dropout masks pinned) leave the same bits in EVERY
+    parameter gradient and both losses: all reductions of the step are ordered sums -- none is a scatter of fp32 atomics whose
+    last-bit noise could, through Adam, flip a bf16 rounding of the next forward (tools/dbg/bench_repro.py runs
+    the same check at the bench's sizes)."""
+    from tvts_amd import arch as A
+    from tvts_amd.data_loader import synth_batch, synth_batch_v1
+    from tvts_amd.model._common import TVTSv2Base
+    from tvts_amd.model.model_dist_TVTS import TVTS
+    a = dict(A.ARCHS[arch_name])
+    a["num_frames"] = max(a["num_frames"], T)
+    for f in flags:
+        a[f] = True
+    v1 = a.get("family") == "v1"
+    m = (TVTS if v1 else TVTSv2Base)(ARGS, arch=a, init_seed=0)
+    for name, p in m.named_parameters():
+        p.requires_grad = A.param_group_of(name, a) >= 0
+    _, _, run = _runner_of(m, a)
+    eng = m.engine
+    if hasattr(eng, "training"):
+        eng.training = True
+    batch = (synth_batch_v1 if v1 else synth_batch)(a, B, T, seed=5, caption_len=32)
+    m._fresh_shadows(); m._sync_requires_grad()
+    pb = eng.prepare_batch(batch)
+    lab = batch["label"].reshape(-1).to(torch.int32).to(DEV)
+    seed0 = eng.drop_seed.clone() if hasattr(eng, "drop_seed") else None
+
+    def grads():
+        if seed0 is not None:
+            eng.drop_seed.copy_(seed0)
+        m.store.grad.zero_()
+        eng.embeds_ready = run.gather.start
+        try:
+            te, ve, pred = eng.forward(pb)
+        finally:
+            eng.embeds_ready = None
+        l1, l2, dte, dve, dpred = run.losses_and_grads(pb, te, ve, pred, lab)
+        eng.backward(dte, dve, dpred)
+        torch.cuda.synchronize()
+        return m.store.grad.clone(), float(l1), float(l2)
+
+    g0, l1, l2 = grads()
+    assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    for _ in range(2):
+        g1, l1b, l2b = grads()
+        if not torch.equal(g0, g1):
+            diff = (g0 - g1).abs()
+            raise AssertionError(f"gradients differ between identical steps: max |d| {float(diff.max()):.3e} in {int((diff > 0).sum())} elements")
+        assert (l1, l2) == (l1b, l2b)
+
+
 # ------------------------------------------------------------------------------------------------ (c) hipGraph replay
 def _runner(a, P, lr_mul=1.0):
     from tvts_amd import arch as A
@@ -316,6 +369,20 @@ def _runner(a, P, lr_mul=1.0):
             groups[gi].append(p)
     opt = FusedHFAdamW([dict(params=groups[i], lr=A.GROUP_HPARAMS[i][0] * lr_mul, weight_decay=A.GROUP_HPARAMS[i][1])
                         for i in range(4)], m.store, model=m)
+    return m, opt, StepRunner(m, opt)
+
+
+def _runner_of(m, a):
+    from tvts_amd import arch as A
+    from tvts_amd.optim import FusedHFAdamW
+    from tvts_amd.step import StepRunner
+    hp = ((1e-4, 0.0),) * 4 if a.get("family") == "v1" else A.GROUP_HPARAMS
+    groups = [[], [], [], []]
+    for name, p in m.named_parameters():
+        gi = A.param_group_of(name, a)
+        if gi >= 0:
+            groups[gi].append(p)
+    opt = FusedHFAdamW([dict(params=groups[i], lr=hp[i][0], weight_decay=hp[i][1]) for i in range(4) if groups[i]], m.store, model=m)
     return m, opt, StepRunner(m, opt)
 
 

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Which parameter gradients differ between two identical steps of a bench configuration (param groups as in training; dev tool, GPU).
+   python tools/dbg/bench_repro.py ARCH PAIRS FRAMES [fp8|fp8-dgrad|bf16-residual ...]"""
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from tvts_amd import arch as A  # noqa: E402
+from tvts_amd.data_loader import synth_batch, synth_batch_v1  # noqa: E402
+from tvts_amd.model._common import TVTSv2Base  # noqa: E402
+from tvts_amd.model.model_dist_TVTS import TVTS  # noqa: E402
+from tvts_amd.optim import FusedHFAdamW  # noqa: E402
+from tvts_amd.step import StepRunner  # noqa: E402
+
+arch_name, B, T = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+flags = set(sys.argv[4:])
+a = dict(A.ARCHS[arch_name])
+a["num_frames"] = max(a["num_frames"], T)
+if "fp8-dgrad" in flags:
+    a["fp8"] = a["fp8_dgrad"] = True
+if "fp8" in flags:
+    a["fp8"] = True
+if "bf16-residual" in flags:
+    a["bf16_residual"] = True
+v1 = a.get("family") == "v1"
+margs = types.SimpleNamespace(local_rank=0, rank=0, world_size=1)
+m = (TVTS if v1 else TVTSv2Base)(margs, arch=a, init_seed=0)
+hp = ((1e-4, 0.0),) * 4 if v1 else A.GROUP_HPARAMS
+groups = [[], [], [], []]
+for name, p in m.named_parameters():
+    gi = A.param_group_of(name, a)
+    if gi < 0:
+        p.requires_grad = False
+    else:
+        groups[gi].append(p)
+opt = FusedHFAdamW([dict(params=groups[i], lr=hp[i][0], weight_decay=hp[i][1]) for i in range(4) if groups[i]], m.store, model=m)
+run = StepRunner(m, opt)
+if hasattr(m.engine, "training"):
+    m.engine.training = True
+batch = (synth_batch_v1 if v1 else synth_batch)(a, B, T, seed=5, caption_len=32)
+m._fresh_shadows(); m._sync_requires_grad()
+pb = m.engine.prepare_batch(batch)
+lab = batch["label"].reshape(-1).to(torch.int32).to(m.store.device) if "label" in batch else None
+eng = m.engine
+seed0 = eng.drop_seed.clone() if hasattr(eng, "drop_seed") else None
+
+
+def grads():
+    if seed0 is not None:
+        eng.drop_seed.copy_(seed0)  # the same dropout masks in every run
+    m.store.grad.zero_()
+    eng.embeds_ready = run.gather.start
+    try:
+        te, ve, pred = eng.forward(pb)
+    finally:
+        eng.embeds_ready = None
+    l1, l2, dte, dve, dpred = run.losses_and_grads(pb, te, ve, pred, lab)
+    eng.backward(dte, dve, dpred)
+    torch.cuda.synchronize()
+    return {n: m.store.g(n).clone() for n, p in m.named_parameters() if p.requires_grad}, float(l1), (None if l2 is None else float(l2))
+
+
+g0, l1, l2 = grads()
+print(arch_name, B, T, sorted(flags), "losses", l1, l2)
+for r in range(3):
+    g1, l1b, l2b = grads()
+    bad = [(n, float((g0[n] - g1[n]).abs().max()), float(g0[n].abs().max())) for n in g0 if not torch.equal(g0[n], g1[n])]
+    print(f"run {r}: {len(bad)} of {len(g0)} gradients differ; losses equal: {(l1, l2) == (l1b, l2b)}")
+    for n, d, s in bad[:12]:
+        print(f"   {n:60s} max |d| {d:.3e}  (max |g| {s:.3e})")

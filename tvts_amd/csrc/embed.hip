@@ -195,7 +195,11 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __re
                                                                const int* __restrict__ keep, int keep_per_frame, int B, int T,
                                                                int n, int W, bf16* __restrict__ dpatch, int ldp,
                                                                float* __restrict__ dcls,
-                                                               float* __restrict__ dpos, float* __restrict__ dtemporal) {
+                                                               float* __restrict__ dpos, float* __restrict__ dtemporal,
+                                                               float* __restrict__ part_t, float* __restrict__ part_c,
+                                                               float* __restrict__ part_p) {
+    // part_t [B][T][W] / part_c [B][W] / part_p [B * T][n][W] (optional, all or none): the block's sums and its slot values go to
+    // partials that colsum_partials_kernel / pos_rows_from_partials_kernel add in a fixed order, instead of fp32 atomics
     const int S = 1 + T * n;
     const int b = blockIdx.x / T, f = blockIdx.x % T;
     for (int c = threadIdx.x; c < W; c += 256) {
@@ -203,14 +207,16 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __re
         for (int i = 0; i < n; ++i) {
             const float v = dtok[(size_t)(b * S + 1 + f * n + i) * ldt + c];
             dpatch[(size_t)((b * T + f) * n + i) * ldp + c] = (bf16)v;
-            atomicAdd(dpos + (size_t)(1 + keep[keep_per_frame ? (b * T + f) * n + i : b * n + i]) * W + c, v);
+            if (part_p) part_p[((size_t)(b * T + f) * n + i) * W + c] = v;
+            else atomicAdd(dpos + (size_t)(1 + keep[keep_per_frame ? (b * T + f) * n + i : b * n + i]) * W + c, v);
             ts += v;
         }
-        atomicAdd(dtemporal + (size_t)f * W + c, ts);
+        if (part_t) part_t[((size_t)b * T + f) * W + c] = ts;
+        else atomicAdd(dtemporal + (size_t)f * W + c, ts);
         if (f == 0) {
             const float v0 = dtok[(size_t)(b * S) * ldt + c];
-            atomicAdd(dcls + c, v0);
-            atomicAdd(dpos + c, v0);
+            if (part_c) part_c[(size_t)b * W + c] = v0;
+            else { atomicAdd(dcls + c, v0); atomicAdd(dpos + c, v0); }
         }
     }
 }
@@ -363,8 +369,22 @@ extern "C" int tvts_vit_assemble_bwd(const float* dtok, int ldt, const int* keep
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }
-    hipLaunchKernelGGL(vit_assemble_bwd_kernel, dim3(B * T), dim3(256), 0, stream, dtok, ldt, keep, keep_per_frame, B, T, n, W,
-                       (bf16*)dpatch, ldp, dcls, dpos, dtemporal);
+    {   // one keep list per frame / tubelet (v1), or shapes the tube kernel does not take
+        const long need = (long)B * T * W + (long)B * W + (long)B * T * n * W;
+        const bool ordered = workspace && workspace_elems >= need && n_pos > 0 && keep_per_frame && W % 4 == 0;
+        float* part_t = ordered ? workspace : nullptr;
+        float* part_c = ordered ? part_t + (size_t)B * T * W : nullptr;
+        float* part_p = ordered ? part_c + (size_t)B * W : nullptr;
+        hipLaunchKernelGGL(vit_assemble_bwd_kernel, dim3(B * T), dim3(256), 0, stream, dtok, ldt, keep, keep_per_frame, B, T, n, W,
+                           (bf16*)dpatch, ldp, dcls, dpos, dtemporal, part_t, part_c, part_p);
+        if (ordered) {
+            // the (clip, frame) pairs are the gather's "clips": keep[B * T][n], slot values [B * T][n][W]
+            hipLaunchKernelGGL(pos_rows_from_partials_kernel, dim3(n_pos, ceil_div(W, 256)), dim3(256), 0, stream, part_p, keep, B * T, n, W, dpos);
+            hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div(T * W, 64)), dim3(1024), 0, stream, part_t, B, T * W,
+                               dtemporal, (float*)nullptr);
+            hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div(W, 64)), dim3(1024), 0, stream, part_c, B, W, dcls, dpos);
+        }
+    }
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
