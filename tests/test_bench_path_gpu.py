@@ -232,33 +232,41 @@ def _step_against_oracle(lib, arch_name, B, T, big_tile):
 
 
 def _sub_batch(batch, idx, NT):
-    """the samples `idx` of a clip-major batch dict (text rows are i * B + b)"""
+    """the samples `idx` of a clip-major batch dict (text rows are i * B + b; v1: the tokenizer's dict of such matrices)"""
     B = batch["video"].shape[0]
+    rows = lambda t: t.reshape(NT, B, -1)[:, idx].reshape(NT * len(idx), -1)  # noqa: E731
     out = {"video": batch["video"][idx], "keep_ind": batch["keep_ind"][idx],
-           "text": batch["text"].reshape(NT, B, -1)[:, idx].reshape(NT * len(idx), -1)}
+           "text": {k: rows(v) for k, v in batch["text"].items()} if isinstance(batch["text"], dict) else rows(batch["text"])}
     if "label" in batch:
         out["label"] = batch["label"][idx]
     return out
 
 
-def test_full_size_step_properties(K, lib):
-    """The workload bench.py times -- ViT-B/16, 8 frames, mask 0.5, 4 x 32-token captions, 192 pairs (BASELINE.json's metric
-    configuration; M = 150 720 token rows) -- is out of the CPU oracle's reach, so the full-size step is tied to the oracle-checked
-    24-pair step (test_b16_step_at_bench_dispatch_against_oracle, same kernels and dispatch) by properties that do not depend on the
-    size: (1) run twice it gives the same bits; (2) a sample's embeddings and sort logits do not depend on the other samples of the
-    batch: the first 24 samples run alone give the rows the full batch gives (different tile counts and kernels for the text tower:
-    equal to bf16 rounding, not bit for bit); (3) rotating the batch rotates the embeddings, leaves both losses where they were and
-    the parameter gradient too -- up to bf16 rounding noise (see the assertion)."""
+@pytest.mark.parametrize("arch_name,B,T,nsub", [("B_16", 192, 8, 24), ("B_32", 384, 8, 24), ("H_14", 48, 16, 4), ("v1", 256, 4, 16)])
+def test_full_size_step_properties(K, lib, arch_name, B, T, nsub):
+    """The workloads bench.py times -- the headline ViT-B/16, 8 frames, mask 0.5, 4 x 32-token captions, 192 pairs (BASELINE.json's
+    metric configuration; M = 150 720 token rows), configs[1] (B/32, 384 pairs), H/14 with 16 frames and the v1 step (dropout off:
+    its masks are drawn per element of the batch) -- are out of the CPU oracle's reach, so the full-size step is tied to the
+    oracle-checked sizes (test_b16_step_at_bench_dispatch_against_oracle: 24 pairs, same kernels and dispatch; tests/test_model_gpu.py,
+    tests/test_v1_gpu.py) by properties that do not depend on the size: (1) run twice it gives the same bits; (2) a sample's embeddings and sort logits do not depend on the other samples of the
+    batch: the first `nsub` samples run alone give the rows the full batch gives (different tile counts and kernels for the text
+    tower: equal to bf16 rounding, not bit for bit); (3) rotating the batch rotates the embeddings, leaves both losses where they were
+    and the parameter gradient too -- up to bf16 rounding noise (see the assertion)."""
     from tvts_amd import arch as A
+    from tvts_amd.data_loader import synth_batch, synth_batch_v1
     from tvts_amd.engine import LossHead
     from tvts_amd.model._common import TVTSv2Base
-    a, oarch, B, T = A.ARCHS["B_16"], O.ARCHS["B_16"], 192, 8
-    NT = oarch["n_trans"]
-    m = TVTSv2Base(ARGS, arch=a)
-    m.load_state_dict(O.synth_params(oarch, seed=11), strict=True)
+    from tvts_amd.model.model_dist_TVTS import TVTS
+    a = dict(A.ARCHS[arch_name])
+    a["num_frames"] = max(a["num_frames"], T)
+    v1 = a.get("family") == "v1"
+    NT = a["n_trans"]
+    m = (TVTS if v1 else TVTSv2Base)(ARGS, arch=a, init_seed=0)
     m._fresh_shadows(); m._sync_requires_grad()
+    if v1:
+        m.engine.training = False
     head = LossHead(m.store.device)
-    batch = O.synth_batch(oarch, B=B, T=T, seed=31, caption_len=32)
+    batch = (synth_batch_v1 if v1 else synth_batch)(a, B, T, seed=31, caption_len=32)
 
     def run(bt):
         pb = m.engine.prepare_batch(bt)
@@ -277,10 +285,10 @@ def test_full_size_step_properties(K, lib):
     assert torch.equal(te, te2) and torch.equal(ve, ve2) and torch.equal(pred, pred2) and (l1, l2) == (l1b, l2b) and torch.equal(g, g2)
     del te2, ve2, pred2, g2
     # (2) the oracle-checked size is a sub-batch of this one
-    idx = torch.arange(24)
+    idx = torch.arange(nsub)
     tes, ves, preds, _, _, _ = run(_sub_batch(batch, idx, NT))
-    for full, sub in ((te[:24], tes), (ve[:24], ves), (pred[:24], preds)):
-        assert min_cos(full, sub) > 0.99999 and rel(full, sub) < 2e-3, (min_cos(full, sub), rel(full, sub))
+    for full, sub in ((te[:nsub], tes), (ve[:nsub], ves), (pred[:nsub], preds)):
+        assert min_cos(full, sub) > 0.9999 and rel(full, sub) < 6e-3, (min_cos(full, sub), rel(full, sub))
     # (3) rotation of the batch
     perm = torch.roll(torch.arange(B), 37)
     tep, vep, predp, l1p, l2p, gp = run(_sub_batch(batch, perm, NT))
@@ -288,15 +296,15 @@ def test_full_size_step_properties(K, lib):
     gn, gnp = float(g.double().norm()), float(gp.double().norm())
     stats = dict(te=rel(tep, te[permd]), ve=rel(vep, ve[permd]), pred=rel(predp, pred[permd]), dl1=l1p - l1, dl2=l2p - l2,
                  g=rel(gp, g), gn=(gnp - gn) / gn)
-    print("rotation:", stats)
+    print("rotation:", arch_name, stats)
     # (not bit for bit: a GEMM row's fp32 summation order depends on its place in the 256-row tile -- the bias joins the accumulators
     # before the last k-step of one half of the wave tile -- and a last-bit difference flips bf16 roundings downstream)
-    # measured: te 1.0e-3, ve 3.0e-3, pred 1.9e-3, losses 2e-4 / 5e-5, gradient 3.0e-3, its norm 1e-4 (the step's distance from the
-    # fp32 oracle is 4-5e-3 on the embeddings: the same bf16 rounding noise)
-    assert stats["te"] < 6e-3 and stats["ve"] < 6e-3 and stats["pred"] < 6e-3, stats
+    # measured on B/16: te 1.0e-3, ve 3.0e-3, pred 1.9e-3, losses 2e-4 / 5e-5, gradient 3.0e-3, its norm 1e-4 (the step's distance
+    # from the fp32 oracle is 4-5e-3 on the embeddings: the same bf16 rounding noise)
+    assert stats["te"] < 6e-3 and stats["ve"] < 6e-3 and stats["pred"] < 1e-2, stats
     assert min_cos(tep, te[permd]) > 0.9999 and min_cos(vep, ve[permd]) > 0.9999
-    assert abs(stats["dl1"]) < 1e-3 and abs(stats["dl2"]) < 1e-3, stats
-    assert stats["g"] < 1e-2 and abs(stats["gn"]) < 1e-3, stats
+    assert abs(stats["dl1"]) < 2e-3 and abs(stats["dl2"]) < 2e-3, stats
+    assert stats["g"] < 2e-2 and abs(stats["gn"]) < 2e-3, stats
 
 
 @pytest.mark.parametrize("arch_name,B,T,flags", [("B_16", 48, 8, ()), ("B_32", 48, 8, ()), ("H_14", 8, 16, ()), ("H_14", 8, 16, ("fp8", "fp8_dgrad")),
