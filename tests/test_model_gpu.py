@@ -98,6 +98,59 @@ def test_small_arch_forward_backward(gpu):
     check_grads(store, grads)
 
 
+def test_captions_of_different_lengths(gpu):
+    """What clip.tokenize hands the step (trainer.py:465-475): captions of different lengths in one batch, zero-padded behind their
+    end token.  The engine trims the context to the longest caption of the batch and reads every caption at ITS end token
+    (argmax of the ids, CLIP/clip/model.py:354); the padded rows behind it can, by causality, neither reach the embedding nor
+    receive a gradient (token 0's embedding row and the positions behind the shortest caption get exactly what the oracle gives)."""
+    from tvts_amd import arch as A
+    m, oarch, P = build(arch=A.small_arch(), seed=13)
+    batch = O.synth_batch(oarch, B=6, T=3, seed=15, caption_len=12)
+    eot = oarch["vocab"] - 1
+    g = torch.Generator().manual_seed(16)
+    lens = torch.randint(3, 13, (batch["text"].shape[0],), generator=g)
+    lens[0], lens[1] = 12, 3  # the longest and the shortest possible
+    for r, n in enumerate(lens.tolist()):
+        batch["text"][r, n - 1] = eot
+        batch["text"][r, n:] = 0
+    assert (batch["text"].argmax(-1) == lens - 1).all()
+    r1, r2, rte, rve, rpred, grads = oracle_step(P, batch, oarch)
+    l1, l2, te, ve, pred, store = engine_step(m, batch)
+    assert min_cos(te, rte) > 0.9995 and rel(te, rte) < 0.02, (min_cos(te, rte), rel(te, rte))
+    assert min_cos(ve, rve) > 0.9995 and rel(ve, rve) < 0.02
+    assert abs(l1 - r1) < 1e-2 and abs(l2 - r2) < 1e-2, (l1, r1, l2, r2)
+    check_grads(store, grads)
+    demb, rdemb = store.g("text_token_embedding.weight").cpu(), grads["text_token_embedding.weight"]
+    assert float(rdemb[0].abs().max()) == 0.0 and float(demb[0].abs().max()) == 0.0  # the padding token learns nothing
+    dpos, rdpos = store.g("text_positional_embedding").cpu(), grads["text_positional_embedding"]
+    assert float(dpos[12:].abs().max()) == 0.0 and rel(dpos[:12], rdpos[:12]) < 0.05
+
+
+def test_full_context_captions_and_a_batch_of_one(gpu):
+    """The two ends of the input contract on the real ViT-B/16: captions that fill CLIP's whole context (77 tokens, end token in the
+    last column: the text tower's attention runs on 77-token sequences instead of the 32-token fused path) mixed with short ones,
+    and a batch of ONE pair (the similarity matrix is 1 x 1, the contrastive loss zero, the sorting loss still trains)."""
+    m, oarch, P = build("B_16", seed=23)
+    batch = O.synth_batch(oarch, B=2, T=2, seed=24, caption_len=77)
+    assert int(batch["text"].argmax(-1).min()) == 76
+    eot = oarch["vocab"] - 1
+    for r, n in ((1, 5), (4, 33), (6, 40)):
+        batch["text"][r, n - 1] = eot
+        batch["text"][r, n:] = 0
+    r1, r2, rte, rve, rpred, grads = oracle_step(P, batch, oarch)
+    l1, l2, te, ve, pred, store = engine_step(m, batch)
+    assert min_cos(te, rte) > 0.9995 and rel(te, rte) < 0.02, (min_cos(te, rte), rel(te, rte))
+    assert min_cos(ve, rve) > 0.9995 and rel(ve, rve) < 0.02
+    assert abs(l1 - r1) < 1e-2 and abs(l2 - r2) < 1e-2, (l1, r1, l2, r2)
+    check_grads(store, grads)
+    one = {k: (v[:1] if k != "text" else v.reshape(oarch["n_trans"], 2, -1)[:, :1].reshape(oarch["n_trans"], -1)) for k, v in batch.items()}
+    r1, r2, rte, rve, rpred, grads = oracle_step(P, one, oarch)
+    l1, l2, te, ve, pred, store = engine_step(m, one)
+    assert abs(r1) < 1e-6 and abs(l1) < 1e-6 and abs(l2 - r2) < 1e-2, (l1, r1, l2, r2)
+    assert min_cos(te, rte) > 0.9995 and min_cos(ve, rve) > 0.9995
+    check_grads(store, grads)
+
+
 def test_small_arch_webvid_batch(gpu):
     """NT = 1: no sorting head, pred None, pred_model receives no gradient (trainer.py:494)."""
     from tvts_amd import arch as A
