@@ -151,6 +151,25 @@ def test_full_context_captions_and_a_batch_of_one(gpu):
     check_grads(store, grads)
 
 
+@pytest.mark.parametrize("T", [1, "max"])
+def test_one_frame_and_the_whole_temporal_table(gpu, T):
+    """clips of ONE frame (the time attention sees the frame's own token and the class token only) and of as many frames as the
+    temporal embedding has rows (num_frames, video_encoder_ViT_B_16.py:190-203)"""
+    from tvts_amd import arch as A
+    a = A.small_arch()
+    T = a["num_frames"] if T == "max" else T
+    m, oarch, P = build(arch=a, seed=31)
+    batch = O.synth_batch(oarch, B=3, T=T, seed=32, caption_len=10)
+    r1, r2, rte, rve, rpred, grads = oracle_step(P, batch, oarch)
+    l1, l2, te, ve, pred, store = engine_step(m, batch)
+    assert min_cos(ve, rve) > 0.9995 and rel(ve, rve) < 0.02, (min_cos(ve, rve), rel(ve, rve))
+    assert rel(pred.view_as(rpred), rpred) < 0.03
+    assert abs(l1 - r1) < 1e-2 and abs(l2 - r2) < 1e-2, (l1, r1, l2, r2)
+    check_grads(store, grads)
+    dt, rdt = store.g("video_model.temporal_embedding").cpu(), grads["video_model.temporal_embedding"]
+    assert float(dt[T:].abs().max() if T < dt.shape[0] else 0.0) == 0.0 and rel(dt[:T], rdt[:T]) < 0.05
+
+
 def test_small_arch_webvid_batch(gpu):
     """NT = 1: no sorting head, pred None, pred_model receives no gradient (trainer.py:494)."""
     from tvts_amd import arch as A
