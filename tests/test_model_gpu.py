@@ -170,6 +170,34 @@ def test_one_frame_and_the_whole_temporal_table(gpu, T):
     assert float(dt[T:].abs().max() if T < dt.shape[0] else 0.0) == 0.0 and rel(dt[:T], rdt[:T]) < 0.05
 
 
+def test_malformed_batches_fail_loudly(gpu):
+    """what the reference answers with an indexing / broadcasting error must not become a read or write past a table"""
+    from tvts_amd import arch as A
+    a = A.small_arch()
+    m, oarch, P = build(arch=a, seed=41)
+    good = O.synth_batch(oarch, B=2, T=2, seed=42, caption_len=8)
+    m.engine.prepare_batch(good)
+
+    def bad(**kw):
+        b = {k: v.clone() for k, v in good.items()}
+        b.update(kw)
+        return b
+    ppf = (a["image"] // a["patch"]) ** 2
+    k = good["keep_ind"].clone(); k[0, 0] = ppf
+    with pytest.raises(IndexError):
+        m.engine.prepare_batch(bad(keep_ind=k))
+    with pytest.raises(ValueError):
+        m.engine.prepare_batch(bad(keep_ind=good["keep_ind"][:1].repeat(3, 1)))
+    t = good["text"].clone(); t[0, 1] = a["vocab"]
+    with pytest.raises(IndexError):
+        m.engine.prepare_batch(bad(text=t))
+    with pytest.raises(ValueError):
+        m.engine.prepare_batch(bad(text=good["text"][:-1]))
+    long_clip = O.synth_batch(oarch, B=2, T=a["num_frames"] + 1, seed=43, caption_len=8)
+    with pytest.raises(ValueError):
+        m.engine.prepare_batch(long_clip)
+
+
 def test_small_arch_webvid_batch(gpu):
     """NT = 1: no sorting head, pred None, pred_model receives no gradient (trainer.py:494)."""
     from tvts_amd import arch as A

@@ -764,8 +764,16 @@ class Engine:
                 video = video.unsqueeze(1)
             video = video.to(self.dev, torch.float32).contiguous()
         B, T = video.shape[:2]
+        # the reference fails on these with an indexing / broadcasting error (temporal_embedding[:T], nn.Embedding, pos[keep_ind]); the
+        # kernels would read or write past the tables instead, so the batch is checked where it enters
+        if T > a["num_frames"]:
+            raise ValueError(f"clips of {T} frames, the temporal embedding has {a['num_frames']} rows")
         ids = data["text"]
         ids_cpu = ids.detach().to("cpu", torch.int64)
+        if ids_cpu.numel() == 0 or ids_cpu.shape[0] % B:
+            raise ValueError(f"text: {tuple(ids_cpu.shape)} token rows for {B} clips (expected n_trans * B rows, clip-major)")
+        if int(ids_cpu.min()) < 0 or int(ids_cpu.max()) >= a["vocab"] or ids_cpu.shape[1] > a["context"]:
+            raise IndexError(f"token ids must lie in [0, {a['vocab']}) and captions within the context of {a['context']}")
         eot = ids_cpu.argmax(dim=-1)
         L = int(eot.max()) + 1
         N = ids_cpu.shape[0]
@@ -784,6 +792,10 @@ class Engine:
                                n_keep(a), device=self.dev)
         else:
             keep = data["keep_ind"].to(torch.int32)
+            if keep.dim() != 2 or keep.shape[0] not in (1, B):
+                raise ValueError(f"keep_ind {tuple(keep.shape)}: expected [B, n_keep] (or [1, n_keep] for the whole batch)")
+            if keep.numel() and (int(keep.min()) < 0 or int(keep.max()) >= patches_per_frame(a)):
+                raise IndexError(f"keep_ind must index the {patches_per_frame(a)} patches of a frame")
         if keep.shape[0] == 1 and B > 1:  # one tube mask for the whole batch (the downstream scripts pass arange(n)[None])
             keep = keep.expand(B, -1)
         keep = keep.contiguous().to(self.dev)
