@@ -494,6 +494,48 @@ def test_full_size_graph_replay_is_the_eager_step(K, lib):
     assert torch.equal(mg.store.flat, flat_e) and torch.equal(mg.store.m, m_e) and torch.equal(mg.store.v, v_e)
 
 
+@pytest.mark.parametrize("arch_name", ["B_16", "H_14"])
+def test_fused_adamw_on_the_whole_parameter_set(K, lib, arch_name):
+    """the optimizer at its real size (H/14: one flat buffer of a billion fp32 parameters, offsets past 2^31 bytes): two fused
+    steps over random gradients against the per-tensor HF-AdamW restatement run tensor by tensor -- every trainable parameter
+    and both moments, the frozen ones bit for bit where they were, the bf16 shadows the rounded master weights"""
+    from tvts_amd import arch as A
+    from tvts_amd.model._common import TVTSv2Base
+    a = A.ARCHS[arch_name]
+    m = TVTSv2Base(ARGS, arch=a, init_seed=0)
+    for name, p in m.named_parameters():
+        p.requires_grad = A.param_group_of(name, a) >= 0
+    _, opt, _ = _runner_of(m, a)
+    m._fresh_shadows(); m._sync_requires_grad()
+    st = m.store
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    names = [n for n, _ in m.named_parameters()]
+    init = {n: st.p(n).clone() for n in names}
+    ref = {n: (init[n].clone(), torch.zeros_like(init[n]), torch.zeros_like(init[n])) for n in names}
+    for step in (1, 2):
+        st.grad.normal_(generator=gen).mul_(1e-2 * step)
+        g = {n: st.g(n).clone() for n in names}
+        opt.step()
+        for n, (pr, mr, vr) in ref.items():
+            gi = A.param_group_of(n, a)
+            if gi >= 0:
+                O.hf_adamw_step(pr, g[n], mr, vr, step, A.GROUP_HPARAMS[gi][0], A.GROUP_HPARAMS[gi][1])
+    torch.cuda.synchronize()
+    moved = 0
+    for n, (pr, mr, vr) in ref.items():
+        if A.param_group_of(n, a) < 0:
+            assert torch.equal(st.p(n), init[n]), n  # frozen: bit for bit where it was
+            continue
+        # the update is lr-sized (1e-4 ... 1e-7 of a parameter): compare the MOVE, not the value
+        move = float((pr - init[n]).abs().max())
+        assert move > 0, n
+        tol = 1e-4 * move + 2.4e-7 * float(pr.abs().max())  # (+ the last bit of the value: the kernel fuses multiply-adds)
+        assert float((st.p(n) - pr).abs().max()) <= tol, (n, float((st.p(n) - pr).abs().max()), move)
+        moved += 1
+    assert moved > 100
+    assert int(st.flat.numel()) * 4 > 2 ** 31 or arch_name != "H_14"  # (H/14: the flat buffer does reach past 2^31 bytes)
+
+
 def test_captured_step_follows_the_learning_rate_schedule(K, lib):
     """lr / weight decay live in a device table that sync_hyper() refreshes: a replayed graph applies the new learning
     rate without being captured again (the epoch-end x0.1 of trainer.py:402-417)."""
