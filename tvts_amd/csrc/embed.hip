@@ -455,16 +455,21 @@ __global__ __launch_bounds__(256) void text_tok_bwd_kernel(const float* __restri
         const int c = c0 + ct * 4;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         if (grp < G && c < Wt) {
-            // eight rows in flight (the two id runs every caption shares -- start and end token -- are N rows long); added in row order
-            for (int k = lo + grp; k < hi; k += 8 * G) {
-                f32x4 v[8];
+            // sixteen rows in flight (the two id runs every caption shares -- start and end token -- are N rows long): the row
+            // numbers first, then the rows (clamped, not predicated: a branch per load would serialise them), added in row order
+            for (int k = lo + grp; k < hi; k += 16 * G) {
+                int idx[16];
+                f32x4 v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int kk = k + u * G;
-                    v[u] = kk < hi ? *(const f32x4*)(dx + (size_t)order[kk] * ldx + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    idx[u] = order[kk < hi ? kk : hi - 1];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a += v[u];
+                for (int u = 0; u < 16; ++u) v[u] = *(const f32x4*)(dx + (size_t)idx[u] * ldx + c);
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (k + u * G < hi) a += v[u];
             }
         }
         part[threadIdx.x] = a;
