@@ -272,7 +272,9 @@ int tvts_text_embed(const int* ids, int ld_ids, int N, int L, const float* emb, 
                     hipStream_t stream);
 /* order / seg (optional, device int32): the rows 0 .. N * L - 1 sorted by token id (ties in row order) and the starts of the runs
  * of equal ids in that list (N * L + 1 entries, non-decreasing, padded with N * L) -- with them both embedding gradients are
- * ordered sums (run-to-run reproducible), without them (NULL) a scatter of fp32 atomics like nn.Embedding's backward */
+ * ordered sums (run-to-run reproducible), without them (NULL) a scatter of fp32 atomics like nn.Embedding's backward.  The runs
+ * may be listed in any order; runs of more than 64 rows among the FIRST 64 are summed by a block per 64 columns instead of one
+ * block (list the long ones first: every caption's start / end token makes a run of N rows) */
 int tvts_text_embed_bwd(const float* dx, int ldx, const int* ids, int ld_ids, int N, int L, int Wt, float* demb, float* dpos,
                         const int* order, const int* seg, hipStream_t stream);
 int tvts_text_mean(const float* t, int NT, int B, int E, float* mean, float* before, hipStream_t stream);

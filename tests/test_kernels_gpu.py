@@ -598,6 +598,28 @@ def test_text_embed_mean_sort_assemble(K):
         assert rel(demb2, e2.grad) < 1e-6 and rel(dpos2, p2.grad) < 1e-6
         outs.append((demb2, dpos2))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # long runs (a token every caption shares: its start and end token) are listed first and summed by a block per 64 columns
+    N2, L2, V2, W2 = 300, 5, 40, 192
+    ids2 = torch.randint(3, V2, (N2, L2), generator=torch.Generator().manual_seed(51), dtype=torch.int32)
+    ids2[:, 0], ids2[:, -1] = 1, 2
+    ids2[:70, 2] = 7
+    dx2 = rnd(N2 * L2, W2, seed=52)
+    order2, seg2 = K.token_sort(ids2)
+    flat2 = ids2.reshape(-1)
+    lens2 = torch.diff(seg2[:int((seg2 < N2 * L2).sum()) + 1].long())
+    assert sorted(order2.tolist()) == list(range(N2 * L2)) and lens2[:2].tolist() == [300, 300] and int(lens2[2]) > 64 and int(lens2[3:].max()) <= 64
+    for s0, s1 in zip(seg2[:-1].tolist(), seg2[1:].tolist()):
+        run = order2[s0:s1]
+        assert len(set(flat2[run.long()].tolist())) <= 1 and run.tolist() == sorted(run.tolist())
+    e3 = torch.zeros(V2, W2, requires_grad=True)
+    e3[ids2.long()].backward(dx2.view(N2, L2, W2))
+    res = []
+    for _ in range(2):
+        demb3, dpos3 = torch.zeros(V2, W2, device=DEV), torch.zeros(L2, W2, device=DEV)
+        K.text_embed_bwd(dx2.to(DEV), ids2.to(DEV), demb3, dpos3, N=N2, L=L2, tok_sort=(order2.to(DEV), seg2.to(DEV)))
+        assert rel(demb3, e3.grad) < 1e-6 and rel(dpos3, dx2.view(N2, L2, W2).sum(0)) < 1e-6
+        res.append(demb3)
+    assert torch.equal(res[0], res[1])
     # caption mean (clip-major) and its backward
     NT, B, E = 4, 3, 128
     t = rnd(NT * B, E, seed=38)

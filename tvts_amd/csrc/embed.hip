@@ -441,12 +441,15 @@ __global__ __launch_bounds__(1024) void text_pos_bwd_kernel(const float* __restr
 // Tokens: the caller hands over the rows sorted by token id (`order`, ties in row order) and the starts of the runs of equal ids
 // (`seg`, N * L + 1 entries, padded with N * L: a fixed grid, empty runs exit).  A block per run adds its rows in order --
 // G = 256 / (Wt / 4) thread groups take every G-th row, each thread four columns, the groups are combined in group order.
+#define TOK_LONG_RUN 64     // a run of more rows than this, listed among the first TOK_LONG_SLOTS runs, is summed by a block per 64 columns
+#define TOK_LONG_SLOTS 64
 __global__ __launch_bounds__(256) void text_tok_bwd_kernel(const float* __restrict__ dx, int ldx, const int* __restrict__ ids,
                                                            int ld_ids, int L, int Wt, const int* __restrict__ order,
                                                            const int* __restrict__ seg, float* __restrict__ demb) {
     __shared__ f32x4 part[256];
     const int lo = seg[blockIdx.x], hi = seg[blockIdx.x + 1];
     if (lo >= hi) return;
+    if (hi - lo > TOK_LONG_RUN && blockIdx.x < TOK_LONG_SLOTS) return;  // text_tok_long_bwd_kernel's
     const int row0 = order[lo];
     const int id = ids[(size_t)(row0 / L) * ld_ids + row0 % L];
     const int cpt = Wt / 4 < 256 ? Wt / 4 : 256;  // column-threads per group
@@ -482,11 +485,50 @@ __global__ __launch_bounds__(256) void text_tok_bwd_kernel(const float* __restri
         __syncthreads();
     }
 }
+// the long runs (every caption's start / end token: N rows each): a block per (run, 64 columns), 16 thread groups over the rows,
+// a thread four columns, sixteen rows in flight per thread, the groups combined in group order
+__global__ __launch_bounds__(256) void text_tok_long_bwd_kernel(const float* __restrict__ dx, int ldx, const int* __restrict__ ids,
+                                                                int ld_ids, int L, int Wt, const int* __restrict__ order,
+                                                                const int* __restrict__ seg, float* __restrict__ demb) {
+    __shared__ f32x4 part[256];
+    const int lo = seg[blockIdx.x], hi = seg[blockIdx.x + 1];
+    if (hi - lo <= TOK_LONG_RUN) return;
+    const int row0 = order[lo];
+    const int id = ids[(size_t)(row0 / L) * ld_ids + row0 % L];
+    const int grp = threadIdx.x >> 4, c = blockIdx.y * 64 + (threadIdx.x & 15) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (c < Wt) {
+        for (int k = lo + grp; k < hi; k += 16 * 16) {
+            int idx[16];
+            f32x4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int kk = k + u * 16;
+                idx[u] = order[kk < hi ? kk : hi - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = *(const f32x4*)(dx + (size_t)idx[u] * ldx + c);
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (k + u * 16 < hi) a += v[u];
+        }
+    }
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (grp == 0 && c < Wt) {
+        f32x4 t = part[threadIdx.x];
+        for (int g = 1; g < 16; ++g) t += part[g * 16 + threadIdx.x];
+        *(f32x4*)(demb + (size_t)id * Wt + c) += t;
+    }
+}
 extern "C" int tvts_text_embed_bwd(const float* dx, int ldx, const int* ids, int ld_ids, int N, int L, int Wt, float* demb,
                                    float* dpos, const int* order, const int* seg, hipStream_t stream) {
     if (order != nullptr && seg != nullptr && Wt % 4 == 0 && ldx % 4 == 0) {
         hipLaunchKernelGGL(text_pos_bwd_kernel, dim3(ceil_div(Wt, 64), L), dim3(1024), 0, stream, dx, ldx, N, L, Wt, dpos);
         hipLaunchKernelGGL(text_tok_bwd_kernel, dim3(N * L), dim3(256), 0, stream, dx, ldx, ids, ld_ids, L, Wt, order, seg, demb);
+        const int slots = N * L < TOK_LONG_SLOTS ? N * L : TOK_LONG_SLOTS;
+        hipLaunchKernelGGL(text_tok_long_bwd_kernel, dim3(slots, ceil_div(Wt, 64)), dim3(256), 0, stream, dx, ldx, ids, ld_ids, L, Wt,
+                           order, seg, demb);
     } else {
         hipLaunchKernelGGL(text_embed_bwd_kernel, dim3(N * L), dim3(256), 0, stream, dx, ldx, ids, ld_ids, N, L, Wt, demb, dpos);
     }
