@@ -153,11 +153,15 @@ def test_gemm_tn_256_tile(K, M, Na, Nb):
 
 
 def test_gemm_tn_tile_selection(K):
-    """The ViT blocks' weight gradients take the 256x256 kernel, the text tower and small outputs the 128x128 one."""
+    """The plan of the weight-gradient entry point (a cost model of tile and range count, csrc/gemm.hip; tools/tn_plan_check.py
+    measures it against both tiles' best): the long contractions of the 192-pair step take the 256x256 kernel -- the text tower's
+    included --, short contractions and small outputs the 128x128 one; at the reference's 24 pairs per GPU the wide ViT gradients
+    already take the 256x256 kernel, at 12 pairs none does."""
     M = 192 * 785
     assert K.gemm_tn_select(M, 2304, 768) == 256 and K.gemm_tn_select(M, 768, 3072) == 256
-    assert K.gemm_tn_select(M, 768, 768) == 256 and K.gemm_tn_select(24576, 2048, 512) == 128
-    assert K.gemm_tn_select(M, 512, 512) == 128
+    assert K.gemm_tn_select(M, 768, 768) == 256 and K.gemm_tn_select(24576, 2048, 512) == 256
+    assert K.gemm_tn_select(24576, 512, 512) == 128 and K.gemm_tn_select(256, 2048, 512) == 128
+    assert K.gemm_tn_select(24 * 785, 2304, 768) == 256 and K.gemm_tn_select(24 * 785, 768, 768) == 128
     assert K.gemm_tn_select(12 * 785, 2304, 768) == 128
     assert K.gemm_tn_select(12 * 785, 2304, 768, tile=256) == 256 and K.gemm_tn_select(M, 2304, 768, tile=128) == 128
 

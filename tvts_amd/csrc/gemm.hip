@@ -577,14 +577,44 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 
 // per-call options of the weight-gradient entry point (TVTS_GEMM_TILE_*, TVTS_TN_*, TVTS_TN_SPLITS in include/tvts_hip.h): test /
 // bench hooks, 0 = automatic choice; no process state, no environment reads on the launch path
-// tile selection: the pipelined 256x256 kernel for long contractions -- M >= 32 768 rows, at least 0.5 M output elements, at
-// most 15 % of the 256-tiling's area wasted: every weight gradient of the ViT blocks (tools/tn_ab.py, M = 150 720: qkv 934 ->
-// 1109, fc1 955 -> 1131, fc2 984 -> 1134, proj 905 -> 925 TF) -- else the 128x128 kernel, which is the faster one on the text
-// tower's M = 24 576 (819 vs 757 TF).  0 auto, 128 / 256 force.
+// Tile and range count: a small cost model of the launch (microseconds), fitted to tools/tn_ab.py (M = 150 720) and
+// tools/tn_splits_small.py (the reference's per-GPU batches, M = 9 420 / 18 840; profiles/r03_tn_plan_small_m.txt):
+//   rounds x rows per range x time per contraction row of one tile  (256: 26.5 ns, one block per CU; 128: 14.8 - 16.5 ns with two
+//   blocks on a CU, 11 ns when the launch leaves every block a CU of its own)  +  8 bytes per output element and range for the partials
+//   (written, read back by the reduce pass: ~8 TB/s, they mostly stay in the caches)  +  launch / prologue / reduce constants.
+// The 256x256 kernel needs at most 15 % of its tiling's area wasted.  Rounds 1-2 picked "256 from M = 32 768, ranges to fill the
+// round": right at 192 pairs, 15-25 % off at the reference's 24 pairs (128-tile kernel where the 256 one is faster) and at 12
+// (14 ranges of partials where 4 are faster).
+// (one range without the reduce pass adds into the output with fp32 atomics when it accumulates: ~12 us per million elements)
+static double tn_model_us(int M, int Na, int Nb, int tile, int sp) {
+    const long tiles = (long)ceil_div(Na, tile) * ceil_div(Nb, tile), items = tiles * sp;
+    const long slots = tile == 256 ? 256 : 512;
+    const long rounds = (items + slots - 1) / slots;
+    const double rows = ceil_div(ceil_div(M, sp), 64) * 64.0;
+    const double narrow = (Na <= 512 || Nb <= 512) ? 1.2 : 1.0;  // the 128-tile kernel on the text tower's / sort head's 512-wide operands
+    const double per_row = tile == 256 ? 0.0265 : (items <= 256 ? 0.011 : (rounds == 1 ? 0.0148 : 0.0165) * narrow);
+    const double partial = sp > 1 ? sp * (double)Na * (double)Nb * 1e-6 : 0.0;
+    return rounds * rows * per_row + partial + (tile == 256 ? 8.0 : 5.0) + (sp > 1 ? 6.0 : 12e-6 * (double)Na * (double)Nb);
+}
+static int tn_best_splits(int M, int Na, int Nb, int tile, double* t_out) {
+    int best = 1;
+    double tb = 1e30;
+    for (int sp = 1; sp <= 64; ++sp) {
+        if (sp > 1 && M / sp < 768) break;
+        const double t = tn_model_us(M, Na, Nb, tile, sp);
+        if (t < tb) { tb = t; best = sp; }
+    }
+    if (t_out) *t_out = tb;
+    return best;
+}
 static bool tn_use_256(int M, int Na, int Nb, int opts) {
     if (opt_tile(opts)) return opt_tile(opts) == 256;
     const double area = 65536.0 * ceil_div(Na, 256) * ceil_div(Nb, 256), elems = (double)Na * (double)Nb;
-    return M >= 32768 && elems >= 0.5e6 && area <= 1.15 * elems;
+    if (area > 1.15 * elems) return false;
+    double t128, t256;
+    tn_best_splits(M, Na, Nb, 128, &t128);
+    tn_best_splits(M, Na, Nb, 256, &t256);
+    return t256 < t128;
 }
 extern "C" int tvts_gemm_tn_select(int M, int Na, int Nb, int opts) { return tn_use_256(M, Na, Nb, opts) ? 256 : 128; }
 
@@ -607,20 +637,8 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     // the early LDS-DMA issue addresses its operand with 32-bit offsets from a wave-uniform base: the operand must fit 4 GiB
     g.early_dma = ((unsigned long long)M * (unsigned long long)(ldp > ldq ? ldp : ldq) * 2ull < (1ull << 32)) ? 1 : 0;
     if (opts & 4) g.early_dma = 0;
-    // split the contraction over M into S ranges (range s lives on XCD s % 8, see the kernel).  S is chosen for
-    // whole rounds of 2 blocks x 256 CUs: the smallest S reaching >= 93 % round efficiency, else the best one.
-    int splits = 1;
-    {
-        double best = 0.0;
-        for (int sp = 1; sp <= 64; ++sp) {
-            if (sp > 1 && M / sp < 768) break;
-            const long blocks = (long)g.tiles_ab * sp;
-            const long slots = t256 ? 256 : 512;  // co-resident blocks: one 512-thread block per CU, or two 256-thread ones
-            const double eff = (double)blocks / ((double)slots * (double)((blocks + slots - 1) / slots));
-            if (eff > best + 1e-9) { best = eff; splits = sp; }
-            if (eff >= 0.93) { splits = sp; break; }
-        }
-    }
+    // split the contraction over M into S ranges (range s lives on XCD s % 8, see the kernel): the modeled optimum
+    int splits = tn_best_splits(M, Na, Nb, tile, nullptr);
     if ((opts >> 8) > 0) splits = opts >> 8;
     // the partials must fit the caller's workspace: fewer, longer ranges beat the atomic fallback
     if (workspace != nullptr && splits > 1 && (long)splits * Na * Nb > workspace_elems) {
