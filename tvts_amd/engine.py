@@ -742,6 +742,25 @@ class Engine:
         return dx
 
     # ------------------------------------------------------------------ whole model
+    def _clip_to_device(self, video: torch.Tensor) -> torch.Tensor:
+        """The clip tensor (the one large input: 925 MB of fp32 at 192 pairs) goes host -> device on a COPY STREAM of the engine:
+        on the compute stream the copy would queue behind the previous step's kernels and run in front of this step's -- 20 ms
+        (pinned) to 46 ms (pageable) of a 140 ms step with nothing else running (tools/bench_fed.py).  On its own stream it travels
+        while the previous step computes; the compute stream waits for it by event, the allocator is told who uses the block."""
+        if video.is_cuda or not torch.cuda.is_available():
+            return video.to(self.dev)
+        cs = getattr(self, "_copy_stream", None)
+        if cs is None:
+            cs = self._copy_stream = torch.cuda.Stream(device=self.dev)
+        cur = torch.cuda.current_stream(self.dev)
+        if torch.cuda.is_current_stream_capturing():
+            return video.to(self.dev)
+        with torch.cuda.stream(cs):
+            d = video.to(self.dev, non_blocking=True)
+        cur.wait_stream(cs)
+        d.record_stream(cur)
+        return d
+
     def prepare_batch(self, data: dict):
         """Host-side (plumbing): dtype/device normalisation of the reference batch dict."""
         a = self.arch
@@ -753,7 +772,7 @@ class Engine:
             if video.dim() == 4:
                 video = video.unsqueeze(1)
             assert video.dim() == 5 and video.shape[-1] == 3, "uint8 video must be [B, T, H, W, 3]"
-            video = video.to(self.dev).contiguous()
+            video = self._clip_to_device(video).contiguous()
             if data.get("crop") is not None:
                 crop = data["crop"].to(torch.int32).contiguous().to(self.dev)
             if data.get("resize") is not None:  # the frames are the decoder's pictures: Resize(size) happens inside the gather
@@ -762,7 +781,7 @@ class Engine:
         else:
             if video.dim() == 4:
                 video = video.unsqueeze(1)
-            video = video.to(self.dev, torch.float32).contiguous()
+            video = self._clip_to_device(video).to(torch.float32).contiguous()
         B, T = video.shape[:2]
         # the reference fails on these with an indexing / broadcasting error (temporal_embedding[:T], nn.Embedding, pos[keep_ind]); the
         # kernels would read or write past the tables instead, so the batch is checked where it enters

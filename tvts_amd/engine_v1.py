@@ -229,7 +229,7 @@ class EngineV1(Engine):
         """v1 batch dict (v1/trainer/trainer.py:121-131): text = the tokenizer's {'input_ids', 'attention_mask'} (right-padded),
         video fp32 [B, T, 3, H, W], keep_ind int64 [B, n_tubes, n_keep] (one mask per tube)."""
         a = self.arch
-        video = data["video"].to(self.dev, torch.float32).contiguous()
+        video = self._clip_to_device(data["video"]).to(torch.float32).contiguous()
         B, T = video.shape[:2]
         tubes = T // a["tubelet"]
         ids = data["text"]["input_ids"].detach().to("cpu", torch.int64)
