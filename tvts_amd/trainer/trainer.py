@@ -112,6 +112,10 @@ class _TrainerBase(Multi_BaseTrainer_dist):
 
     def _train_epoch(self, epoch):
         total_loss = [0.0] * len(self.data_loader)
+        # every step's loss is kept on the device and read at the end of the epoch (and on the logging steps): the reference's
+        # per-step `.item()` (trainer.py:503) would stop the host at every step, and with it the next batch's host-to-device copy
+        # that otherwise travels under the running step (Engine._clip_to_device) -- the logged and returned values are the same
+        step_loss = torch.zeros(len(self.data_loader), self.len_epoch, dtype=torch.float32, device=self.model.store.device)
         for loader in self.data_loader:
             if hasattr(loader, "train_sampler") and loader.train_sampler is not None:
                 loader.train_sampler.set_epoch(epoch)
@@ -137,12 +141,16 @@ class _TrainerBase(Multi_BaseTrainer_dist):
                 log_now = batch_idx % self.log_step == 0 and self.args.local_rank == 0
                 l1 = out["loss1"]
                 l2 = out["loss2"] if out["loss2"] is not None else torch.zeros_like(l1)
-                loss = float(l1 + l2)  # the reference syncs once per step as well (trainer.py:503)
-                total_loss[dl_idx] += loss
+                if batch_idx < self.len_epoch:
+                    torch.add(l1.reshape(()), l2.reshape(()), out=step_loss[dl_idx, batch_idx])
+                else:
+                    total_loss[dl_idx] += float(l1 + l2)
                 if log_now:
-                    self.logger.debug(self.LOG_LINE.format(epoch, dl_idx, self._progress(batch_idx, dl_idx), float(l1), float(l2), loss))
+                    self.logger.debug(self.LOG_LINE.format(epoch, dl_idx, self._progress(batch_idx, dl_idx), float(l1), float(l2), float(l1 + l2)))
             # max_samples_per_epoch is stored and never read by the reference's TVTSv2 trainers (trainer.py:93,387,681):
             # the whole YT loader is iterated, so the per-epoch LR schedule sees the same number of steps here
+        for dl_idx, row in enumerate(step_loss.cpu().tolist()):
+            total_loss[dl_idx] += sum(row)  # the same per-step fp32 values the reference adds up as Python floats
         log = {f"loss_{dl_idx}": total_loss[dl_idx] / self.len_epoch for dl_idx in range(len(self.data_loader))}
         if self.do_validation:
             val_log = self._valid_epoch(epoch)
