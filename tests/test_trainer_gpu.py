@@ -88,6 +88,25 @@ def test_train_validate_checkpoint_resume(tmp_path, capsys):
     assert (tmp_path / "checkpoint-epoch2.pth").exists()
 
 
+def test_resumed_run_continues_bit_for_bit(tmp_path):
+    """two epochs in one go against one epoch, a checkpoint, a fresh process-like rebuild with `resume` and the second epoch: the
+    same parameters and Adam moments bit for bit (the checkpoint holds the fp32 master weights, both moments and the step count;
+    the bf16 shadows are rebuilt from the masters; every reduction of the step has a fixed order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    tr_a, m_a, _ = build(tmp_path / "a", epochs=2)
+    tr_a.train()
+    tr_b, m_b, _ = build(tmp_path / "b", epochs=1)
+    tr_b.train()
+    tr_c, m_c, _ = build(tmp_path / "b", epochs=2, resume=tmp_path / "b" / "checkpoint-epoch1.pth")
+    assert tr_c.start_epoch == 2
+    tr_c.train()
+    assert tr_c.optimizer.global_step == tr_a.optimizer.global_step
+    assert torch.equal(m_c.store.flat, m_a.store.flat)
+    assert torch.equal(m_c.store.m, m_a.store.m) and torch.equal(m_c.store.v, m_a.store.v)
+
+
 def test_load_checkpoint_constructor_argument(tmp_path):
     """`TVTSv2_*(args, load_checkpoint=path)` (model_dist_TVTSv2_ViT_B_16.py:51-56) and the downstream class
     (downstream/model_TVTSv2_ViT_B_16.py:42-46) read the file `_save_checkpoint` writes -- which carries the config OBJECT, so
