@@ -33,6 +33,12 @@ def worker(rank, world, port, h14, q):
     batches = [O.synth_batch(oarch, B=3, T=3, seed=50 + r, caption_len=9) for r in range(world)]
     out = runner.step(batches[rank])
     torch.cuda.synchronize()
+    # the data-parallel invariant: after the all-reduce every rank holds the SAME averaged gradient, bit for bit (the replicas
+    # would drift apart otherwise), and the same global contrastive loss
+    chk = torch.stack([m.store.grad.view(torch.int32).to(torch.int64).sum(), out["loss1"].reshape(()).view(torch.int32).to(torch.int64)])
+    both = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(both, chk)
+    same = all(torch.equal(both[0], b) for b in both[1:])
     if rank == 0:
         leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
         total, loss1, l2 = O.multi_rank_step(leaves, batches, oarch)
@@ -46,7 +52,8 @@ def worker(rank, world, port, h14, q):
         worst = min((float(torch.nn.functional.cosine_similarity(grads[k].flatten().double(), v.flatten().double(), dim=0)), k)
                     for k, v in ref.items() if float(v.norm()) > 1e-3 * tot_r)
         print("grad norm", tot, tot_r, "worst cos", worst, flush=True)
-        ok = abs(l1e - r1) < 1e-2 and abs(tot - tot_r) < 0.02 * tot_r and worst[0] > 0.98
+        print("ranks hold the same gradient bits and loss:", same, flush=True)
+        ok = same and abs(l1e - r1) < 1e-2 and abs(tot - tot_r) < 0.02 * tot_r and worst[0] > 0.98
         q.put(bool(ok))
     dist.barrier()
     dist.destroy_process_group()
