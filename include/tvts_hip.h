@@ -29,7 +29,10 @@ enum {
                                    MFMA; both accumulate the same products in fp32 */
     TVTS_TN_NO_EARLY_DMA = 4,   /* tvts_gemm_tn_bf16: LDS-DMA through the builtin path (the one operands past 4 GiB take) */
     TVTS_TN_AFAST_0 = 8,        /* tvts_gemm_tn_bf16: tile walk of an m-range, b-dimension fastest ... */
-    TVTS_TN_AFAST_1 = 16        /* ... or a-dimension fastest (default: the shorter one) */
+    TVTS_TN_AFAST_1 = 16,       /* ... or a-dimension fastest (default: the shorter one) */
+    TVTS_GEMM_STREAMK = 32,     /* tvts_gemm_nt_bf16 / tvts_gemm_tn_bf16: force the stream-K walk (work split by K stage, ordered sum of the
+                                   partial tiles in the block that arrives last); -22 without a workspace or on a shape it cannot take */
+    TVTS_GEMM_NO_STREAMK = 64   /* ... never take it */
 };
 /* persistent grid of the 256x256 NT kernels (bf16 and fp8): at most n blocks, one per CU (8 .. 256, multiple of 8; 0 = the whole
  * chip) -- leaves CUs to kernels of other streams (the RCCL kernels of the side stream when world > 1), and a measurement
@@ -49,10 +52,17 @@ enum {
  *      v2/CLIP/clip/model.py:175-181; v2/model/sort_transformer.py:21-23,41-42.  K % 64 == 0, N % 4 == 0.
  *      out = [gate'(gate_h) *] act(A.B^T + bias) [+ residual]; preact (bf16) receives A.B^T + bias when act != 0.
  *      gate_act = TVTS_GATE_ADD_BF16: out = A.B^T + bias + gate_h (bf16 residual: x + proj(.) / x + mlp(.) of
- *      video_encoder_ViT_B_16.py:117-123 with the residual stream kept in bf16; `residual` is the fp32 form of the same sum) */
+ *      video_encoder_ViT_B_16.py:117-123 with the residual stream kept in bf16; `residual` is the fp32 form of the same sum)
+ *      workspace (optional, workspace_bytes >= tvts_gemm_nt_workspace_bytes()): scratch of the stream-K walk the entry point
+ *      takes when an output of few tiles would leave the persistent grid a fraction of a round (the reference's own per-GPU
+ *      batches of 12 / 24 pairs): fp32 partial tiles + one arrival counter per output tile.  Its first 64 KiB must be ZERO
+ *      on the first call and are zero again after every call; one workspace serves one stream (calls in flight at the same
+ *      time need workspaces of their own).  Without it the tile-granular walk is the only one. */
 int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                       const float* residual, int ldr, int act, void* preact, int ldp, const void* gate_h, int ldh,
-                      int gate_act, void* out, int ldc, int out_f32, int opts, hipStream_t stream);
+                      int gate_act, void* out, int ldc, int out_f32, void* workspace, long workspace_bytes, int opts,
+                      hipStream_t stream);
+long tvts_gemm_nt_workspace_bytes(void);
 /* the output tile (128 or 256) tvts_gemm_nt_bf16 picks for an [M, N] result under `opts`: lets a parity test assert that the
  * kernel it means to exercise is the one that ran */
 int tvts_gemm_nt_select(int M, int N, int opts);

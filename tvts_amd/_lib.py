@@ -28,17 +28,17 @@ def parse_header(path: str = HEADER_PATH):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|void)\s+(tvts_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int|long|void)\s+(tvts_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         argtypes, argnames = [], []
-        for a in [x.strip() for x in args.split(",") if x.strip()]:
+        for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
             argnames.append(re.split(r"[\s\*]+", a)[-1])
             if "*" in a:
                 argtypes.append(ctypes.c_void_p)
             else:
                 ty = a.replace("const", "").split()[0]
                 argtypes.append(_CTYPES[ty])
-        protos[name] = (ctypes.c_int if ret == "int" else None, argtypes, argnames)
+        protos[name] = ({"int": ctypes.c_int, "long": ctypes.c_long}.get(ret), argtypes, argnames)
     return protos
 
 

@@ -166,17 +166,18 @@ static inline int opt_cus(int opts) {
     return n == 0 ? 256 : n > 256 ? 256 : n;
 }
 
-static bool nt_use_256(int M, int N, int opts) {
+static bool nt_use_256(int M, int N, int K, bool has_ws, int opts) {
     const int forced = opt_tile(opts);
     if (forced == 128) return false;
     if (N % 8) return false;
-    if (forced == 256) return true;
+    if (forced == 256 || (opts & 32)) return true;
     if (N % 256) return false;
+    (void)K; (void)has_ws;
     // ... or as soon as the 128x128 kernel would need a second round of its 512 co-resident blocks (129-149 tiles of 256: the text
     // tower at 24 pairs, M = 18 936 x N = 512: 54 vs 72 us at K = 2048, profiles/r03_gemm_tile_choice_small_m.txt)
     return (long)ceil_div(M, 256) * (N / 256) >= NT_MIN_TILES_256 || (long)ceil_div(M, 128) * (N / 128) > 512;
 }
-extern "C" int tvts_gemm_nt_select(int M, int N, int opts) { return nt_use_256(M, N, opts) ? 256 : 128; }
+extern "C" int tvts_gemm_nt_select(int M, int N, int opts) { return nt_use_256(M, N, 0, false, opts) ? 256 : 128; }
 
 // Wide outputs (>= 10 tile columns: the MLP's 4x expansion): walk the tiles in column groups of 6 or 5.  An XCD's 32
 // co-resident tiles then span 5-6 weight panels x 5-6 row panels instead of all 12-20 weight panels x 2-3 row panels
@@ -188,15 +189,48 @@ static int nt_column_group(int N) {
     return 0;
 }
 
+// ---- stream-K plan of the 256x256 NT kernel (gemm_nt256.h).  Workspace layout: [NT_SK_MAX_TILES arrival counters][grid x 2
+// partial tiles of 256 x 256 fp32]; the counters must be zero on entry and are zero again when the launch has finished.
+static const int NT_SK_MAX_TILES = 16384;
+static inline size_t nt_sk_workspace_bytes(int grid) { return (size_t)NT_SK_MAX_TILES * 4 + (size_t)grid * 2 * 65536 * 4; }
+extern "C" long tvts_gemm_nt_workspace_bytes(void) { return (long)nt_sk_workspace_bytes(256); }
+// Measured (tools/gemm_sk.py, profiles/r04_gemm_streamk_nt.txt): the stage-granular walk LOSES to the tile walk on every shape
+// of the step at 12 / 24 pairs (1.2 - 2.3x): a 256 x 256 fp32 partial is 256 KiB, every block leaves two of them, and the
+// epilogue (6.7 of a tile's 20.5 us at K = 768) is not split by splitting K -- it is serialised in the block that arrives last.
+// It therefore only runs when a call asks for it (TVTS_GEMM_STREAMK: parity tests, benches); what the small batches gain comes
+// from running the weight gradients beside the input-gradient chain (tvts_amd/engine.py, wgrad stream).
+static bool nt_sk_wanted(int opts) { return (opts & 32) != 0 && !(opts & 64); }
+
 template <bool FP8>
-static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, hipStream_t stream) {
+static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, hipStream_t stream, void* workspace = nullptr,
+                        long workspace_bytes = 0) {
     const int nt_cus = opt_cus(opts);
     const bool fp8_mx = !(opts & 4);
     g.tiles_n = ceil_div(g.N, 256);
     g.tiles_m = ceil_div(g.M, 256);
     g.gc = nt_column_group(g.N);
     const int total_tiles = g.tiles_m * g.tiles_n;
-    const int grid = total_tiles < nt_cus ? ((total_tiles + 7) / 8) * 8 : nt_cus;  // persistent: one block per CU, multiple of 8 (XCDs)
+    int grid = total_tiles < nt_cus ? ((total_tiles + 7) / 8) * 8 : nt_cus;  // persistent: one block per CU, multiple of 8 (XCDs)
+    g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0;
+    if constexpr (!FP8) {
+        // stream-K: needs the caller's workspace, at least 3 stages per block on the emptiest XCD (no empty blocks: the
+        // contributor lists are contiguous block ranges), and pays off where the tile walk wastes a good part of a round
+        const int nk = g.K / BK;
+        const long min_units = (long)(total_tiles / 8) * nk;  // the XCD with the fewest tiles
+        int sk_grid = nt_cus;
+        while (sk_grid > 8 && min_units / (sk_grid / 8) < 3) sk_grid -= 8;
+        const bool can = workspace != nullptr && total_tiles >= 8 && total_tiles <= NT_SK_MAX_TILES && min_units / (sk_grid / 8) >= 3 &&
+                         (size_t)workspace_bytes >= nt_sk_workspace_bytes(sk_grid) && nk >= 2;
+        if ((opts & 32) && !can) return TVTS_EINVAL;  // forced, but the shape / workspace cannot take it
+        if (can && nt_sk_wanted(opts)) {
+            grid = sk_grid;
+            g.sk_cnt = (int*)workspace;
+            g.sk_ws = (float*)((char*)workspace + (size_t)NT_SK_MAX_TILES * 4);
+            const int upb = (int)(min_units / (sk_grid / 8));
+            const int tol = nk / 8 < (upb / 2 - 1) ? nk / 8 : (upb / 2 - 1);
+            g.sk_tol = tol > 0 ? tol : 0;
+        }
+    }
     // every production instantiation staggers the LDS-DMA issue of the two waves of a SIMD (ABL 32768: +1-3 % on every shape of
     // the step, tools/gemm_ab.py; the same change is worth 6-10 % on the weight-gradient kernel)
     // ... and pins the written order of fragment reads and MFMA groups in the bf16 K loop (ABL 131072, round 3: hipcc otherwise
@@ -257,6 +291,15 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
             }
         }
     }
+    if constexpr (!FP8) {
+        if (g.sk_ws) {  // stream-K: the generic patch epilogue (bias and side inputs are read by the block that sums the pieces)
+            constexpr int SKF = SD | 524288;
+            if (gated) kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, SKF> : gate_act == ACT_GELU_ERF ? gemm_nt256p_kernel<0, 2, false, SKF>
+                            : gemm_nt256p_kernel<0, 3, false, SKF>;
+            else if (act != ACT_NONE) kern = act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, false, SKF> : gemm_nt256p_kernel<2, 0, false, SKF>;
+            else kern = g.residual ? gemm_nt256p_kernel<0, 0, false, 256 | SKF> : gemm_nt256p_kernel<0, 0, false, SKF>;
+        }
+    }
     if (!kern) return TVTS_EINVAL;
     const int lds_bytes = 163840;  // 2 x 64 KiB stages + 8 x 4 KiB epilogue patches
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -269,7 +312,7 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
 extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                                  const float* bias, const float* residual, int ldr, int act, void* preact,
                                  int ldp, const void* gate_h, int ldh, int gate_act, void* out, int ldc,
-                                 int out_f32, int opts, hipStream_t stream) {
+                                 int out_f32, void* workspace, long workspace_bytes, int opts, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return TVTS_EINVAL;
     if (K % BK != 0 || N % 4 != 0 || lda % 8 != 0 || ldb % 8 != 0) return TVTS_EINVAL;
     if ((ldc % 4) || (residual && (ldr % 4)) || (preact && (ldp % 4)) || (gate_h && (ldh % 4))) return TVTS_EINVAL;
@@ -278,11 +321,12 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.sa = nullptr; g.sb = nullptr; g.sa_rows = 0; g.gc = 0;
-    if (nt_use_256(M, N, opts)) {
+    g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0;
+    if (nt_use_256(M, N, K, workspace != nullptr, opts)) {
         if (ldc % 8 || (preact && ldp % 8) || (gate_h && ldh % 8)) {
             if (opt_tile(opts) == 256) return TVTS_EINVAL;  // forced, but the 16-byte epilogue accesses do not fit
         } else {
-            return launch_nt256<false>(g, act, gate_act, gate_h != nullptr, opts, stream);
+            return launch_nt256<false>(g, act, gate_act, gate_h != nullptr, opts, stream, workspace, workspace_bytes);
         }
     }
     g.tiles_n = ceil_div(N, BN);
@@ -319,6 +363,7 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
     g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = nullptr; g.ldh = 0; g.gate_act = ACT_NONE;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
+    g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0;
     return launch_nt256<true>(g, act, ACT_NONE, false, opts, stream);
 }
 
@@ -335,6 +380,7 @@ extern "C" int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int 
     g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = nullptr; g.ldr = 0; g.act = ACT_NONE;
     g.preact = nullptr; g.ldp = 0; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
     g.out = out; g.ldc = ldc; g.out_f32 = 0; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
+    g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0;
     return launch_nt256<true>(g, ACT_NONE, gate_act, true, opts, stream);
 }
 

@@ -20,8 +20,41 @@ struct GemmNT {
     int sa_rows; // fp8: scale_a holds one scale per row of A (per-token activation scales) instead of one for the tensor
     int gc;      // 256x256 pipelined kernel: tile columns per column group (0 = plain row-major tile order)
     const float* sa; const float* sb;  // fp8 operands: per-tensor scales (device scalars), out = sa*sb * (A B^T) + ...
+    // stream-K (ABL & 524288): fp32 partial tiles [grid][2][256 x 256] and one arrival counter per output tile (zero between launches)
+    float* sk_ws; int* sk_cnt; int sk_tol;
 };
 
+// ------------------------------------------------------------------------------------------------
+// Stream-K (round 4): at the reference's own per-GPU batches (12 / 24 pairs: M = 9 420 / 18 840) an output of 111 ... 444
+// tiles of 256 x 256 leaves the 256 persistent blocks 0.43 ... 0.87 of a round -- tile quantisation, not the K loop, is what
+// the step loses there.  With ABL & 524288 the unit of work is a K STAGE, not a tile: XCD x still owns a contiguous range of
+// tiles (its share of the weight / activation panels stays in that XCD's L2), and its P blocks split the range's
+// range_n * nk stages evenly -- block b takes stages [sk_bound(b), sk_bound(b + 1)), i.e. the tail of one tile, whole tiles,
+// and the head of another.  A piece that does not cover its tile's whole K leaves as an fp32 partial in the accumulator
+// layout (slot 1 of the block if the piece starts the tile, slot 0 otherwise: a block has at most one of each), then the
+// block counts itself in at the tile's arrival counter; the LAST block to arrive adds the partials IN CONTRIBUTOR ORDER
+// (k ascending, every one re-read from the workspace, its own included) and runs the ordinary fused epilogue -- the order is
+// a function of the shape and the grid only, so results are bit-reproducible whoever arrives last, and nobody ever waits
+// for another block (no co-residency assumption, no deadlock with kernels of other streams).  All contributors of a tile
+// sit on one XCD; the fences are agent-scope all the same, so correctness does not rest on the block -> XCD mapping.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int sk_bound(int U, int P, int b, int nk, int tol) {
+    if (b <= 0) return 0;
+    if (b >= P) return U;
+    int u = (int)(((unsigned)U * (unsigned)b) / (unsigned)P);  // U * P < 2^31 (dispatcher)
+    const int r = u % nk;  // a boundary within `tol` stages of a tile edge moves onto it: no partial for a sliver
+    if (r <= tol) u -= r;
+    else if (nk - r <= tol) u += nk - r;
+    return u;
+}
+// the largest block index whose first stage is <= u
+__device__ __forceinline__ int sk_owner(int U, int P, int nk, int tol, int u) {
+    int b = (int)(((unsigned)u * (unsigned)P) / (unsigned)U);
+    b = b < P - 1 ? b : P - 1;
+    while (b + 1 < P && sk_bound(U, P, b + 1, nk, tol) <= u) ++b;
+    while (b > 0 && sk_bound(U, P, b, nk, tol) > u) --b;
+    return b;
+}
 __device__ __forceinline__ bf16x8 frag_rows128(const char* lds_tile, int row, int chunk) {
     return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
@@ -66,6 +99,45 @@ __device__ __forceinline__ void stage_issue256_asm(const StageOff256& o, const b
                  "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
                  "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(o.off[0]), "v"(o.off[1]), "v"(o.off[2]), "v"(o.off[3]), "s"(ubase), "s"(lds_addr) : "memory", "scc");
+}
+// A piece of tile `tile` ends here without covering the tile's whole K: it leaves as a partial, and the block counts itself in.
+// Returns true (block-uniform) in the block that arrived last -- that block sums the pieces and runs the epilogue once its own
+// stage range is done (sk_gather, behind the main loop: the accumulators of the loop are dead there, so the ordered sum does not
+// compete with them for registers; inside the loop the very same code made hipcc spill 125 registers, fragments included).
+__device__ __forceinline__ bool sk_publish(const GemmNT& g, const f32x4 (&acc)[4][8], int tile, int n_pieces, bool starts_tile,
+                                           int wave, int lane, int* flag) {
+    // Agent-scope (sc1) stores and loads on the partials themselves instead of a device-wide fence: a release fence is
+    // buffer_wbl2 -- a write-back of the XCD's whole L2 -- and 512 of them per launch cost 150-200 us (the first build of this
+    // path: 217 us for a 47 us GEMM).  An sc1 store is written through, an sc1 load is served coherently at agent scope
+    // (the accesses LLVM's gfx942 memory model uses for agent-scope atomics), so `vmcnt(0)` behind the stores is the release.
+    const char* mine = uniform_ptr(g.sk_ws + ((size_t)blockIdx.x * 2 + (starts_tile ? 1 : 0)) * 65536 + (size_t)wave * 8192);
+    const unsigned voff = (unsigned)lane * 16u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(voff), "v"(acc[j][i]), "s"(mine + (j * 8 + i) * 1024) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *(volatile int*)flag = __hip_atomic_fetch_add(g.sk_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return *(volatile int*)flag == n_pieces - 1;
+}
+// the ordered sum of the n pieces of a tile (k ascending; piece 0 starts the tile: slot 1 of its block, the others slot 0)
+__device__ __forceinline__ void sk_gather(const GemmNT& g, f32x4 (&acc)[4][8], int first, int n, int xcd, int wave, int lane) {
+    const unsigned voff = (unsigned)lane * 16u;
+    for (int c = 0; c < n; ++c) {
+        const char* p = uniform_ptr(g.sk_ws + ((size_t)((first + c) * 8 + xcd) * 2 + (c == 0 ? 1 : 0)) * 65536 + (size_t)wave * 8192);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v[i]) : "v"(voff), "s"(p + (j * 8 + i) * 1024) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = c == 0 ? v[i] : acc[j][i] + v[i];
+        }
+    }
 }
 // tile index -> tile origin.  gc == 0: row-major over (m, n).  gc > 0: column groups of gc tile columns, row-major
 // inside a group, so the tiles an XCD works on at one time span gc weight panels instead of all of them.
@@ -685,9 +757,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     const int range_lo = xcd * q + (xcd < rem ? xcd : rem);
     const int range_n = q + (xcd < rem ? 1 : 0);
     const int nk = g.K / BK;
-    if (slot >= range_n) return;
-    const int ntl = (range_n - slot + per_xcd - 1) / per_xcd;
-    const int total_st = ntl * nk;
+    constexpr bool SK = (ABL & 524288) != 0;  // stream-K: this block owns stages [u0, u1) of the XCD's range_n * nk
+    static_assert(!SK || (!FP8 && (ABL & (1024 | 8192)) == 0), "stream-K: bf16 operands, generic patch epilogue");
+    int u0 = 0, total_st;
+    if constexpr (SK) {
+        u0 = sk_bound(range_n * nk, per_xcd, slot, nk, g.sk_tol);
+        total_st = sk_bound(range_n * nk, per_xcd, slot + 1, nk, g.sk_tol) - u0;
+        if (total_st <= 0) return;
+    } else {
+        if (slot >= range_n) return;
+        total_st = ((range_n - slot + per_xcd - 1) / per_xcd) * nk;
+    }
+    // the tl-th tile of this block: stream-K walks the XCD's range contiguously, the tile-granular walk strides by the blocks per XCD
+    auto tile_of = [&](int tl_) -> int { return SK ? range_lo + tl_ : range_lo + slot + tl_ * per_xcd; };
     const int gc = g.gc;
     if constexpr ((ABL & 24) != 0) {  // experiment: blocks start in 2 (8) / 4 (16) phases spread over one tile time (~1 us per stage)
         const int phases = (ABL & 16) ? 4 : 2;
@@ -696,10 +778,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     }
 
     // DMA cursor
-    int i_st = 0, i_kt = 0, i_tl = 0, i_m0, i_n0;
+    int i_st = 0, i_kt = SK ? u0 % nk : 0, i_tl = SK ? u0 / nk : 0, i_m0, i_n0;
     StageOff256 oa, ob;
     {
-        tile_origin256(g, range_lo + slot, gc, i_m0, i_n0);
+        tile_origin256(g, tile_of(i_tl), gc, i_m0, i_n0);
         stage_offsets256(oa, g.lda, i_m0, g.M - 1, wave, lane);
         stage_offsets256(ob, g.ldb, i_n0, g.N - 1, wave, lane);
     }
@@ -729,7 +811,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         ++i_st;
         if (++i_kt == nk) {
             i_kt = 0; ++i_tl;
-            tile_origin256(g, range_lo + slot + i_tl * per_xcd, gc, i_m0, i_n0);
+            tile_origin256(g, tile_of(i_tl), gc, i_m0, i_n0);
             const int ln = fresh_lane();
             stage_offsets256(oa, g.lda, i_m0, g.M - 1, wave, ln);
             stage_offsets256(ob, g.ldb, i_n0, g.N - 1, wave, ln);
@@ -745,11 +827,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int kt = 0, tl = 0, m0, n0;
+    int kt = SK ? u0 % nk : 0, tl = SK ? u0 / nk : 0, m0, n0;
+    int seg_k0 = kt;  // stream-K: the K stage the current piece began at
+    int fin_tl[2] = {-1, -1}, fin_first[2] = {0, 0}, fin_n[2] = {0, 0};  // tiles (at most two) this block arrived last at
     int young_stores = 0;
     bool trace_next = false;
     f32x4 bias4[4];  // register-path epilogue only
-    tile_origin256(g, range_lo + slot, gc, m0, n0);
+    tile_origin256(g, tile_of(tl), gc, m0, n0);
     const int arow = wm * 128 + (lane & 15), brow = wn * 64 + (lane & 15), gq = lane >> 4;
     // fragment registers: two A half-sets (4 MFMA row-tiles each) and two B sets, refilled while the matrix pipe
     // works on the other one
@@ -846,7 +930,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                 if (g.sa_rows) epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, le, patch, g.sb[0], g.sa);
                 else epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, le, patch, g.sa[0] * g.sb[0]);
                 kt = 0; ++tl;
-                tile_origin256(g, range_lo + slot + tl * per_xcd, gc, m0, n0);
+                tile_origin256(g, tile_of(tl), gc, m0, n0);
                 if (more) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (frag_rd) bQ[j] = LDQ(nxt + 32768, brow + j * 16);
@@ -929,7 +1013,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         const bool do_issue = i_st < total_st && !(TVTS_LOOP_ABL & 1);
         if (do_issue && ((ABL & 32768) == 0 || wave < 4)) issue();
         // register-path epilogue: the next tile's first fragments are read behind the epilogue instead of across it (32 registers)
-        const bool defer_frag = (ABL & (1024 | 8192)) != 0 && kt + 1 == nk;
+        const bool defer_frag = ((ABL & (1024 | 8192)) != 0 && kt + 1 == nk) || (SK && (kt + 1 == nk || st + 1 == total_st));
         if (st + 1 < total_st && !defer_frag) {
             LOAD_B(bF[0], nxt, 0);
             LOAD_A(aF[0], nxt, 0, 0);
@@ -938,7 +1022,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
         MFMA16(aF[1], bF[1], 1);
         SB();
         if (do_issue && (ABL & 32768) != 0 && wave >= 4) issue();
-        if (++kt == nk) {
+        ++kt;
+        bool run_epi = kt == nk;
+        if constexpr (SK) {
+            // a piece ends with its tile or with the block's stage range; one that does not cover the tile's whole K leaves as a
+            // partial -- the block that arrives last at a tile notes it and finishes it behind the loop
+            const bool seg_end = kt == nk || st + 1 == total_st;
+            if (seg_end && (seg_k0 != 0 || kt != nk)) {
+                run_epi = false;
+                const int U = range_n * nk;
+                const int first = sk_owner(U, per_xcd, nk, g.sk_tol, tl * nk), last = sk_owner(U, per_xcd, nk, g.sk_tol, (tl + 1) * nk - 1);
+                if (sk_publish(g, acc, tile_of(tl), last - first + 1, seg_k0 == 0, wave, lane, (int*)(smem + 131072))) {
+                    if (seg_k0 != 0) { fin_tl[0] = tl; fin_first[0] = first; fin_n[0] = last - first + 1; }
+                    else { fin_tl[1] = tl; fin_first[1] = first; fin_n[1] = last - first + 1; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                kt = 0; ++tl;
+                tile_origin256(g, tile_of(tl), gc, m0, n0);
+                if (st + 1 < total_st) {
+                    LOAD_B(bF[0], nxt, 0);
+                    LOAD_A(aF[0], nxt, 0, 0);
+                }
+            }
+            if (seg_end) seg_k0 = 0;
+        }
+        if (run_epi) {
             if constexpr ((ABL & 2048) != 0) {  // experiment library: per-tile time stamps of wave 0 (g.sa carries the trace buffer)
                 if (wave == 0 && lane == 0 && tl < 32) {
                     unsigned long long* tr = (unsigned long long*)g.sa + ((size_t)blockIdx.x * 32 + tl) * 6;
@@ -975,11 +1086,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                 young_stores = full ? (per_slab >= 4 ? 32 : 16) : 0;
             }
             kt = 0; ++tl;
-            tile_origin256(g, range_lo + slot + tl * per_xcd, gc, m0, n0);
-            if ((ABL & (1024 | 8192)) != 0 && st + 1 < total_st) {
+            tile_origin256(g, tile_of(tl), gc, m0, n0);
+            if (((ABL & (1024 | 8192)) != 0 || SK) && st + 1 < total_st) {
                 LOAD_B(bF[0], nxt, 0);
                 LOAD_A(aF[0], nxt, 0, 0);
             }
+        }
+    }
+    if constexpr (SK) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            if (fin_tl[w] < 0) continue;  // block-uniform
+            if (threadIdx.x == 0) g.sk_cnt[tile_of(fin_tl[w])] = 0;  // every piece has arrived: zero again for the next launch
+            sk_gather(g, acc, fin_first[w], fin_n[w], xcd, wave, lane);
+            tile_origin256(g, tile_of(fin_tl[w]), gc, m0, n0);
+            epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, 1.0f);
         }
     }
 #undef SB

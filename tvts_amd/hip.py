@@ -48,7 +48,7 @@ def _ld(t: torch.Tensor) -> int:
 # the call (include/tvts_hip.h, TVTS_GEMM_* / TVTS_TN_* / TVTS_ATTN_*).  Tests and benches that want a whole engine step on an
 # alternative path wrap it in `with hip.options(nt_tile=256): ...`; the defaults below are what every call uses otherwise.
 # The one product use: `nt_cus` -- the CU reservation of the persistent GEMM grid when world > 1 (tvts_amd/dist.py).
-_DEFAULTS = dict(nt_tile=0, nt_cus=0, fp8_k32=False, tn_tile=0, tn_splits=0, tn_early_dma=None, tn_a_fast=None,
+_DEFAULTS = dict(nt_tile=0, nt_cus=0, nt_streamk=None, tn_streamk=None, fp8_k32=False, tn_tile=0, tn_splits=0, tn_early_dma=None, tn_a_fast=None,
                  attn_tr=True, attn_shared=True, attn_fused=True, attn_ablate=0)
 _OPTS = dict(_DEFAULTS)
 
@@ -85,11 +85,16 @@ def _tile_bits(t):
     return {0: 0, None: 0, 128: 1, 256: 2}[t]
 
 
-def nt_opts(tile=None, cus=None, fp8_k32=None):
+def _sk_bits(sk):
+    return 0 if sk is None else (32 if sk else 64)  # TVTS_GEMM_STREAMK / TVTS_GEMM_NO_STREAMK
+
+
+def nt_opts(tile=None, cus=None, fp8_k32=None, streamk=None):
     tile = _OPTS["nt_tile"] if tile is None else tile
     cus = _OPTS["nt_cus"] if cus is None else cus
     k32 = _OPTS["fp8_k32"] if fp8_k32 is None else fp8_k32
-    return _tile_bits(tile) | (4 if k32 else 0) | (((int(cus) // 8) & 63) << 8)
+    streamk = _OPTS["nt_streamk"] if streamk is None else streamk
+    return _tile_bits(tile) | (4 if k32 else 0) | (((int(cus) // 8) & 63) << 8) | _sk_bits(streamk)
 
 
 def tn_opts(tile=None, splits=None, early_dma=None, a_fast=None):
@@ -121,9 +126,23 @@ def gemm_tn_select(M, Na, Nb, tile=None):
     return _lib.load().tvts_gemm_tn_select(M, Na, Nb, tn_opts(tile=tile))
 
 
-def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None, tile=None, cus=None):
-    """out[M,N] = [act'(gate_h) *] act(a[M,K] @ b[N,K]^T + bias) [+ residual]; a, b bf16; out bf16 or fp32."""
+NT_WORKSPACE = None  # scratch of the stream-K walk of gemm_nt (arrival counters + fp32 partial tiles), one per process = one stream
+
+
+def _nt_workspace(dev):
+    """zeroed once: every launch leaves the arrival counters at zero again (include/tvts_hip.h)"""
+    global NT_WORKSPACE
+    if NT_WORKSPACE is None or NT_WORKSPACE.device != dev:
+        NT_WORKSPACE = torch.zeros(_lib.load().tvts_gemm_nt_workspace_bytes(), dtype=torch.uint8, device=dev)
+    return NT_WORKSPACE
+
+
+def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None, tile=None, cus=None,
+            streamk=None, workspace=True):
+    """out[M,N] = [act'(gate_h) *] act(a[M,K] @ b[N,K]^T + bias) [+ residual]; a, b bf16; out bf16 or fp32.
+    streamk: None = the entry point's own choice, True / False force / forbid the stream-K walk (needs the workspace)."""
     lib = _lib.load()
+    ws = _nt_workspace(a.device) if workspace else None
     M = a.shape[0] if M is None else M
     N, K = b.shape
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape[1] == K
@@ -138,7 +157,8 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
                                _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
                                _ld(preact) if preact is not None else 0, _p(gate_h),
                                _ld(gate_h) if gate_h is not None else 0, ACT[gate_act], _p(out), _ld(out),
-                               1 if out.dtype == torch.float32 else 0, nt_opts(tile, cus), _stream())
+                               1 if out.dtype == torch.float32 else 0, _p(ws), ws.numel() if ws is not None else 0,
+                               nt_opts(tile, cus, streamk=streamk), _stream())
     _chk(rc, "tvts_gemm_nt_bf16")
     if GEMM_PROFILE is not None:
         ev1.record()
