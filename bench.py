@@ -193,6 +193,8 @@ def main():
                     "1-2 (default since round 3: bf16; profiles/r03_bf16_streams_ab.txt)")
     ap.add_argument("--bf16-residual", action="store_true", help="also carry the residual stream itself in bf16 (opt-in: +5 %% throughput, "
                     "but the |d loss| <= 1e-2 gate of SURVEY 8d fails on one small configuration; profiles/r03_bf16_streams_ab.txt)")
+    ap.add_argument("--wgrad-stream", choices=("auto", "on", "off"), default="auto", help="weight gradients of the ViT blocks on a side "
+                    "stream beside the input-gradient chain (auto = off: measured slower, profiles/r04_wgrad_side_stream.txt)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
@@ -249,6 +251,8 @@ def main():
         a["bf16_grad_stream"] = False
     if args.bf16_residual:
         a["bf16_residual"] = True
+    if args.wgrad_stream != "auto":
+        a["wgrad_stream"] = args.wgrad_stream == "on"
     margs = types.SimpleNamespace(local_rank=local_rank, rank=rank, world_size=world)
     v1 = a.get("family") == "v1"
     if v1:

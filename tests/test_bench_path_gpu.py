@@ -360,6 +360,54 @@ def test_every_gradient_is_bit_reproducible(K, lib, arch_name, B, T, flags):
         assert (l1, l2) == (l1b, l2b)
 
 
+@pytest.mark.parametrize("arch_name,B,T", [("B_16", 12, 8), ("B_32", 24, 8), ("H_14", 2, 16)])
+def test_wgrad_side_stream_gives_the_same_bits(K, lib, arch_name, B, T):
+    """The reference's own per-GPU batches (v2/configs/dist-yt-web-pt-vit-b-16.json:21 = 12, ...b-32.json:21 = 24, ...h-14.json:21 = 2):
+    the weight gradients of the ViT blocks launched on the engine's side stream (arch["wgrad_stream"], the automatic choice at these
+    sizes) leave the same bits in every gradient as the single-stream backward -- the same kernels write the same tensors, only
+    beside the input-gradient chain instead of inside it -- eagerly and through a captured hipGraph."""
+    from tvts_amd import arch as A
+    from tvts_amd.data_loader import synth_batch
+    from tvts_amd.model._common import TVTSv2Base
+    res = {}
+    for side in (False, True):
+        a = dict(A.ARCHS[arch_name], wgrad_stream=side)
+        a["num_frames"] = max(a["num_frames"], T)
+        m = TVTSv2Base(ARGS, arch=a, init_seed=0)
+        for name, p in m.named_parameters():
+            p.requires_grad = A.param_group_of(name, a) >= 0
+        _, _, run = _runner_of(m, a)
+        eng = m.engine
+        batch = synth_batch(a, B, T, seed=5, caption_len=32)
+        m._fresh_shadows(); m._sync_requires_grad()
+        pb = eng.prepare_batch(batch)
+        lab = batch["label"].reshape(-1).to(torch.int32).to(DEV)
+
+        def grads():
+            m.store.grad.zero_()
+            eng.embeds_ready = run.gather.start
+            try:
+                te, ve, pred = eng.forward(pb)
+            finally:
+                eng.embeds_ready = None
+            l1, l2, dte, dve, dpred = run.losses_and_grads(pb, te, ve, pred, lab)
+            eng.backward(dte, dve, dpred)
+            return l1, l2
+        grads(); grads()
+        torch.cuda.synchronize()
+        eager = m.store.grad.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            grads()
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(eager, m.store.grad), f"captured backward differs from the eager one (side stream {side})"
+        res[side] = eager
+        del g, m
+    assert float(res[True].abs().max()) > 0 and torch.equal(res[False], res[True])
+
+
 # ------------------------------------------------------------------------------------------------ (c) hipGraph replay
 def _runner(a, P, lr_mul=1.0):
     from tvts_amd import arch as A

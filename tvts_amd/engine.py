@@ -191,6 +191,19 @@ class Engine:
         #     is not the default.
         self.bf16_residual = bool(a.get("bf16_residual", False)) and a.get("family") != "v1"
         self.bf16_grad_stream = bool(a.get("bf16_grad_stream", True)) or self.bf16_residual
+        # Weight gradients of the space-time blocks on a SIDE STREAM (round 4).  dW = dY^T X depends on dY only, not on the
+        # input-gradient chain that continues from dY, so the weight-gradient kernels can run beside the chain's NT GEMMs,
+        # attention and LayerNorm backwards.  At the reference's own per-GPU batches (12 / 24 pairs: 111 ... 444 output tiles
+        # for 256 persistent blocks) the chain leaves a third to a half of the CUs idle; the side stream's kernels fill them.
+        # MEASURED (profiles/r04_wgrad_side_stream.txt) and NOT the default: the kernels do overlap in the replayed graph, but a
+        # weight-gradient block (64 KiB LDS, two per CU) and an NT block (160 KiB, the whole CU) cannot share a CU, so the pairs
+        # mostly take turns (NT 63 us + TN 50 us alone -> 112 us side by side), and every fork / join edge between the two
+        # streams costs the graph 5-15 us: 12 / 24 / 48 / 192 pairs run 667.9 / 933.4 / 1130 / 1325 pairs/s with it against
+        # 692.9 / 958.5 / 1154 / 1351 without.  arch["wgrad_stream"] = True switches it on (bit-identical gradients,
+        # tests/test_bench_path_gpu.py::test_wgrad_side_stream_gives_the_same_bits).
+        self.wgrad_stream = a.get("wgrad_stream", False)
+        self._wg_stream = None
+        self._wg_ws = None
         self.dev = store.device
         self.buf: Dict[str, torch.Tensor] = {}
         self.requires_grad = {name: True for name in store.shapes}
@@ -258,12 +271,32 @@ class Engine:
             return
         K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
 
-    def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, dy8=None, **epi):
+    def _wgrad_side(self, M) -> bool:
+        return bool(self.wgrad_stream)
+
+    def _side(self):
+        """(side stream, its own split-partial workspace): the weight-gradient kernels of one stream share one workspace, the two
+        streams never do"""
+        if self._wg_stream is None:
+            self._wg_stream = torch.cuda.Stream(device=self.dev)
+            self._wg_ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.dev)
+        return self._wg_stream, self._wg_ws
+
+    def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, dy8=None, side=False, **epi):
         """dW += dy^T a_in, db += colsum(dy) (if trainable); d_in = dy W (optional, with epilogue).  dy8: the e4m3 copy of dy
-        (bytes, per-token scales) when its producer already wrote one (_ln_bwd with fp8_for)."""
+        (bytes, per-token scales) when its producer already wrote one (_ln_bwd with fp8_for).  side: the weight gradient is
+        launched on the side stream behind everything the current stream has queued so far (dy is complete there); the caller
+        keeps dy and a_in untouched until it has joined the side stream."""
         want_b = bool(bname) and self.requires_grad[bname]
         if self.requires_grad[wname]:  # bias gradient (column sums of dy) rides along in the same kernel
-            K.gemm_tn(dy, a_in, self.P.g2d(wname), M=M, accumulate=True, colsum=self.P.g(bname) if want_b else None)
+            if side:
+                ws, scratch = self._side()
+                ws.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(ws):
+                    K.gemm_tn(dy, a_in, self.P.g2d(wname), M=M, accumulate=True, colsum=self.P.g(bname) if want_b else None,
+                              workspace=scratch)
+            else:
+                K.gemm_tn(dy, a_in, self.P.g2d(wname), M=M, accumulate=True, colsum=self.P.g(bname) if want_b else None)
         elif want_b:
             K.colsum(dy, self.P.g(bname), M=M)
         if d_in is not None:
@@ -554,33 +587,49 @@ class Engine:
                 self._ln_bwd(dlnc, B_[f"vit.x{a['layers']}"], "video_model.ln_post", "vit.lnpost", dx, res1=dx,
                              rows=self.ctx["vid_rows"])
             K.cast_f32_bf16(dx, dxb)
-        dh = self._b("vit.s.dh", (M, 4 * W))
         datt = self._b("vit.s.datt", (M, W))
-        dqkv = self._b("vit.s.dqkv", (M, 3 * W))
-        dsrb = self._b("vit.s.dsresb", (M, W))
         dsr = None if lowp else self._f("vit.s.dsres", (M, W))
-        dtrb = self._b("vit.s.dtresb", (M, W))
+        # the weight gradients of the blocks on the side stream: the output gradients they read (dh, dsrb, dqkv of the space and of
+        # the time branch, dtrb, and the block's own dxb) then live in buffers of the layer's parity, and the chain joins the side
+        # stream's work of layer l + 1 before layer l overwrites the first of them (its ln_3 backward writes the dxb that layer
+        # l + 1 read) -- the side stream may lag one layer behind, never two
+        side = self._wgrad_side(M)
+        side_done = {}
+        cur = torch.cuda.current_stream(self.dev)
         for l in reversed(range(a["layers"])):
             pre, tg = f"video_model.transformer.resblocks.{l}.", f"vit{l}"
             x_in = B_[f"vit.x{l}"]
+            par = str(l % 2) if side else ""
+            dh = self._b("vit.s.dh" + par, (M, 4 * W))
+            dsrb = self._b("vit.s.dsresb" + par, (M, W))
+            dtrb = self._b("vit.s.dtresb" + par, (M, W))
+            dqkv = self._b("vit.s.dqkv" + par, (M, 3 * W))
+            dqkv_t = self._b("vit.s.dqkv_t" + par, (M, 3 * W)) if side else dqkv
             # (e4m3 input gradients: the LayerNorm backward that produces an output gradient also writes its e4m3 copy, d*8)
-            self._lin_bwd(dxb, B_[tg + ".a"], pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dh, M, dy8=dxb8,
+            self._lin_bwd(dxb, B_[tg + ".a"], pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dh, M, dy8=dxb8, side=side,
                           gate_h=B_[tg + ".h"], gate_act=a["act"])
-            self._lin_bwd(dh, B_[tg + ".ln2"], pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", dln, M)
+            self._lin_bwd(dh, B_[tg + ".ln2"], pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", dln, M, side=side)
             dsrb8 = self._ln_bwd(dln, B_[tg + ".s_res"], pre + "ln_2", tg + ".ln2", dsr, dx_bf16=dsrb, res1=dxb if lowp else dx,
                                  fp8_for=pre + "attn.proj.weight")
             # spatial attention branch
-            self._lin_bwd(dsrb, B_[tg + ".att_s"], pre + "attn.proj.weight", pre + "attn.proj.bias", datt, M, dy8=dsrb8)
+            self._lin_bwd(dsrb, B_[tg + ".att_s"], pre + "attn.proj.weight", pre + "attn.proj.bias", datt, M, dy8=dsrb8, side=side)
             self._st_attention_bwd(B_[tg + ".qkv_s"], B_[tg + ".att_s"], datt, B_[tg + ".lse_s"], dqkv, "space", B, T, n, "vit.s")
-            self._lin_bwd(dqkv, B_[tg + ".ln1"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", dln, M)
+            self._lin_bwd(dqkv, B_[tg + ".ln1"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", dln, M, side=side)
             # the time-residual gradient is a side branch (t_res only feeds ln_1): it lives in bf16 only -- as the operand of
             # the timeattn.proj GEMMs and as the bf16 residual term of the ln_3 backward
             dtrb8 = self._ln_bwd(dln, B_[tg + ".t_res"], pre + "ln_1", tg + ".ln1", None, dx_bf16=dtrb,
                                  fp8_for=pre + "timeattn.proj.weight")
             # temporal attention branch
-            self._lin_bwd(dtrb, B_[tg + ".att_t"], pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", datt, M, dy8=dtrb8)
-            self._st_attention_bwd(B_[tg + ".qkv_t"], B_[tg + ".att_t"], datt, B_[tg + ".lse_t"], dqkv, "time", B, T, n, "vit.s")
-            self._lin_bwd(dqkv, B_[tg + ".ln3"], pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", dln, M)
+            self._lin_bwd(dtrb, B_[tg + ".att_t"], pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", datt, M, dy8=dtrb8,
+                          side=side)
+            self._st_attention_bwd(B_[tg + ".qkv_t"], B_[tg + ".att_t"], datt, B_[tg + ".lse_t"], dqkv_t, "time", B, T, n, "vit.s")
+            self._lin_bwd(dqkv_t, B_[tg + ".ln3"], pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", dln, M, side=side)
+            if side:
+                side_done[l] = torch.cuda.Event()
+                side_done[l].record(self._wg_stream)
+                if l + 1 in side_done:  # layer l + 1's weight gradients are final: its dxb may be overwritten, its range may travel
+                    cur.wait_event(side_done.pop(l + 1))
+                    self._ready(f"video_model.transformer.resblocks.{l + 1}.")
             nx = "B" if (a["layers"] - l) % 2 == 1 else "A"
             dxbi = self._b("vit.dxb" + nx, (M, W))
             dxi = None if lowp else self._f("vit.dx" + nx, (M, W))
@@ -588,7 +637,11 @@ class Engine:
             dxb8 = self._ln_bwd(dln, x_in, pre + "ln_3", tg + ".ln3", dxi, dx_bf16=dxbi, res1=dsrb if lowp else dsr, res2=dtrb,
                                 fp8_for=f"video_model.transformer.resblocks.{l - 1}.mlp.c_proj.weight" if l > 0 else None)
             dx, dxb = dxi, dxbi
-            self._ready(pre)
+            if not side:
+                self._ready(pre)
+        if side:
+            cur.wait_stream(self._wg_stream)
+            self._ready("video_model.transformer.resblocks.0.")
         dtok = self._f("vit.dtok", (M, W))
         self._ln_bwd(dxb if lowp else dx, B_["vit.tok"], "video_model.ln_pre", "vit.lnpre", dtok)
         dpatch = self._b("vit.dpatch", (Mp, W))

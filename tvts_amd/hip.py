@@ -268,7 +268,8 @@ def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True, 
     lib = _lib.load()
     M = p.shape[0] if M is None else M
     assert p.dtype == torch.bfloat16 and q.dtype == torch.bfloat16 and out.dtype == torch.float32
-    ws = _tn_workspace(p.device) if workspace else None
+    # workspace: True = this process's shared scratch (one stream), a float32 tensor = the caller's (a second stream's own), False = none
+    ws = workspace if isinstance(workspace, torch.Tensor) else (_tn_workspace(p.device) if workspace else None)
     if GEMM_PROFILE is not None:
         ev0, ev1 = Event(), Event()
         ev0.record()
