@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 4: e4m3 forward GEMMs in the ViT blocks")
     ap.add_argument("--fp8-dgrad", action="store_true", help="... and e4m3 input-gradient GEMMs (output gradient one scale per token, "
                     "transposed e4m3 weight copies); the weight gradients stay bf16")
+    ap.add_argument("--bf16-grad-stream", action="store_true", help="carry the GRADIENT of the ViT blocks' residual stream in bf16 (round 3's "
+                    "default: +1 %% throughput, 2.4x the error of the embedding-side gradients; opt-in since round 4)")
     ap.add_argument("--fp32-streams", action="store_true", help="carry the gradient of the ViT blocks' residual stream in fp32 as in rounds "
                     "1-2 (default since round 3: bf16; profiles/r03_bf16_streams_ab.txt)")
     ap.add_argument("--bf16-residual", action="store_true", help="also carry the residual stream itself in bf16 (opt-in: +5 %% throughput, "
@@ -249,6 +251,8 @@ def main():
         a["sort_used_rows_only"] = False
     if args.fp32_streams:
         a["bf16_grad_stream"] = False
+    if args.bf16_grad_stream:
+        a["bf16_grad_stream"] = True
     if args.bf16_residual:
         a["bf16_residual"] = True
     if args.wgrad_stream != "auto":

@@ -1,7 +1,7 @@
 // BENCH-ONLY experiment library (libtvts_exp.so): variants of the production 256x256 NT kernel, instantiated from the
 // production header so that A/B timings compare like with like.  Nothing under tvts_amd/*.py loads this library;
-// tools/gemm_ab.py does.  A variant that wins moves into gemm_nt256.h / gemm.hip; one that does not stays here (or is deleted).
-#include "../gemm_nt256.h"
+// experiments/gemm_ab.py does.  A variant that wins moves into gemm_nt256.h / gemm.hip; one that does not stays here (or is deleted).
+#include "gemm_nt256.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 

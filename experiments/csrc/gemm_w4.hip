@@ -1,10 +1,10 @@
 // EXPERIMENT (bench only, never loaded by the product): the 256x256 NT tile with FOUR waves -- one per SIMD, wave tile 128x128,
 // 256 accumulator registers (AGPRs) + two fragment sets -- instead of the production kernel's eight waves of 128x64.  Two thirds of
 // the LDS fragment bytes per MFMA, no second wave on the SIMD to hide a wave's own waits behind: what hipcc makes of a single
-// instruction stream per SIMD decides it.  K loop only (plain bf16 stores, no fused epilogue): tools/gemm_w4.py times it against
+// instruction stream per SIMD decides it.  K loop only (plain bf16 stores, no fused epilogue): experiments/gemm_w4.py times it against
 // the production kernel on long contractions.
-#include "../common.h"
-#include "../gemm_nt256.h"
+#include "common.h"
+#include "gemm_nt256.h"
 
 struct StageOff4 { unsigned off[8]; };
 __device__ __forceinline__ void stage_offsets4(StageOff4& o, int ld, int row0, int row_max, int wave, int lane) {

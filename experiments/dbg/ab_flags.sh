@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of compile-time variants of the GEMM kernels on ONE box: rebuilds libtvts_hip.so with each extra -D flag set and runs a command.
-# usage: tools/dbg/ab_flags.sh '<command>' "" "-DTVTS_NT_SD=163840" ...      (the first, empty, set is the production build)
+# usage: experiments/dbg/ab_flags.sh '<command>' "" "-DTVTS_NT_SD=163840" ...      (the first, empty, set is the production build)
 cmd="$1"; shift
 cd $GRAFT_REPO_ROOT/tvts_amd/csrc
 for fl in "$@"; do

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which parameter gradients differ between two identical steps of a bench configuration (param groups as in training; dev tool, GPU).
-   python tools/dbg/bench_repro.py ARCH PAIRS FRAMES [fp8|fp8-dgrad|bf16-residual ...]"""
+   python experiments/dbg/bench_repro.py ARCH PAIRS FRAMES [fp8|fp8-dgrad|bf16-residual ...]"""
 import os
 import sys
 import types

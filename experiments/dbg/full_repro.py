@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which parameter gradients differ between two identical full-size engine steps (dev tool, GPU).  python tools/dbg/full_repro.py [PAIRS=192]"""
+"""Which parameter gradients differ between two identical full-size engine steps (dev tool, GPU).  python experiments/dbg/full_repro.py [PAIRS=192]"""
 import os
 import sys
 import types

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU idle gaps between consecutive kernels of eager bench steps (where the host falls behind the GPU).  usage: tools/dbg/gaps.sh [bench args]
+# GPU idle gaps between consecutive kernels of eager bench steps (where the host falls behind the GPU).  usage: experiments/dbg/gaps.sh [bench args]
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_gaps
 rm -rf $out; mkdir -p $out

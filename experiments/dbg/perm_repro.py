@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Does a sample's forward depend on its position in the batch?  (dev tool, GPU)  python tools/dbg/perm_repro.py [PAIRS=192]"""
+"""Does a sample's forward depend on its position in the batch?  (dev tool, GPU)  python experiments/dbg/perm_repro.py [PAIRS=192]"""
 import os
 import sys
 import types

@@ -1,6 +1,6 @@
 #!/bin/bash
 # timing variants of the 256x256 TN kernel: rebuilds libtvts_hip.so on the GPU box with extra -D flags and times the big shapes
-# usage: tools/dbg/tn_abl.sh "-DTN_ABL=1" "-DTN_EARLY_BARRIER=1" ...
+# usage: experiments/dbg/tn_abl.sh "-DTN_ABL=1" "-DTN_EARLY_BARRIER=1" ...
 cd $GRAFT_REPO_ROOT/tvts_amd/csrc
 for fl in "" "$@"; do
   touch gemm.hip

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of NT GEMM kernel variants from the bench-only experiment library (tvts_amd/csrc/exp -> libtvts_exp.so) against the
+"""A/B of NT GEMM kernel variants from the bench-only experiment library (experiments/csrc -> libtvts_exp.so) against the
 production kernel on the B/16 step's shapes: interleaved rounds in one process, medians (dev tool, GPU only).
 
-    python tools/gemm_ab.py [PAIRS=192] [ROUNDS=7]
+    python experiments/gemm_ab.py [PAIRS=192] [ROUNDS=7]
 """
 import ctypes
 import os
@@ -14,7 +14,7 @@ import torch  # noqa: E402
 
 from tvts_amd import hip as K  # noqa: E402
 
-lib = ctypes.CDLL(os.path.join(ROOT, "tvts_amd", "libtvts_exp.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "experiments", "libtvts_exp.so"))
 vp, ci = ctypes.c_void_p, ctypes.c_int
 lib.tvts_exp_gemm_nt.argtypes = [ci, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, ci, vp, ci, ci, vp, ci, ci, vp]
 lib.tvts_exp_gemm_nt.restype = ci

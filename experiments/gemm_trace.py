@@ -2,7 +2,7 @@
 """Per-tile time stamps of the 256x256 NT kernel (experiment library, ABL & 2048): where a block's time goes -- main loop vs
 epilogue -- and how the blocks' epilogues are phased against each other (dev tool, GPU only).
 
-    python tools/gemm_trace.py [PAIRS=192]
+    python experiments/gemm_trace.py [PAIRS=192]
 """
 import ctypes
 import os

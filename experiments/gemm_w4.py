@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""EXPERIMENT: the four-wave (one per SIMD, 128x128 wave tile, AGPR accumulators) 256x256 NT kernel of tvts_amd/csrc/exp/gemm_w4.hip
+"""EXPERIMENT: the four-wave (one per SIMD, 128x128 wave tile, AGPR accumulators) 256x256 NT kernel of experiments/csrc/gemm_w4.hip
 against the production kernel (plain bf16 output both) and hipBLASLt.  Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC
--I include -shared tvts_amd/csrc/exp/gemm_w4.hip -o tvts_amd/libtvts_w4.so   (dev tool, GPU only; delete the .so afterwards)"""
+-I include -shared experiments/csrc/gemm_w4.hip -o tvts_amd/libtvts_w4.so   (dev tool, GPU only; delete the .so afterwards)"""
 import ctypes
 import os
 import sys
@@ -12,7 +12,7 @@ import torch  # noqa: E402
 
 from tvts_amd import hip as K  # noqa: E402
 
-lib = ctypes.CDLL(os.path.join(ROOT, "tvts_amd", "libtvts_w4.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "experiments", "libtvts_w4.so"))
 ci, vp = ctypes.c_int, ctypes.c_void_p
 lib.tvts_exp_gemm_w4.argtypes = [ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp]
 lib.tvts_exp_gemm_w4.restype = ci

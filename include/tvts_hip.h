@@ -106,8 +106,9 @@ int tvts_quant_fp8_rows(const void* x, long ld, int rows, int cols, void* out, l
  * sim_matrix model_dist..B_16.py:126): C[i,j] (+)= alpha * sum_k A[i*sai+k*sak] * B[k*sbk+j*sbj] + bias[j] */
 int tvts_gemm_small_f32(const float* A, long sai, long sak, const float* B, long sbk, long sbj, int M, int N, int K,
                         float alpha, const float* bias, float* C, long ldc, int accumulate, hipStream_t stream);
-/* bias gradient: out[n] += sum_m X[m,n] */
-int tvts_colsum_bf16(const void* X, int ld, int M, int N, float* out, hipStream_t stream);
+/* bias gradient: out[n] += sum_m X[m,n].  workspace (optional): partial sums of row ranges, added in range order (deterministic, and
+ * a grid over the rows as well as the columns); without it one block per 64 columns walks every row */
+int tvts_colsum_bf16(const void* X, int ld, int M, int N, float* out, float* workspace, long workspace_elems, hipStream_t stream);
 
 /* ---- LayerNorm (norm.hip): video_encoder_ViT_B_16.py:79-85 (eps 1e-5), sort_transformer.py:99 (eps 1e-6) */
 int tvts_layernorm_fwd(const void* x, int ldx, int x_bf16, const int* rows, const float* gamma, const float* beta, float eps, int M,

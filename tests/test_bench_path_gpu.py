@@ -228,7 +228,7 @@ def _step_against_oracle(lib, arch_name, B, T, big_tile):
     gn = gn ** 0.5
     worst.sort()
     assert abs(gn - gn_ref) < 0.01 * gn_ref, (gn, gn_ref, worst[:5])
-    assert worst[0][0] > 0.98, worst[:8]
+    assert worst[0][0] > 0.995, worst[:8]
 
 
 def _sub_batch(batch, idx, NT):
@@ -312,7 +312,7 @@ def test_full_size_step_properties(K, lib, arch_name, B, T, nsub):
 def test_every_gradient_is_bit_reproducible(K, lib, arch_name, B, T, flags):
     """Two identical steps (the training step's parameter groups, v1 with its dropout masks pinned) leave the same bits in EVERY
     parameter gradient and both losses: all reductions of the step are ordered sums -- none is a scatter of fp32 atomics whose
-    last-bit noise could, through Adam, flip a bf16 rounding of the next forward (tools/dbg/bench_repro.py runs
+    last-bit noise could, through Adam, flip a bf16 rounding of the next forward (experiments/dbg/bench_repro.py runs
     the same check at the bench's sizes)."""
     from tvts_amd import arch as A
     from tvts_amd.data_loader import synth_batch, synth_batch_v1
@@ -500,7 +500,7 @@ def test_graph_replayed_steps_match_eager_steps_and_the_oracle(K, lib):
     box.  The cause was not reordering noise but a BIFURCATION: the type-embedding gradient (one of the lr 1e-4 parameters) was a
     sum of fp32 atomics, its 1e-8 noise moved the type embedding's master weights by an ulp after the first Adam step, and in
     ~12 % of the runs that flipped one bf16 rounding in the next forward -- a discrete alternative trajectory, 7e-5 away in the
-    third loss (tools/dbg/step_repro2.py found it: 36 of 300 steps).  Since round 3 every reduction of the step has a fixed order
+    third loss (experiments/dbg/step_repro2.py found it: 36 of 300 steps).  Since round 3 every reduction of the step has a fixed order
     (loss scalars, bias gradients, CLS shares, LayerNorm sums, type / temporal / class embeddings and -- last -- the rows of the
     embedding tables): 300 of 300 repeated steps and graph replays end in the same losses bit for bit
     (profiles/r03_step_repro_spread_b16.txt).  Graph vs eager: losses, gradient norms and the parameters after three steps equal

@@ -67,7 +67,7 @@ def engine_step(m, batch):
     return float(loss1), (float(loss2) if loss2 is not None else 0.0), te.clone(), ve.clone(), pred, m.store
 
 
-def check_grads(store, grads, gn_tol=0.01, cos_tol=0.98):
+def check_grads(store, grads, gn_tol=0.01, cos_tol=0.995):
     tot_ref = sum(float(g.norm()) ** 2 for g in grads.values()) ** 0.5
     tot = 0.0
     worst = []
@@ -433,10 +433,10 @@ def test_b32_config1_against_reference_golden(gpu, golden):
           "g_temporal": ("video_model.temporal_embedding", (slice(None), slice(0, 16)))}
     for k, (name, idx) in sl.items():
         # slices of single gradient tensors against the reference's: the SURVEY 8d gate for a tensor is cosine >= 0.98, i.e. rel-L2
-        # <= 0.2; these slices are held to 0.12 (0.08 in round 2: the positional-embedding gradient sits behind ln_pre's cancellation
-        # at the END of the backward chain and measures up to 0.096 since the residual-stream gradient is carried in bf16 -- 0.04
-        # with the fp32 chain; profiles/r03_bf16_streams_ab.txt)
-        assert rel(store.g(name)[idx], torch.tensor(f[k])) < 0.12, (k, rel(store.g(name)[idx], torch.tensor(f[k])))
+        # <= 0.2; these slices are held to 0.08 (the positional-embedding gradient, behind ln_pre's cancellation at the END of the
+        # backward chain, measures 0.04 with the fp32 gradient chain -- the default again since round 4 -- and 0.096 with the opt-in
+        # bf16 gradient stream; profiles/r03_bf16_streams_ab.txt)
+        assert rel(store.g(name)[idx], torch.tensor(f[k])) < 0.08, (k, rel(store.g(name)[idx], torch.tensor(f[k])))
 
 
 def test_h14_full_size_against_reference_golden(gpu, golden):
@@ -637,38 +637,38 @@ def test_b16_config2_against_reference_golden(gpu, golden):
                            "g_head": ("pred_model.head.weight", (slice(None), slice(None))),
                            "g_pos": ("video_model.positional_embedding", (slice(None), slice(0, 16)))}.items():
         # slices of single gradient tensors against the reference's: the SURVEY 8d gate for a tensor is cosine >= 0.98, i.e. rel-L2
-        # <= 0.2; these slices are held to 0.12 (0.08 in round 2: the positional-embedding gradient sits behind ln_pre's cancellation
-        # at the END of the backward chain and measures up to 0.096 since the residual-stream gradient is carried in bf16 -- 0.04
-        # with the fp32 chain; profiles/r03_bf16_streams_ab.txt)
-        assert rel(store.g(name)[idx], torch.tensor(f[k])) < 0.12, (k, rel(store.g(name)[idx], torch.tensor(f[k])))
+        # <= 0.2; these slices are held to 0.08 (the positional-embedding gradient, behind ln_pre's cancellation at the END of the
+        # backward chain, measures 0.04 with the fp32 gradient chain -- the default again since round 4 -- and 0.096 with the opt-in
+        # bf16 gradient stream; profiles/r03_bf16_streams_ab.txt)
+        assert rel(store.g(name)[idx], torch.tensor(f[k])) < 0.08, (k, rel(store.g(name)[idx], torch.tensor(f[k])))
 
 
 @pytest.mark.parametrize("h14", [False, True])
 def test_residual_stream_precision_options(gpu, h14):
-    """Default since round 3: the residual stream of the space-time blocks in fp32, its GRADIENT in bf16 (bf16 res1 in the ln_2 /
-    ln_3 backward, no fp32 copy of the chain).  arch["bf16_grad_stream"] = False restores the fp32 chain of rounds 1-2;
+    """Default: the residual stream of the space-time blocks and its gradient in fp32.  arch["bf16_grad_stream"] = True (round 3's
+    default, opt-in since round 4) carries the GRADIENT in bf16 (bf16 res1 in the ln_2 / ln_3 backward, no fp32 copy of the chain);
     arch["bf16_residual"] = True (opt-in, bench.py --bf16-residual) also carries the forward stream in bf16 (bf16 residual added
     in the GEMM epilogues' gate slot, LayerNorms on bf16 rows).  All three hold the SURVEY 8d gradient gates against the oracle and
     differ from each other by bf16 roundings of the streams (two per block and direction)."""
     from tvts_amd import arch as A
     mk = (lambda **kw: A.small_arch_h(**kw)) if h14 else A.small_arch
-    m0, oarch, P = build(arch=mk(), seed=4)
+    m0, oarch, P = build(arch=mk(bf16_grad_stream=True), seed=4)
     batch = O.synth_batch(oarch, B=4, T=3, seed=6, caption_len=11)
     r1, r2, rte, rve, rpred, grads = oracle_step(P, batch, oarch)
     l1, l2, te, ve, pred, store0 = engine_step(m0, batch)
     assert m0.engine.bf16_grad_stream and not m0.engine.bf16_residual
     assert m0.engine.buf["vit.x1"].dtype == torch.float32 and "vit.s.dsres" not in m0.engine.buf
-    check_grads(store0, grads)
+    check_grads(store0, grads, cos_tol=0.99)   # the opt-in bf16 streams: measured >= 0.998 on B/16, gate one notch under the default's
     g0 = store0.grad.clone()
-    m2, _, _ = build(arch=mk(bf16_grad_stream=False), seed=4)       # both streams fp32 (rounds 1-2)
+    m2, _, _ = build(arch=mk(), seed=4)       # both streams fp32 (the default)
     j1, j2, te2, ve2, pred2, store2 = engine_step(m2, batch)
-    assert "vit.s.dsres" in m2.engine.buf
+    assert "vit.s.dsres" in m2.engine.buf and not m2.engine.bf16_grad_stream
     check_grads(store2, grads)
     assert torch.equal(ve2, ve) and torch.equal(te2, te) and j1 == l1 and j2 == l2   # same forward
     m1, _, _ = build(arch=mk(bf16_residual=True), seed=4)           # both streams bf16
     k1, k2, te1, ve1, pred1, store1 = engine_step(m1, batch)
     assert m1.engine.bf16_grad_stream and m1.engine.buf["vit.x1"].dtype == torch.bfloat16 and m1.engine.buf["vit0.s_res"].dtype == torch.bfloat16
-    check_grads(store1, grads)
+    check_grads(store1, grads, cos_tol=0.99)
     assert min_cos(ve1, rve) > 0.9995 and rel(ve1, rve) < 0.02 and abs(k1 - r1) < 2e-2 and abs(k2 - r2) < 1e-2
     assert min_cos(ve1, ve) > 0.9999 and not torch.equal(ve1, ve)
     for ga in (g0, store1.grad):

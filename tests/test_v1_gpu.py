@@ -206,7 +206,7 @@ def engine_step(m, batch):
     return float(loss1), (float(loss2) if loss2 is not None else 0.0), te.clone(), ve.clone(), pred
 
 
-def check_grads(store, grads, gn_tol=0.01, cos_tol=0.98):
+def check_grads(store, grads, gn_tol=0.01, cos_tol=0.995):
     tot_ref = sum(float(g.norm()) ** 2 for g in grads.values()) ** 0.5
     tot, worst = 0.0, []
     for k, g in grads.items():

@@ -883,36 +883,56 @@ extern "C" int tvts_gemm_small_f32(const float* A, long sai, long sak, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// bias gradient: out[n] += sum_m X[m,n]  (bf16 in).  A block owns 64 columns for ALL rows: 8 column threads (8 columns each)
-// x 32 row lanes striding the rows, merged through LDS in row-lane order -- no atomics, run-to-run reproducible.  (Only used
-// where a bias trains under a frozen weight; the trained layers get their bias gradient inside the weight-gradient kernel.)
+// bias gradient: out[n] += sum_m X[m,n]  (bf16 in).  A block owns 64 columns and one of gridDim.y row ranges: 8 column threads
+// (8 columns each) x 32 row lanes striding the range, merged through LDS in row-lane order.  With a workspace the row ranges'
+// sums go to partials [range][N] that colsum_ranges_kernel adds in range order -- no atomics, run-to-run reproducible, and
+// (rows / 4096) x (N / 64) blocks instead of N / 64 (12 blocks for a 768-wide bias at 150 k rows); without one a single range.
+// (Only used where a bias trains under a frozen weight; the trained layers get their bias gradient inside the weight-gradient kernel.)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, int ld, int M, int N,
-                                                     float* __restrict__ out) {
-    __shared__ float part[32][65];
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, int ld, int M, int N, int rows_per_range,
+                                                     float* __restrict__ out, float* __restrict__ part) {
+    __shared__ float lds[32][65];
     const int ct = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int col = blockIdx.x * 64 + ct * 8;
+    const int r0 = blockIdx.y * rows_per_range;
+    const int r1 = r0 + rows_per_range < M ? r0 + rows_per_range : M;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (col < N) {
-        for (int r = rl; r < M; r += 32) {
+        for (int r = r0 + rl; r < r1; r += 32) {
             const bf16x8 v = *(const bf16x8*)(X + (size_t)r * ld + col);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part[rl][ct * 8 + e] = s[e];
+    for (int e = 0; e < 8; ++e) lds[rl][ct * 8 + e] = s[e];
     __syncthreads();
-    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < N) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && n < N) {
         float t = 0.f;
-        for (int r = 0; r < 32; ++r) t += part[r][threadIdx.x];
-        out[blockIdx.x * 64 + threadIdx.x] += t;
+        for (int r = 0; r < 32; ++r) t += lds[r][threadIdx.x];
+        if (part) part[(size_t)blockIdx.y * N + n] = t;
+        else out[n] += t;
     }
 }
+__global__ __launch_bounds__(256) void colsum_ranges_kernel(const float* __restrict__ part, int ranges, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float t = out[n];
+    for (int y = 0; y < ranges; ++y) t += part[(size_t)y * N + n];
+    out[n] = t;
+}
 
-extern "C" int tvts_colsum_bf16(const void* X, int ld, int M, int N, float* out, hipStream_t stream) {
+extern "C" int tvts_colsum_bf16(const void* X, int ld, int M, int N, float* out, float* workspace, long workspace_elems,
+                                hipStream_t stream) {
     if (M <= 0 || N <= 0 || N % 8 || ld % 8) return TVTS_EINVAL;
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, stream, (const bf16*)X, ld, M, N, out);
+    int ranges = ceil_div(M, 4096);
+    if (ranges > 256) ranges = 256;
+    if (workspace == nullptr || (long)ranges * N > workspace_elems) ranges = 1;
+    const int rows = ceil_div(M, ranges);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), ranges), dim3(256), 0, stream, (const bf16*)X, ld, M, N, rows, out,
+                       ranges > 1 ? workspace : nullptr);
+    if (ranges > 1) hipLaunchKernelGGL(colsum_ranges_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, stream, workspace, ranges, N, out);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

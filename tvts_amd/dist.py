@@ -12,10 +12,9 @@
 
 Two transports, same semantics:
   ``native`` the C ABI of include/tvts_comm.h: RCCL calls on a side HIP stream the library owns, fork / join by events against
-             the compute stream, no host synchronisation anywhere in the step.  The DEFAULT whenever world > 1 on the RCCL
-             backend and libtvts_comm.so loads (``TVTS_COMM=torch`` switches it off);
-  ``torch``  torch.distributed collectives (backend nccl = RCCL on the GPUs, gloo on CPU tensors in the tests): the default at
-             world 1 and on non-RCCL backends, the fallback when the library cannot be loaded.
+             the compute stream, no host synchronisation anywhere in the step.  OPT-IN (``TVTS_COMM=native``) since round 4:
+             never run on more than one GPU, and its bring-up can hang instead of falling back (see transport());
+  ``torch``  torch.distributed collectives (backend nccl = RCCL on the GPUs, gloo on CPU tensors in the tests): the default.
 
 CU reservation (``TVTS_NT_CUS``, default none): the persistent 256x256 GEMM blocks fill a CU completely, so an RCCL kernel only
 gets CUs at a GEMM kernel boundary or on CUs the persistent grid leaves free.  tools/overlap_probe.py (profiles/r03_overlap_probe.txt)
@@ -150,49 +149,69 @@ class NativeComm:
 _TRANSPORT: Optional[str] = None
 
 
+_NT_CUS_APPLIED = False
+
+
+def _apply_cu_reservation():
+    """TVTS_NT_CUS (the persistent GEMM grid leaves CUs to the RCCL kernels): applied once, whenever the resolved transport is
+    native -- forced by TVTS_COMM=native or not"""
+    global _NT_CUS_APPLIED
+    if _NT_CUS_APPLIED:
+        return
+    _NT_CUS_APPLIED = True
+    cus = int(os.environ.get("TVTS_NT_CUS", "0"))
+    if cus:
+        from . import hip as K
+        K.set_default(nt_cus=cus)
+
+
 def transport() -> str:
-    """'native' or 'torch' (see the module docstring); decided once per process."""
+    """'native' or 'torch' (see the module docstring); decided once per process.
+
+    Round 4: the native transport is OPT-IN again (TVTS_COMM=native).  It has still never run on more than one MI355X, and its
+    bring-up is not hang-proof: if one rank fails inside communicator creation AFTER the id broadcast (ncclCommInitRank,
+    hipStreamCreate), the others are already blocked inside ncclCommInitRank / the self-test's collectives on the side stream
+    and never reach the agreement below -- a hang where the documented behaviour is a fallback.  Until it has run on real
+    multi-GPU hardware the default at every world size is torch.distributed (RCCL underneath on the nccl backend)."""
     global _TRANSPORT
-    t = os.environ.get("TVTS_COMM")
-    if t is not None:
-        if t not in ("torch", "native"):
-            raise ValueError(f"TVTS_COMM={t!r}: expected 'torch' or 'native'")
-        return t
-    if _TRANSPORT is None:
-        _TRANSPORT = "torch"
-        W, _ = world()
-        if W > 1 and torch.cuda.is_available() and dist.get_backend() == "nccl":
-            # Every rank must end up on the same transport: each stage (the library loads; the communicator comes up and a small
-            # all-reduce / all-gather with known answers is right) is followed by an agreement over torch.distributed, and one
-            # rank's failure sends all of them to the torch transport instead of leaving the others inside a collective.
-            def agree(ok: bool) -> bool:
-                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                return bool(flag.item())
-            err = None
+    if _TRANSPORT is not None:
+        return _TRANSPORT
+    t = os.environ.get("TVTS_COMM", "torch")
+    if t not in ("torch", "native"):
+        raise ValueError(f"TVTS_COMM={t!r}: expected 'torch' or 'native'")
+    _TRANSPORT = "torch"
+    W, _ = world()
+    if t == "native" and torch.cuda.is_available() and (W == 1 or dist.get_backend() == "nccl"):
+        # Every rank must end up on the same transport: each stage (the library loads; the communicator comes up and a small
+        # all-reduce / all-gather with known answers is right) is followed by an agreement over torch.distributed, and one
+        # rank's failure at those points sends all of them to the torch transport.
+        def agree(ok: bool) -> bool:
+            if W == 1:
+                return ok
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+        err = None
+        try:
+            from . import _lib
+            _lib.load_comm()
+        except Exception as e:  # the library is optional: torch.distributed carries the same exchange steps
+            err = e
+        if agree(err is None):
             try:
-                from . import _lib
-                _lib.load_comm()
-            except Exception as e:  # the library is optional: torch.distributed carries the same exchange steps
+                NativeComm.get().self_test()
+            except Exception as e:
                 err = e
             if agree(err is None):
-                try:
-                    NativeComm.get().self_test()
-                except Exception as e:
-                    err = e
-                if agree(err is None):
-                    _TRANSPORT = "native"
-                elif NativeComm._inst is not None:
-                    NativeComm._inst.close()
-            if _TRANSPORT != "native":
-                import warnings
-                why = f"{type(err).__name__}: {err}" if err is not None else "another rank failed"
-                warnings.warn(f"native transport (libtvts_comm.so) not usable ({why}); exchange steps go through torch.distributed")
-        if _TRANSPORT == "native":
-            cus = int(os.environ.get("TVTS_NT_CUS", "0"))
-            if cus:
-                from . import hip as K
-                K.set_default(nt_cus=cus)
+                _TRANSPORT = "native"
+            elif NativeComm._inst is not None:
+                NativeComm._inst.close()
+        if _TRANSPORT != "native":
+            import warnings
+            why = f"{type(err).__name__}: {err}" if err is not None else "another rank failed"
+            warnings.warn(f"native transport (libtvts_comm.so) not usable ({why}); exchange steps go through torch.distributed")
+    if _TRANSPORT == "native":
+        _apply_cu_reservation()
     return _TRANSPORT
 
 

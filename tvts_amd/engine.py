@@ -181,16 +181,17 @@ class Engine:
         # Precision of the space-time blocks' residual stream (round 3).  Every consumer but the residual adds themselves reads
         # these tensors as bf16 anyway (LayerNorm outputs and GEMM operands are bf16): fp32 buys exact accumulation along the
         # 12 / 32 blocks, at 2.1 GB per block of HBM traffic in the forward + saved activations and 1.4 GB in the backward chain
-        # (192 pairs).  Measured on B/16 against the fp32 oracle (tools/dbg/grad_margins.py, profiles/r03_bf16_streams_ab.txt):
-        #   gradient stream bf16 (DEFAULT, arch["bf16_grad_stream"]): +1.4 %; forward untouched; gradient norm -0.25 %, worst
-        #     tensor cosine 0.9983 (gates 1 % / 0.98) -- the embedding-side gradients behind ln_pre's cancellation carry 2.4x the
-        #     error of the fp32 chain (5.8 % rel-L2);
+        # (192 pairs).  Measured on B/16 against the fp32 oracle (experiments/dbg/grad_margins.py, profiles/r03_bf16_streams_ab.txt):
+        #   gradient stream bf16 (OPT-IN since round 4, arch["bf16_grad_stream"], bench.py --bf16-grad-stream; round 3 had it on):
+        #     +1.4 %; forward untouched; gradient norm -0.25 %, worst tensor cosine 0.9983 -- but the embedding-side gradients
+        #     behind ln_pre's cancellation carry 2.4x the error of the fp32 chain (5.8 % rel-L2 instead of 2.4 %), and the golden
+        #     gradient slices needed their gate widened from 0.08 to 0.12 to pass: parity is the first gate, 1 % is not worth it;
         #   residual stream bf16 as well (OPT-IN, arch["bf16_residual"], bench.py --bf16-residual): +5 % in total (1354-1372
         #     pairs/s); video embedding rel-L2 0.89 % (gate 2 %; 0.39 % in fp32), row cosine 0.99995 (gate 0.9995), but the
         #     |d loss| <= 1e-2 gate fails on one small 3-pair NT = 1 configuration (0.0155) -- parity is the first gate, so it
         #     is not the default.
         self.bf16_residual = bool(a.get("bf16_residual", False)) and a.get("family") != "v1"
-        self.bf16_grad_stream = bool(a.get("bf16_grad_stream", True)) or self.bf16_residual
+        self.bf16_grad_stream = bool(a.get("bf16_grad_stream", False)) or self.bf16_residual
         # Weight gradients of the space-time blocks on a SIDE STREAM (round 4).  dW = dY^T X depends on dY only, not on the
         # input-gradient chain that continues from dY, so the weight-gradient kernels can run beside the chain's NT GEMMs,
         # attention and LayerNorm backwards.  At the reference's own per-GPU batches (12 / 24 pairs: 111 ... 444 output tiles

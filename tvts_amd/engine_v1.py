@@ -39,10 +39,15 @@ class EngineV1(Engine):
         self.training = True                                   # the nn.Module wrapper mirrors its own .training flag here
         self.text_drop_p = float(self.arch.get("text_dropout", 0.1))
         # seed of the step's dropout masks (int64 device scalar = the bits of an unsigned 64-bit counter)
-        self.drop_seed = torch.tensor([int(self.arch.get("dropout_seed", 0x1234ABCD))], dtype=torch.int64, device=self.dev)
+        # every data-parallel rank draws its own masks, as the reference's ranks do (each seeds its own generator): the rank is mixed
+        # into the seed with an odd 64-bit constant.  The seed is trainer state: Trainer_TVTS saves it with the checkpoint.
+        from .dist import world
+        seed = (int(self.arch.get("dropout_seed", 0x1234ABCD)) + world()[1] * self.DROP_RANK_STRIDE) & ((1 << 64) - 1)
+        self.drop_seed = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device=self.dev)
         self._drop_active = 0.0
 
     DROP_STEP_STRIDE = 0x51ED270B7F4A7C15  # added to the seed (mod 2^64) once per training forward
+    DROP_RANK_STRIDE = 0x9E3779B97F4A7C15  # ... and once per rank below this one
 
     def _advance_drop_seed(self):
         """new masks for this step (a device op: a captured graph advances the seed on every replay)"""

@@ -294,7 +294,8 @@ def gemm_small(a, b, out, *, M, N, K, sa, sb, alpha=1.0, bias=None, accumulate=F
 def colsum(x, out, *, M=None):
     lib = _lib.load()
     M = x.shape[0] if M is None else M
-    _chk(lib.tvts_colsum_bf16(_p(x), _ld(x), M, x.shape[1], _p(out), _stream()), "tvts_colsum_bf16")
+    ws = _tn_workspace(x.device)
+    _chk(lib.tvts_colsum_bf16(_p(x), _ld(x), M, x.shape[1], _p(out), _p(ws), ws.numel(), _stream()), "tvts_colsum_bf16")
 
 
 def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=None, q8=None, row_scale=None):

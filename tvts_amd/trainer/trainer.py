@@ -51,6 +51,33 @@ class AllGather(AllGather_multi):
         return out
 
 
+class _Cycled:
+    """A loader that starts over (with a fresh iterator, i.e. a fresh shuffle) whenever it runs dry."""
+
+    def __init__(self, loader):
+        self.loader, self.it = loader, iter(loader)
+
+    def __next__(self):
+        for _ in range(2):
+            try:
+                return next(self.it)
+            except StopIteration:
+                self.it = iter(self.loader)
+        raise RuntimeError("empty data loader")
+
+
+def _lockstep(loaders, len_epoch):
+    """One list of batches (one per loader, in loader order) per loop iteration.  The first loader whose length is the epoch
+    length paces the epoch and is iterated exactly once; every other loader is cycled beside it (v2/trainer/trainer.py:438-461:
+    the YT-Temporal loader drives, the WebVid / CC3M loaders restart as often as needed)."""
+    pace = next((i for i, dl in enumerate(loaders) if len(dl) == len_epoch), None)
+    if pace is None:
+        raise ValueError(f"no data loader has the epoch length {len_epoch}")
+    others = {i: _Cycled(dl) for i, dl in enumerate(loaders) if i != pace}
+    for lead_batch in loaders[pace]:
+        yield [lead_batch if i == pace else next(others[i]) for i in range(len(loaders))]
+
+
 class _TrainerBase(Multi_BaseTrainer_dist):
     TRUNCATE = True
     CACHE_CAPTIONS = True
@@ -119,23 +146,7 @@ class _TrainerBase(Multi_BaseTrainer_dist):
         for loader in self.data_loader:
             if hasattr(loader, "train_sampler") and loader.train_sampler is not None:
                 loader.train_sampler.set_epoch(epoch)
-        iter_dl = [None] * len(self.data_loader)
-        loop_dl, loop_dl_idx = None, 0
-        for dl_idx, dl in enumerate(self.data_loader):
-            if loop_dl is None and len(dl) == self.len_epoch:
-                loop_dl, loop_dl_idx = dl, dl_idx
-            else:
-                iter_dl[dl_idx] = iter(dl)
-        for batch_idx, loop_dl_data in enumerate(loop_dl):
-            data_li = [None] * len(self.data_loader)
-            for dl_idx in range(len(iter_dl)):
-                if dl_idx != loop_dl_idx:
-                    try:
-                        data_li[dl_idx] = next(iter_dl[dl_idx])
-                    except StopIteration:
-                        iter_dl[dl_idx] = iter(self.data_loader[dl_idx])
-                        data_li[dl_idx] = next(iter_dl[dl_idx])
-            data_li[loop_dl_idx] = loop_dl_data
+        for batch_idx, data_li in enumerate(_lockstep(self.data_loader, self.len_epoch)):
             for dl_idx, data in enumerate(data_li):
                 out = self.runner.step(self._tokenize(data))
                 log_now = batch_idx % self.log_step == 0 and self.args.local_rank == 0
@@ -215,17 +226,15 @@ class _TrainerBase(Multi_BaseTrainer_dist):
 
 
 def verbose(epoch, metrics, mode, name="TEST"):
-    """v2/trainer/trainer.py:942-947."""
-    r1, r5, r10, r50 = metrics["R1"], metrics["R5"], metrics["R10"], metrics["R50"]
-    msg = f"[{mode}]{name:s} epoch {epoch}, R@1: {r1:.1f}"
-    msg += f", R@5: {r5:.1f}, R@10: {r10:.1f}, R@50: {r50:.1f}"
-    msg += f", MedR: {metrics['MedR']:g}, MeanR: {metrics['MeanR']:.1f}"
-    print(msg)
+    """The one-line retrieval summary the reference prints per loader and metric (v2/trainer/trainer.py:942-947): same text."""
+    recalls = ", ".join(f"R@{k}: {metrics['R%d' % k]:.1f}" for k in (1, 5, 10, 50))
+    print(f"[{mode}]{name:s} epoch {epoch}, {recalls}, MedR: {metrics['MedR']:g}, MeanR: {metrics['MeanR']:.1f}")
 
 
 def format_nested_metrics_for_writer(metrics, mode, name="TEST"):
-    """v2/trainer/trainer.py:950-955."""
-    return {f"[{mode}]{name}_{key}": val for key, val in metrics.items()}
+    """Scalar names of the writer: ``[<metric fn>]<loader>_<statistic>`` (v2/trainer/trainer.py:950-955)."""
+    tag = f"[{mode}]{name}_"
+    return {tag + stat: value for stat, value in metrics.items()}
 
 
 class Trainer_TVTSv2_B_32(_TrainerBase):
@@ -256,6 +265,15 @@ class Trainer_TVTS(_TrainerBase):
         super().__init__(args, model, loss, metrics, optimizer, config, data_loader, valid_data_loader, lr_scheduler, len_epoch,
                          writer, visualizer, tokenizer, max_samples_per_epoch)
         self.base_lr = optimizer.state_dict()["param_groups"][0]["lr"]  # v1/base/base_trainer.py:30
+
+    # the dropout generator's state travels with the checkpoint: a resumed run draws the masks the uninterrupted run would have
+    def _extra_state(self):
+        eng = self.model.engine
+        return {"drop_seed": int(eng.drop_seed.item())} if hasattr(eng, "drop_seed") else None
+
+    def _load_extra_state(self, state):
+        if state and "drop_seed" in state and hasattr(self.model.engine, "drop_seed"):
+            self.model.engine.drop_seed.fill_(int(state["drop_seed"]))
 
     def _adjust_learning_rate(self, optimizer, epoch, args):
         lr = self.base_lr
