@@ -203,6 +203,24 @@ def synth_params(arch, seed: int = 0) -> Params:
     return out
 
 
+def synth_clip_state_dict(layout, seed: int = 0) -> Dict[str, Tensor]:
+    """A seeded stand-in for a pretrained CLIP / OpenCLIP state dict: one N(0, 0.02^2) tensor per (key, shape) of ``layout``,
+    drawn per key (independent of key order) like synth_params.  The constructor-initialisation fixtures
+    (tests/golden/ctor_init_*.npz, make_golden.py::gen_ctor_init) feed it to the REAL reference constructors; the tests feed the
+    same tensors to this package's constructor (v2/model/model_dist_TVTSv2_ViT_B_16.py:19-45, ..._H_14.py:44-83)."""
+    out: Dict[str, Tensor] = {}
+    for name, shape in layout.items():
+        g = torch.Generator().manual_seed(_key_seed(seed, "clip/" + name))
+        out[name] = 0.02 * torch.randn(tuple(int(x) for x in shape), generator=g, dtype=torch.float32)
+    return out
+
+
+def tensor_crc(t: Tensor) -> int:
+    """CRC-32 of a tensor's fp32 bytes: bit-identity check for the fixtures that cannot carry 10^8-element tensors"""
+    import zlib
+    return zlib.crc32(t.detach().to(torch.float32).contiguous().cpu().numpy().tobytes())
+
+
 def synth_batch(arch, B: int, T: int, seed: int = 0, n_trans: Optional[int] = None,
                 caption_len: int = 32) -> Dict[str, Tensor]:
     """Synthetic clip-caption batch in the reference's batch-dict contract."""

@@ -636,6 +636,82 @@ def gen_model_b16():
          batch_seed=1, B=2, T=4, gn_names=np.array(names), gn_vals=torch.stack(vals), **sel)
 
 
+def _ctor_fixture(name, model, clip_sd, consumed_keys):
+    """per-tensor record of a freshly constructed reference model: CRC-32 of the bytes, and what kind of value it holds"""
+    sd = model.state_dict()
+    names, crcs, kinds, means, stds = [], [], [], [], []
+    by_crc = {O.tensor_crc(v): k for k, v in clip_sd.items()}
+    for k, v in sd.items():
+        c = O.tensor_crc(v)
+        names.append(k); crcs.append(c)
+        v = v.float()
+        const = bool((v == v.flatten()[0]).all())
+        kinds.append(0 if c in by_crc else (1 if const else 2))  # 0 = a pretrained tensor, bit for bit; 1 = constant; 2 = random
+        means.append(float(v.mean())); stds.append(float(v.std()) if v.numel() > 1 else 0.0)
+    save(name, names=np.array(names), crc=np.array(crcs, dtype=np.uint64), kind=np.array(kinds), mean=np.array(means),
+         std=np.array(stds), const_value=np.array([float(sd[k].flatten()[0]) for k in names]),
+         clip_keys=np.array(list(clip_sd.keys())), clip_shapes=np.array([",".join(str(int(x)) for x in v.shape) for v in clip_sd.values()]),
+         consumed=np.array(sorted(consumed_keys)), seed=77)
+
+
+def gen_ctor_init():
+    """A13: what the REAL constructors leave in the state dict when load_checkpoint is empty.  The pretrained model is the
+    reference's own CLIP class (B/16, B/32) / OpenCLIP towers (H/14) holding O.synth_clip_state_dict(<its own state-dict layout>, 77)
+    -- the stand-in for CLIP/models/ViT-B-16.pt, which is not in the tree."""
+    ns = import_reference()
+    args = types.SimpleNamespace(local_rank=0, rank=0, world_size=1)
+    for tag, cls_mod, patch in (("b16", ns.m16.TVTSv2_B_16, 16), ("b32", ns.m32.TVTSv2_B_32, 32)):
+        holder = {}
+
+        def fake_load(path, device="cpu", _patch=patch, _holder=holder, **kw):
+            assert str(_patch) in path, path
+            m = ns.clip_model.CLIP(512, 224, 12, 768, _patch, 77, 49408, 512, 8, 12)
+            layout = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            sd = O.synth_clip_state_dict(layout, 77)
+            m.load_state_dict(sd, strict=True)
+            _holder["sd"] = sd
+            return m, None
+        sys.modules["CLIP.clip"].load = fake_load
+        model = cls_mod(args, load_checkpoint="")
+        sd = holder["sd"]
+        consumed = [k for k in sd if not k.startswith("visual.")] + [k for k in sd if k.startswith("visual.")]
+        _ctor_fixture("ctor_init_" + tag, model, sd, consumed)
+        del model
+    # H/14: OpenCLIP.create_model replaced by a factory that builds the reference's own OpenCLIP towers from ViT-H-14.json
+    import json
+    ns = import_reference_h14()
+    with open(os.path.join(REF, "OpenCLIP/model_configs/ViT-H-14.json")) as f:
+        cfg = json.load(f)
+    holder = {}
+
+    def create_model(name, pretrained=None, cache_dir=None, **kw):
+        assert name == "ViT-H-14" and pretrained == "laion2b_s32b_b79k" and cache_dir == "OpenCLIP/models"
+        t, v = cfg["text_cfg"], cfg["vision_cfg"]
+        text = ns.oc.TextTransformer(context_length=t["context_length"], vocab_size=t["vocab_size"], width=t["width"],
+                                     heads=t["heads"], layers=t["layers"], output_dim=cfg["embed_dim"],
+                                     act_layer=torch.nn.GELU, norm_layer=ns.oc.LayerNorm)
+        visual = ns.oc.VisionTransformer(image_size=v["image_size"], patch_size=v["patch_size"], width=v["width"], layers=v["layers"],
+                                         heads=v["width"] // v["head_width"], mlp_ratio=4.0, output_dim=cfg["embed_dim"],
+                                         act_layer=torch.nn.GELU, norm_layer=ns.oc.LayerNorm)
+        layout = {k: tuple(x.shape) for k, x in text.state_dict().items() if k != "attn_mask"}
+        layout.update({"visual." + k: tuple(x.shape) for k, x in visual.state_dict().items()})
+        sd = O.synth_clip_state_dict(layout, 77)
+        text.load_state_dict({k: x for k, x in sd.items() if not k.startswith("visual.")}, strict=False)
+        visual.load_state_dict({k[7:]: x for k, x in sd.items() if k.startswith("visual.")}, strict=True)
+        holder["sd"] = sd
+        return types.SimpleNamespace(transformer=text.transformer, token_embedding=text.token_embedding,
+                                     positional_embedding=text.positional_embedding, ln_final=text.ln_final,
+                                     text_projection=text.text_projection, attn_mask=text.attn_mask, visual=visual)
+    sys.modules["OpenCLIP"].create_model = create_model
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        model = ns.mh.TVTSv2_H_14(args, load_checkpoint="")
+    finally:
+        os.chdir(cwd)
+    _ctor_fixture("ctor_init_h14", model, holder["sd"], list(holder["sd"]))
+
+
 def gen_groups():
     """Name -> optimizer group, by executing the reference entrypoint's own grouping statements
     (train_dist_TVTSv2_ViT_B_16.py:66-107) on a module exposing the A13 parameter names."""
@@ -706,7 +782,7 @@ def gen_ddp2():
 
 
 GENS = {"block": gen_block, "vit": gen_vit, "text": gen_text, "sort": gen_sort, "model_tiny": gen_model_tiny,
-        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream, "transform": gen_transform, "transform_resize": gen_transform_resize, "tokenize": gen_tokenize, "downstream_more": gen_downstream_more, "model_b16": gen_model_b16}
+        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream, "transform": gen_transform, "transform_resize": gen_transform_resize, "tokenize": gen_tokenize, "downstream_more": gen_downstream_more, "model_b16": gen_model_b16, "ctor_init": gen_ctor_init}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -110,9 +110,20 @@ class TVTSv2Base(nn.Module):
     ENGINE = Engine
     INIT = staticmethod(reference_init_)
 
-    def __init__(self, args, load_checkpoint=None, arch=None, init_seed=0):
+    def __init__(self, args, load_checkpoint=None, arch=None, init_seed=0, pretrained=None):
+        """``args`` / ``load_checkpoint``: the reference's constructor (model_dist_TVTSv2_ViT_B_16.py:11-14).
+
+        ``pretrained`` -- what an empty ``load_checkpoint`` initialises from (ignored when a checkpoint is given, whose strict load
+        overwrites every tensor anyway):
+          None   the reference's behaviour for the named classes (TVTSv2_B_32 / B_16 / H_14): the pretrained CLIP / OpenCLIP model
+                 of the kept packages (model/clip_init.py), an error if it cannot be loaded -- never a silent random start;
+                 with an explicit ``arch`` dict (tests, benches, smoke) it means False;
+          False  the constructor's random initialisation only (reference_init_);
+          a mapping / a path: a CLIP-layout state dict (full model: ``visual.*``, ``transformer.*``, ``token_embedding.weight``, ...)."""
         super().__init__()
         self.args = args
+        if pretrained is None and (arch is not None or self.ARCH_NAME is None or ARCHS[self.ARCH_NAME].get("family") == "v1"):
+            pretrained = False
         self.arch = dict(arch if arch is not None else ARCHS[self.ARCH_NAME])
         self.num_clips = 4
         self.n_trans = self.arch["n_trans"]
@@ -120,6 +131,18 @@ class TVTSv2Base(nn.Module):
         self.store = ParamStore(self.arch, dev)
         self.engine = self.ENGINE(self.store)
         self.INIT(self.store, init_seed)
+        self.initialised_from = "random"
+        if load_checkpoint in ["", None] and pretrained is not False:
+            from . import clip_init
+            if pretrained is None:
+                sd = clip_init.load_reference_clip(self.arch)
+            elif isinstance(pretrained, (str, bytes)) or hasattr(pretrained, "__fspath__"):
+                sd = clip_init.load_clip_file(pretrained)
+            else:
+                sd = pretrained
+            clip_init.apply_clip_init_(self.store, sd)
+            self.initialised_from = "clip"
+            print("ViT initialized with {} weights.".format("OpenCLIP" if self.arch.get("block_order") == "openclip" else "CLIP"))
         self._register_tree()
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         self._versions = None
