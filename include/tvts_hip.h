@@ -69,9 +69,14 @@ int tvts_gemm_nt_select(int M, int N, int opts);
 /* weight gradient: out[Na,Nb] (+)= P[M,Na]^T . Q[M,Nb], bf16 in, fp32 out (autograd of the Linear sites above) */
 /* colsum (optional): colsum[a] += sum_m P[m,a] -- the bias gradient, fused into the same pass.
  * workspace (optional, workspace_elems floats): scratch for the split-M partials; with it the kernel stores
- * partials and a reduce pass combines them (deterministic), without it the partials meet through fp32 atomics. */
+ * partials that are combined in range order (deterministic), without it the partials meet through fp32 atomics.
+ * counters (optional, n_counters ints, ZERO on the first call and zero again after every call; one array per stream): with them
+ * and TVTS_GEMM_STREAMK in `opts` the block that arrives last at an output tile adds that tile's partials itself (same order, same
+ * bits as the separate reduce pass, one launch less -- and measured slower: the partials then travel at agent scope and one block
+ * sums them); otherwise a reduce pass follows the kernel. */
 int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb, float* out, int ldo,
-                      int accumulate, float* colsum, float* workspace, long workspace_elems, int opts, hipStream_t stream);
+                      int accumulate, float* colsum, float* workspace, long workspace_elems, int* counters, int n_counters,
+                      int opts, hipStream_t stream);
 /* the tile (128: 128x128 kernel, two blocks per CU; 256: pipelined 256x256 kernel) tvts_gemm_tn_bf16 picks for M rows into an
  * [Na, Nb] output under `opts` */
 int tvts_gemm_tn_select(int M, int Na, int Nb, int opts);

@@ -152,6 +152,36 @@ def test_gemm_tn_256_tile(K, M, Na, Nb):
         assert rel(out, ref) < 3e-5
 
 
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("M,Na,Nb", [(9420, 768, 768), (9420, 2304, 768), (18840, 768, 3072), (4097, 1280, 640), (40001, 768, 768), (3000, 248, 264)])
+def test_gemm_tn_fused_reduce_gives_the_bits_of_the_reduce_pass(K, M, Na, Nb, tile):
+    """The m-range partials of a weight gradient meet either in tn_reduce_kernel or -- fused, round 4 -- in the block that arrives
+    last at the output tile (agent-scope partial stores, an arrival counter per tile).  Both add the ranges in range order on top
+    of the output, so the results are the same bits: output (accumulating and not), bias gradient, launch after launch, at the
+    reference's per-GPU batches (M = 12 / 24 x 785) and on ragged shapes."""
+    p, q = bf(rnd(M, Na, seed=29)).to(DEV), bf(rnd(M, Nb, seed=30)).to(DEV)
+    base = rnd(Na, Nb, seed=31).to(DEV)
+    res = {}
+    for fused in (False, True):
+        with K.options(tn_tile=tile, tn_splits=5):
+            out = base.clone()
+            cs = torch.ones(Na, device=DEV)
+            K.gemm_tn(p, q, out, accumulate=True, colsum=cs, fused=fused)
+            out2 = torch.full((Na, Nb), float("nan"), dtype=torch.float32, device=DEV)
+            K.gemm_tn(p, q, out2, accumulate=False, fused=fused)
+            for _ in range(3):  # the counters are zero again after every launch
+                out3 = torch.full((Na, Nb), float("nan"), dtype=torch.float32, device=DEV)
+                K.gemm_tn(p, q, out3, accumulate=False, fused=fused)
+                assert torch.equal(out2, out3)
+        torch.cuda.synchronize()
+        res[fused] = (out, cs, out2)
+    ref = p.float().t().double() @ q.float().double()
+    assert rel(res[True][2], ref) < 3e-5
+    for x, y in zip(res[False], res[True]):
+        assert torch.equal(x, y)
+    assert int(K._tn_counters(K._tn_workspace(p.device)).abs().sum()) == 0
+
+
 def test_gemm_tn_tile_selection(K):
     """The plan of the weight-gradient entry point (a cost model of tile and range count, csrc/gemm.hip; tools/tn_plan_check.py
     measures it against both tiles' best): the long contractions of the 192-pair step take the 256x256 kernel -- the text tower's

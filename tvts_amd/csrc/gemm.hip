@@ -407,12 +407,92 @@ struct GemmTN {
                     // for several m-ranges WITHOUT a workspace -- the engine always passes one: bias gradients are
                     // run-to-run reproducible.)
     int splits;
+    int* cnt;        // fused reduce (round 4): one arrival counter per output tile, zero between launches; nullptr -> tn_reduce_kernel
+    int accumulate;  // fused reduce: out += sum of the partials (else out = ...)
 };
 // column-sum partial of (m-range split, column a): exactly one wave of one block owns it
 __device__ __forceinline__ void tn_colsum_out(const GemmTN& g, int split, int a, float v) {
-    if (g.cs_ws) g.cs_ws[(size_t)split * g.Na + a] = v;
+    if (g.cs_ws) {
+        if (g.cnt) __hip_atomic_store(g.cs_ws + (size_t)split * g.Na + a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: read by the last block
+        else g.cs_ws[(size_t)split * g.Na + a] = v;
+    }
     else if (g.splits == 1) g.colsum[a] += v;
     else atomicAdd(g.colsum + a, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused reduce of the split partials (round 4).  The m-range partials of a tile used to meet in a second launch
+// (tn_reduce_kernel: 88 launches of 8-19 us per step at the reference's 12 pairs per GPU, a twentieth of that step).  With a
+// counter array from the caller every block stores its partial with agent-scope (sc1) stores and counts itself in at its
+// tile; the block that arrives LAST adds the partials of all ranges IN RANGE ORDER on top of the output -- (out + p0) + p1 + ...,
+// the very expression of tn_reduce_kernel, so the two paths give the same bits whoever arrives last -- and the column sums of
+// the bias gradient likewise.  Nobody waits for anybody.  Taken while a tile's partials are small enough for one block to sum
+// (splits x tile bytes <= 1.5 MiB); many ranges of a big tile keep the parallel reduce pass.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void st_sc1(float* p, const f32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+template <int NI, int NJ>
+__device__ __forceinline__ void tn_fused_reduce(const GemmTN& g, f32x4 (&acc)[NI][NJ], int t, int split, int a_base, int b_base,
+                                                int lane, int* flag) {
+    const int ai = lane & 15, bq = (lane >> 4) * 4;
+    float* mine = g.ws + (size_t)split * g.Na * g.Nb;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int a = a_base + i * 16 + ai;
+        if (a >= g.Na) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int b = b_base + j * 16 + bq;
+            if (b < g.Nb) st_sc1(mine + (size_t)a * g.Nb + b, acc[i][j]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial (and the column-sum partial before it) has left: that is the release
+    __syncthreads();
+    if (threadIdx.x == 0) *(volatile int*)flag = __hip_atomic_fetch_add(g.cnt + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*(volatile int*)flag != g.splits - 1) return;
+    if (threadIdx.x == 0) g.cnt[t] = 0;  // every range has arrived: zero again for the next launch
+    const size_t plane = (size_t)g.Na * g.Nb;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int a = a_base + i * 16 + ai;
+        if (a >= g.Na) continue;  // (a whole row-tile of lanes sits out: no wait below depends on it)
+        f32x4 s[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int b = b_base + j * 16 + bq;
+            s[j] = (g.accumulate && b < g.Nb) ? *(const f32x4*)(g.out + (size_t)a * g.ldo + b) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int k = 0; k < g.splits; ++k) {
+            const float* p = g.ws + (size_t)k * plane + (size_t)a * g.Nb;
+            f32x4 v[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int b = b_base + j * 16 + bq;
+                v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (b < g.Nb) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[j]) : "v"(p + b) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                asm volatile("" : "+v"(v[j]));  // the value is only defined behind the wait
+                s[j] += v[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int b = b_base + j * 16 + bq;
+            if (b < g.Nb) *(f32x4*)(g.out + (size_t)a * g.ldo + b) = s[j];
+        }
+    }
+}
+// the bias gradient's share of the same: column a's sums of all ranges on top of colsum[a], in range order (called by the lanes
+// that wrote the partial of column a, in the block that arrived last)
+__device__ __forceinline__ void tn_fused_colsum(const GemmTN& g, int a) {
+    float s = g.colsum[a];
+    for (int k = 0; k < g.splits; ++k) s += __hip_atomic_load(g.cs_ws + (size_t)k * g.Na + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    g.colsum[a] = s;
 }
 
 __device__ __forceinline__ void stage_cols128(const bf16* __restrict__ base, int ld, int m0, int m_max, int c0,
@@ -575,6 +655,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
             if (a < g.Na) tn_colsum_out(g, split, a, cs[i][0]);
         }
     }
+    if (g.cnt) {  // fused reduce: partial + arrival; the last block of the tile sums the ranges in order
+        tn_fused_reduce<4, 4>(g, acc, t, split, a0 + wa * 64, b0 + wb * 64, lane, (int*)smem);
+        if (*(volatile int*)smem == g.splits - 1 && do_cs && g.cs_ws && lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int a = a0 + wa * 64 + i * 16 + lane;
+                if (a < g.Na) tn_fused_colsum(g, a);
+            }
+        }
+        return;
+    }
     // acc[i][j]: MFMA A-operand = Q (rows = b within tile j), B-operand = P (cols = a within tile i)
     // lane: col = a = l&15, rows = b = (l>>4)*4 + r  -> 4 consecutive b for one a: 16-B fp32 access
     float* obase = g.ws ? g.ws + (size_t)split * g.Na * g.Nb : g.out;
@@ -666,11 +757,11 @@ extern "C" int tvts_gemm_tn_select(int M, int Na, int Nb, int opts) { return tn_
 
 extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb,
                                  float* out, int ldo, int accumulate, float* colsum, float* workspace,
-                                 long workspace_elems, int opts, hipStream_t stream) {
+                                 long workspace_elems, int* counters, int n_counters, int opts, hipStream_t stream) {
     if (M <= 0 || Na <= 0 || Nb <= 0) return TVTS_EINVAL;
     if (Na % 8 || Nb % 8 || ldp % 8 || ldq % 8 || ldo % 4) return TVTS_EINVAL;
     GemmTN g;
-    g.ws = nullptr; g.cs_ws = nullptr; g.splits = 1; g.early_dma = 0; g.tiles_a = 0; g.a_fast = 0;
+    g.ws = nullptr; g.cs_ws = nullptr; g.splits = 1; g.early_dma = 0; g.tiles_a = 0; g.a_fast = 0; g.cnt = nullptr; g.accumulate = accumulate;
     g.P = (const bf16*)P; g.ldp = ldp; g.Q = (const bf16*)Q; g.ldq = ldq; g.M = M; g.Na = Na; g.Nb = Nb;
     g.out = out; g.ldo = ldo; g.colsum = colsum;
     const bool t256 = tn_use_256(M, Na, Nb, opts);
@@ -700,6 +791,15 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     if (use_ws && colsum != nullptr && (long)splits * Na * Nb + (long)splits * Na <= workspace_elems)
         g.cs_ws = workspace + (size_t)splits * Na * Nb;
     g.splits = splits;
+    // fused reduce: the last block of a tile sums its ranges -- only when the call asks for it (TVTS_GEMM_STREAMK).  Measured
+    // (profiles/r04_tn_fused_reduce.txt): the ranges of a tile live on different XCDs, so the partials must travel at agent scope
+    // (write-through stores, loads past the L2), and ONE block then reads splits x 64 KiB in dependent round trips where the
+    // reduce pass spreads the same bytes over 2 048 blocks: 613 / 876 / 1 287 pairs/s at 12 / 24 / 192 pairs with it against
+    // 693 / 958 / 1 332 with the separate pass.  Same bits either way (tests/test_kernels_gpu.py).
+    const bool fused = use_ws && counters != nullptr && g.tiles_ab <= n_counters && (opts & 32) && !(opts & 64) &&
+                       (colsum == nullptr || g.cs_ws != nullptr);
+    if ((opts & 32) && splits > 1 && !fused) return TVTS_EINVAL;
+    if (fused) g.cnt = counters;
     if (!use_ws && !accumulate && splits > 1) {
         hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)Nb * 4, Na, stream);
         if (e != hipSuccess) return (int)e;
@@ -716,7 +816,7 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
         if (e2 != hipSuccess) return (int)e2;
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(NTHREADS), 65536, stream, g);
     }
-    if (use_ws) {
+    if (use_ws && !fused) {
         const long n4 = (long)Na * Nb / 4;
         int rb = (int)((n4 + 255) / 256);
         if (rb > 2048) rb = 2048;

@@ -252,6 +252,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmTN g) {
             if (a + 16 < g.Na) tn_colsum_out(g, split, a + 16, cs1);
         }
     }
+    if (g.cnt) {  // fused reduce (gemm.hip): partial + arrival; the last block of the tile sums the ranges in order
+        tn_fused_reduce<8, 4>(g, acc, t, split, a0 + wa * 128, b0 + wb * 64, lane, (int*)smem);
+        if (*(volatile int*)smem == g.splits - 1 && do_cs && g.cs_ws && lane < 16) {
+            const int a = a0 + wa * 128 + 2 * wb * 16 + lane;
+            if (a < g.Na) tn_fused_colsum(g, a);
+            if (a + 16 < g.Na) tn_fused_colsum(g, a + 16);
+        }
+        return;
+    }
     // acc[i][j]: lane holds a = a-tile i column (lane & 15), b = b-tile j rows (lane >> 4) * 4 .. + 3 -> one 16-B fp32 access
     float* obase = g.ws ? g.ws + (size_t)split * g.Na * g.Nb : g.out;
     const int old_ = g.ws ? g.Nb : g.ldo;

@@ -97,12 +97,13 @@ def nt_opts(tile=None, cus=None, fp8_k32=None, streamk=None):
     return _tile_bits(tile) | (4 if k32 else 0) | (((int(cus) // 8) & 63) << 8) | _sk_bits(streamk)
 
 
-def tn_opts(tile=None, splits=None, early_dma=None, a_fast=None):
+def tn_opts(tile=None, splits=None, early_dma=None, a_fast=None, streamk=None):
+    streamk = _OPTS["tn_streamk"] if streamk is None else streamk
     tile = _OPTS["tn_tile"] if tile is None else tile
     splits = _OPTS["tn_splits"] if splits is None else splits
     early_dma = _OPTS["tn_early_dma"] if early_dma is None else early_dma
     a_fast = _OPTS["tn_a_fast"] if a_fast is None else a_fast
-    o = _tile_bits(tile) | (int(splits) << 8)
+    o = _tile_bits(tile) | (int(splits) << 8) | _sk_bits(streamk)
     if early_dma is not None and not early_dma:
         o |= 4
     if a_fast is not None:
@@ -263,19 +264,33 @@ def _tn_workspace(dev):
     return TN_WORKSPACE
 
 
-def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True, tile=None, splits=None, early_dma=None, a_fast=None):
-    """out[Na,Nb] (+)= p[M,Na]^T @ q[M,Nb]; p, q bf16; out fp32."""
+TN_COUNTERS = {}  # per workspace: zeroed arrival counters of the fused reduce (every launch leaves them at zero again)
+
+
+def _tn_counters(ws):
+    c = TN_COUNTERS.get(ws.data_ptr())
+    if c is None:
+        c = TN_COUNTERS[ws.data_ptr()] = torch.zeros(4096, dtype=torch.int32, device=ws.device)
+    return c
+
+
+def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True, tile=None, splits=None, early_dma=None, a_fast=None,
+            fused=None):
+    """out[Na,Nb] (+)= p[M,Na]^T @ q[M,Nb]; p, q bf16; out fp32.  fused: None = the entry point's choice, True / False force /
+    forbid the in-kernel reduce of the split partials (the last block of a tile adds them) against the separate reduce pass."""
     lib = _lib.load()
     M = p.shape[0] if M is None else M
     assert p.dtype == torch.bfloat16 and q.dtype == torch.bfloat16 and out.dtype == torch.float32
     # workspace: True = this process's shared scratch (one stream), a float32 tensor = the caller's (a second stream's own), False = none
     ws = workspace if isinstance(workspace, torch.Tensor) else (_tn_workspace(p.device) if workspace else None)
+    cnt = _tn_counters(ws) if ws is not None else None
     if GEMM_PROFILE is not None:
         ev0, ev1 = Event(), Event()
         ev0.record()
     rc = lib.tvts_gemm_tn_bf16(_p(p), _ld(p), _p(q), _ld(q), M, p.shape[1], q.shape[1], _p(out), _ld(out),
                                1 if accumulate else 0, _p(colsum), _p(ws), ws.numel() if ws is not None else 0,
-                               tn_opts(tile, splits, early_dma, a_fast), _stream())
+                               _p(cnt), cnt.numel() if cnt is not None else 0,
+                               tn_opts(tile, splits, early_dma, a_fast, fused), _stream())
     _chk(rc, "tvts_gemm_tn_bf16")
     if GEMM_PROFILE is not None:
         ev1.record()
