@@ -23,6 +23,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (measured 2495)
+PEAK_HBM_BPS = 8.0e12        # HBM3E peak, MI355X_MICROARCH.md
+ACHIEVABLE_HBM_BPS = 6.3e12  # what a streaming copy reaches on this part (same guide)
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 peak (MX-scaled K = 128 MFMA; the non-scaled 16x16x32 fp8 form issues at the bf16 rate)
 
 
@@ -345,6 +347,23 @@ def main():
     if not args.dense_sort_head and not v1:  # ... and the text tower's last block on the EOT row of every caption
         Wt_, L_ = a["text_width"], args.caption_len
         skipped += 3.0 * args.n_trans * (L_ - 1) * (18 * Wt_ * Wt_ + 4 * L_ * Wt_)
+    # proof of participation for a SCALE record: every rank adds 1 (and its device index) through the step's own transport path
+    ranks_seen, devices_seen = 1, [torch.cuda.current_device()]
+    if world > 1:
+        probe = torch.zeros(world + 1, dtype=torch.float32, device=dev)
+        probe[0] = 1.0
+        probe[1 + rank] = float(torch.cuda.current_device()) + 1.0
+        dist.all_reduce(probe)
+        ranks_seen = int(round(float(probe[0])))
+        devices_seen = [int(round(float(x))) - 1 for x in probe[1:].tolist()]
+    native_ok = None
+    if D.transport() == "native":
+        try:
+            nc = D.NativeComm.get()
+            nc.self_test()
+            native_ok = {"self_test": "ok", "comm_world": int(nc.W), "comm_rank": int(nc.rank)}
+        except Exception as e:
+            native_ok = {"self_test": f"failed: {type(e).__name__}: {e}"}
     pairs_per_s = world * B * args.steps / dt
     line = {
         "metric": "video-text pairs/sec/node, TVTSv2 pretrain step", "value": pairs_per_s, "unit": "pairs/s",
@@ -360,6 +379,7 @@ def main():
                    "last_blocks": "dense" if args.dense_sort_head else "sort head / text tower last block on the rows the model reads (NT transcript rows / EOT row)",
                    "final_loss": loss,
                    "exchange": {"transport": D.transport() + (f" ({backend})" if world > 1 else ""),
+                                "ranks_seen": ranks_seen, "devices_seen": devices_seen, "native": native_ok,
                                 "grad_payload": runner.sync.payload, "grad_bytes_per_step": runner.sync.bytes_sent}},
         "step_mfma_frac": pairs_per_s * (fwd + bwd - skipped) / (world * PEAK_BF16_TFLOPS * 1e12),
     }
@@ -370,12 +390,14 @@ def main():
         # contains the all-gather / all-reduce of the data-parallel path); rank 0 records.
         if rank == 0:
             K.GEMM_PROFILE = []
+            K.HBM_PROFILE = []
         one_step(0, device_step=False)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
     if rank == 0 and not args.no_roofline:
         recs, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+        hrecs, K.HBM_PROFILE = K.HBM_PROFILE, None
         tot_ms = sum(r[2].elapsed_ms(r[3]) for r in recs)
         tot_fl = sum(r[1] for r in recs)
         by = {}
@@ -408,6 +430,21 @@ def main():
                                               "peak": PEAK_FP8_TFLOPS if k.endswith("fp8") else PEAK_BF16_TFLOPS,
                                               "frac": v[1] / (v[2] * 1e-3) / 1e12 / (PEAK_FP8_TFLOPS if k.endswith("fp8") else PEAK_BF16_TFLOPS)}
                                           for k, v in by.items()}}
+        # the HBM-bound families of the same instrumented step (LayerNorm, attention, AdamW, weight transposes): algorithmic bytes
+        # of every launch (each operand and result once) over its HIP-event duration, against the 8 TB/s peak of
+        # MI355X_MICROARCH.md and against the ~6.3 TB/s a streaming kernel reaches on this part
+        fam = {}
+        for name, nbytes, e0, e1 in hrecs:
+            d = fam.setdefault(name, [0, 0.0, 0.0]); d[0] += 1; d[1] += nbytes; d[2] += e0.elapsed_ms(e1)
+        step_ms = 1e3 * dt / args.steps
+        line["roofline"]["hbm_kernels"] = {
+            k: {"launches": v[0], "ms": v[2], "share_of_step": v[2] / step_ms, "algorithmic_GB": v[1] / 1e9,
+                "GBps": v[1] / (v[2] * 1e-3) / 1e9 if v[2] > 0 else None,
+                "frac_of_peak_8TBps": v[1] / (v[2] * 1e-3) / PEAK_HBM_BPS if v[2] > 0 else None,
+                "frac_of_achievable_6.3TBps": v[1] / (v[2] * 1e-3) / ACHIEVABLE_HBM_BPS if v[2] > 0 else None}
+            for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])}
+        line["roofline"]["hbm_kernels_note"] = ("HIP events around every launch of one eager step; attention entries include their "
+                                                "CLS merge / delta / finalize kernels; small-row LayerNorms (text / sort-head rows) apart")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.arch, T, args.caption_len, pairs=args.cpu_pairs, max_seconds=args.cpu_seconds,
                                             n_trans=args.n_trans)

@@ -13,6 +13,32 @@ import torch
 from . import _lib
 
 GEMM_PROFILE = None  # bench.py: list collecting (kind, flops, start_event, end_event) per MFMA GEMM launch
+HBM_PROFILE = None   # bench.py: list collecting (family, algorithmic bytes, start_event, end_event) per HBM-bound launch
+
+
+class _hbm:
+    """Brackets one launch of an HBM-bound kernel family with HIP events on the launch stream while bench.py's instrumented step
+    collects them (HBM_PROFILE is a list); free otherwise.  nbytes = the ALGORITHMIC bytes of the launch: every operand and result
+    crossing HBM once."""
+
+    def __init__(self, family, nbytes):
+        self.family, self.nbytes = family, nbytes
+
+    def __enter__(self):
+        if HBM_PROFILE is not None:
+            self.e0, self.e1 = Event(), Event()
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if HBM_PROFILE is not None and exc[0] is None:
+            self.e1.record()
+            HBM_PROFILE.append((self.family, float(self.nbytes() if callable(self.nbytes) else self.nbytes), self.e0, self.e1))
+        return False
+
+
+def _nb(*tensors_rows):
+    """bytes of (tensor, rows) pairs: rows x row width x element size (None entries are skipped)"""
+    return sum(r * t.shape[-1] * t.element_size() for t, r in tensors_rows if t is not None)
 
 ACT = {"none": 0, None: 0, "quick_gelu": 1, "gelu": 2, "add": 3}  # "add": gate slot only (bf16 residual added to the result)
 MODE = {"full": 0, "space": 1, "time": 2, "cls": 3}
@@ -317,14 +343,17 @@ def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=Non
     """q8 (uint8 [M, W]) + row_scale (float32 [>= M]): also write the bf16 output as e4m3 bytes with one scale per row."""
     lib = _lib.load()
     M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
+    fam = "ln_fwd" if M >= 4096 else "ln_fwd_small"
     if q8 is not None:
         assert y.dtype == torch.bfloat16 and q8.dtype == torch.uint8 and row_scale.dtype == torch.float32 and row_scale.numel() >= M
-        rc = lib.tvts_layernorm_fwd_fp8(_p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(rows), _p(gamma), _p(beta), eps, M,
-                                        x.shape[1], _p(y), _ld(y), _p(q8), q8.stride(0), _p(row_scale), _p(mean), _p(rstd), _stream())
+        with _hbm(fam, _nb((x, M), (y, M), (q8, M)) + 12 * M):
+            rc = lib.tvts_layernorm_fwd_fp8(_p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(rows), _p(gamma), _p(beta), eps, M,
+                                            x.shape[1], _p(y), _ld(y), _p(q8), q8.stride(0), _p(row_scale), _p(mean), _p(rstd), _stream())
         _chk(rc, "tvts_layernorm_fwd_fp8")
         return
-    rc = lib.tvts_layernorm_fwd(_p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(rows), _p(gamma), _p(beta), eps, M, x.shape[1], _p(y), _ld(y),
-                                1 if y.dtype == torch.float32 else 0, _p(mean), _p(rstd), _stream())
+    with _hbm(fam, _nb((x, M), (y, M)) + 8 * M):
+        rc = lib.tvts_layernorm_fwd(_p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(rows), _p(gamma), _p(beta), eps, M, x.shape[1], _p(y), _ld(y),
+                                    1 if y.dtype == torch.float32 else 0, _p(mean), _p(rstd), _stream())
     _chk(rc, "tvts_layernorm_fwd")
 
 
@@ -347,23 +376,27 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2
     ws = _ln_workspace(x.device) if (workspace and dgamma is not None) else None
     M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
     assert res2 is None or res2.dtype == torch.bfloat16
+    fam = "ln_bwd" if M >= 4096 else "ln_bwd_small"
+    nbytes = _nb((dy, M), (x, M), (res1, M), (res2, M), (dx, M), (dx_bf16, M), (q8, M)) + 8 * M
     if q8 is not None:
         assert rows is None and dx_bf16 is not None and dy.dtype == torch.bfloat16 and row_scale is not None and row_scale.numel() >= M
-        rc = lib.tvts_layernorm_bwd_fp8(_p(dy), _ld(dy), _p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(mean), _p(rstd),
+        with _hbm(fam, nbytes):
+            rc = lib.tvts_layernorm_bwd_fp8(_p(dy), _ld(dy), _p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(mean), _p(rstd),
                                         _p(gamma), _p(res1), 1 if (res1 is not None and res1.dtype == torch.bfloat16) else 0,
                                         _ld(res1) if res1 is not None else 0, _p(res2),
                                         _ld(res2) if res2 is not None else 0, M, x.shape[1], _p(dx), _ld(dx) if dx is not None else 0,
-                                        _p(dx_bf16), _ld(dx_bf16), _p(q8), q8.stride(0), _p(row_scale), _p(dgamma), _p(dbeta), _p(ws),
-                                        ws.numel() if ws is not None else 0, _stream())
+                                            _p(dx_bf16), _ld(dx_bf16), _p(q8), q8.stride(0), _p(row_scale), _p(dgamma), _p(dbeta), _p(ws),
+                                            ws.numel() if ws is not None else 0, _stream())
         _chk(rc, "tvts_layernorm_bwd_fp8")
         return
-    rc = lib.tvts_layernorm_bwd(_p(dy), _ld(dy), 1 if dy.dtype == torch.float32 else 0, _p(x), _ld(x),
+    with _hbm(fam, nbytes):
+        rc = lib.tvts_layernorm_bwd(_p(dy), _ld(dy), 1 if dy.dtype == torch.float32 else 0, _p(x), _ld(x),
                                 1 if x.dtype == torch.bfloat16 else 0, _p(rows),
                                 _p(mean), _p(rstd), _p(gamma), _p(res1), 1 if (res1 is not None and res1.dtype == torch.bfloat16) else 0,
                                 _ld(res1) if res1 is not None else 0, _p(res2),
                                 _ld(res2) if res2 is not None else 0, M, x.shape[1], _p(dx),
-                                _ld(dx) if dx is not None else 0, _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0,
-                                _p(dgamma), _p(dbeta), _p(ws), ws.numel() if ws is not None else 0, _stream())
+                                    _ld(dx) if dx is not None else 0, _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0,
+                                    _p(dgamma), _p(dbeta), _p(ws), ws.numel() if ws is not None else 0, _stream())
     _chk(rc, "tvts_layernorm_bwd")
 
 
@@ -377,8 +410,10 @@ def _attn_fn(lib, name, head_dim):
 
 def attn_fwd(mode, qkv, out, lse2, *, B, heads, S, T=0, n=0, causal=False, head_dim=64, **opt):
     lib = _lib.load()
-    rc = _attn_fn(lib, "fwd", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(out), _ld(out), _p(lse2),
-                           attn_opts(**opt), _stream())
+    M = B * S
+    with _hbm("attn_fwd_" + mode, _nb((qkv, M), (out, M)) + 8 * M * heads):
+        rc = _attn_fn(lib, "fwd", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(out), _ld(out), _p(lse2),
+                                            attn_opts(**opt), _stream())
     _chk(rc, "tvts_attn_fwd")
 
 
@@ -484,17 +519,21 @@ def attn_bwd_dkv(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, cau
 def attn_fwd_divided(mode, qkv, out, lse2, cls_ws, *, B, heads, S, T, n, head_dim=64, **opt):
     """Forward of one divided-attention site (patch rows + CLS row); cls_ws is fp32 scratch."""
     lib = _lib.load()
-    rc = _attn_fn(lib, "fwd_divided", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, _p(out), _ld(out), _p(lse2),
-                                                _p(cls_ws), cls_ws.numel(), attn_opts(**opt), _stream())
+    M = B * S
+    with _hbm("attn_fwd_" + mode, _nb((qkv, M), (out, M)) + 8 * M * heads):  # (launches its CLS merge kernel as well)
+        rc = _attn_fn(lib, "fwd_divided", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, _p(out), _ld(out), _p(lse2),
+                                                    _p(cls_ws), cls_ws.numel(), attn_opts(**opt), _stream())
     _chk(rc, "tvts_attn_fwd_divided")
 
 
 def attn_bwd(mode, qkv, dO, O, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None, head_dim=64, **opt):
     """Whole backward of one attention site into dqkv (delta / cls_acc are scratch)."""
     lib = _lib.load()
-    rc = _attn_fn(lib, "bwd", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO), _p(O),
-                                        _ld(O), _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc),
-                                        cls_acc.numel() if cls_acc is not None else 0, attn_opts(**opt), _stream())
+    M = B * S
+    with _hbm("attn_bwd_" + mode, _nb((qkv, M), (dO, M), (O, M), (dqkv, M)) + 8 * M * heads):  # (delta / CLS finalize kernels included)
+        rc = _attn_fn(lib, "bwd", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO), _p(O),
+                                            _ld(O), _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc),
+                                            cls_acc.numel() if cls_acc is not None else 0, attn_opts(**opt), _stream())
     _chk(rc, "tvts_attn_bwd")
 
 
@@ -686,9 +725,13 @@ def adamw_hf(p, g, m, v, shadow, chunk_group, lr4, wd4, step, beta1=0.9, beta2=0
     lib = _lib.load()
     lr = (ctypes.c_float * 4)(*lr4)
     wd = (ctypes.c_float * 4)(*wd4)
-    _chk(lib.tvts_adamw_hf(_p(p), _p(g), _p(m), _p(v), _p(shadow), _p(chunk_group), chunk_group.numel(),
+    # 30 B per element of every chunk that steps: p, m, v read + written (24), g read (4), bf16 shadow written (2)
+    with _hbm("adamw", lambda: 30.0 * 1024 * float((chunk_group >= 0).sum()) if chunk_group.dtype != torch.uint8
+              else 30.0 * 1024 * float((chunk_group < 255).sum())):
+        rc = (lib.tvts_adamw_hf(_p(p), _p(g), _p(m), _p(v), _p(shadow), _p(chunk_group), chunk_group.numel(),
                            ctypes.cast(lr, ctypes.c_void_p), ctypes.cast(wd, ctypes.c_void_p), step, _p(step_dev), _p(hyper_dev), beta1, beta2, eps,
-                           grad_scale, _stream()), "tvts_adamw_hf")
+                           grad_scale, _stream()))
+    _chk(rc, "tvts_adamw_hf")
 
 
 def cast_f32_bf16(src, dst):
@@ -716,7 +759,9 @@ def add_rows_f32(dst, src):
 
 def transpose_batched(src, dst, tiles, ntiles):
     lib = _lib.load()
-    _chk(lib.tvts_transpose_bf16_batched(_p(src), _p(dst), _p(tiles), ntiles, _stream()), "tvts_transpose_bf16_batched")
+    with _hbm("weight_transpose", 4.0 * dst.numel()):
+        rc = lib.tvts_transpose_bf16_batched(_p(src), _p(dst), _p(tiles), ntiles, _stream())
+    _chk(rc, "tvts_transpose_bf16_batched")
 
 
 def probe_tr16(inp, out):
