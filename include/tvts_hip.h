@@ -92,6 +92,13 @@ int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int 
 int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
                           int scale_a_rows, const float* scale_b, const float* bias, const void* gate_h, int ldh, int gate_act,
                           void* out, int ldc, int opts, hipStream_t stream);
+/* weight gradient of such a layer on e4m3 operands: out[Na,Nb] (+)= scale_p * scale_q * sum_m P8[m,Na] * Q8[m,Nb].  The contraction runs
+ * over the tokens, so the operands carry ONE scale per tensor (device scalars; tvts_quant_fp8 / tvts_quant_fp8_rows2 write such
+ * copies) -- not the per-token scales of the forward / input-gradient operands.  Na, Nb, ldp, ldq (bytes) multiples of 16.
+ * workspace: split-M partials, reduced in range order (deterministic).  The bias gradient is not part of it. */
+int tvts_gemm_tn_fp8(const void* P8, int ldp, const void* Q8, int ldq, int M, int Na, int Nb, const float* scale_p,
+                     const float* scale_q, float* out, int ldo, int accumulate, float* workspace, long workspace_elems,
+                     int opts, hipStream_t stream);
 /* (main loop of tvts_gemm_nt_fp8*: v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales, the fp8 issue rate of gfx950;
  * TVTS_GEMM_FP8_K32 selects the 16x16x32 fp8 form) */
 /* per-tensor fp8 quantisation: amax[0] = max |x| ; q = rne(x * 448 / amax) as e4m3, scale_out[0] = amax / 448 */

@@ -857,6 +857,39 @@ def test_gemm_nt_fp8(K, M, N, K_):
     assert rel(out, ref + res.cpu().double()) < 5e-5
 
 
+@pytest.mark.parametrize("M,Na,Nb", [(128, 256, 256), (1000, 512, 256), (4097, 1280, 640), (9420, 768, 2304), (58416 // 4, 1280, 5120), (333, 272, 48)])
+def test_gemm_tn_fp8(K, M, Na, Nb):
+    """e4m3 weight gradient (BASELINE config 5): out (+)= sp * sq * P8^T Q8 through ds_read_b64_tr_b8 fragments and the K = 128 scaled
+    MFMA -- exact products of the e4m3 values with fp32 accumulation, token ranges that end inside a 128-row stage, ragged tiles,
+    accumulate / overwrite, with and without the split workspace, and the same bits launch after launch."""
+    p, q = rnd(M, Na, seed=61), rnd(M, Nb, seed=62) * 0.5
+    p8, sp = K.quantize_fp8(p.to(DEV))
+    q8, sq = K.quantize_fp8(q.to(DEV))
+    pd, qd = p8.cpu().view(torch.float8_e4m3fn).float().double(), q8.cpu().view(torch.float8_e4m3fn).float().double()
+    ref = (pd.t() @ qd) * (float(sp) * float(sq))
+    out = torch.full((Na, Nb), float("nan"), dtype=torch.float32, device=DEV)
+    K.gemm_tn_fp8(p8, sp, q8, sq, out, accumulate=False)
+    assert rel(out, ref) < 5e-5, rel(out, ref)
+    assert rel(out, p.double().t() @ q.double()) < 0.06   # against the unquantised product: two e4m3 tensors' rounding
+    out2 = torch.full((Na, Nb), float("nan"), dtype=torch.float32, device=DEV)
+    K.gemm_tn_fp8(p8, sp, q8, sq, out2, accumulate=False)
+    assert torch.equal(out, out2)
+    base = rnd(Na, Nb, seed=63).to(DEV)
+    out3 = base.clone()
+    K.gemm_tn_fp8(p8, sp, q8, sq, out3, accumulate=True)
+    assert rel(out3, ref + base.cpu().double()) < 5e-5
+    out4 = base.clone()
+    K.gemm_tn_fp8(p8, sp, q8, sq, out4, accumulate=True, workspace=False)   # one range, read-modify-write epilogue
+    assert rel(out4, ref + base.cpu().double()) < 5e-5
+    K.gemm_tn_fp8(p8, sp, q8, sq, out4, accumulate=False, splits=3) if M >= 3072 else None
+    if M >= 3072:
+        assert rel(out4, ref) < 5e-5
+    # column slices of wider byte matrices (leading dimension != width)
+    if Na >= 512:
+        K.gemm_tn_fp8(p8[:, 256:512], sp, q8[:, :Nb // 2 // 16 * 16], sq, out[:256, :Nb // 2 // 16 * 16], accumulate=False)
+        assert rel(out[:256, :Nb // 2 // 16 * 16], ref[256:512, :Nb // 2 // 16 * 16]) < 5e-5
+
+
 def test_gemm_nt_fp8_main_loops_agree_and_grid_limit(K):
     """the K = 128 scaled-MFMA main loop and the 16x16x32 fp8 loop accumulate the same e4m3 products in fp32: identical bits on a
     shape with ragged row tiles, every epilogue form; a persistent grid limited to 64 CUs (TVTS_GEMM_CUS in the call's opts) changes

@@ -827,6 +827,56 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
     return TVTS_OK;
 }
 
+#include "gemm_tn8.h"
+
+// e4m3 weight gradient (include/tvts_hip.h): the 256x256 scaled-MFMA kernel of gemm_tn8.h over (m-range, tile) items, partials
+// through the caller's workspace + the ordered reduce pass like the bf16 entry point.  Na, Nb multiples of 16, ldp / ldq of 16 (bytes).
+extern "C" int tvts_gemm_tn_fp8(const void* P8, int ldp, const void* Q8, int ldq, int M, int Na, int Nb, const float* scale_p,
+                                const float* scale_q, float* out, int ldo, int accumulate, float* workspace, long workspace_elems,
+                                int opts, hipStream_t stream) {
+    if (M <= 0 || Na <= 0 || Nb <= 0 || !scale_p || !scale_q) return TVTS_EINVAL;
+    if (Na % 16 || Nb % 16 || ldp % 16 || ldq % 16 || ldo % 4) return TVTS_EINVAL;
+    if ((unsigned long long)M * (unsigned long long)(ldp > ldq ? ldp : ldq) >= (1ull << 32)) return TVTS_EINVAL;  // 32-bit DMA offsets
+    GemmTN8 g;
+    g.P = (const unsigned char*)P8; g.ldp = ldp; g.Q = (const unsigned char*)Q8; g.ldq = ldq; g.M = M; g.Na = Na; g.Nb = Nb;
+    g.out = out; g.ldo = ldo; g.sp = scale_p; g.sq = scale_q; g.accumulate = accumulate; g.ws = nullptr;
+    g.tiles_a = ceil_div(Na, 256); g.tiles_b = ceil_div(Nb, 256); g.tiles_ab = g.tiles_a * g.tiles_b;
+    g.a_fast = g.tiles_a < g.tiles_b ? 1 : 0;
+    // contraction ranges by the cost model of the bf16 entry point: rounds of the 256 CUs x stages per range x ~1.9 us per 128-row
+    // stage (tools/tn_fp8_bench.py) + 8 bytes per output element and range for the partials; ranges of at least 1 024 token rows
+    int splits = 1;
+    if ((opts >> 8) > 0) {
+        splits = opts >> 8;
+    } else {
+        double best = 1e30;
+        for (int sp = 1; sp <= 64; ++sp) {
+            if (sp > 1 && M / sp < 1024) break;
+            const double rounds = (double)ceil_div(g.tiles_ab * sp, 256);
+            const double t = rounds * ceil_div(ceil_div(M, sp), 128) * 1.9 + (sp > 1 ? sp * (double)Na * (double)Nb * 1e-6 + 6.0 : 0.0);
+            if (t < best) { best = t; splits = sp; }
+        }
+    }
+    if (workspace == nullptr) splits = 1;
+    else if ((long)splits * Na * Nb > workspace_elems) splits = (int)(workspace_elems / ((long)Na * Nb)) >= 2 ? (int)(workspace_elems / ((long)Na * Nb)) : 1;
+    g.m_per_split = ceil_div(ceil_div(M, splits), 128) * 128;
+    splits = ceil_div(M, g.m_per_split);
+    if (splits > 1) g.ws = workspace;
+    g.n_items = g.tiles_ab * splits;
+    const int grid = ceil_div(g.n_items, 8) * 8;
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gemm_tn8_kernel, dim3(grid), dim3(512), 131072, stream, g);
+    if (splits > 1) {
+        const long n4 = (long)Na * Nb / 4;
+        int rb = (int)((n4 + 255) / 256);
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(rb), dim3(256), 0, stream, workspace, splits, Na, Nb, out, ldo, accumulate,
+                           (const float*)nullptr, (float*)nullptr);
+    }
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // tiny strided fp32 matmul: C[i,j] (+)= alpha * sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj]  (16x16 LDS tiles)
 // ------------------------------------------------------------------------------------------------

@@ -323,6 +323,23 @@ def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True, 
         GEMM_PROFILE.append(("gemm_tn", 2.0 * M * p.shape[1] * q.shape[1], ev0, ev1, (M, p.shape[1], q.shape[1], "cs" if colsum is not None else "")))
 
 
+def gemm_tn_fp8(p8, sp, q8, sq, out, *, M=None, accumulate=True, workspace=True, splits=None):
+    """out[Na,Nb] (+)= sp * sq * p8[M,Na]^T @ q8[M,Nb]; p8 / q8 uint8 e4m3 bytes under one scale per tensor (float32[1] each)."""
+    lib = _lib.load()
+    M = p8.shape[0] if M is None else M
+    assert p8.dtype == torch.uint8 and q8.dtype == torch.uint8 and out.dtype == torch.float32 and sp.numel() == 1 and sq.numel() == 1
+    ws = workspace if isinstance(workspace, torch.Tensor) else (_tn_workspace(p8.device) if workspace else None)
+    if GEMM_PROFILE is not None:
+        ev0, ev1 = Event(), Event()
+        ev0.record()
+    rc = lib.tvts_gemm_tn_fp8(_p(p8), p8.stride(0), _p(q8), q8.stride(0), M, p8.shape[1], q8.shape[1], _p(sp), _p(sq), _p(out), _ld(out),
+                              1 if accumulate else 0, _p(ws), ws.numel() if ws is not None else 0, int(splits or 0) << 8, _stream())
+    _chk(rc, "tvts_gemm_tn_fp8")
+    if GEMM_PROFILE is not None:
+        ev1.record()
+        GEMM_PROFILE.append(("gemm_tn_fp8", 2.0 * M * p8.shape[1] * q8.shape[1], ev0, ev1, (M, p8.shape[1], q8.shape[1], "fp8")))
+
+
 def gemm_small(a, b, out, *, M, N, K, sa, sb, alpha=1.0, bias=None, accumulate=False):
     """out[i,j] (+)= alpha * sum_k a[i*sa[0]+k*sa[1]] * b[k*sb[0]+j*sb[1]] + bias[j] (fp32)."""
     lib = _lib.load()
