@@ -193,6 +193,8 @@ def main():
                     "transposed e4m3 weight copies); the weight gradients stay bf16")
     ap.add_argument("--bf16-grad-stream", action="store_true", help="carry the GRADIENT of the ViT blocks' residual stream in bf16 (round 3's "
                     "default: +1 %% throughput, 2.4x the error of the embedding-side gradients; opt-in since round 4)")
+    ap.add_argument("--fp8-wgrad", action="store_true", help="BASELINE config 5 in full: e4m3 weight gradients as well (implies --fp8-dgrad); every "
+                    "e4m3 operand copy under one delayed scale per tensor, tvts_gemm_tn_fp8")
     ap.add_argument("--fp32-streams", action="store_true", help="carry the gradient of the ViT blocks' residual stream in fp32 as in rounds "
                     "1-2 (default since round 3: bf16; profiles/r03_bf16_streams_ab.txt)")
     ap.add_argument("--bf16-residual", action="store_true", help="also carry the residual stream itself in bf16 (opt-in: +5 %% throughput, "
@@ -244,6 +246,9 @@ def main():
     a = dict(A.ARCHS[args.arch])
     if args.frames > a["num_frames"]:  # BASELINE config 3: 16-frame clips need a temporal table past the reference's 12 rows
         a["num_frames"] = args.frames
+    if args.fp8_wgrad:
+        args.fp8_dgrad = True
+        a["fp8_wgrad"] = True
     if args.fp8_dgrad:
         args.fp8 = True
         a["fp8_dgrad"] = True
@@ -369,7 +374,7 @@ def main():
         "metric": "video-text pairs/sec/node, TVTSv2 pretrain step", "value": pairs_per_s, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("fp8 e4m3 forward" + (" + input-gradient" if args.fp8_dgrad else "") + " GEMMs (ViT blocks, v_mfma_scale_f32_16x16x128_f8f6f4) + bf16") if args.fp8 else "bf16", "data": "synthetic",
+        "dtype": ("fp8 e4m3 forward" + (" + input-gradient" if args.fp8_dgrad else "") + (" + weight-gradient" if args.fp8_wgrad else "") + " GEMMs (ViT blocks, v_mfma_scale_f32_16x16x128_f8f6f4) + bf16") if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": (f"TVTS v1 ViT-B/16 tubelet 2, {T}-frame 224^2, mask {a['mask_ratio']}, DistilBERT, " if v1 else
                                 f"TVTSv2 ViT-{args.arch.replace('_', '/')} {T}-frame 224^2, mask {a['mask_ratio']}, ")
                                + f"{args.caption_len}-token captions x{args.n_trans}, full pretrain step (fwd+losses+bwd+HF-AdamW)",

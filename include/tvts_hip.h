@@ -95,10 +95,11 @@ int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int ldb, int M,
 /* weight gradient of such a layer on e4m3 operands: out[Na,Nb] (+)= scale_p * scale_q * sum_m P8[m,Na] * Q8[m,Nb].  The contraction runs
  * over the tokens, so the operands carry ONE scale per tensor (device scalars; tvts_quant_fp8 / tvts_quant_fp8_rows2 write such
  * copies) -- not the per-token scales of the forward / input-gradient operands.  Na, Nb, ldp, ldq (bytes) multiples of 16.
- * workspace: split-M partials, reduced in range order (deterministic).  The bias gradient is not part of it. */
+ * workspace: split-M partials, reduced in range order (deterministic).  colsum (optional): colsum[a] += scale_p * sum_m P8[m,a] --
+ * the bias gradient from the SAME e4m3 bytes the weight gradient is made of (a ones operand on the matrix pipe). */
 int tvts_gemm_tn_fp8(const void* P8, int ldp, const void* Q8, int ldq, int M, int Na, int Nb, const float* scale_p,
-                     const float* scale_q, float* out, int ldo, int accumulate, float* workspace, long workspace_elems,
-                     int opts, hipStream_t stream);
+                     const float* scale_q, float* out, int ldo, int accumulate, float* colsum, float* workspace,
+                     long workspace_elems, int opts, hipStream_t stream);
 /* (main loop of tvts_gemm_nt_fp8*: v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales, the fp8 issue rate of gfx950;
  * TVTS_GEMM_FP8_K32 selects the 16x16x32 fp8 form) */
 /* per-tensor fp8 quantisation: amax[0] = max |x| ; q = rne(x * 448 / amax) as e4m3, scale_out[0] = amax / 448 */
@@ -113,7 +114,14 @@ int tvts_quant_fp8_multi(const void* table, int n, hipStream_t stream);
 /* per-row (per-token) quantisation of a bf16 activation in one pass: row_scale[r] = amax(x[r,:]) / 448 (1 for an all-zero
  * row), out[r,:] = e4m3(x[r,:] / row_scale[r]); cols % 8 == 0 */
 int tvts_quant_fp8_rows(const void* x, long ld, int rows, int cols, void* out, long ldo, float* row_scale,
-                        hipStream_t stream);
+                        const float* tscale, float* amax_acc, hipStream_t stream);
+/* Per-tensor (delayed) scaling -- the form the e4m3 WEIGHT GRADIENT needs, whose contraction over the tokens cannot carry per-token
+ * scales: with tscale (device scalar) every row is quantised under that one scale instead of its own amax / 448 (row_scale may then be
+ * null), so the same bytes serve tvts_gemm_nt_fp8* (scale_a = tscale, scale_a_rows = 0) and tvts_gemm_tn_fp8; amax_acc (device scalar,
+ * optional, in either mode) receives max(amax_acc, max |x|) of the call.  tvts_fp8_update_scales turns a step's amax values into the
+ * next step's scales: scale[i] = amax[i] / 448 where amax[i] > 0, amax[i] = 0.  The same two arguments exist on the LayerNorm forms
+ * below. */
+int tvts_fp8_update_scales(float* amax, float* scale, int n, hipStream_t stream);
 /* strided fp32 matmul for the tiny products (text_projection model_dist..B_16.py:108, head sort_transformer.py:113,
  * sim_matrix model_dist..B_16.py:126): C[i,j] (+)= alpha * sum_k A[i*sai+k*sak] * B[k*sbk+j*sbj] + bias[j] */
 int tvts_gemm_small_f32(const float* A, long sai, long sak, const float* B, long sbk, long sbj, int M, int N, int K,
@@ -129,8 +137,8 @@ int tvts_layernorm_fwd(const void* x, int ldx, int x_bf16, const int* rows, cons
  * (row_scale[M] = amax(row) / 448): the fp8 operand of the GEMM that follows (BASELINE config 4), identical to
  * tvts_quant_fp8_rows run on y */
 int tvts_layernorm_fwd_fp8(const void* x, int ldx, int x_bf16, const int* rows, const float* gamma, const float* beta, float eps,
-                           int M, int W, void* y, int ldy, void* q8, int ldq, float* row_scale, float* mean, float* rstd,
-                           hipStream_t stream);
+                           int M, int W, void* y, int ldy, void* q8, int ldq, float* row_scale, const float* tscale, float* amax_acc,
+                           float* mean, float* rstd, hipStream_t stream);
 /* dx = LayerNorm backward (+ res1 + res2): res1 is the residual-stream gradient, fp32 or (res1_bf16 != 0, bf16 dy only) bf16 --
  * the space-time block's backward carries it in bf16, the precision its GEMM consumers read it in anyway; res2 a bf16 side branch */
 int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const void* x, int ldx, int x_bf16, const int* rows, const float* mean,
@@ -142,8 +150,8 @@ int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const void* x, int 
  * residual, or x bf16 without residuals */
 int tvts_layernorm_bwd_fp8(const void* dy, int lddy, const void* x, int ldx, int x_bf16, const float* mean, const float* rstd,
                            const float* gamma, const void* res1, int res1_bf16, int ldr, const void* res2_bf16, int ldr2, int M, int W, float* dx,
-                           int lddx, void* dx_bf16, int lddxb, void* q8, int ldq, float* row_scale, float* dgamma, float* dbeta,
-                           float* workspace, long workspace_elems, hipStream_t stream);
+                           int lddx, void* dx_bf16, int lddxb, void* q8, int ldq, float* row_scale, const float* tscale, float* amax_acc,
+                           float* dgamma, float* dbeta, float* workspace, long workspace_elems, hipStream_t stream);
 
 /* ---- attention (attention.hip), head dim 64, packed qkv [rows, 3*heads*64]:
  *      divided space-time attention video_encoder_ViT_B_16.py:11-15,38-76; causal text attention

@@ -881,6 +881,12 @@ def test_gemm_tn_fp8(K, M, Na, Nb):
     out4 = base.clone()
     K.gemm_tn_fp8(p8, sp, q8, sq, out4, accumulate=True, workspace=False)   # one range, read-modify-write epilogue
     assert rel(out4, ref + base.cpu().double()) < 5e-5
+    cs = torch.ones(Na, device=DEV)   # bias gradient from the same bytes: scale_p * column sums of the e4m3 values
+    K.gemm_tn_fp8(p8, sp, q8, sq, out2, accumulate=False, colsum=cs)
+    assert torch.equal(out, out2) and rel(cs, 1 + pd.sum(0) * float(sp)) < 2e-5, rel(cs, 1 + pd.sum(0) * float(sp))
+    cs2 = torch.ones(Na, device=DEV)
+    K.gemm_tn_fp8(p8, sp, q8, sq, out2, accumulate=False, colsum=cs2, workspace=False)
+    assert rel(cs2, 1 + pd.sum(0) * float(sp)) < 2e-5
     K.gemm_tn_fp8(p8, sp, q8, sq, out4, accumulate=False, splits=3) if M >= 3072 else None
     if M >= 3072:
         assert rel(out4, ref) < 5e-5
@@ -1042,6 +1048,31 @@ def test_fp8_multi_tensor_quantisation(K):
             deq = qt.cpu().view(torch.float8_e4m3fn).float() * float(s1)
             assert rel(deq, w.t().float()) < 0.05
     assert float(scal[3 * 3 + 1]) == 1.0 and int(qs[3].max()) == 0
+
+
+def test_fp8_tensor_scale_mode_of_the_quantising_kernels(K):
+    """Per-tensor (delayed) scaling: with `tscale` the row quantiser and the LayerNorm forms write every row under that one scale
+    (bit patterns of torch.float8_e4m3fn on x / tscale, saturating), `amax` receives the tensor's max |x|, and
+    tvts_fp8_update_scales turns maxima into scales."""
+    x = (rnd(1233, 1280, seed=57) * torch.linspace(0.01, 30.0, 1233)[:, None]).bfloat16()
+    ts = torch.tensor([0.05], device=DEV)
+    am = torch.zeros(1, device=DEV)
+    q, rs = K.quantize_fp8_rows(x.to(DEV), tscale=ts, amax=am)
+    assert rs is None and abs(float(am) - float(x.float().abs().max())) == 0.0
+    want = _e4m3(x.float() * (1.0 / torch.tensor(0.05, dtype=torch.float32)))
+    assert torch.equal(q.cpu().view(torch.uint8), want.view(torch.uint8))
+    # LayerNorm forward, tensor mode: same bytes as quantising its bf16 output under the scale
+    xx, g, b = rnd(300, 768, seed=58).to(DEV), (1 + 0.1 * rnd(768, seed=59)).to(DEV), (0.1 * rnd(768, seed=60)).to(DEV)
+    y = torch.empty(300, 768, dtype=torch.bfloat16, device=DEV)
+    q8 = torch.empty(300, 768, dtype=torch.uint8, device=DEV)
+    ts2, am2 = torch.tensor([0.02], device=DEV), torch.zeros(1, device=DEV)
+    K.layernorm_fwd(xx, g, b, 1e-5, y, q8=q8, tscale=ts2, amax=am2)
+    assert float(am2) == float(y.float().abs().max())
+    qq, _ = K.quantize_fp8_rows(y, tscale=ts2)
+    assert torch.equal(q8, qq)
+    amax, scale = torch.tensor([4.48, 0.0, 896.0], device=DEV), torch.tensor([1.0, 7.0, 1.0], device=DEV)
+    K.fp8_update_scales(amax, scale)
+    assert torch.allclose(scale.cpu(), torch.tensor([0.01, 7.0, 2.0])) and float(amax.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("rows,cols", [(300, 256), (1233, 1280), (77, 5120), (9, 5128), (5, 8)])

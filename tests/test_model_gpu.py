@@ -611,6 +611,49 @@ def test_fp8_dgrad_path(gpu, h14):
     assert not torch.equal(g0, g1)   # the e4m3 path did run
 
 
+@pytest.mark.parametrize("h14", [False, True])
+def test_fp8_wgrad_path(gpu, h14):
+    """arch["fp8_wgrad"] (BASELINE config 5 in full): the weight gradients of the ViT blocks' six linear layers on e4m3 operands as
+    well -- tvts_gemm_tn_fp8 (ds_read_b64_tr_b8 fragments, K = 128 scaled MFMA), every operand copy under ONE delayed scale per
+    tensor, the bias gradients from the same bytes.  The first step is the calibration step: per-token copies and bf16 weight
+    gradients (= the fp8_dgrad path, bit for bit) while the maxima are recorded; Engine.end_step() turns them into scales and the
+    second step runs per tensor.  Its results are held to the fp8 tolerance against the oracle and stay aligned with the
+    per-token / bf16-weight-gradient ones."""
+    from tvts_amd import arch as A
+    mk = (lambda **kw: A.small_arch_h(width=640, heads=8, **kw)) if h14 else A.small_arch
+    m0, oarch, P = build(arch=mk(fp8=True, fp8_dgrad=True), seed=4)
+    batch = O.synth_batch(oarch, B=4, T=3, seed=6, caption_len=11)
+    r1, r2, rte, rve, rpred, grads = oracle_step(P, batch, oarch)
+    l1, l2, te, ve, pred, store0 = engine_step(m0, batch)
+    g0 = store0.grad.clone()
+    m1, _, _ = build(arch=mk(fp8_wgrad=True), seed=4)
+    assert m1.engine.fp8_wgrad and m1.arch["fp8"] and m1.arch["fp8_dgrad"] and not m1.engine._f8_tensor_mode
+    k1, k2, te1, ve1, pred1, store = engine_step(m1, batch)        # calibration step: the fp8_dgrad path
+    assert torch.equal(ve1, ve) and torch.equal(te1, te) and torch.equal(store.grad, g0)
+    m1.engine.end_step()
+    assert m1.engine._f8_tensor_mode and len(m1.engine._f8_ids) == 12 * oarch["layers"]
+    n = len(m1.engine._f8_ids)
+    assert bool((m1.engine._f8_scale[:n] > 0).all()) and float(m1.engine._f8_amax.abs().max()) == 0.0
+    q1, q2, te2, ve2, pred2, store = engine_step(m1, batch)        # per-tensor scales, e4m3 weight gradients
+    assert min_cos(ve2, rve) > 0.999 and min_cos(te2, rte) > 0.9995 and abs(q1 - r1) < 5e-2 and abs(q2 - r2) < 5e-2, (q1, r1, q2, r2)
+    check_grads(store, grads, gn_tol=0.05, cos_tol=0.9)
+    g2 = store.grad.clone()
+    cos = float(torch.nn.functional.cosine_similarity(g0.double().flatten(), g2.double().flatten(), dim=0))
+    assert cos > 0.99 and abs(float(g2.double().norm()) / float(g0.double().norm()) - 1) < 0.03, cos
+    assert not torch.equal(g0, g2)
+    # the bias gradients come from the e4m3 bytes of the output gradient: aligned with the bf16 column sums
+    for l in range(oarch["layers"]):
+        for nm in ("attn.qkv.bias", "mlp.c_fc.bias", "mlp.c_proj.bias"):
+            k = f"video_model.transformer.resblocks.{l}.{nm}"
+            a_, b_ = store.g(k).double().flatten().cpu(), grads[k].double().flatten()
+            assert float(torch.nn.functional.cosine_similarity(a_, b_, dim=0)) > 0.97, k
+    m1.engine.end_step()
+    _, _, _, _, _, store = engine_step(m1, batch)                  # scales = the previous step's maxima
+    g3 = store.grad.clone()
+    _, _, _, _, _, store = engine_step(m1, batch)                  # no end_step in between: the same scales
+    assert torch.equal(g3, store.grad)                             # identical scales, identical steps: identical bits
+
+
 def test_b16_config2_against_reference_golden(gpu, golden):
     """The headline architecture (BASELINE config 2's model): the real TVTSv2_B_16 class ran in the build container at
     B=2, T=4 with tube mask 0.5 (98 of 196 patches kept: the fused SPACE / TIME attention kernels' shapes)."""

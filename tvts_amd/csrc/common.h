@@ -95,4 +95,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// Per-tensor (delayed) scaling of the e4m3 copies (BASELINE config 5, fp8 weight gradients): the quantising kernels take
+//   tscale   the tensor's scale of THIS step (device scalar, = last step's amax / 448): every row is quantised under it instead of
+//            under its own amax / 448 -- one copy then serves the forward / input-gradient GEMMs (a constant "per-row" scale)
+//            AND the weight-gradient GEMM, whose contraction over the tokens cannot carry per-token scales;
+//   amax_acc the running max |x| of this step (device scalar, >= 0): becomes the next step's scale (tvts_fp8_update_scales).
+// A wave folds the amax of all the rows it walked into one atomic, and only when it would raise the value.
+__device__ __forceinline__ void amax_publish(float* amax_acc, float wave_amax, int lane) {
+    if (amax_acc && lane == 0 && wave_amax > *(volatile float*)amax_acc) atomicMax((int*)amax_acc, __float_as_int(wave_amax));
+}
+__device__ __forceinline__ float q8_scale(const float* tscale, float row_amax) {
+    if (tscale) {
+        const float s = tscale[0];
+        return s > 0.f ? s : 1.0f;
+    }
+    return row_amax > 0.f ? row_amax / 448.0f : 1.0f;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

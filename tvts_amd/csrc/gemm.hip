@@ -832,14 +832,15 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
 // e4m3 weight gradient (include/tvts_hip.h): the 256x256 scaled-MFMA kernel of gemm_tn8.h over (m-range, tile) items, partials
 // through the caller's workspace + the ordered reduce pass like the bf16 entry point.  Na, Nb multiples of 16, ldp / ldq of 16 (bytes).
 extern "C" int tvts_gemm_tn_fp8(const void* P8, int ldp, const void* Q8, int ldq, int M, int Na, int Nb, const float* scale_p,
-                                const float* scale_q, float* out, int ldo, int accumulate, float* workspace, long workspace_elems,
-                                int opts, hipStream_t stream) {
+                                const float* scale_q, float* out, int ldo, int accumulate, float* colsum, float* workspace,
+                                long workspace_elems, int opts, hipStream_t stream) {
     if (M <= 0 || Na <= 0 || Nb <= 0 || !scale_p || !scale_q) return TVTS_EINVAL;
     if (Na % 16 || Nb % 16 || ldp % 16 || ldq % 16 || ldo % 4) return TVTS_EINVAL;
     if ((unsigned long long)M * (unsigned long long)(ldp > ldq ? ldp : ldq) >= (1ull << 32)) return TVTS_EINVAL;  // 32-bit DMA offsets
     GemmTN8 g;
     g.P = (const unsigned char*)P8; g.ldp = ldp; g.Q = (const unsigned char*)Q8; g.ldq = ldq; g.M = M; g.Na = Na; g.Nb = Nb;
     g.out = out; g.ldo = ldo; g.sp = scale_p; g.sq = scale_q; g.accumulate = accumulate; g.ws = nullptr;
+    g.colsum = colsum; g.cs_ws = nullptr;
     g.tiles_a = ceil_div(Na, 256); g.tiles_b = ceil_div(Nb, 256); g.tiles_ab = g.tiles_a * g.tiles_b;
     g.a_fast = g.tiles_a < g.tiles_b ? 1 : 0;
     // contraction ranges by the cost model of the bf16 entry point: rounds of the 256 CUs x stages per range x ~1.9 us per 128-row
@@ -857,10 +858,16 @@ extern "C" int tvts_gemm_tn_fp8(const void* P8, int ldp, const void* Q8, int ldq
         }
     }
     if (workspace == nullptr) splits = 1;
-    else if ((long)splits * Na * Nb > workspace_elems) splits = (int)(workspace_elems / ((long)Na * Nb)) >= 2 ? (int)(workspace_elems / ((long)Na * Nb)) : 1;
+    else if ((long)splits * (Na * (long)Nb + Na) > workspace_elems) {
+        const long fit = workspace_elems / (Na * (long)Nb + Na);
+        splits = fit >= 2 ? (int)fit : 1;
+    }
     g.m_per_split = ceil_div(ceil_div(M, splits), 128) * 128;
     splits = ceil_div(M, g.m_per_split);
-    if (splits > 1) g.ws = workspace;
+    if (splits > 1) {
+        g.ws = workspace;
+        if (colsum) g.cs_ws = workspace + (size_t)splits * Na * Nb;
+    }
     g.n_items = g.tiles_ab * splits;
     const int grid = ceil_div(g.n_items, 8) * 8;
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -871,7 +878,7 @@ extern "C" int tvts_gemm_tn_fp8(const void* P8, int ldp, const void* Q8, int ldq
         int rb = (int)((n4 + 255) / 256);
         if (rb > 2048) rb = 2048;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3(rb), dim3(256), 0, stream, workspace, splits, Na, Nb, out, ldo, accumulate,
-                           (const float*)nullptr, (float*)nullptr);
+                           (const float*)g.cs_ws, colsum);
     }
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;

@@ -17,8 +17,12 @@
 // of 2 a-tiles x 4 b-tiles; the P pairs are double-buffered across chunks, the four Q operands are re-read in place for the next
 // stage behind the last MFMAs that use them: 64 fragment registers + 128 accumulators.
 // One (m-range, tile) work item per block; partials to the workspace + tn_reduce_kernel (ordered, deterministic), or the output
-// itself with one range.  No fused bias gradient (the e4m3 bytes do not sum to the bf16 column sums): the caller keeps the bias
-// gradient on the bf16 tensor.  Included by gemm.hip.
+// itself with one range.  Bias gradient (optional): the blocks of the first tile column also multiply a ones operand (e4m3 1.0 in
+// every byte) with two of the wave's eight P operands per stage -- every row of that product is the column sum of the stage -- so
+// the four b-waves of an a-half cover its 8 column blocks with 2 extra MFMAs (+6 %) and 8 registers each; the sums leave as
+// per-range partials behind the output partials and are added in range order by tn_reduce_kernel.  They are the sums of the
+// QUANTISED output gradient (scale_p * sum of the e4m3 values), consistent with the weight gradient made of the same bytes.
+// Included by gemm.hip.
 #pragma once
 
 typedef __attribute__((ext_vector_type(2))) int tn8_i32x2;
@@ -33,6 +37,8 @@ struct GemmTN8 {
     int tiles_a, tiles_b, tiles_ab, m_per_split, n_items, a_fast;
     int accumulate;  // one range, no workspace: out += (else =)
     float* ws;       // split partials [splits][Na][Nb]
+    float* colsum;   // optional bias gradient: colsum[a] += sp * sum_m P8[m,a]
+    float* cs_ws;    // its split partials [splits][Na] (nullptr with one range: the owner adds its sum itself)
 };
 
 // one 32-byte operand: tokens 32 g + 8 j + (0..7), j = 0..3, of the 16-column block whose lane offset is `off`
@@ -139,6 +145,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(GemmTN8 g) {
     asm volatile("" : "+v"(mx_one));
 #define TN8_MFMA(bv, av, c) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(bv), "v"(av), "v"(mx_one))
     tn8_i32x8 pQ[2][2], qQ[4];
+    // bias gradient: wave (wa, wb) of a first-column block sums a-tiles 2 wb, 2 wb + 1 of its half = pair wb of the stage's four P pairs
+    const bool do_cs = g.colsum != nullptr && tb == 0;  // block-uniform
+    f32x4 cs[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    tn8_i32x8 ones;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) ones[d] = 0x38383838;  // e4m3 1.0
+    asm volatile("" : "+v"(ones));
+#define TN8_CS(pv, pr) if (do_cs && wb == (pr)) { TN8_MFMA(ones, pv[0], cs[0]); TN8_MFMA(ones, pv[1], cs[1]); }
     int valid = m_end - m_begin;  // token rows of the current stage that belong to the m-range (>= 128: all)
 #define TN8_LOAD_P(dst, buf, pr, vld)                                                                   \
     _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                                                  \
@@ -158,18 +172,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(GemmTN8 g) {
         const int valid_n = valid - 128;
         TN8_LOAD_P(pQ[1], cur, 1, valid);
         TN8_MFMA8(pQ[0], 0);
+        TN8_CS(pQ[0], 0);
         __builtin_amdgcn_sched_barrier(0);
         TN8_LOAD_P(pQ[0], cur, 2, valid);
         TN8_MFMA8(pQ[1], 1);
+        TN8_CS(pQ[1], 1);
         __builtin_amdgcn_sched_barrier(0);
         TN8_LOAD_P(pQ[1], cur, 3, valid);
         TN8_MFMA8(pQ[0], 2);
+        TN8_CS(pQ[0], 2);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         RAW_BARRIER_P();
         const bool do_issue = i_st < nk;
         if (do_issue && wave < 4) issue();
         const bool more = st + 1 < nk;
+        TN8_CS(pQ[1], 3);  // (before pQ[0] is reloaded: the compiler keeps the order of the volatile asm)
         if (more) TN8_LOAD_P(pQ[0], nxt, 0, valid_n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -182,12 +200,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(GemmTN8 g) {
         if (do_issue && wave >= 4) issue();
         valid = valid_n;
     }
+#undef TN8_CS
 #undef TN8_OFF
 #undef TN8_MFMA
 #undef TN8_LOAD_P
 #undef TN8_LOAD_Q
 #undef TN8_MFMA8
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results (asm: the compiler does not know they are MFMAs)
+    if (do_cs && lane < 16) {  // the ones operand makes every row of cs[] the column sum: row 0 = element 0 of lanes 0 .. 15
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int a = a0 + wa * 128 + (wb * 2 + t2) * 16 + lane;
+            if (a < g.Na) {
+                const float v = cs[t2][0] * g.sp[0];
+                if (g.cs_ws) g.cs_ws[(size_t)split * g.Na + a] = v;
+                else g.colsum[a] += v;
+            }
+        }
+    }
     const float scale = g.sp[0] * g.sq[0];
     // acc[i][j]: lane holds a = a-tile i column (lane & 15), b = b-tile j rows (lane >> 4) * 4 .. + 3 -> one 16-B fp32 access
     float* obase = g.ws ? g.ws + (size_t)split * g.Na * g.Nb : g.out;

@@ -39,11 +39,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
                                                      float eps, int M, int W, TO* __restrict__ y, int ldy,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      unsigned char* __restrict__ q8 = nullptr, int ldq = 0,
-                                                     float* __restrict__ row_scale = nullptr) {
+                                                     float* __restrict__ row_scale = nullptr,
+                                                     const float* __restrict__ tscale = nullptr, float* __restrict__ amax_acc = nullptr) {
     const int lane = threadIdx.x & 63;
     const int stride = gridDim.x * 4;
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
+    float run_amax = 0.f;
     f32x4 gm[IT], bt[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
         }
         if (Q8) {
             am = wave_max(am);
-            const float scale = am > 0.f ? am / 448.0f : 1.0f;
+            run_amax = fmaxf(run_amax, am);
+            const float scale = q8_scale(tscale, am);
             const float inv = 1.0f / scale;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
                     *(int*)(q8 + (size_t)r * ldq + c) = pk;
                 }
             }
-            if (lane == 0) row_scale[r] = scale;
+            if (lane == 0 && row_scale) row_scale[r] = scale;
         }
         if (lane == 0) {
             if (mean_out) mean_out[r] = mean;
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
             for (int it = 0; it < IT; ++it) v[it] = nx[it];
         }
     }
+    if (Q8) amax_publish(amax_acc, run_amax, lane);
 }
 
 template <typename TO, typename TX>
@@ -142,8 +146,8 @@ static void launch_ln_fwd(int it, dim3 grid, hipStream_t stream, const TX* x, in
 template <typename TX>
 static void launch_ln_fwd_q8(int it, dim3 grid, hipStream_t stream, const TX* x, int ldx, const int* rows, const float* gamma,
                              const float* beta, float eps, int M, int W, bf16* y, int ldy, float* mean, float* rstd,
-                             unsigned char* q8, int ldq, float* row_scale) {
-#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<bf16, N, TX, true>), grid, dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd, q8, ldq, row_scale); break;
+                             unsigned char* q8, int ldq, float* row_scale, const float* tscale, float* amax_acc) {
+#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<bf16, N, TX, true>), grid, dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd, q8, ldq, row_scale, tscale, amax_acc); break;
     switch (it) { LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) default: LN_FWD_CASE(5) }
 #undef LN_FWD_CASE
 }
@@ -151,13 +155,13 @@ static void launch_ln_fwd_q8(int it, dim3 grid, hipStream_t stream, const TX* x,
 // LayerNorm forward that also emits the e4m3 copy of its bf16 output with per-row scales (see Q8 above)
 extern "C" int tvts_layernorm_fwd_fp8(const void* x, int ldx, int x_bf16, const int* rows, const float* gamma, const float* beta,
                                       float eps, int M, int W, void* y, int ldy, void* q8, int ldq, float* row_scale,
-                                      float* mean, float* rstd, hipStream_t stream) {
-    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || ldy % 4 || ldq % 4 || !q8 || !row_scale) return TVTS_EINVAL;
+                                      const float* tscale, float* amax_acc, float* mean, float* rstd, hipStream_t stream) {
+    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || ldy % 4 || ldq % 4 || !q8 || (!row_scale && !tscale)) return TVTS_EINVAL;
     int blocks = ceil_div(M, 4);
     if (blocks > 2048) blocks = 2048;
     const int it = ceil_div(W, 256);
-    if (x_bf16) launch_ln_fwd_q8<bf16>(it, dim3(blocks), stream, (const bf16*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd, (unsigned char*)q8, ldq, row_scale);
-    else launch_ln_fwd_q8<float>(it, dim3(blocks), stream, (const float*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd, (unsigned char*)q8, ldq, row_scale);
+    if (x_bf16) launch_ln_fwd_q8<bf16>(it, dim3(blocks), stream, (const bf16*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd, (unsigned char*)q8, ldq, row_scale, tscale, amax_acc);
+    else launch_ln_fwd_q8<float>(it, dim3(blocks), stream, (const float*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd, (unsigned char*)q8, ldq, row_scale, tscale, amax_acc);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
@@ -196,8 +200,10 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
                                                         int lddxb, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                         float* __restrict__ partial,
                                                         unsigned char* __restrict__ q8 = nullptr, int ldq = 0,
-                                                        float* __restrict__ row_scale = nullptr) {
+                                                        float* __restrict__ row_scale = nullptr,
+                                                        const float* __restrict__ tscale = nullptr, float* __restrict__ amax_acc = nullptr) {
     typedef typename RawDy<TDY>::T DyV;
+    float run_amax = 0.f;
     __shared__ float red[2][4][IT * 256];  // [gamma|beta][wave][column slot]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 ag[IT], ab[IT], gm[IT];
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
         }
         if (Q8) {  // second sweep over the kept copy or the recomputed outputs
             am = wave_max(am);
-            const float scale = am > 0.f ? am / 448.0f : 1.0f;
+            run_amax = fmaxf(run_amax, am);
+            const float scale = q8_scale(tscale, am);
             const float inv = 1.0f / scale;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
@@ -304,10 +311,11 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
                     *(int*)(q8 + (size_t)cur.xr * ldq + c) = pk;
                 }
             }
-            if (lane == 0) row_scale[cur.xr] = scale;
+            if (lane == 0 && row_scale) row_scale[cur.xr] = scale;
         }
         if (more) cur = nxt;
     }
+    if (Q8) amax_publish(amax_acc, run_amax, lane);
     if (!dgamma) return;
     // block reduce the per-wave partials, then one atomic per column per block
 #pragma unroll
@@ -366,14 +374,15 @@ template <typename TDY, bool R1, bool R2, typename TX = float, bool Q8 = false, 
 static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int lddy, const TX* x, int ldx, const int* rows,
                           const float* mean, const float* rstd, const float* gamma, const TR1* res1, const bf16* res2,
                           int ldr2, int ldr, int W, float* dx, int lddx, bf16* dxb, int lddxb, float* dgamma, float* dbeta,
-                          float* ws, long ws_elems, unsigned char* q8 = nullptr, int ldq = 0, float* row_scale = nullptr) {
+                          float* ws, long ws_elems, unsigned char* q8 = nullptr, int ldq = 0, float* row_scale = nullptr,
+                          const float* tscale = nullptr, float* amax_acc = nullptr) {
     // persistent grid: as many blocks per CU as the variant's registers allow (see __launch_bounds__ above)
     const int per_cu = it <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3);
     int blocks = ceil_div(M, 4);
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     const dim3 grid(blocks);
     float* partial = (dgamma && ws && ws_elems >= (long)blocks * 2 * W) ? ws : nullptr;
-#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N, R1, R2, TX, Q8, TR1>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta, partial, q8, ldq, row_scale); break;
+#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N, R1, R2, TX, Q8, TR1>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta, partial, q8, ldq, row_scale, tscale, amax_acc); break;
     switch (it) { LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) default: LN_BWD_CASE(5) }
 #undef LN_BWD_CASE
     if (partial)
@@ -443,14 +452,14 @@ extern "C" int tvts_layernorm_bwd(const void* dy, int lddy, int dy_f32, const vo
 extern "C" int tvts_layernorm_bwd_fp8(const void* dy, int lddy, const void* x_, int ldx, int x_bf16, const float* mean,
                                       const float* rstd, const float* gamma, const void* res1_, int res1_bf16, int ldr, const void* res2_bf16,
                                       int ldr2, int M, int W, float* dx, int lddx, void* dx_bf16, int lddxb, void* q8, int ldq,
-                                      float* row_scale, float* dgamma, float* dbeta, float* workspace, long workspace_elems,
-                                      hipStream_t stream) {
-    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || lddy % 4 || !dx_bf16 || lddxb % 4 || !q8 || ldq % 4 || !row_scale)
+                                      float* row_scale, const float* tscale, float* amax_acc, float* dgamma, float* dbeta,
+                                      float* workspace, long workspace_elems, hipStream_t stream) {
+    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || lddy % 4 || !dx_bf16 || lddxb % 4 || !q8 || ldq % 4 || (!row_scale && !tscale))
         return TVTS_EINVAL;
     if ((dx && lddx % 4) || (res1_ && ldr % 4) || (res2_bf16 && ldr2 % 4)) return TVTS_EINVAL;
     const bf16* res2 = (const bf16*)res2_bf16;
     const int it = ceil_div(W, 256);
-#define Q8_ARGS it, M, stream, (const bf16*)dy, lddy, x, ldx, (const int*)nullptr, mean, rstd, gamma, res1, res2, ldr2, ldr, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems, (unsigned char*)q8, ldq, row_scale
+#define Q8_ARGS it, M, stream, (const bf16*)dy, lddy, x, ldx, (const int*)nullptr, mean, rstd, gamma, res1, res2, ldr2, ldr, W, dx, lddx, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems, (unsigned char*)q8, ldq, row_scale, tscale, amax_acc
     if (x_bf16) {
         const bf16* x = (const bf16*)x_;
         if (res1_ && !res1_bf16) return TVTS_EINVAL;

@@ -320,11 +320,13 @@ extern "C" int tvts_quant_fp8_multi(const void* table, int n, hipStream_t stream
 //      shuffles, scaled by 448 / amax and written as e4m3 bytes + the row's scale.  3 bytes of traffic per element instead of
 //      the 5 of tvts_amax + tvts_quant_fp8, and a tighter scale than one amax for the whole tensor.
 __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16* __restrict__ x, long ld, int rows, int cols,
-                                                             unsigned char* __restrict__ out, long ldo, float* __restrict__ row_scale) {
+                                                             unsigned char* __restrict__ out, long ldo, float* __restrict__ row_scale,
+                                                             const float* __restrict__ tscale, float* __restrict__ amax_acc) {
     constexpr int MAXV = 10;  // 10 x 64 lanes x 8 bf16 = 5120 columns held in registers
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
     const bool in_regs = cols <= MAXV * 512;
+    float run_amax = 0.f;
     for (long r = wave0; r < rows; r += nwaves) {
         const bf16* xr = x + r * ld;
         bf16x8 v[MAXV];
@@ -347,9 +349,10 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16* __restr
             }
         }
         m = wave_max(m);
-        const float scale = m > 0.f ? m / 448.0f : 1.0f;
+        run_amax = fmaxf(run_amax, m);
+        const float scale = q8_scale(tscale, m);
         const float inv = 1.0f / scale;
-        if (lane == 0) row_scale[r] = scale;
+        if (lane == 0 && row_scale) row_scale[r] = scale;
         unsigned char* orow = out + r * ldo;
         auto emit = [&](const bf16x8& u, int c) {
             int pk[2];
@@ -375,14 +378,30 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16* __restr
             for (int c = lane * 8; c < cols; c += 512) emit(*(const bf16x8*)(xr + c), c);
         }
     }
+    amax_publish(amax_acc, run_amax, lane);
+}
+// next step's scales from this step's amax values, for n tensors at once: scale[i] = amax[i] / 448 (unchanged while amax[i] == 0:
+// a tensor that was not produced this step keeps its scale), amax[i] = 0
+__global__ void fp8_update_scales_kernel(float* __restrict__ amax, float* __restrict__ scale, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float a = amax[i];
+    if (a > 0.f) scale[i] = a / 448.0f;
+    amax[i] = 0.f;
+}
+extern "C" int tvts_fp8_update_scales(float* amax, float* scale, int n, hipStream_t stream) {
+    if (n <= 0 || !amax || !scale) return TVTS_EINVAL;
+    hipLaunchKernelGGL(fp8_update_scales_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, amax, scale, n);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
 }
 extern "C" int tvts_quant_fp8_rows(const void* x, long ld, int rows, int cols, void* out, long ldo, float* row_scale,
-                                   hipStream_t stream) {
-    if (rows <= 0 || cols <= 0 || cols % 8 || ld % 8 || ldo % 8 || !x || !out || !row_scale) return TVTS_EINVAL;
+                                   const float* tscale, float* amax_acc, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0 || cols % 8 || ld % 8 || ldo % 8 || !x || !out || (!row_scale && !tscale)) return TVTS_EINVAL;
     const long want = ((long)rows + 3) / 4;
     const int blocks = (int)(want < 8192 ? want : 8192);
     hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, ld, rows, cols,
-                       (unsigned char*)out, ldo, row_scale);
+                       (unsigned char*)out, ldo, row_scale, tscale, amax_acc);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

@@ -36,6 +36,8 @@ class ParamStore:
     """
 
     def __init__(self, arch: dict, device: torch.device):
+        if arch.get("fp8_wgrad"):  # e4m3 weight gradients ride on the e4m3 forward and input-gradient operand copies
+            arch["fp8"] = arch["fp8_dgrad"] = True
         self.arch = arch
         self.device = device
         self.shapes = param_shapes(arch)
@@ -203,6 +205,12 @@ class Engine:
         # 692.9 / 958.5 / 1154 / 1351 without.  arch["wgrad_stream"] = True switches it on (bit-identical gradients,
         # tests/test_bench_path_gpu.py::test_wgrad_side_stream_gives_the_same_bits).
         self.wgrad_stream = a.get("wgrad_stream", False)
+        # e4m3 weight gradients (BASELINE config 5): per-tensor delayed scaling of every e4m3 operand copy, see _q8 below
+        self.fp8_wgrad = bool(a.get("fp8_wgrad", False))
+        self._f8_ids: Dict[str, int] = {}
+        self._f8_scale = self._f8_amax = None
+        self._f8_tensor_mode = False
+        self._x8: Dict[str, tuple] = {}
         self._wg_stream = None
         self._wg_ws = None
         self.dev = store.device
@@ -261,17 +269,48 @@ class Engine:
     def _f(self, name, shape, zero=False):
         return self._b(name, shape, torch.float32, zero)
 
-    # ------------------------------------------------------------------ linear helpers
-    def _lin(self, a, wname, bname, out, M, a8=None, **epi):
-        if wname in self.P.w8:  # fp8 weight/activation path (BASELINE config 4): forward GEMMs of the ViT blocks
-            w8, ws, _ = self.P.w8[wname]
-            if a8 is None:  # activations that do not come out of a LayerNorm: one pass, one scale per token
-                a8 = self._fp8_bufs(M, a.shape[1])
-                K.quantize_fp8_rows(a[:M], q=a8[0], row_scale=a8[1])
-            K.gemm_nt_fp8(a8[0], a8[1], w8, ws, out[:M], bias=self.P.p(bname) if bname else None, **epi)
-            return
-        K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
+    # ------------------------------------------------------------------ e4m3 copies (BASELINE config 4 / 5)
+    # Two regimes of the e4m3 operand copies:
+    #   per TOKEN  (arch["fp8"], arch["fp8_dgrad"]): one scale per row, written by the producing LayerNorm or by a one-pass row
+    #              quantiser, applied per row in the GEMM epilogue; the weight gradients stay bf16;
+    #   per TENSOR (arch["fp8_wgrad"], round 4): the weight gradient contracts over the tokens, so its operands can only carry one
+    #              scale per tensor -- and a copy under one scale serves the forward / input-gradient GEMMs as well.  Delayed
+    #              scaling: every producer quantises under the tensor's scale of LAST step (amax / 448) and records this step's
+    #              amax; end_step() turns the maxima into the next scales.  The first step has no scales yet: it runs per token
+    #              with bf16 weight gradients while the maxima are recorded ("calibration"), and end_step() switches over.
+    def _f8_slot(self, name):
+        """(scale, amax) device scalars of tensor `name` (views of two flat arrays, so that one kernel updates all of them)"""
+        i = self._f8_ids.get(name)
+        if i is None:
+            if self._f8_scale is None:
+                cap = 16 * (self.arch["layers"] + 2)
+                self._f8_scale = torch.zeros(cap, dtype=torch.float32, device=self.dev)
+                self._f8_amax = torch.zeros(cap, dtype=torch.float32, device=self.dev)
+            i = self._f8_ids[name] = len(self._f8_ids)
+            assert i < self._f8_scale.numel(), "more e4m3 tensors than the scale table holds"
+        return self._f8_scale[i:i + 1], self._f8_amax[i:i + 1]
 
+    def end_step(self):
+        """Called once per optimisation step (StepRunner.run) after the backward: this step's amax values become the per-tensor
+        scales of the next step, and from the second step on the e4m3 copies are per-tensor and the weight gradients e4m3."""
+        if self.fp8_wgrad and self._f8_scale is not None:
+            K.fp8_update_scales(self._f8_amax, self._f8_scale)
+            self._f8_tensor_mode = True
+
+    def _q8(self, M, W, name, persistent=False):
+        """Buffers for the e4m3 copy of tensor `name` [M, W]: (bytes, scale operand for the GEMMs, kwargs for the producing kernel).
+        persistent: the bytes outlive the next producer of the same width (an activation the weight gradient reads in the backward)."""
+        q = self._b(("fp8.x." + name) if (persistent and self.fp8_wgrad) else "fp8.q%d" % W, (M, W), torch.uint8)
+        if not self.fp8_wgrad:
+            rs = self._f("fp8.row_scale", (max(M, 2),))  # never a 1-element tensor: that means "one scale for the tensor"
+            return q, rs, dict(row_scale=rs)
+        sc, am = self._f8_slot(name)
+        if self._f8_tensor_mode:
+            return q, sc, dict(tscale=sc, amax=am)
+        rs = self._f("fp8.row_scale", (max(M, 2),))
+        return q, rs, dict(row_scale=rs, amax=am)
+
+    # ------------------------------------------------------------------ linear helpers
     def _wgrad_side(self, M) -> bool:
         return bool(self.wgrad_stream)
 
@@ -283,14 +322,35 @@ class Engine:
             self._wg_ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.dev)
         return self._wg_stream, self._wg_ws
 
+    def _lin(self, a, wname, bname, out, M, a8=None, **epi):
+        if wname in self.P.w8:  # fp8 weight/activation path (BASELINE config 4): forward GEMMs of the ViT blocks
+            w8, ws, _ = self.P.w8[wname]
+            if a8 is None:  # activations that do not come out of a LayerNorm: one pass
+                q, sa, kw = self._q8(M, a.shape[1], "x." + wname, persistent=True)
+                K.quantize_fp8_rows(a[:M], q=q, **kw)
+                a8 = (q, sa)
+            self._x8[wname] = a8
+            K.gemm_nt_fp8(a8[0], a8[1], w8, ws, out[:M], bias=self.P.p(bname) if bname else None, **epi)
+            return
+        K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
+
     def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, dy8=None, side=False, **epi):
         """dW += dy^T a_in, db += colsum(dy) (if trainable); d_in = dy W (optional, with epilogue).  dy8: the e4m3 copy of dy
-        (bytes, per-token scales) when its producer already wrote one (_ln_bwd with fp8_for).  side: the weight gradient is
-        launched on the side stream behind everything the current stream has queued so far (dy is complete there); the caller
-        keeps dy and a_in untouched until it has joined the side stream."""
+        when its producer already wrote one (_ln_bwd with fp8_for).  side: the weight gradient is launched on the side stream
+        behind everything the current stream has queued so far (dy is complete there); the caller keeps dy and a_in untouched
+        until it has joined the side stream."""
         want_b = bool(bname) and self.requires_grad[bname]
+        f8w = self.fp8_wgrad and self._f8_tensor_mode and wname in self.P.w8t and wname in self._x8
+        if (f8w or (d_in is not None and wname in self.P.w8t)) and dy8 is None:
+            q, sa, kw = self._q8(M, dy.shape[1], "dy." + wname)
+            K.quantize_fp8_rows(dy[:M], q=q, **kw)
+            dy8 = (q, sa)
         if self.requires_grad[wname]:  # bias gradient (column sums of dy) rides along in the same kernel
-            if side:
+            if f8w:  # e4m3 weight gradient: both operands under one scale per tensor, the bias gradient from the same bytes
+                x8 = self._x8[wname]
+                K.gemm_tn_fp8(dy8[0], dy8[1], x8[0], x8[1], self.P.g2d(wname), M=M, accumulate=True,
+                              colsum=self.P.g(bname) if want_b else None)
+            elif side:
                 ws, scratch = self._side()
                 ws.wait_stream(torch.cuda.current_stream(self.dev))
                 with torch.cuda.stream(ws):
@@ -301,43 +361,36 @@ class Engine:
         elif want_b:
             K.colsum(dy, self.P.g(bname), M=M)
         if d_in is not None:
-            if wname in self.P.w8t:  # e4m3 input gradient (arch["fp8_dgrad"]): dy one scale per token, the transposed weight's e4m3 copy
-                d8 = dy8
-                if d8 is None:
-                    d8 = self._fp8_bufs(M, dy.shape[1])
-                    K.quantize_fp8_rows(dy[:M], q=d8[0], row_scale=d8[1])
+            if wname in self.P.w8t:  # e4m3 input gradient (arch["fp8_dgrad"]): the transposed weight's e4m3 copy
                 w8t, wst = self.P.w8t[wname]
-                K.gemm_nt_fp8(d8[0], d8[1], w8t, wst, d_in[:M], **epi)
+                K.gemm_nt_fp8(dy8[0], dy8[1], w8t, wst, d_in[:M], **epi)
                 return
             K.gemm_nt(dy, self.P.wt(wname), d_in, M=M, **epi)
-
-    def _fp8_bufs(self, M, W):
-        # (e4m3 bytes [M, W], per-token scales) -- shared scratch: an activation's fp8 copy only lives until its GEMM is launched
-        return (self._b("fp8.q%d" % W, (M, W), torch.uint8),
-                self._f("fp8.row_scale", (max(M, 2),)))  # never a 1-element tensor: that means "one scale for the tensor"
 
     def _ln(self, x, name, eps, y, tag, rows=None, M=None, fp8_for=None):
         """fp8_for: name of the weight the output feeds; when that GEMM runs in fp8 the LayerNorm also emits the e4m3 copy
         (returned, to be handed to _lin as a8)."""
         M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
         mean, rstd = self._f(tag + ".mean", (M,)), self._f(tag + ".rstd", (M,))
-        a8 = self._fp8_bufs(M, y.shape[1]) if (fp8_for is not None and fp8_for in self.P.w8) else None
-        K.layernorm_fwd(x, self.P.p(name + ".weight"), self.P.p(name + ".bias"), eps, y, mean, rstd, rows=rows, M=M,
-                        q8=a8[0] if a8 else None, row_scale=a8[1] if a8 else None)
+        a8, kw = None, {}
+        if fp8_for is not None and fp8_for in self.P.w8:
+            q, sa, kw = self._q8(M, y.shape[1], "x." + fp8_for, persistent=True)
+            a8, kw = (q, sa), dict(kw, q8=q)
+        K.layernorm_fwd(x, self.P.p(name + ".weight"), self.P.p(name + ".bias"), eps, y, mean, rstd, rows=rows, M=M, **kw)
         return a8
 
     def _ln_bwd(self, dy, x, name, tag, dx, dx_bf16=None, res1=None, res2=None, rows=None, M=None, fp8_for=None):
         """fp8_for: name of the weight whose input-gradient GEMM consumes dx_bf16; when that GEMM runs on e4m3 operands the
         LayerNorm backward also emits the e4m3 copy (returned, to be handed to _lin_bwd as dy8)."""
         tr = self.requires_grad[name + ".weight"]
-        d8 = None
+        d8, kw = None, {}
         if (fp8_for is not None and fp8_for in self.P.w8t and rows is None and dx_bf16 is not None and dy.dtype == torch.bfloat16
                 and not (res2 is not None and res1 is None)):
-            d8 = self._fp8_bufs(dx_bf16.shape[0] if M is None else M, dx_bf16.shape[1])
+            q, sa, kw = self._q8(dx_bf16.shape[0] if M is None else M, dx_bf16.shape[1], "dy." + fp8_for)
+            d8, kw = (q, sa), dict(kw, q8=q)
         K.layernorm_bwd(dy, x, self.buf[tag + ".mean"], self.buf[tag + ".rstd"], self.P.p(name + ".weight"), dx,
                         dx_bf16=dx_bf16, res1=res1, res2=res2, dgamma=self.P.g(name + ".weight") if tr else None,
-                        dbeta=self.P.g(name + ".bias") if tr else None, rows=rows, M=M,
-                        q8=d8[0] if d8 else None, row_scale=d8[1] if d8 else None)
+                        dbeta=self.P.g(name + ".bias") if tr else None, rows=rows, M=M, **kw)
         return d8
 
     # ------------------------------------------------------------------ generic pre-LN block (text tower, sort head)

@@ -229,17 +229,27 @@ def quantize_fp8_multi(table, n):
     _chk(_lib.load().tvts_quant_fp8_multi(_p(table), n, _stream()), "tvts_quant_fp8_multi")
 
 
-def quantize_fp8_rows(x, q=None, row_scale=None):
+def quantize_fp8_rows(x, q=None, row_scale=None, tscale=None, amax=None):
     """per-row (per-token) e4m3 quantisation of a bf16 matrix in one pass -> (q uint8 [rows, cols], row_scale float32[rows]);
-    x[r] ~ q[r] * row_scale[r]."""
+    x[r] ~ q[r] * row_scale[r].  tscale (float32[1], device): every row under THAT scale instead (per-tensor, delayed scaling;
+    row_scale is then optional and returned as None when absent); amax (float32[1]): receives max(amax, max |x|)."""
     lib = _lib.load()
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.bfloat16
     q = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if q is None else q
-    row_scale = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if row_scale is None else row_scale
-    assert row_scale.numel() >= x.shape[0] and row_scale.dtype == torch.float32
-    _chk(lib.tvts_quant_fp8_rows(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(q), q.stride(0), _p(row_scale), _stream()),
-         "tvts_quant_fp8_rows")
+    if row_scale is None and tscale is None:
+        row_scale = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    assert row_scale is None or (row_scale.numel() >= x.shape[0] and row_scale.dtype == torch.float32)
+    with _hbm("quant_fp8_rows", _nb((x, x.shape[0]), (q, x.shape[0]))):
+        rc = lib.tvts_quant_fp8_rows(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(q), q.stride(0), _p(row_scale), _p(tscale), _p(amax),
+                                     _stream())
+    _chk(rc, "tvts_quant_fp8_rows")
     return q, row_scale
+
+
+def fp8_update_scales(amax, scale):
+    """scale[i] = amax[i] / 448 where amax[i] > 0, then amax[i] = 0: a step's running maxima become the next step's per-tensor scales"""
+    assert amax.dtype == scale.dtype == torch.float32 and amax.numel() == scale.numel()
+    _chk(_lib.load().tvts_fp8_update_scales(_p(amax), _p(scale), amax.numel(), _stream()), "tvts_fp8_update_scales")
 
 
 def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None, k32=None,
@@ -323,8 +333,9 @@ def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True, 
         GEMM_PROFILE.append(("gemm_tn", 2.0 * M * p.shape[1] * q.shape[1], ev0, ev1, (M, p.shape[1], q.shape[1], "cs" if colsum is not None else "")))
 
 
-def gemm_tn_fp8(p8, sp, q8, sq, out, *, M=None, accumulate=True, workspace=True, splits=None):
-    """out[Na,Nb] (+)= sp * sq * p8[M,Na]^T @ q8[M,Nb]; p8 / q8 uint8 e4m3 bytes under one scale per tensor (float32[1] each)."""
+def gemm_tn_fp8(p8, sp, q8, sq, out, *, M=None, accumulate=True, colsum=None, workspace=True, splits=None):
+    """out[Na,Nb] (+)= sp * sq * p8[M,Na]^T @ q8[M,Nb]; p8 / q8 uint8 e4m3 bytes under one scale per tensor (float32[1] each);
+    colsum[a] += sp * sum_m p8[m,a] (the bias gradient from the same bytes)."""
     lib = _lib.load()
     M = p8.shape[0] if M is None else M
     assert p8.dtype == torch.uint8 and q8.dtype == torch.uint8 and out.dtype == torch.float32 and sp.numel() == 1 and sq.numel() == 1
@@ -333,7 +344,7 @@ def gemm_tn_fp8(p8, sp, q8, sq, out, *, M=None, accumulate=True, workspace=True,
         ev0, ev1 = Event(), Event()
         ev0.record()
     rc = lib.tvts_gemm_tn_fp8(_p(p8), p8.stride(0), _p(q8), q8.stride(0), M, p8.shape[1], q8.shape[1], _p(sp), _p(sq), _p(out), _ld(out),
-                              1 if accumulate else 0, _p(ws), ws.numel() if ws is not None else 0, int(splits or 0) << 8, _stream())
+                              1 if accumulate else 0, _p(colsum), _p(ws), ws.numel() if ws is not None else 0, int(splits or 0) << 8, _stream())
     _chk(rc, "tvts_gemm_tn_fp8")
     if GEMM_PROFILE is not None:
         ev1.record()
@@ -356,16 +367,16 @@ def colsum(x, out, *, M=None):
     _chk(lib.tvts_colsum_bf16(_p(x), _ld(x), M, x.shape[1], _p(out), _p(ws), ws.numel(), _stream()), "tvts_colsum_bf16")
 
 
-def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=None, q8=None, row_scale=None):
+def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=None, q8=None, row_scale=None, tscale=None, amax=None):
     """q8 (uint8 [M, W]) + row_scale (float32 [>= M]): also write the bf16 output as e4m3 bytes with one scale per row."""
     lib = _lib.load()
     M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
     fam = "ln_fwd" if M >= 4096 else "ln_fwd_small"
     if q8 is not None:
-        assert y.dtype == torch.bfloat16 and q8.dtype == torch.uint8 and row_scale.dtype == torch.float32 and row_scale.numel() >= M
+        assert y.dtype == torch.bfloat16 and q8.dtype == torch.uint8 and (tscale is not None or (row_scale.dtype == torch.float32 and row_scale.numel() >= M))
         with _hbm(fam, _nb((x, M), (y, M), (q8, M)) + 12 * M):
             rc = lib.tvts_layernorm_fwd_fp8(_p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(rows), _p(gamma), _p(beta), eps, M,
-                                            x.shape[1], _p(y), _ld(y), _p(q8), q8.stride(0), _p(row_scale), _p(mean), _p(rstd), _stream())
+                                            x.shape[1], _p(y), _ld(y), _p(q8), q8.stride(0), _p(row_scale), _p(tscale), _p(amax), _p(mean), _p(rstd), _stream())
         _chk(rc, "tvts_layernorm_fwd_fp8")
         return
     with _hbm(fam, _nb((x, M), (y, M)) + 8 * M):
@@ -385,7 +396,7 @@ def _ln_workspace(dev):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2=None, dgamma=None, dbeta=None,
-                  rows=None, M=None, workspace=True, q8=None, row_scale=None):
+                  rows=None, M=None, workspace=True, q8=None, row_scale=None, tscale=None, amax=None):
     """dx (fp32, may be None when only the bf16 copy is wanted) = LN backward [+ res1 (fp32 or bf16) + res2 (bf16)];
     dgamma / dbeta are ACCUMULATED (+=) from per-block partials in a shared scratch buffer.  q8 / row_scale: also the e4m3
     copy of dx_bf16 with one scale per row (bf16 dy, every row)."""
@@ -396,13 +407,13 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2
     fam = "ln_bwd" if M >= 4096 else "ln_bwd_small"
     nbytes = _nb((dy, M), (x, M), (res1, M), (res2, M), (dx, M), (dx_bf16, M), (q8, M)) + 8 * M
     if q8 is not None:
-        assert rows is None and dx_bf16 is not None and dy.dtype == torch.bfloat16 and row_scale is not None and row_scale.numel() >= M
+        assert rows is None and dx_bf16 is not None and dy.dtype == torch.bfloat16 and (tscale is not None or (row_scale is not None and row_scale.numel() >= M))
         with _hbm(fam, nbytes):
             rc = lib.tvts_layernorm_bwd_fp8(_p(dy), _ld(dy), _p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(mean), _p(rstd),
                                         _p(gamma), _p(res1), 1 if (res1 is not None and res1.dtype == torch.bfloat16) else 0,
                                         _ld(res1) if res1 is not None else 0, _p(res2),
                                         _ld(res2) if res2 is not None else 0, M, x.shape[1], _p(dx), _ld(dx) if dx is not None else 0,
-                                            _p(dx_bf16), _ld(dx_bf16), _p(q8), q8.stride(0), _p(row_scale), _p(dgamma), _p(dbeta), _p(ws),
+                                            _p(dx_bf16), _ld(dx_bf16), _p(q8), q8.stride(0), _p(row_scale), _p(tscale), _p(amax), _p(dgamma), _p(dbeta), _p(ws),
                                             ws.numel() if ws is not None else 0, _stream())
         _chk(rc, "tvts_layernorm_bwd_fp8")
         return

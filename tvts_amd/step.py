@@ -55,6 +55,8 @@ class StepRunner:
             self.eng.embeds_ready = None
         loss1, loss2, d_te, d_ve, dpred = self.losses_and_grads(pb, te, ve, pred, labels)
         self.eng.backward(d_te, d_ve, dpred)
+        if hasattr(self.eng, "end_step"):
+            self.eng.end_step()  # (e4m3 weight gradients: this step's amax values become the next step's per-tensor scales)
         scale = self.sync.finish()
         if self.fused:
             self.opt.grad_scale = scale
