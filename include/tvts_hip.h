@@ -85,13 +85,18 @@ int tvts_gemm_tn_select(int M, int Na, int Nb, int opts);
  * weight; scale_a: one scale for the tensor, or (scale_a_rows != 0) M per-row scales as written by tvts_quant_fp8_rows */
 int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
                      int scale_a_rows, const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact, int ldp,
-                     void* out, int ldc, int out_f32, int opts, hipStream_t stream);
+                     void* out, int ldc, int out_f32, void* q8out, int ldq8, const float* q8_scale, float* q8_amax, int opts,
+                     hipStream_t stream);
+/* q8out (optional; activation forms with a bf16 result, here and in tvts_gemm_nt_fp8_gate): the epilogue also writes
+ * q8out[m, n] = e4m3(out[m, n] / q8_scale[0]) and folds max |out| into q8_amax -- the per-tensor copy the next GEMMs of
+ * BASELINE config 5 read (the following layer's forward and weight gradient), without a quantiser pass over the result */
 /* input gradient of such a layer (autograd of nn.Linear + the GELU of video_encoder_ViT_H_14.py's Mlp): out[M,N] (bf16) =
  * gate_act'(gate_h[M,N]) * (scale_a[m] * scale_b * (A[M,K] B[N,K]^T)), A = e4m3 copy of the output gradient (per-token scales),
  * B = e4m3 copy of the transposed weight; the un-gated input gradients take tvts_gemm_nt_fp8 itself */
 int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
                           int scale_a_rows, const float* scale_b, const float* bias, const void* gate_h, int ldh, int gate_act,
-                          void* out, int ldc, int opts, hipStream_t stream);
+                          void* out, int ldc, void* q8out, int ldq8, const float* q8_scale, float* q8_amax, int opts,
+                          hipStream_t stream);
 /* weight gradient of such a layer on e4m3 operands: out[Na,Nb] (+)= scale_p * scale_q * sum_m P8[m,Na] * Q8[m,Nb].  The contraction runs
  * over the tokens, so the operands carry ONE scale per tensor (device scalars; tvts_quant_fp8 / tvts_quant_fp8_rows2 write such
  * copies) -- not the per-token scales of the forward / input-gradient operands.  Na, Nb, ldp, ldq (bytes) multiples of 16.

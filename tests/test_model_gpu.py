@@ -390,6 +390,8 @@ def test_training_curve_fp8_dgrad_tracks_oracle(gpu):
     batch = O.synth_batch(oarch, B=4, T=2, seed=8, caption_len=9)
     curve, oarch, P = engine_curve(a8, batch)
     curve_fwd, _, _ = engine_curve(A.small_arch_h(width=640, heads=8, fp8=True), batch)
+    # ... and BASELINE config 5 in full: e4m3 weight gradients under per-tensor delayed scales (step 0 calibrates per token)
+    curve_w, _, _ = engine_curve(A.small_arch_h(width=640, heads=8, fp8_wgrad=True), batch)
     Pr = {k: v.clone() for k, v in P.items()}
     state, O_HP = {}, O.GROUP_HPARAMS
     O.GROUP_HPARAMS = tuple(hp)
@@ -404,6 +406,9 @@ def test_training_curve_fp8_dgrad_tracks_oracle(gpu):
     assert ref_curve[-1] < ref_curve[0] - 0.02 and curve[-1] < curve[0] - 0.02, (ref_curve, curve)
     assert np.all(np.abs(curve - ref_curve) < 0.03 * np.abs(ref_curve) + 1e-2), (curve, ref_curve)
     assert np.all(np.abs(curve - curve_fwd) < 0.02 * np.abs(curve_fwd) + 1e-2), (curve, curve_fwd)
+    assert curve_w[0] == curve[0] and curve_w[-1] < curve_w[0] - 0.02                       # the calibration step is the per-token step
+    assert np.all(np.abs(curve_w - ref_curve) < 0.03 * np.abs(ref_curve) + 1e-2), (curve_w, ref_curve)
+    assert np.all(np.abs(curve_w - curve) < 0.02 * np.abs(curve) + 1e-2), (curve_w, curve)
 
 
 def test_b32_config1_against_reference_golden(gpu, golden):
@@ -512,15 +517,17 @@ def test_sort_head_used_rows_only(gpu, h14):
     check_grads(store, grads)
 
 
-def test_h14_full_size_fp8_against_reference_golden(gpu, golden):
-    """BASELINE config 4 on its own architecture: the full-size TVTSv2 ViT-H/14 (32 layers, width 1280, head dim 80, 1.22 G
-    parameters) with the e4m3 forward and input-gradient GEMMs against the REFERENCE's fp32 outputs of the same parameters and
+@pytest.mark.parametrize("wgrad", [False, True])
+def test_h14_full_size_fp8_against_reference_golden(gpu, golden, wgrad):
+    """BASELINE config 4 / 5 on its own architecture: the full-size TVTSv2 ViT-H/14 (32 layers, width 1280, head dim 80, 1.22 G
+    parameters) with the e4m3 forward and input-gradient GEMMs -- and (wgrad) the e4m3 weight gradients under per-tensor delayed
+    scales, second step after the calibration step -- against the REFERENCE's fp32 outputs of the same parameters and
     batch (the golden of test_h14_full_size_against_reference_golden) at the fp8 tolerance: video embeddings cosine >= 0.995,
     losses within 5e-2, total gradient norm within 5 %, per-tensor gradient norms of every sizeable tensor within 15 %."""
     from tvts_amd import arch as A
     from tvts_amd.model._common import TVTSv2Base
     f = golden("model_h14_cfg3")
-    a = dict(A.ARCHS["H_14"], fp8=True, fp8_dgrad=True)
+    a = dict(A.ARCHS["H_14"], fp8=True, fp8_dgrad=True, fp8_wgrad=wgrad)
     oarch = O.ARCHS["H_14"]
     P = O.synth_params(oarch, seed=0)
     m = TVTSv2Base(ARGS, arch=a)
@@ -528,6 +535,10 @@ def test_h14_full_size_fp8_against_reference_golden(gpu, golden):
     del P
     batch = O.synth_batch(oarch, B=2, T=4, seed=0)
     l1, l2, te, ve, pred, store = engine_step(m, batch)
+    if wgrad:
+        m.engine.end_step()
+        l1, l2, te, ve, pred, store = engine_step(m, batch)
+        assert m.engine._f8_tensor_mode and len(m.engine._f8_ids) == 12 * a["layers"]
     assert len(store.w8) == len(store.w8t) == 6 * a["layers"]
     rte, rve, rpred = torch.tensor(f["te"]), torch.tensor(f["ve"]), torch.tensor(f["pred"])
     assert min_cos(te, rte) > 0.9995                                  # the text tower is not quantised
@@ -647,6 +658,11 @@ def test_fp8_wgrad_path(gpu, h14):
             k = f"video_model.transformer.resblocks.{l}.{nm}"
             a_, b_ = store.g(k).double().flatten().cpu(), grads[k].double().flatten()
             assert float(torch.nn.functional.cosine_similarity(a_, b_, dim=0)) > 0.97, k
+    # the MLP's two operand copies written by the producing GEMMs' epilogues instead of quantiser passes (opt-in): the same bytes
+    m3, _, _ = build(arch=mk(fp8_wgrad=True, fp8_epilogue_copies=True), seed=4)
+    engine_step(m3, batch); m3.engine.end_step()
+    _, _, _, ve3, _, store3 = engine_step(m3, batch)
+    assert torch.equal(ve3, ve2) and torch.equal(store3.grad, g2)
     m1.engine.end_step()
     _, _, _, _, _, store = engine_step(m1, batch)                  # scales = the previous step's maxima
     g3 = store.grad.clone()

@@ -291,6 +291,14 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
             }
         }
     }
+    if constexpr (FP8) {
+        if (g.q8) {  // the epilogue also writes the per-tensor e4m3 copy of its bf16 result (activation / gate forms of the scaled-MFMA loop)
+            constexpr int QF = SD | 65536 | 1048576;
+            if (!fp8_mx || g.out_f32 || g.residual || (g.ldq8 % 8)) return TVTS_EINVAL;
+            if (gated) kern = gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, true, QF> : gate_act == ACT_GELU_ERF ? gemm_nt256p_kernel<0, 2, true, QF> : nullptr;
+            else kern = act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, true, QF> : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, true, QF> : nullptr;
+        }
+    }
     if constexpr (!FP8) {
         if (g.sk_ws) {  // stream-K: the generic patch epilogue (bias and side inputs are read by the block that sums the pieces)
             constexpr int SKF = SD | 524288;
@@ -321,7 +329,7 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.sa = nullptr; g.sb = nullptr; g.sa_rows = 0; g.gc = 0;
-    g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0;
+    g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0; g.q8 = nullptr; g.ldq8 = 0; g.q8_scale = nullptr; g.q8_amax = nullptr;
     if (nt_use_256(M, N, K, workspace != nullptr, opts)) {
         if (ldc % 8 || (preact && ldp % 8) || (gate_h && ldh % 8)) {
             if (opt_tile(opts) == 256) return TVTS_EINVAL;  // forced, but the 16-byte epilogue accesses do not fit
@@ -355,8 +363,9 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
 // of tvts_quant_fp8_rows (BASELINE config 4's weight/activation path).  Same pipelined 256x256 kernel: K % 128 == 0, lda / ldb % 16 == 0.
 extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
                                 int scale_a_rows, const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact,
-                                int ldp, void* out, int ldc, int out_f32, int opts, hipStream_t stream) {
-    if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b) return TVTS_EINVAL;
+                                int ldp, void* out, int ldc, int out_f32, void* q8out, int ldq8, const float* q8_scale, float* q8_amax,
+                                int opts, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b || (q8out && !q8_scale)) return TVTS_EINVAL;
     if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || (residual && ldr % 4) || (preact && ldp % 8)) return TVTS_EINVAL;
     GemmNT g;
     g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;  // byte-identical bf16 view, half as wide
@@ -364,6 +373,7 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = nullptr; g.ldh = 0; g.gate_act = ACT_NONE;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
     g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0;
+    g.q8 = (unsigned char*)q8out; g.ldq8 = ldq8; g.q8_scale = q8_scale; g.q8_amax = q8_amax;
     return launch_nt256<true>(g, act, ACT_NONE, false, opts, stream);
 }
 
@@ -372,8 +382,9 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
 // and, optionally, the activation-gradient gate of the MLP's first layer (gate_h = its saved pre-activation)
 extern "C" int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* scale_a,
                                      int scale_a_rows, const float* scale_b, const float* bias, const void* gate_h, int ldh,
-                                     int gate_act, void* out, int ldc, int opts, hipStream_t stream) {
-    if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b || !gate_h) return TVTS_EINVAL;
+                                     int gate_act, void* out, int ldc, void* q8out, int ldq8, const float* q8_scale, float* q8_amax,
+                                     int opts, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b || !gate_h || (q8out && !q8_scale)) return TVTS_EINVAL;
     if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || ldh % 8) return TVTS_EINVAL;
     GemmNT g;
     g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;
@@ -381,6 +392,7 @@ extern "C" int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int 
     g.preact = nullptr; g.ldp = 0; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
     g.out = out; g.ldc = ldc; g.out_f32 = 0; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
     g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0;
+    g.q8 = (unsigned char*)q8out; g.ldq8 = ldq8; g.q8_scale = q8_scale; g.q8_amax = q8_amax;
     return launch_nt256<true>(g, ACT_NONE, gate_act, true, opts, stream);
 }
 

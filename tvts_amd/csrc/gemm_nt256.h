@@ -22,6 +22,10 @@ struct GemmNT {
     const float* sa; const float* sb;  // fp8 operands: per-tensor scales (device scalars), out = sa*sb * (A B^T) + ...
     // stream-K (ABL & 524288): fp32 partial tiles [grid][2][256 x 256] and one arrival counter per output tile (zero between launches)
     float* sk_ws; int* sk_cnt; int sk_tol;
+    // e4m3 copy of the (bf16) result under one scale per tensor, written by the epilogue (ABL & 1048576; BASELINE config 5: the GELU
+    // output is the operand of the next layer's forward AND weight-gradient GEMMs, the gated input gradient that of the previous
+    // layer's): q8[m, n] = e4m3(out[m, n] / q8_scale[0]), q8_amax = max(q8_amax, max |out|)
+    unsigned char* q8; int ldq8; const float* q8_scale; float* q8_amax;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -239,8 +243,10 @@ __device__ __forceinline__ void side_prefetch(const GemmNT& g, int m_base, int n
 // 2 = side inputs (residual / gate) are not loaded, 4 = results are not stored (one never-taken store keeps them live).
 // ABL & 256 = side inputs come from `side` (prefetched one slab ahead) instead of being loaded here.
 template <int ACT, int GATE, int ABL = 0>
-__device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch, int m_base, int nb, int lane, const SideSlab& side) {
+__device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch, int m_base, int nb, int lane, const SideSlab& side,
+                                              float q8inv = 0.f, float* q8am = nullptr) {
     constexpr bool PF = (ABL & 256) != 0;
+    constexpr bool Q8OUT = (ABL & 1048576) != 0;
     if (g.out_f32) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -303,6 +309,24 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
             if (!(ABL & 4) || v[0] == 1.2345e33f) store16<ABL>((bf16*)g.out + (size_t)m * g.ldc + n, o);
+            if constexpr (Q8OUT) {  // the same 8 values as e4m3 bytes under the tensor's scale (what the bf16 consumers see, quantised)
+                float f[8];
+                float am = *q8am;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float w = (float)o[e];
+                    am = fmaxf(am, fabsf(w));
+                    f[e] = fminf(fmaxf(w * q8inv, -448.0f), 448.0f);
+                }
+                *q8am = am;
+                int p0 = 0, p1 = 0;
+                p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], p0, false);
+                p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], p0, true);
+                p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], p1, false);
+                p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], p1, true);
+                typedef __attribute__((ext_vector_type(2))) int i32x2_;
+                *(i32x2_*)(g.q8 + (size_t)m * g.ldq8 + n) = (i32x2_){p0, p1};
+            }
         }
     }
 }
@@ -331,6 +355,12 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
         bias4[j] = (g.bias && n < g.N) ? *(const f32x4*)(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     constexpr bool PF = (ABL & 256) != 0;
+    constexpr bool Q8OUT = (ABL & 1048576) != 0;
+    float q8inv = 0.f, q8am = 0.f;
+    if constexpr (Q8OUT) {
+        const float s8 = g.q8_scale[0];
+        q8inv = s8 > 0.f ? 1.0f / s8 : 1.0f;
+    }
     SideSlab side;  // ONE buffer: slab i + 1 is requested as soon as slab i has consumed it (a second buffer spills)
     const bool has_side = (g.residual != nullptr) || GATE != ACT_NONE;
     if (PF && has_side) side_prefetch<GATE, ABL>(g, m0 + wm * 128, nb, lane, side);
@@ -346,9 +376,10 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
             *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i] * sc + bias4[j];
             acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        patch_readout<ACT, GATE, ABL>(g, patch, m0 + wm * 128 + i * 16, nb, lane, side);
+        patch_readout<ACT, GATE, ABL>(g, patch, m0 + wm * 128 + i * 16, nb, lane, side, q8inv, &q8am);
         if (PF && has_side && i + 1 < 8) side_prefetch<GATE, ABL>(g, m0 + wm * 128 + (i + 1) * 16, nb, lane, side);
     }
+    if constexpr (Q8OUT) amax_publish(g.q8_amax, wave_max(q8am), lane);  // one conditional atomic per wave and tile
 }
 
 // ------------------------------------------------------------------------------------------------

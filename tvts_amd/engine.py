@@ -211,6 +211,8 @@ class Engine:
         self._f8_scale = self._f8_amax = None
         self._f8_tensor_mode = False
         self._x8: Dict[str, tuple] = {}
+        self._x8_ready: Dict[str, tuple] = {}   # operand copies written by a producer's epilogue, waiting for their consumer
+        self._dy8_ready: Dict[str, tuple] = {}
         self._wg_stream = None
         self._wg_ws = None
         self.dev = store.device
@@ -322,9 +324,30 @@ class Engine:
             self._wg_ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.dev)
         return self._wg_stream, self._wg_ws
 
-    def _lin(self, a, wname, bname, out, M, a8=None, **epi):
+    def _q8_out(self, M, W, name, persistent=False):
+        """kwargs that make an e4m3 GEMM's epilogue write the per-tensor e4m3 copy of its bf16 result (tensor mode only), and the
+        (bytes, scale) pair its consumers take"""
+        # OPT-IN (arch["fp8_epilogue_copies"]): measured on H/14, 16 frames, 48 pairs (profiles/r04_kernel_summary_h14_b48_fp8_wgrad.txt):
+        # the two quantiser passes it removes are worth 8.6 ms per step, the two epilogues that take their work over get 105 / 120 us
+        # slower per launch (7.2 ms: they are the epilogue-bound GELU / gate forms, and the extra stores spill 30-40 bytes more) --
+        # 295.3 against 295.8 ms per step, not worth a second path by default
+        if not (self.fp8_wgrad and self._f8_tensor_mode and self.arch.get("fp8_epilogue_copies")):
+            return {}, None
+        q, sc, kw = self._q8(M, W, name, persistent=persistent)
+        return dict(q8out=q, q8_scale=sc, q8_amax=kw["amax"]), (q, sc)
+
+    def _lin(self, a, wname, bname, out, M, a8=None, q8_for=None, **epi):
+        """q8_for: the weight whose GEMMs read `out` as their activation; in the per-tensor e4m3 regime the epilogue of this GEMM
+        then writes that operand copy itself (the MLP's GELU output), instead of a quantiser pass over `out`."""
         if wname in self.P.w8:  # fp8 weight/activation path (BASELINE config 4): forward GEMMs of the ViT blocks
             w8, ws, _ = self.P.w8[wname]
+            if a8 is None:
+                a8 = self._x8_ready.pop(wname, None)
+            if q8_for is not None and q8_for in self.P.w8:
+                kw8, nxt = self._q8_out(M, out.shape[1], "x." + q8_for, persistent=True)
+                epi = dict(epi, **kw8)
+                if nxt is not None:
+                    self._x8_ready[q8_for] = nxt
             if a8 is None:  # activations that do not come out of a LayerNorm: one pass
                 q, sa, kw = self._q8(M, a.shape[1], "x." + wname, persistent=True)
                 K.quantize_fp8_rows(a[:M], q=q, **kw)
@@ -334,13 +357,15 @@ class Engine:
             return
         K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
 
-    def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, dy8=None, side=False, **epi):
+    def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, dy8=None, side=False, q8_for=None, **epi):
         """dW += dy^T a_in, db += colsum(dy) (if trainable); d_in = dy W (optional, with epilogue).  dy8: the e4m3 copy of dy
         when its producer already wrote one (_ln_bwd with fp8_for).  side: the weight gradient is launched on the side stream
         behind everything the current stream has queued so far (dy is complete there); the caller keeps dy and a_in untouched
         until it has joined the side stream."""
         want_b = bool(bname) and self.requires_grad[bname]
         f8w = self.fp8_wgrad and self._f8_tensor_mode and wname in self.P.w8t and wname in self._x8
+        if dy8 is None:
+            dy8 = self._dy8_ready.pop(wname, None)
         if (f8w or (d_in is not None and wname in self.P.w8t)) and dy8 is None:
             q, sa, kw = self._q8(M, dy.shape[1], "dy." + wname)
             K.quantize_fp8_rows(dy[:M], q=q, **kw)
@@ -363,6 +388,12 @@ class Engine:
         if d_in is not None:
             if wname in self.P.w8t:  # e4m3 input gradient (arch["fp8_dgrad"]): the transposed weight's e4m3 copy
                 w8t, wst = self.P.w8t[wname]
+                if q8_for is not None and q8_for in self.P.w8t and epi.get("gate_h") is not None:
+                    # the gated input gradient is the output gradient of layer q8_for: its per-tensor e4m3 copy leaves this epilogue
+                    kw8, nxt = self._q8_out(M, d_in.shape[1], "dy." + q8_for)
+                    epi = dict(epi, **kw8)
+                    if nxt is not None:
+                        self._dy8_ready[q8_for] = nxt
                 K.gemm_nt_fp8(dy8[0], dy8[1], w8t, wst, d_in[:M], **epi)
                 return
             K.gemm_nt(dy, self.P.wt(wname), d_in, M=M, **epi)
@@ -562,7 +593,8 @@ class Engine:
             ln2 = self._b(tg + ".ln2", (M, W))
             a8 = self._ln(s_res, pre + "ln_2", 1e-5, ln2, tg + ".ln2", fp8_for=pre + "mlp.c_fc.weight")
             h, act = self._b(tg + ".h", (M, 4 * W)), self._b(tg + ".a", (M, 4 * W))
-            self._lin(ln2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", act, M, act=a["act"], preact=h, a8=a8)
+            self._lin(ln2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", act, M, act=a["act"], preact=h, a8=a8,
+                      q8_for=pre + "mlp.c_proj.weight")
             xo = xbuf(f"vit.x{l + 1}", (M, W))
             self._lin(act, pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", xo, M, residual=s_res)
             x = xo
@@ -661,7 +693,7 @@ class Engine:
             dqkv_t = self._b("vit.s.dqkv_t" + par, (M, 3 * W)) if side else dqkv
             # (e4m3 input gradients: the LayerNorm backward that produces an output gradient also writes its e4m3 copy, d*8)
             self._lin_bwd(dxb, B_[tg + ".a"], pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dh, M, dy8=dxb8, side=side,
-                          gate_h=B_[tg + ".h"], gate_act=a["act"])
+                          q8_for=pre + "mlp.c_fc.weight", gate_h=B_[tg + ".h"], gate_act=a["act"])
             self._lin_bwd(dh, B_[tg + ".ln2"], pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", dln, M, side=side)
             dsrb8 = self._ln_bwd(dln, B_[tg + ".s_res"], pre + "ln_2", tg + ".ln2", dsr, dx_bf16=dsrb, res1=dxb if lowp else dx,
                                  fp8_for=pre + "attn.proj.weight")

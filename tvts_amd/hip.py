@@ -253,7 +253,7 @@ def fp8_update_scales(amax, scale):
 
 
 def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None, k32=None,
-                cus=None):
+                cus=None, q8out=None, q8_scale=None, q8_amax=None):
     """out[M,N] = act(sa*sb * (a8[M,K] @ b8[N,K]^T) + bias) [+ residual]; a8 / b8 uint8 e4m3 bit patterns; sb float32[1]; sa
     float32[1] (one scale for the tensor) or float32[>= M] (one per row, quantize_fp8_rows); preact receives the bf16
     pre-activation like gemm_nt.  gate_h / gate_act: the input-gradient form, out = gate_act'(gate_h) * (sa*sb * (a8 @ b8^T)).
@@ -274,7 +274,8 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
         assert residual is None and act is None and preact is None and out.dtype == torch.bfloat16
         assert bias is None or gate_act == "add"
         rc = lib.tvts_gemm_nt_fp8_gate(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(bias), _p(gate_h),
-                                       _ld(gate_h), ACT[gate_act], _p(out), _ld(out), nt_opts(None, cus, k32), _stream())
+                                       _ld(gate_h), ACT[gate_act], _p(out), _ld(out), _p(q8out), q8out.stride(0) if q8out is not None else 0, _p(q8_scale),
+                                       _p(q8_amax), nt_opts(None, cus, k32), _stream())
         _chk(rc, "tvts_gemm_nt_fp8_gate")
         if GEMM_PROFILE is not None:
             ev1.record()
@@ -283,7 +284,8 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
     rc = lib.tvts_gemm_nt_fp8(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(bias), _p(residual),
                               _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
                               _ld(preact) if preact is not None else 0, _p(out), _ld(out),
-                              1 if out.dtype == torch.float32 else 0, nt_opts(None, cus, k32), _stream())
+                              1 if out.dtype == torch.float32 else 0, _p(q8out), q8out.stride(0) if q8out is not None else 0,
+                              _p(q8_scale), _p(q8_amax), nt_opts(None, cus, k32), _stream())
     _chk(rc, "tvts_gemm_nt_fp8")
     if GEMM_PROFILE is not None:
         ev1.record()
