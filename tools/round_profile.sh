@@ -3,7 +3,7 @@
 #   1. rocprofv3 --kernel-trace of the default bench step (eager launches)  -> gpurun_out/<tag>/kernel_summary_default_b192.txt
 #   2. tools/pmc_traffic.sh (FETCH_SIZE / WRITE_SIZE passes) + the per-shape join -> pmc_step_traffic_*.json, pmc_gemm_traffic_by_shape.txt
 #   3. bench lines: default, the reference's per-GPU batch (12 pairs), WebVid-style NT = 1, B/32 (configs[1]), H/14 16 frames
-#      bf16 / fp8 forward / fp8 forward + input gradients (+ its kernel trace, the fp8 GEMM and attention micro-benchmarks), v1 -> bench_*.json(l)
+#      bf16 / fp8 forward / + input gradients / + weight gradients (+ its kernel trace, the fp8 GEMM and attention micro-benchmarks), v1 -> bench_*.json(l)
 tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
@@ -26,9 +26,11 @@ python tools/pmc_join.py gpurun_out/gemm_order.json gpurun_out > $out/pmc_gemm_t
   python bench.py --arch B_32 --batch 24 --steps 20 --warmup 5 --no-cpu-baseline; } 2>/dev/null | grep '^{' > $out/bench_b32_t8.jsonl
 { python bench.py --arch H_14 --frames 16 --batch 48 --steps 8 --warmup 3 --no-cpu-baseline
   python bench.py --arch H_14 --frames 16 --batch 48 --steps 8 --warmup 3 --no-cpu-baseline --fp8
-  python bench.py --arch H_14 --frames 16 --batch 48 --steps 8 --warmup 3 --no-cpu-baseline --fp8-dgrad; } 2>/dev/null | grep '^{' > $out/bench_h14_t16_b48.jsonl
-tools/profile_step.sh ${tag}_h14fp8 --arch H_14 --frames 16 --batch 48 --fp8-dgrad > $out/profile_h14fp8.log 2>&1
-cp gpurun_out/prof_${tag}_h14fp8/summary.txt $out/kernel_summary_h14_b48_fp8_dgrad.txt
+  python bench.py --arch H_14 --frames 16 --batch 48 --steps 8 --warmup 3 --no-cpu-baseline --fp8-dgrad
+  python bench.py --arch H_14 --frames 16 --batch 48 --steps 8 --warmup 3 --no-cpu-baseline --fp8-wgrad; } 2>/dev/null | grep '^{' > $out/bench_h14_t16_b48.jsonl
+tools/profile_step.sh ${tag}_h14fp8 --arch H_14 --frames 16 --batch 48 --fp8-wgrad > $out/profile_h14fp8.log 2>&1
+cp gpurun_out/prof_${tag}_h14fp8/summary.txt $out/kernel_summary_h14_b48_fp8_wgrad.txt
+python tools/tn_fp8_bench.py > $out/tn_fp8_bench.txt 2>&1
 PAIRS=48 python tools/gemm_fp8_cmp.py > $out/gemm_fp8_cmp.txt 2>&1
 PAIRS=192 python tools/attn_bench.py > $out/attn_bench.txt 2>&1
 { python bench.py --arch v1 --frames 4 --batch 256 --steps 20 --warmup 5 --cpu-pairs 8
