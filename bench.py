@@ -98,7 +98,8 @@ def cpu_baseline_worker(arch_name, T, caption_len, pairs, max_seconds, threads, 
     return {"value": pairs / dt, "unit": "pairs/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"{n} full step(s) (fwd+bwd+HF-AdamW) of the fp32 torch-CPU oracle, {arch_name}, T={T}, "
                       f"{pairs} pairs/step, {caption_len}-token captions x{n_trans}, {threads} torch threads on a host with "
-                      f"{os.cpu_count()} logical CPUs"}
+                      f"{os.cpu_count()} logical CPUs (not all of them: 32 threads measured best on the 256-CPU host -- 0.98 pairs/s "
+                      f"against 0.52 with 64 and 0.25 with 128; 256 time out)"}
 
 
 def host_threads():
@@ -128,9 +129,9 @@ def cpu_baseline(arch_name, T, caption_len, pairs, max_seconds, n_trans=4):
 def gemm_bytes(kind, shp):
     """operand + result bytes of one GEMM launch if every matrix crossed HBM exactly once (the floor `traffic` is read
     against)."""
-    if kind == "gemm_tn":
+    if kind in ("gemm_tn", "gemm_tn_fp8"):
         M, Na, Nb = shp[:3]
-        return 2.0 * M * (Na + Nb) + 4.0 * Na * Nb
+        return (1.0 if kind.endswith("fp8") else 2.0) * M * (Na + Nb) + 4.0 * Na * Nb
     M, N, K, odt, res, act, gate = shp
     eb = 1.0 if odt == "fp8" else 2.0
     b = eb * K * (M + N) + M * N * (4.0 if odt == "f32" else 2.0)
@@ -423,6 +424,8 @@ def main():
             traffic = None
         line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_BF16_TFLOPS,
+                            "frac_of": "the MFMA GEMM launches alone (summed 2MNK over summed launch durations); the WHOLE step on its "
+                                       "executed FLOPs is step_mfma_frac",
                             "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
                             "traffic_unit": "HBM bytes per step over the same launches (rocprofv3 --pmc FETCH_SIZE x2 + "
                                             "WRITE_SIZE, tools/pmc_traffic.sh)" if traffic else None,
