@@ -229,6 +229,33 @@ def _step_against_oracle(lib, arch_name, B, T, big_tile):
     worst.sort()
     assert abs(gn - gn_ref) < 0.01 * gn_ref, (gn, gn_ref, worst[:5])
     assert worst[0][0] > 0.995, worst[:8]
+    # the same step with every NT GEMM that can take it on the stream-K walk (K-stage work split, ordered sum of the partial tiles in
+    # the last-arriving block) and every split weight gradient reduced inside its kernel: the same gates against the oracle, and
+    # two such steps leave the same bits (the sums are ordered whoever arrives last)
+    from tvts_amd import hip as K2
+    g_default = m.store.grad.clone()
+
+    def forced_step():
+        m.store.grad.zero_()
+        te_, ve_, pred_ = m.engine.forward(pb)
+        l1_, dv_, dt_ = head.contrastive(ve_, te_)
+        l2_, dp_ = head.sorting(pred_, batch["label"].reshape(-1).to(torch.int32).to(DEV))
+        m.engine.backward(dt_, dv_, dp_)
+        torch.cuda.synchronize()
+        return float(l1_), float(l2_), te_.clone(), ve_.clone(), m.store.grad.clone()
+    with K2.options(nt_streamk=True, tn_streamk=True):
+        n0 = K2.STREAMK_TAKEN[0]
+        s1, s2, te_s, ve_s, g_s = forced_step()
+        taken = K2.STREAMK_TAKEN[0] - n0
+        _, _, _, _, g_s2 = forced_step()
+    assert taken >= 200, taken                      # the ViT blocks' GEMMs did take the forced paths
+    assert torch.equal(g_s, g_s2)
+    assert min_cos(ve_s, rve) > 0.9995 and rel(ve_s.cpu(), rve.detach()) < 0.02
+    assert abs(s1 - float(r1)) < 1e-2 and abs(s2 - float(r2)) < 1e-2
+    gn_s = float(g_s.double().norm())
+    assert abs(gn_s - gn_ref) < 0.01 * gn_ref and not torch.equal(g_s, g_default)
+    cos = float(torch.nn.functional.cosine_similarity(g_s.double().flatten(), g_default.double().flatten(), dim=0))
+    assert cos > 0.9999, cos
 
 
 def _sub_batch(batch, idx, NT):

@@ -152,6 +152,40 @@ def test_gemm_tn_256_tile(K, M, Na, Nb):
         assert rel(out, ref) < 3e-5
 
 
+@pytest.mark.parametrize("M,N,K_", [(9420, 768, 768), (9420, 2304, 768), (9420, 768, 3072), (18840, 3072, 768), (5000, 1280, 1280), (9432, 768, 2304)])
+def test_gemm_nt_streamk(K, M, N, K_):
+    """The stream-K walk of the 256x256 NT kernel (TVTS_GEMM_STREAMK; round 4, for the reference's per-GPU batches: M = 12 / 24 x 785):
+    work split by K stage inside each XCD's tile range, pieces that do not cover a tile's K leave as fp32 partials, the block that
+    arrives last adds them in k order and runs the fused epilogue.  Every epilogue form against an fp64 product, and the same bits
+    launch after launch (with other launches in between: the arrival counters are zero again after every call)."""
+    a, b = bf(rnd(M, K_, seed=71)).to(DEV), bf(rnd(N, K_, seed=72) * K_ ** -0.5).to(DEV)
+    bias = rnd(N, seed=73).to(DEV)
+    ref = a.double() @ b.double().t() + bias.double()
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    res = rnd(M, N, seed=74).to(DEV)
+    K.gemm_nt(a, b, out, bias=bias, residual=res, streamk=True)
+    assert rel(out, ref + res.double()) < 2e-5, rel(out, ref + res.double())
+    outb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt(a, b, outb, bias=bias, streamk=True)
+    other = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt(a, b, other, streamk=True)
+    outb2 = torch.empty_like(outb)
+    K.gemm_nt(a, b, outb2, bias=bias, streamk=True)
+    assert torch.equal(outb, outb2) and rel(outb.float(), ref) < 4e-3
+    # activation + pre-activation side output, and the activation-gradient gate
+    pre, act = torch.empty_like(outb), torch.empty_like(outb)
+    K.gemm_nt(a, b, act, bias=bias, act="quick_gelu", preact=pre, streamk=True)
+    z = ref
+    assert rel(pre.float(), z) < 4e-3 and rel(act.float(), z * torch.sigmoid(1.702 * z)) < 5e-3
+    gate = torch.empty_like(outb)
+    K.gemm_nt(a, b, gate, gate_h=pre, gate_act="quick_gelu", streamk=True)
+    h = pre.float().double()
+    sg = torch.sigmoid(1.702 * h)
+    assert rel(gate.float(), (ref - bias.double()) * (sg * (1 + 1.702 * h * (1 - sg)))) < 6e-3
+    ws = K._nt_workspace(a.device)
+    assert int(ws[:65536].view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("M,Na,Nb", [(9420, 768, 768), (9420, 2304, 768), (18840, 768, 3072), (4097, 1280, 640), (40001, 768, 768), (3000, 248, 264)])
 def test_gemm_tn_fused_reduce_gives_the_bits_of_the_reduce_pass(K, M, Na, Nb, tile):

@@ -153,6 +153,7 @@ def gemm_tn_select(M, Na, Nb, tile=None):
     return _lib.load().tvts_gemm_tn_select(M, Na, Nb, tn_opts(tile=tile))
 
 
+STREAMK_TAKEN = [0]  # launches that took the stream-K walk / the fused reduce under a forcing option (tests assert the path ran)
 NT_WORKSPACE = None  # scratch of the stream-K walk of gemm_nt (arrival counters + fp32 partial tiles), one per process = one stream
 
 
@@ -180,12 +181,19 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
     if GEMM_PROFILE is not None:
         ev0, ev1 = Event(), Event()
         ev0.record()
-    rc = lib.tvts_gemm_nt_bf16(_p(a), _ld(a), _p(b), _ld(b), M, N, K, _p(bias), _p(residual),
-                               _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
-                               _ld(preact) if preact is not None else 0, _p(gate_h),
-                               _ld(gate_h) if gate_h is not None else 0, ACT[gate_act], _p(out), _ld(out),
-                               1 if out.dtype == torch.float32 else 0, _p(ws), ws.numel() if ws is not None else 0,
-                               nt_opts(tile, cus, streamk=streamk), _stream())
+    def launch(sk):
+        return lib.tvts_gemm_nt_bf16(_p(a), _ld(a), _p(b), _ld(b), M, N, K, _p(bias), _p(residual),
+                                     _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
+                                     _ld(preact) if preact is not None else 0, _p(gate_h),
+                                     _ld(gate_h) if gate_h is not None else 0, ACT[gate_act], _p(out), _ld(out),
+                                     1 if out.dtype == torch.float32 else 0, _p(ws), ws.numel() if ws is not None else 0,
+                                     nt_opts(tile, cus, streamk=sk), _stream())
+    want_sk = _OPTS["nt_streamk"] if streamk is None else streamk
+    rc = launch(streamk)
+    if rc == -22 and want_sk and streamk is None:  # the process-wide option means "wherever the shape can take it"
+        rc = launch(False)
+    elif rc == 0 and want_sk:
+        STREAMK_TAKEN[0] += 1
     _chk(rc, "tvts_gemm_nt_bf16")
     if GEMM_PROFILE is not None:
         ev1.record()
@@ -325,10 +333,17 @@ def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True, 
     if GEMM_PROFILE is not None:
         ev0, ev1 = Event(), Event()
         ev0.record()
-    rc = lib.tvts_gemm_tn_bf16(_p(p), _ld(p), _p(q), _ld(q), M, p.shape[1], q.shape[1], _p(out), _ld(out),
-                               1 if accumulate else 0, _p(colsum), _p(ws), ws.numel() if ws is not None else 0,
-                               _p(cnt), cnt.numel() if cnt is not None else 0,
-                               tn_opts(tile, splits, early_dma, a_fast, fused), _stream())
+    def launch(fu):
+        return lib.tvts_gemm_tn_bf16(_p(p), _ld(p), _p(q), _ld(q), M, p.shape[1], q.shape[1], _p(out), _ld(out),
+                                     1 if accumulate else 0, _p(colsum), _p(ws), ws.numel() if ws is not None else 0,
+                                     _p(cnt), cnt.numel() if cnt is not None else 0,
+                                     tn_opts(tile, splits, early_dma, a_fast, fu), _stream())
+    want_fu = _OPTS["tn_streamk"] if fused is None else fused
+    rc = launch(fused)
+    if rc == -22 and want_fu and fused is None:
+        rc = launch(False)
+    elif rc == 0 and want_fu:
+        STREAMK_TAKEN[0] += 1
     _chk(rc, "tvts_gemm_tn_bf16")
     if GEMM_PROFILE is not None:
         ev1.record()
