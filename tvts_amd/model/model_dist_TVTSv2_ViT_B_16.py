@@ -5,6 +5,3 @@ from ._common import TVTSv2Base, sim_matrix  # noqa: F401
 class TVTSv2_B_16(TVTSv2Base):
     ARCH_NAME = "B_16"
 
-
-if __name__ == "__main__":
-    pass

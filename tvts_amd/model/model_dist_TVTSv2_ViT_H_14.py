@@ -5,6 +5,3 @@ from ._common import TVTSv2Base, sim_matrix  # noqa: F401
 class TVTSv2_H_14(TVTSv2Base):
     ARCH_NAME = "H_14"
 
-
-if __name__ == "__main__":
-    pass
