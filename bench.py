@@ -202,6 +202,8 @@ def main():
                     "but the |d loss| <= 1e-2 gate of SURVEY 8d fails on one small configuration; profiles/r03_bf16_streams_ab.txt)")
     ap.add_argument("--wgrad-stream", choices=("auto", "on", "off"), default="auto", help="weight gradients of the ViT blocks on a side "
                     "stream beside the input-gradient chain (auto = off: measured slower, profiles/r04_wgrad_side_stream.txt)")
+    ap.add_argument("--tn-grouped", choices=("auto", "on", "off"), default="auto", help="the six weight gradients of a ViT block in one grouped "
+                    "launch (auto: below 40 000 token rows per GPU)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
@@ -263,6 +265,10 @@ def main():
         a["bf16_grad_stream"] = True
     if args.bf16_residual:
         a["bf16_residual"] = True
+    if args.tn_grouped != "auto":
+        a["tn_grouped"] = args.tn_grouped == "on"
+    if os.environ.get("TVTS_TN_GROUP_SPLITS"):
+        a["tn_group_splits"] = int(os.environ["TVTS_TN_GROUP_SPLITS"])
     if args.wgrad_stream != "auto":
         a["wgrad_stream"] = args.wgrad_stream == "on"
     margs = types.SimpleNamespace(local_rank=local_rank, rank=rank, world_size=world)

@@ -77,6 +77,15 @@ int tvts_gemm_nt_select(int M, int N, int opts);
 int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int Na, int Nb, float* out, int ldo,
                       int accumulate, float* colsum, float* workspace, long workspace_elems, int* counters, int n_counters,
                       int opts, hipStream_t stream);
+/* Several weight gradients in ONE launch + ONE ordered reduce launch (the six of a ViT block at the reference's per-GPU batches, where
+ * each alone fills a fraction of a round): problems = HOST array of n records
+ *   struct { const void* P; int ldp; const void* Q; int ldq; int M, Na, Nb; float* out; int ldo; int accumulate; float* colsum; }
+ * (the arguments of tvts_gemm_tn_bf16); table_dev = device memory for the plan (tvts_gemm_tn_grouped_table_bytes(n)).  upload != 0
+ * writes the plan (a synchronous copy: not during a stream capture); upload == 0 re-uses the plan a previous call with the SAME
+ * problems and workspace left there.  Every problem's result has the bits of tvts_gemm_tn_bf16 called with the same range count. */
+int tvts_gemm_tn_bf16_grouped(const void* problems, int n, void* table_dev, long table_bytes, int upload, float* workspace,
+                              long workspace_elems, int opts, hipStream_t stream);
+long tvts_gemm_tn_grouped_table_bytes(int n);
 /* the tile (128: 128x128 kernel, two blocks per CU; 256: pipelined 256x256 kernel) tvts_gemm_tn_bf16 picks for M rows into an
  * [Na, Nb] output under `opts` */
 int tvts_gemm_tn_select(int M, int Na, int Nb, int opts);

@@ -216,6 +216,45 @@ def test_gemm_tn_fused_reduce_gives_the_bits_of_the_reduce_pass(K, M, Na, Nb, ti
     assert int(K._tn_counters(K._tn_workspace(p.device)).abs().sum()) == 0
 
 
+def test_gemm_tn_grouped_gives_the_bits_of_the_single_launches(K):
+    """tvts_gemm_tn_bf16_grouped: the six weight gradients of a ViT block (M = 12 x 785 token rows, the reference's per-GPU batch) in
+    one launch + one reduce launch.  With the same range count every problem's output and bias gradient are the bits of its own
+    tvts_gemm_tn_bf16 launch; the automatic plan holds the fp32 tolerance; the plan is re-used by later runs."""
+    M, W = 9420, 768
+    shapes = [(W, 4 * W), (4 * W, W), (W, W), (3 * W, W), (W, W), (3 * W, W)]
+    ps = [bf(rnd(M, na, seed=90 + i)).to(DEV) for i, (na, nb) in enumerate(shapes)]
+    qs = [bf(rnd(M, nb, seed=190 + i)).to(DEV) for i, (na, nb) in enumerate(shapes)]
+    base = [rnd(na, nb, seed=290 + i).to(DEV) for i, (na, nb) in enumerate(shapes)]
+
+    def problems(outs, css):
+        return [dict(p=p, q=q, out=o, M=M, accumulate=True, colsum=c) for p, q, o, c in zip(ps, qs, outs, css)]
+    ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=DEV)
+    outs = [b.clone() for b in base]
+    css = [torch.ones(na, device=DEV) if i % 2 == 0 else None for i, (na, nb) in enumerate(shapes)]
+    grp = K.TnGroup(problems(outs, css), ws, splits=4)
+    grp.run()
+    torch.cuda.synchronize()
+    for i, (na, nb) in enumerate(shapes):
+        o = base[i].clone()
+        c = torch.ones(na, device=DEV) if css[i] is not None else None
+        K.gemm_tn(ps[i], qs[i], o, M=M, accumulate=True, colsum=c, tile=128, splits=4, fused=False)
+        assert torch.equal(o, outs[i]), i
+        if c is not None:
+            assert torch.equal(c, css[i]), i
+    for o, b in zip(outs, base):
+        o.copy_(b)
+    grp.run()   # the uploaded plan again
+    for i in range(len(shapes)):
+        o = base[i].clone()
+        K.gemm_tn(ps[i], qs[i], o, M=M, accumulate=True, tile=128, splits=4, fused=False)
+        assert torch.equal(o, outs[i])
+    outs2 = [b.clone() for b in base]
+    K.TnGroup(problems(outs2, [None] * 6), ws).run()   # automatic range count
+    for i in range(len(shapes)):
+        ref = base[i].cpu().double() + ps[i].cpu().float().t().double() @ qs[i].cpu().float().double()
+        assert rel(outs2[i], ref) < 3e-5, (i, rel(outs2[i], ref))
+
+
 def test_gemm_tn_tile_selection(K):
     """The plan of the weight-gradient entry point (a cost model of tile and range count, csrc/gemm.hip; tools/tn_plan_check.py
     measures it against both tiles' best): the long contractions of the 192-pair step take the 256x256 kernel -- the text tower's

@@ -566,18 +566,13 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* lds_tile, int u, int ct, i
     return __builtin_bit_cast(bf16x8, both);
 }
 
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][P 16K | Q 16K]
+// the body of the 128x128 weight-gradient kernel for work item `item` of problem g (shared by the single-problem kernel and the
+// grouped one below)
+__device__ __forceinline__ void tn128_item(const GemmTN& g, int item, char* smem) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave >> 1, wb = wave & 1;
-
-    // Work items are (m-range, output tile) pairs in range-major order; XCD x (= blockIdx % 8) takes the x-th
-    // contiguous eighth of that list, so the P/Q rows of an m-range are pulled into ONE XCD's L2 (two at a
-    // boundary) and shared there by all output tiles, instead of being fetched by all eight L2s.
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per = gridDim.x >> 3;
-    const int item = xcd * per + jx;
     if (item >= g.n_items) return;
     const int split = item / g.tiles_ab;
     const int t = item % g.tiles_ab;
@@ -698,6 +693,55 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
                 *(f32x4*)dst = acc[i][j];
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmTN g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][P 16K | Q 16K]
+    // Work items are (m-range, output tile) pairs in range-major order; XCD x (= blockIdx % 8) takes the x-th
+    // contiguous eighth of that list, so the P/Q rows of an m-range are pulled into ONE XCD's L2 (two at a
+    // boundary) and shared there by all output tiles, instead of being fetched by all eight L2s.
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per = gridDim.x >> 3;
+    tn128_item(g, xcd * per + jx, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouped weight gradients (round 4, the reference's per-GPU batches): the six weight gradients of a ViT block in ONE launch
+// and their split partials in ONE reduce launch.  At M = 9 420 a weight gradient is 100-430 work items for 512 block slots
+// and ends after 0.2-0.85 of a round, twelve launches of 9-50 us per block of the model; grouped, the ~2 000 items of the six
+// problems share the slots round after round (the XCD-contiguous walk runs over the concatenated item list) and ten launch
+// ramps per block disappear.  The plan (one GemmTN per problem + the item prefix) lives in device memory the caller owns;
+// every problem keeps its own contraction ranges, workspace slice and ordered reduce, so the results are the bits of the
+// one-by-one launches.
+// ------------------------------------------------------------------------------------------------
+struct TnGroup { const GemmTN* tab; const int* prefix; int n; };
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_grouped_kernel(TnGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int item = xcd * per + jx;
+    if (item >= grp.prefix[grp.n]) return;
+    int p = 0;
+    while (p + 1 < grp.n && item >= grp.prefix[p + 1]) ++p;
+    const GemmTN g = grp.tab[p];  // block-uniform
+    tn128_item(g, item - grp.prefix[p], smem);
+}
+__global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnGroup grp) {
+    const GemmTN g = grp.tab[blockIdx.y];
+    if (!g.ws) return;  // one range: the kernel wrote the output itself
+    if (g.cs_ws) {
+        for (int a = blockIdx.x * 256 + threadIdx.x; a < g.Na; a += gridDim.x * 256) {
+            float s = g.colsum[a];
+            for (int k = 0; k < g.splits; ++k) s += g.cs_ws[(size_t)k * g.Na + a];
+            g.colsum[a] = s;
+        }
+    }
+    const size_t n4 = (size_t)g.Na * g.Nb / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t e = i * 4;
+        const int a = (int)(e / g.Nb), b = (int)(e % g.Nb);
+        f32x4 s = g.accumulate ? *(const f32x4*)(g.out + (size_t)a * g.ldo + b) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < g.splits; ++k) s += *(const f32x4*)(g.ws + (size_t)k * g.Na * g.Nb + e);
+        *(f32x4*)(g.out + (size_t)a * g.ldo + b) = s;
     }
 }
 
@@ -835,6 +879,91 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
         hipLaunchKernelGGL(tn_reduce_kernel, dim3(rb), dim3(256), 0, stream, workspace, splits, Na, Nb, out, ldo, accumulate,
                            g.cs_ws, colsum);
     }
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ---- grouped weight gradients (see gemm_tn_grouped_kernel).  problems: HOST array of n tvts_tn_problem; table_dev: device memory
+// for the plan, n * sizeof(GemmTN) + (n + 1) * 4 bytes (tvts_gemm_tn_grouped_table_bytes).  upload != 0: the plan is written to
+// table_dev (a synchronous copy: not inside a stream capture); upload == 0: table_dev already holds the plan of these very
+// problems (same pointers, shapes, workspace) from an earlier call, only the launches are enqueued -- the form a captured step uses.
+struct tvts_tn_problem_ { const void* P; int ldp; const void* Q; int ldq; int M, Na, Nb; float* out; int ldo; int accumulate; float* colsum; };
+extern "C" long tvts_gemm_tn_grouped_table_bytes(int n) { return (long)n * (long)sizeof(GemmTN) + (long)(n + 1) * 4 + 64; }
+extern "C" int tvts_gemm_tn_bf16_grouped(const void* problems, int n, void* table_dev, long table_bytes, int upload, float* workspace,
+                                         long workspace_elems, int opts, hipStream_t stream) {
+    if (n <= 0 || n > 64 || !problems || !table_dev || !workspace || table_bytes < tvts_gemm_tn_grouped_table_bytes(n)) return TVTS_EINVAL;
+    const tvts_tn_problem_* pr = (const tvts_tn_problem_*)problems;
+    GemmTN tab[64];
+    int prefix[65];
+    long tiles_total = 0, out_total = 0;
+    int Mmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (pr[i].M <= 0 || pr[i].Na % 8 || pr[i].Nb % 8 || pr[i].ldp % 8 || pr[i].ldq % 8 || pr[i].ldo % 4 || pr[i].Nb % 4) return TVTS_EINVAL;
+        tiles_total += (long)ceil_div(pr[i].Na, 128) * ceil_div(pr[i].Nb, 128);
+        out_total += (long)pr[i].Na * pr[i].Nb;
+        Mmax = pr[i].M > Mmax ? pr[i].M : Mmax;
+    }
+    // ONE range count for the group: rounds of the 512 block slots over ALL items x rows per range (0.0148 us per contraction row of a
+    // 128-tile item, the single-problem model's figure) + the partials' bytes; the slots are filled by the other problems' items,
+    // so a group takes fewer, longer ranges than its members would alone
+    int sp_best = 1;
+    if ((opts >> 8) > 0) {
+        sp_best = opts >> 8;
+    } else {
+        double best = 1e30;
+        for (int sp = 1; sp <= 32; ++sp) {
+            if (sp > 1 && Mmax / sp < 512) break;
+            if (sp > 1 && (double)sp * ((double)out_total + 4096.0 * n) > (double)workspace_elems) break;
+            const double rounds = (double)((tiles_total * sp + 511) / 512);
+            const double t = rounds * (ceil_div(ceil_div(Mmax, sp), 64) * 64.0) * 0.0148 + (sp > 1 ? sp * (double)out_total * 1e-6 : 0.0);
+            if (t < best) { best = t; sp_best = sp; }
+        }
+    }
+    float* ws = workspace;
+    long used = 0;
+    prefix[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmTN& g = tab[i];
+        const tvts_tn_problem_& q = pr[i];
+        g.P = (const bf16*)q.P; g.ldp = q.ldp; g.Q = (const bf16*)q.Q; g.ldq = q.ldq; g.M = q.M; g.Na = q.Na; g.Nb = q.Nb;
+        g.out = q.out; g.ldo = q.ldo; g.colsum = q.colsum; g.accumulate = q.accumulate; g.cnt = nullptr;
+        g.tiles_a = ceil_div(q.Na, 128); g.tiles_b = ceil_div(q.Nb, 128); g.tiles_ab = g.tiles_a * g.tiles_b;
+        g.a_fast = g.tiles_a < g.tiles_b ? 1 : 0;
+        g.early_dma = ((unsigned long long)q.M * (unsigned long long)(q.ldp > q.ldq ? q.ldp : q.ldq) * 2ull < (1ull << 32)) ? 1 : 0;
+        int splits = sp_best;
+        while (splits > 1 && q.M / splits < 256) --splits;
+        g.m_per_split = ceil_div(ceil_div(q.M, splits), 64) * 64;
+        splits = ceil_div(q.M, g.m_per_split);
+        g.splits = splits;
+        g.ws = nullptr; g.cs_ws = nullptr;
+        if (splits > 1) {
+            const long need = (long)splits * q.Na * q.Nb + (q.colsum ? (long)splits * q.Na : 0);
+            if (used + need > workspace_elems) return TVTS_EINVAL;
+            g.ws = ws + used;
+            if (q.colsum) g.cs_ws = ws + used + (long)splits * q.Na * q.Nb;
+            used += (need + 63) / 64 * 64;
+        }
+        g.atomic = (q.accumulate || splits > 1) ? 1 : 0;
+        g.n_items = g.tiles_ab * splits;
+        prefix[i + 1] = prefix[i] + g.n_items;
+        if (splits == 1 && !q.accumulate) { /* the single owner of every element stores it */ }
+    }
+    char* td = (char*)table_dev;
+    if (upload) {
+        hipError_t e = hipMemcpy(td, tab, (size_t)n * sizeof(GemmTN), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemcpy(td + (size_t)n * sizeof(GemmTN), prefix, (size_t)(n + 1) * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return (int)e;
+    }
+    TnGroup grp;
+    grp.tab = (const GemmTN*)td; grp.prefix = (const int*)(td + (size_t)n * sizeof(GemmTN)); grp.n = n;
+    const int grid = ceil_div(prefix[n], 8) * 8;
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e2 != hipSuccess) return (int)e2;
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(grid), dim3(NTHREADS), 65536, stream, grp);
+    bool any_ws = false;
+    for (int i = 0; i < n; ++i) any_ws = any_ws || tab[i].ws != nullptr;
+    if (any_ws) hipLaunchKernelGGL(tn_reduce_grouped_kernel, dim3(384, n), dim3(256), 0, stream, grp);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

@@ -205,6 +205,12 @@ class Engine:
         # 692.9 / 958.5 / 1154 / 1351 without.  arch["wgrad_stream"] = True switches it on (bit-identical gradients,
         # tests/test_bench_path_gpu.py::test_wgrad_side_stream_gives_the_same_bits).
         self.wgrad_stream = a.get("wgrad_stream", False)
+        # The six weight gradients of a ViT block in ONE grouped launch + one reduce launch (round 4, tvts_gemm_tn_bf16_grouped):
+        # arch["tn_grouped"] True / False, None = automatic (up to TN_GROUPED_MAX_ROWS token rows per GPU, where a single weight
+        # gradient fills a fraction of a round of the chip and its launch ramp is a third of its time)
+        self.tn_grouped = a.get("tn_grouped", None)
+        self._tn_groups: Dict[object, object] = {}
+        self._tn_group_ws = None
         # e4m3 weight gradients (BASELINE config 5): per-tensor delayed scaling of every e4m3 operand copy, see _q8 below
         self.fp8_wgrad = bool(a.get("fp8_wgrad", False))
         self._f8_ids: Dict[str, int] = {}
@@ -357,7 +363,28 @@ class Engine:
             return
         K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
 
-    def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, dy8=None, side=False, q8_for=None, **epi):
+    TN_GROUPED_MAX_ROWS = 12000  # measured (profiles/r04_tn_grouped.txt): +1.5 % at 12 pairs (M = 9 420), -0.4 % at 24, -2 % at 48
+
+    def _tn_grouped_on(self, M) -> bool:
+        on = self.tn_grouped
+        if on is None:
+            on = M <= self.TN_GROUPED_MAX_ROWS
+        return bool(on) and not self.fp8_wgrad and not self.wgrad_stream
+
+    def _tn_group_run(self, key, problems):
+        """launch the deferred weight gradients of one block together; the plan is cached per block while the buffers stay the same"""
+        if not problems:
+            return
+        grp = self._tn_groups.get(key)
+        sig = tuple((pr["p"].data_ptr(), pr["q"].data_ptr(), pr["out"].data_ptr(), pr["M"],
+                     pr["colsum"].data_ptr() if pr["colsum"] is not None else 0) for pr in problems)
+        if grp is None or grp[0] != sig:
+            if self._tn_group_ws is None:
+                self._tn_group_ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.dev)
+            grp = self._tn_groups[key] = (sig, K.TnGroup(problems, self._tn_group_ws, splits=int(self.arch.get("tn_group_splits", 0))))
+        grp[1].run()
+
+    def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, dy8=None, side=False, q8_for=None, defer=None, **epi):
         """dW += dy^T a_in, db += colsum(dy) (if trainable); d_in = dy W (optional, with epilogue).  dy8: the e4m3 copy of dy
         when its producer already wrote one (_ln_bwd with fp8_for).  side: the weight gradient is launched on the side stream
         behind everything the current stream has queued so far (dy is complete there); the caller keeps dy and a_in untouched
@@ -371,7 +398,9 @@ class Engine:
             K.quantize_fp8_rows(dy[:M], q=q, **kw)
             dy8 = (q, sa)
         if self.requires_grad[wname]:  # bias gradient (column sums of dy) rides along in the same kernel
-            if f8w:  # e4m3 weight gradient: both operands under one scale per tensor, the bias gradient from the same bytes
+            if defer is not None and not f8w:  # launched with the block's other weight gradients (the caller keeps dy untouched till then)
+                defer.append(dict(p=dy, q=a_in, out=self.P.g2d(wname), M=M, accumulate=True, colsum=self.P.g(bname) if want_b else None))
+            elif f8w:  # e4m3 weight gradient: both operands under one scale per tensor, the bias gradient from the same bytes
                 x8 = self._x8[wname]
                 K.gemm_tn_fp8(dy8[0], dy8[1], x8[0], x8[1], self.P.g2d(wname), M=M, accumulate=True,
                               colsum=self.P.g(bname) if want_b else None)
@@ -680,36 +709,41 @@ class Engine:
         # stream's work of layer l + 1 before layer l overwrites the first of them (its ln_3 backward writes the dxb that layer
         # l + 1 read) -- the side stream may lag one layer behind, never two
         side = self._wgrad_side(M)
+        grouped = self._tn_grouped_on(M)
         side_done = {}
         cur = torch.cuda.current_stream(self.dev)
         for l in reversed(range(a["layers"])):
             pre, tg = f"video_model.transformer.resblocks.{l}.", f"vit{l}"
             x_in = B_[f"vit.x{l}"]
             par = str(l % 2) if side else ""
+            defer = [] if grouped else None
             dh = self._b("vit.s.dh" + par, (M, 4 * W))
             dsrb = self._b("vit.s.dsresb" + par, (M, W))
             dtrb = self._b("vit.s.dtresb" + par, (M, W))
             dqkv = self._b("vit.s.dqkv" + par, (M, 3 * W))
-            dqkv_t = self._b("vit.s.dqkv_t" + par, (M, 3 * W)) if side else dqkv
+            dqkv_t = self._b("vit.s.dqkv_t" + par, (M, 3 * W)) if (side or grouped) else dqkv
             # (e4m3 input gradients: the LayerNorm backward that produces an output gradient also writes its e4m3 copy, d*8)
-            self._lin_bwd(dxb, B_[tg + ".a"], pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dh, M, dy8=dxb8, side=side,
+            self._lin_bwd(dxb, B_[tg + ".a"], pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dh, M, dy8=dxb8, side=side, defer=defer,
                           q8_for=pre + "mlp.c_fc.weight", gate_h=B_[tg + ".h"], gate_act=a["act"])
-            self._lin_bwd(dh, B_[tg + ".ln2"], pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", dln, M, side=side)
+            self._lin_bwd(dh, B_[tg + ".ln2"], pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", dln, M, side=side, defer=defer)
             dsrb8 = self._ln_bwd(dln, B_[tg + ".s_res"], pre + "ln_2", tg + ".ln2", dsr, dx_bf16=dsrb, res1=dxb if lowp else dx,
                                  fp8_for=pre + "attn.proj.weight")
             # spatial attention branch
-            self._lin_bwd(dsrb, B_[tg + ".att_s"], pre + "attn.proj.weight", pre + "attn.proj.bias", datt, M, dy8=dsrb8, side=side)
+            self._lin_bwd(dsrb, B_[tg + ".att_s"], pre + "attn.proj.weight", pre + "attn.proj.bias", datt, M, dy8=dsrb8, side=side,
+                          defer=defer)
             self._st_attention_bwd(B_[tg + ".qkv_s"], B_[tg + ".att_s"], datt, B_[tg + ".lse_s"], dqkv, "space", B, T, n, "vit.s")
-            self._lin_bwd(dqkv, B_[tg + ".ln1"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", dln, M, side=side)
+            self._lin_bwd(dqkv, B_[tg + ".ln1"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", dln, M, side=side, defer=defer)
             # the time-residual gradient is a side branch (t_res only feeds ln_1): it lives in bf16 only -- as the operand of
             # the timeattn.proj GEMMs and as the bf16 residual term of the ln_3 backward
             dtrb8 = self._ln_bwd(dln, B_[tg + ".t_res"], pre + "ln_1", tg + ".ln1", None, dx_bf16=dtrb,
                                  fp8_for=pre + "timeattn.proj.weight")
             # temporal attention branch
             self._lin_bwd(dtrb, B_[tg + ".att_t"], pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", datt, M, dy8=dtrb8,
-                          side=side)
+                          side=side, defer=defer)
             self._st_attention_bwd(B_[tg + ".qkv_t"], B_[tg + ".att_t"], datt, B_[tg + ".lse_t"], dqkv_t, "time", B, T, n, "vit.s")
-            self._lin_bwd(dqkv_t, B_[tg + ".ln3"], pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", dln, M, side=side)
+            self._lin_bwd(dqkv_t, B_[tg + ".ln3"], pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", dln, M, side=side, defer=defer)
+            if grouped:  # the block's six weight gradients (+ bias gradients) in one launch, their partials in one reduce launch:
+                self._tn_group_run(l, defer)  # every output gradient they read is still intact (dqkv of the two branches apart)
             if side:
                 side_done[l] = torch.cuda.Event()
                 side_done[l].record(self._wg_stream)

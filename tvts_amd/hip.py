@@ -350,6 +350,53 @@ def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True, 
         GEMM_PROFILE.append(("gemm_tn", 2.0 * M * p.shape[1] * q.shape[1], ev0, ev1, (M, p.shape[1], q.shape[1], "cs" if colsum is not None else "")))
 
 
+class TnGroup:
+    """The weight gradients of one group (a ViT block's six) launched together: tvts_gemm_tn_bf16_grouped.  Build it once with the
+    problems -- dicts of the gemm_tn arguments p, q, out, M, accumulate, colsum -- and call run(); the device plan is uploaded on the
+    first run outside a stream capture and re-used while the problems stay the same tensors (the engine's buffers are persistent)."""
+
+    class _Rec(ctypes.Structure):
+        _fields_ = [("P", ctypes.c_void_p), ("ldp", ctypes.c_int), ("Q", ctypes.c_void_p), ("ldq", ctypes.c_int), ("M", ctypes.c_int),
+                    ("Na", ctypes.c_int), ("Nb", ctypes.c_int), ("out", ctypes.c_void_p), ("ldo", ctypes.c_int),
+                    ("accumulate", ctypes.c_int), ("colsum", ctypes.c_void_p)]
+
+    def __init__(self, problems, workspace, splits=0):
+        lib = _lib.load()
+        self.n = len(problems)
+        self.keep = problems  # the tensors stay alive with the plan
+        self.recs = (self._Rec * self.n)()
+        for r, pr in zip(self.recs, problems):
+            p, q, out = pr["p"], pr["q"], pr["out"]
+            assert p.dtype == torch.bfloat16 and q.dtype == torch.bfloat16 and out.dtype == torch.float32
+            r.P, r.ldp, r.Q, r.ldq = p.data_ptr(), _ld(p), q.data_ptr(), _ld(q)
+            r.M, r.Na, r.Nb = int(pr.get("M") or p.shape[0]), p.shape[1], q.shape[1]
+            r.out, r.ldo, r.accumulate = out.data_ptr(), _ld(out), 1 if pr.get("accumulate", True) else 0
+            r.colsum = pr["colsum"].data_ptr() if pr.get("colsum") is not None else None
+        self.key = tuple((r.P, r.Q, r.out, r.colsum, r.M, r.Na, r.Nb, r.ldp, r.ldq, r.ldo, r.accumulate) for r in self.recs)
+        self.ws = workspace
+        self.table = torch.zeros(lib.tvts_gemm_tn_grouped_table_bytes(self.n), dtype=torch.uint8, device=workspace.device)
+        self.uploaded = False
+        self.opts = int(splits) << 8
+        self.flops = sum(2.0 * r.M * r.Na * r.Nb for r in self.recs)
+
+    def run(self):
+        lib = _lib.load()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not self.uploaded and capturing:
+            raise HipError("TnGroup: the plan must be uploaded by one eager run before the step is captured")
+        if GEMM_PROFILE is not None:
+            ev0, ev1 = Event(), Event()
+            ev0.record()
+        rc = lib.tvts_gemm_tn_bf16_grouped(ctypes.cast(self.recs, ctypes.c_void_p), self.n, _p(self.table), self.table.numel(),
+                                           0 if self.uploaded else 1, _p(self.ws), self.ws.numel(), self.opts, _stream())
+        _chk(rc, "tvts_gemm_tn_bf16_grouped")
+        self.uploaded = True
+        if GEMM_PROFILE is not None:
+            ev1.record()
+            r0 = self.recs[0]
+            GEMM_PROFILE.append(("gemm_tn", self.flops, ev0, ev1, (r0.M, sum(r.Na * r.Nb for r in self.recs) // max(r0.Nb, 1), r0.Nb, "grouped")))
+
+
 def gemm_tn_fp8(p8, sp, q8, sq, out, *, M=None, accumulate=True, colsum=None, workspace=True, splits=None):
     """out[Na,Nb] (+)= sp * sq * p8[M,Na]^T @ q8[M,Nb]; p8 / q8 uint8 e4m3 bytes under one scale per tensor (float32[1] each);
     colsum[a] += sp * sum_m p8[m,a] (the bias gradient from the same bytes)."""
