@@ -398,7 +398,7 @@ def test_wgrad_side_stream_gives_the_same_bits(K, lib, arch_name, B, T):
     from tvts_amd.model._common import TVTSv2Base
     res = {}
     for side in (False, True):
-        a = dict(A.ARCHS[arch_name], wgrad_stream=side)
+        a = dict(A.ARCHS[arch_name], wgrad_stream=side, tn_grouped=False)  # (grouping re-plans the contraction ranges: other bits)
         a["num_frames"] = max(a["num_frames"], T)
         m = TVTSv2Base(ARGS, arch=a, init_seed=0)
         for name, p in m.named_parameters():
@@ -433,6 +433,60 @@ def test_wgrad_side_stream_gives_the_same_bits(K, lib, arch_name, B, T):
         res[side] = eager
         del g, m
     assert float(res[True].abs().max()) > 0 and torch.equal(res[False], res[True])
+
+
+def test_grouped_weight_gradients_match_the_single_launches(K, lib):
+    """At the reference's per-GPU batch (B/16, 12 pairs: M = 9 420) the six weight gradients of a ViT block leave in one grouped launch
+    (arch["tn_grouped"], the automatic choice up to 12 000 token rows).  Same products, same ordered partial sums per problem -- only the
+    number of contraction ranges differs from the one-by-one plan, i.e. fp32 summation order: every gradient within 1e-5 relative,
+    run-to-run bit-reproducible, and capturable."""
+    from tvts_amd import arch as A
+    from tvts_amd.data_loader import synth_batch
+    from tvts_amd.model._common import TVTSv2Base
+    res = {}
+    for grouped in (False, True):
+        a = dict(A.ARCHS["B_16"], tn_grouped=grouped)
+        m = TVTSv2Base(ARGS, arch=a, init_seed=0)
+        for name, p in m.named_parameters():
+            p.requires_grad = A.param_group_of(name, a) >= 0
+        _, _, run = _runner_of(m, a)
+        eng = m.engine
+        batch = synth_batch(a, 12, 8, seed=5, caption_len=32)
+        m._fresh_shadows(); m._sync_requires_grad()
+        pb = eng.prepare_batch(batch)
+        lab = batch["label"].reshape(-1).to(torch.int32).to(DEV)
+
+        def step():
+            m.store.grad.zero_()
+            eng.embeds_ready = run.gather.start
+            try:
+                te, ve, pred = eng.forward(pb)
+            finally:
+                eng.embeds_ready = None
+            l1, l2, dte, dve, dpred = run.losses_and_grads(pb, te, ve, pred, lab)
+            eng.backward(dte, dve, dpred)
+        step(); step()
+        torch.cuda.synchronize()
+        g1 = m.store.grad.clone()
+        step()
+        torch.cuda.synchronize()
+        assert torch.equal(g1, m.store.grad)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            step()
+        gr.replay(); gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g1, m.store.grad), f"captured backward differs (grouped {grouped})"
+        assert (len(eng._tn_groups) == a["layers"]) == grouped
+        res[grouped] = (g1, m.store)
+        del gr
+    g0, g1 = res[False][0], res[True][0]
+    assert not torch.equal(g0, g1)
+    st = res[True][1]
+    for name in st.shapes:
+        if "resblocks" in name and name.startswith("video_model") and float(res[False][1].g(name).abs().max()) > 0:
+            a_, b_ = res[False][1].g(name).double(), st.g(name).double()
+            assert float((a_ - b_).norm() / b_.norm().clamp_min(1e-30)) < 1e-5, name
 
 
 # ------------------------------------------------------------------------------------------------ (c) hipGraph replay
