@@ -103,3 +103,16 @@ def test_constructor_initialises_like_the_reference(golden, tag):
         cls(args, load_checkpoint="")
     m2 = cls(args, load_checkpoint="", pretrained=False)
     assert m2.initialised_from == "random"
+    del m, m2
+    # the downstream inference classes initialise the same way (v2/downstream/model_TVTSv2_ViT_B_16.py:15-41; no sorting head there)
+    import importlib
+    dcls = getattr(importlib.import_module(f"tvts_amd.downstream.model_TVTSv2_ViT_{ARCH_OF[tag]}"), f"TVTSv2_{ARCH_OF[tag]}")
+    d = dcls(pretrained=clip_sd)
+    dsd = d.state_dict()
+    for n, crc, kind in zip(names, f["crc"], f["kind"]):
+        if n.startswith("pred_model."):
+            assert n not in dsd
+        elif int(kind) == 0 and n != "video_model.temporal_embedding":
+            assert O.tensor_crc(dsd[n].float().cpu()) == int(crc), n
+    with pytest.raises(RuntimeError, match="pretrained"):
+        dcls()

@@ -21,7 +21,7 @@ def model():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from tvts_amd.downstream.model_TVTSv2_ViT_B_16 import TVTSv2_B_16
-    m = TVTSv2_B_16(load_checkpoint=None)
+    m = TVTSv2_B_16(load_checkpoint=None, pretrained=False)
     arch = dict(O.ARCHS["B_16"], mask_ratio=0.0, sort_head=False)
     P = O.synth_params(arch, seed=0)
     assert list(m.state_dict().keys()) == list(P.keys())  # no pred_model.* keys, reference order
@@ -75,7 +75,7 @@ def test_downstream_other_archs_against_reference_golden(name, B, T, n, golden):
         pytest.skip("needs a GPU")
     import importlib
     mod = importlib.import_module(f"tvts_amd.downstream.model_TVTSv2_ViT_{name}")
-    m = getattr(mod, f"TVTSv2_{name}")(load_checkpoint=None)
+    m = getattr(mod, f"TVTSv2_{name}")(load_checkpoint=None, pretrained=False)
     arch = dict(O.ARCHS[name], mask_ratio=0.0, sort_head=False)
     m.load_state_dict(O.synth_params(arch, seed=0), strict=True)
     f = golden("downstream_" + name.lower().replace("_", ""))

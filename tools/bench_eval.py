@@ -72,7 +72,7 @@ def main():
     torch.cuda.empty_cache()
     # N2: downstream inference model, 12 unmasked frames, one caption per video
     from tvts_amd.downstream.model_TVTSv2_ViT_B_16 import TVTSv2_B_16
-    d = TVTSv2_B_16()
+    d = TVTSv2_B_16(pretrained=False)
     Bd = max(8, B // 4)
     db = synth_batch(dict(a, mask_ratio=0.0), Bd, 12, seed=3, n_trans=1)
     pbd = d.engine.prepare_batch(db)

@@ -124,6 +124,8 @@ class TVTSv2Base(nn.Module):
         self.args = args
         if pretrained is None and (arch is not None or self.ARCH_NAME is None or ARCHS[self.ARCH_NAME].get("family") == "v1"):
             pretrained = False
+        if isinstance(pretrained, str) and pretrained == "reference":  # (a subclass that builds its own arch dict asks for the reference's source)
+            pretrained = None
         self.arch = dict(arch if arch is not None else ARCHS[self.ARCH_NAME])
         self.num_clips = 4
         self.n_trans = self.arch["n_trans"]
@@ -136,7 +138,7 @@ class TVTSv2Base(nn.Module):
             from . import clip_init
             if pretrained is None:
                 sd = clip_init.load_reference_clip(self.arch)
-            elif isinstance(pretrained, (str, bytes)) or hasattr(pretrained, "__fspath__"):
+            elif isinstance(pretrained, (str, bytes)) or hasattr(pretrained, "__fspath__"):  # a path
                 sd = clip_init.load_clip_file(pretrained)
             else:
                 sd = pretrained
