@@ -193,6 +193,16 @@ int tvts_attn_bwd(int mode, const void* qkv, int ld, int B, int heads, int S, in
  * cls_ws: fp32 scratch of >= B * heads * max(T, ceil(n / 28)) * (dh + 2) elements (partial softmax states of the CLS query) */
 int tvts_attn_fwd_divided(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
                       float* lse2, float* cls_ws, long cls_ws_elems, int opts, hipStream_t stream);
+/* the two site entry points with the per-tensor e4m3 copy of their result written by the kernels themselves (BASELINE config 5: the
+ * attention output feeds the projection's forward and weight-gradient GEMMs, dqkv the qkv projection's input- and weight-gradient
+ * GEMMs): q8out[r, c] = e4m3(result[r, c] / q8_scale[0]) with the result's leading dimension (ldq8 == ldo resp. lddq, in bytes),
+ * q8_amax = max(q8_amax, max |result|).  Fused geometries only (SPACE n + 1 <= 112, TIME T + 1 <= 32), -22 otherwise. */
+int tvts_attn_fwd_divided_q8(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
+                      float* lse2, float* cls_ws, long cls_ws_elems, void* q8out, int ldq8, const float* q8_scale, float* q8_amax,
+                      int opts, hipStream_t stream);
+int tvts_attn_bwd_q8(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
+              int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float* cls_acc,
+              long cls_acc_elems, void* q8out, int ldq8, const float* q8_scale, float* q8_amax, int opts, hipStream_t stream);
 
 /* the same entry points for head dim 80 (ViT-H/14, 1280 / 16 heads); qkv is [rows, 3*heads*80] */
 /* FULL attention over sequences padded to S with the padded keys masked: keys at positions >= kv_len[b] (device int32[B]) get
@@ -276,6 +286,16 @@ int tvts_attn80_bwd(int mode, const void* qkv, int ld, int B, int heads, int S, 
  * cls_ws: fp32 scratch of >= B * heads * max(T, ceil(n / 28)) * (dh + 2) elements (partial softmax states of the CLS query) */
 int tvts_attn80_fwd_divided(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
                       float* lse2, float* cls_ws, long cls_ws_elems, int opts, hipStream_t stream);
+/* the two site entry points with the per-tensor e4m3 copy of their result written by the kernels themselves (BASELINE config 5: the
+ * attention output feeds the projection's forward and weight-gradient GEMMs, dqkv the qkv projection's input- and weight-gradient
+ * GEMMs): q8out[r, c] = e4m3(result[r, c] / q8_scale[0]) with the result's leading dimension (ldq8 == ldo resp. lddq, in bytes),
+ * q8_amax = max(q8_amax, max |result|).  Fused geometries only (SPACE n + 1 <= 112, TIME T + 1 <= 32), -22 otherwise. */
+int tvts_attn80_fwd_divided_q8(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
+                      float* lse2, float* cls_ws, long cls_ws_elems, void* q8out, int ldq8, const float* q8_scale, float* q8_amax,
+                      int opts, hipStream_t stream);
+int tvts_attn80_bwd_q8(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal, const void* dO,
+              int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv, int lddq, float* cls_acc,
+              long cls_acc_elems, void* q8out, int ldq8, const float* q8_scale, float* q8_amax, int opts, hipStream_t stream);
 
 /* ---- token assembly (embed.hip): video_encoder_ViT_B_16.py:176-216; model_dist..B_16.py:69-76,98-100;
  *      sort_transformer.py:124-128 */

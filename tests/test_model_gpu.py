@@ -658,6 +658,17 @@ def test_fp8_wgrad_path(gpu, h14):
             k = f"video_model.transformer.resblocks.{l}.{nm}"
             a_, b_ = store.g(k).double().flatten().cpu(), grads[k].double().flatten()
             assert float(torch.nn.functional.cosine_similarity(a_, b_, dim=0)) > 0.97, k
+    # the attention outputs' / attention input gradients' copies come out of the divided-attention kernels themselves (default);
+    # with the quantiser passes instead (fp8_attn_copies = False): the same bytes, the same maxima, the same step
+    m4, _, _ = build(arch=mk(fp8_wgrad=True, fp8_attn_copies=False), seed=4)
+    engine_step(m4, batch); m4.engine.end_step()
+    n4 = len(m4.engine._f8_ids)
+    ids = {k: (m1.engine._f8_ids[k], m4.engine._f8_ids[k]) for k in m4.engine._f8_ids}
+    _, _, _, ve4, _, store4 = engine_step(m4, batch)
+    assert torch.equal(ve4, ve2) and torch.equal(store4.grad, g2)
+    for k, (i1, i4) in ids.items():
+        assert float(m1.engine._f8_amax[i1]) == float(m4.engine._f8_amax[i4]), k
+    assert n4 == n
     # the MLP's two operand copies written by the producing GEMMs' epilogues instead of quantiser passes (opt-in): the same bytes
     m3, _, _ = build(arch=mk(fp8_wgrad=True, fp8_epilogue_copies=True), seed=4)
     engine_step(m3, batch); m3.engine.end_step()

@@ -68,6 +68,36 @@ struct AttnGeom {
     float drop_inv;
     const unsigned long long* drop_seed;  // device memory (a captured graph draws new masks on every replay); + drop_site per call
     unsigned long long drop_site;
+    // per-tensor e4m3 copy of the kernel's bf16 result (fused divided kernels; BASELINE config 5): q8[r, c] = e4m3(res[r, c] / q8_scale[0])
+    // for every element the kernel stores at q8_ref + r * ld + c, q8 has the same leading dimension (in bytes); q8_amax = max |res|
+    const bf16* q8_ref; unsigned char* q8; const float* q8_scale; float* q8_amax;
+};
+// per-thread state of that copy
+struct Q8Out {
+    const bf16* ref; unsigned char* q8; float inv; float am;
+    __device__ __forceinline__ void init(const AttnGeom& g) {
+        ref = g.q8_ref; q8 = g.q8; am = 0.f; inv = 0.f;
+        if (q8) { const float sc = g.q8_scale[0]; inv = sc > 0.f ? 1.0f / sc : 1.0f; }
+    }
+    __device__ __forceinline__ void emit8(const bf16* dst8, const bf16x8& w) {  // the 8 values stored at dst8, as 8 e4m3 bytes
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (float)w[e];
+            am = fmaxf(am, fabsf(x));
+            f[e] = fminf(fmaxf(x * inv, -448.0f), 448.0f);
+        }
+        int p0 = 0, p1 = 0;
+        p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], p0, false);
+        p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], p0, true);
+        p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], p1, false);
+        p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], p1, true);
+        typedef __attribute__((ext_vector_type(2))) int i32x2_;
+        *(i32x2_*)(q8 + (dst8 - ref)) = (i32x2_){p0, p1};
+    }
+    __device__ __forceinline__ void finish(const AttnGeom& g, int lane) {
+        if (q8) amax_publish(g.q8_amax, wave_max(am), lane);
+    }
 };
 __device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned long long idx, unsigned thr) {
     unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
@@ -204,7 +234,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // contiguous bytes and four neighbouring lanes complete the segment.  rowfn(row) -> destination of that row's first
 // head column, or nullptr for a masked row.
 template <typename RowFn>
-__device__ __forceinline__ void store_tile_rows(char* patch, const f32x4 (&v)[DT], int lane, RowFn rowfn) {
+__device__ __forceinline__ void store_tile_rows(char* patch, const f32x4 (&v)[DT], int lane, RowFn rowfn, Q8Out* q8o = nullptr) {
     const int li = lane & 15, gq = lane >> 4;
     const int rrow = lane >> 2, rc = lane & 3;
     bf16* dst = rowfn(rrow);
@@ -224,7 +254,10 @@ __device__ __forceinline__ void store_tile_rows(char* patch, const f32x4 (&v)[DT
         asm volatile("" ::: "memory");
         const bf16x8 w = *(const bf16x8*)(patch + rrow * 64 + ((rc ^ (rrow & 3)) << 4));
         asm volatile("" ::: "memory");
-        if (dst && 2 * d2 + (rc >> 1) < DT) *(bf16x8*)(dst + d2 * 32 + rc * 8) = w;
+        if (dst && 2 * d2 + (rc >> 1) < DT) {
+            *(bf16x8*)(dst + d2 * 32 + rc * 8) = w;
+            if (q8o && q8o->q8) q8o->emit8(dst + d2 * 32 + rc * 8, w);
+        }
     }
 }
 
@@ -1211,6 +1244,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void attn_bwd_space_fused_kernel(
     char* opatch = (char*)(st_dl + RA) + wave * 1024;  // this wave's output-staging patch
     const int gq = lane >> 4, li = lane & 15;
     const int hcol = r.h * DH;
+    Q8Out q8o;
+    q8o.init(g);
 
     // ---- stage Q | K | V | dO of the group's tokens (rows m..RA-1 zero), all loads in flight before the first store
     {
@@ -1293,7 +1328,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void attn_bwd_space_fused_kernel(
         }
         store_tile_rows(opatch, acc, lane, [&](int rr) -> bf16* {
             const int j = qt * 16 + rr;
-            return (j >= 1 && j < m) ? dqkv + (size_t)k_row<MODE_SPACE>(g, r, j) * lddq + hcol : nullptr; });
+            return (j >= 1 && j < m) ? dqkv + (size_t)k_row<MODE_SPACE>(g, r, j) * lddq + hcol : nullptr; }, &q8o);
         if (qj == 0) {  // this frame's share of the CLS query gradient
             if (g.cls_parts) {  // its own slot of the per-frame partials (plain stores; summed in frame order by the finalize kernel)
                 float* a = cls_acc + (((size_t)(r.b * g.heads + r.h) * g.cls_parts + r.sub) * 3 + 2) * DH;
@@ -1381,9 +1416,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void attn_bwd_space_fused_kernel(
                 const int j = kt * 16 + rr;
                 return (j >= 1 && j < m) ? dqkv + (size_t)k_row<MODE_SPACE>(g, r, j) * lddq + third * g.W + hcol : nullptr; };
         };
-        store_tile_rows(opatch, dk, lane, krowp(1));
-        store_tile_rows(opatch, dv, lane, krowp(2));
+        store_tile_rows(opatch, dk, lane, krowp(1), &q8o);
+        store_tile_rows(opatch, dv, lane, krowp(2), &q8o);
     }
+    q8o.finish(g, lane);
 }
 
 // FUSED TIME-geometry backward.  The groups (b, patch slot, head) are tiny (T + 1 tokens) and very many, so a WAVE owns
@@ -1421,6 +1457,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
     const size_t ocls = (size_t)(r.b * g.S) * g.heads + r.h;
     const float lse_c = lse2[ocls], dl_c = delta[ocls];
     for (int i = lane; i < 3 * DH; i += 64) csum[i] = 0.f;
+    Q8Out q8o;
+    q8o.init(g);
 
     bf16x8 stg[4][PT];
     float lse_pf = 0.f;
@@ -1509,7 +1547,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
             }
             store_tile_rows(opatch, acc, lane, [&](int rr) -> bf16* {
                 const int j = qt * 16 + rr;
-                return (j >= 1 && j < m) ? dqkv + (size_t)k_row<MODE_TIME>(g, r, j) * lddq + hcol : nullptr; });
+                return (j >= 1 && j < m) ? dqkv + (size_t)k_row<MODE_TIME>(g, r, j) * lddq + hcol : nullptr; }, &q8o);
             if (qt == 0 && li == 0) {  // column 0 = the CLS query: this group's share of its gradient
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
@@ -1580,10 +1618,11 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
                     const int j = kt * 16 + rr;
                     return (j >= 1 && j < m) ? dqkv + (size_t)k_row<MODE_TIME>(g, r, j) * lddq + third * g.W + hcol : nullptr; };
             };
-            store_tile_rows(opatch, dk, lane, krowp(1));
-            store_tile_rows(opatch, dv, lane, krowp(2));
+            store_tile_rows(opatch, dk, lane, krowp(1), &q8o);
+            store_tile_rows(opatch, dv, lane, krowp(2), &q8o);
         }
     }
+    q8o.finish(g, lane);
     // combine the four waves' CLS sums: one partial per block
     __syncthreads();
     if (threadIdx.x < 3 * DH) {
@@ -1617,6 +1656,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_space_fused_kernel(AttnGeom g
     char* opatch = Vs + TB + wave * 1024;  // this wave's output-staging patch
     const int gq = lane >> 4, li = lane & 15;
     const int hcol = r.h * DH;
+    Q8Out q8o;
+    q8o.init(g);
     {
         constexpr int PER = (RA * NCH + 255) / 256;
         bf16x8 stg[2][PER];
@@ -1694,7 +1735,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_space_fused_kernel(AttnGeom g
             for (int dt = 0; dt < DT; ++dt) on[dt] = o[dt] * inv;
             store_tile_rows(opatch, on, lane, [&](int rr) -> bf16* {
                 const int j = qt * 16 + rr;
-                return (j >= 1 && j < m) ? out + (size_t)k_row<MODE_SPACE>(g, r, j) * ldo + hcol : nullptr; });
+                return (j >= 1 && j < m) ? out + (size_t)k_row<MODE_SPACE>(g, r, j) * ldo + hcol : nullptr; }, &q8o);
         }
         if (qj >= 1 && qj < m) {
             if (gq == 0) lse2[(size_t)k_row<MODE_SPACE>(g, r, qj) * g.heads + r.h] = mx + log2f(l);
@@ -1711,6 +1752,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_space_fused_kernel(AttnGeom g
             ld_frags(qkv + (size_t)k_row<MODE_SPACE>(g, r, qn < m ? qn : m - 1) * g.ld + hcol, gq, qf);
         }
     }
+    q8o.finish(g, lane);
 }
 
 template <int MT, bool TR>
@@ -1737,6 +1779,8 @@ __global__ __launch_bounds__(256) void attn_fwd_time_fused_kernel(AttnGeom g, co
     f32x4 Or[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) Or[dt] = (f32x4){0, 0, 0, 0};
+    Q8Out q8o;
+    q8o.init(g);
 
     bf16x8 qf[MT][KS], kf[MT][KS], vst[PT];
     auto issue = [&](int p) {
@@ -1822,7 +1866,7 @@ __global__ __launch_bounds__(256) void attn_fwd_time_fused_kernel(AttnGeom g, co
                 for (int dt = 0; dt < DT; ++dt) on[dt] = o[dt] * inv;
                 store_tile_rows(opatch, on, lane, [&](int rr) -> bf16* {
                     const int j = qt * 16 + rr;
-                    return (j >= 1 && j < m) ? out + (size_t)k_row<MODE_TIME>(g, r, j) * ldo + hcol : nullptr; });
+                    return (j >= 1 && j < m) ? out + (size_t)k_row<MODE_TIME>(g, r, j) * ldo + hcol : nullptr; }, &q8o);
             }
             if (qj >= 1 && qj < m && gq == 0) lse2[(size_t)k_row<MODE_TIME>(g, r, qj) * g.heads + r.h] = mx + log2f(l);
             if (qt == 0) {  // column 0 = the CLS query: fold this group's state into the running one
@@ -1835,6 +1879,7 @@ __global__ __launch_bounds__(256) void attn_fwd_time_fused_kernel(AttnGeom g, co
             }
         }
     }
+    q8o.finish(g, lane);
     // the four waves' CLS states -> one partial per block
     float* cst = (float*)(smem + wave * WB + TB);
     if (li == 0) {
@@ -2147,22 +2192,34 @@ __global__ __launch_bounds__(64 * SEQ_BWD_WAVES) void attn_bwd_seq_fused_kernel(
 
 // CLS output row = merge of the G partial softmax states of (b, h)
 __global__ void attn_cls_merge_kernel(const float* __restrict__ cls_part, int G, int heads, int S, bf16* __restrict__ out,
-                                      int ldo, float* __restrict__ lse2) {
+                                      int ldo, float* __restrict__ lse2, unsigned char* __restrict__ q8 = nullptr,
+                                      const float* __restrict__ q8_scale = nullptr, float* __restrict__ q8_amax = nullptr) {
     const int bh = blockIdx.x, d = threadIdx.x;
-    if (d >= DH) return;
-    const float* cp = cls_part + (size_t)bh * G * (DH + 2);
-    float M = -1e30f;
-    for (int i = 0; i < G; ++i) M = fmaxf(M, cp[(size_t)i * (DH + 2)]);
-    float L = 0.f, O = 0.f;
-    for (int i = 0; i < G; ++i) {
-        const float sc = __builtin_amdgcn_exp2f(cp[(size_t)i * (DH + 2)] - M);
-        L += cp[(size_t)i * (DH + 2) + 1] * sc;
-        O += cp[(size_t)i * (DH + 2) + 2 + d] * sc;
+    const bool live = d < DH;  // (no early exit: every lane takes part in the amax reduction below)
+    float ax = 0.f;
+    if (live) {
+        const float* cp = cls_part + (size_t)bh * G * (DH + 2);
+        float M = -1e30f;
+        for (int i = 0; i < G; ++i) M = fmaxf(M, cp[(size_t)i * (DH + 2)]);
+        float L = 0.f, O = 0.f;
+        for (int i = 0; i < G; ++i) {
+            const float sc = __builtin_amdgcn_exp2f(cp[(size_t)i * (DH + 2)] - M);
+            L += cp[(size_t)i * (DH + 2) + 1] * sc;
+            O += cp[(size_t)i * (DH + 2) + 2 + d] * sc;
+        }
+        const int b = bh / heads, h = bh % heads;
+        const size_t row = (size_t)b * S;
+        const bf16 ov = (bf16)(O / L);
+        out[row * ldo + h * DH + d] = ov;
+        if (q8) {  // the CLS row's bytes of the per-tensor e4m3 copy (one byte per thread: 48 rows of 58 416, plumbing)
+            const float sc = q8_scale[0], x = (float)ov;
+            const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(x * (sc > 0.f ? 1.0f / sc : 1.0f), -448.0f), 448.0f), 0.f, 0, false);
+            q8[row * ldo + h * DH + d] = (unsigned char)(pk & 0xff);
+            ax = fabsf(x);
+        }
+        if (d == 0) lse2[row * heads + h] = M + log2f(L);
     }
-    const int b = bh / heads, h = bh % heads;
-    const size_t row = (size_t)b * S;
-    out[row * ldo + h * DH + d] = (bf16)(O / L);
-    if (d == 0) lse2[row * heads + h] = M + log2f(L);
+    if (q8) amax_publish(q8_amax, wave_max(ax), threadIdx.x & 63);
 }
 
 // cls_acc [B, heads, parts, 3, DH] = fp32 partial sums of (dK, dV, dQ) of the CLS token (parts = 1: the atomically accumulated
@@ -2170,16 +2227,27 @@ __global__ void attn_cls_merge_kernel(const float* __restrict__ cls_part, int G,
 // slot order -> run-to-run reproducible) -> bf16 into the CLS row of dqkv; the dQ slot is only used by the fused kernels (the
 // split path writes the CLS dQ from its own CLS-query pass).
 __global__ void attn_cls_finalize_kernel(const float* __restrict__ cls_acc, int B, int heads, int S, int W, int with_q,
-                                         bf16* __restrict__ dqkv, int lddq, int parts) {
+                                         bf16* __restrict__ dqkv, int lddq, int parts, unsigned char* __restrict__ q8 = nullptr,
+                                         const float* __restrict__ q8_scale = nullptr, float* __restrict__ q8_amax = nullptr) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b, h, slot, d)
-    if (idx >= B * heads * 3 * DH) return;
     const int d = idx % DH, slot = (idx / DH) % 3, h = (idx / (3 * DH)) % heads, b = idx / (3 * DH * heads);
-    if (slot == 2 && !with_q) return;
-    const int third = slot == 2 ? 0 : 1 + slot;
-    const float* src = cls_acc + ((size_t)(b * heads + h) * parts * 3 + slot) * DH + d;
-    float v = 0.f;
-    for (int pidx = 0; pidx < parts; ++pidx) v += src[(size_t)pidx * 3 * DH];
-    dqkv[(size_t)(b * S) * lddq + third * W + h * DH + d] = (bf16)v;
+    const bool live = idx < B * heads * 3 * DH && !(slot == 2 && !with_q);
+    float ax = 0.f;
+    if (live) {
+        const int third = slot == 2 ? 0 : 1 + slot;
+        const float* src = cls_acc + ((size_t)(b * heads + h) * parts * 3 + slot) * DH + d;
+        float v = 0.f;
+        for (int pidx = 0; pidx < parts; ++pidx) v += src[(size_t)pidx * 3 * DH];
+        const bf16 ov = (bf16)v;
+        dqkv[(size_t)(b * S) * lddq + third * W + h * DH + d] = ov;
+        if (q8) {
+            const float sc = q8_scale[0], x = (float)ov;
+            const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(x * (sc > 0.f ? 1.0f / sc : 1.0f), -448.0f), 448.0f), 0.f, 0, false);
+            q8[(size_t)(b * S) * lddq + third * W + h * DH + d] = (unsigned char)(pk & 0xff);
+            ax = fabsf(x);
+        }
+    }
+    if (q8) amax_publish(q8_amax, wave_max(ax), threadIdx.x & 63);
 }
 
 }  // namespace NS_DH
@@ -2201,6 +2269,7 @@ static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int 
     g.B = B; g.heads = heads; g.S = S; g.T = T; g.n = n; g.causal = causal; g.ld = ld; g.W = heads * DH; g.kv_len = nullptr;
     g.cls_nq = 1; g.cls_q0 = 0; g.cls_qpos = nullptr; g.cls_parts = 0;
     g.drop_thr = 0; g.drop_inv = 1.f; g.drop_seed = nullptr; g.drop_site = 0;
+    g.q8_ref = nullptr; g.q8 = nullptr; g.q8_scale = nullptr; g.q8_amax = nullptr;
     g.scale = 1.0f / sqrtf((float)DH);
     g.scale2 = g.scale * 1.4426950408889634f;
     g.ablate = 0;  // timing-ablation bits of the fused backward (opts bits 4..6 of tvts_attn_bwd; results are wrong by construction)
@@ -2550,15 +2619,20 @@ static __global__ void zero_f32_kernel(float* __restrict__ p, int n) {
 
 // Whole backward of one attention site: D = rowsum(dO*O), dQ, dK, dV (and, for the divided space / time geometries,
 // the CLS query and the CLS key/value reduction).  SPACE groups that fit 112 rows take the fused single-launch kernel.
-extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
-                        const void* dO, int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv,
-                        int lddq, float* cls_acc, long cls_acc_elems, int opts, hipStream_t stream) {
+static int bwd_impl(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+                    const void* dO, int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv,
+                    int lddq, float* cls_acc, long cls_acc_elems, void* q8out, int ldq8, const float* q8_scale, float* q8_amax,
+                    int opts, hipStream_t stream) {
     if (mode == MODE_CLS) return TVTS_EINVAL;
     ATTN_OPTS(opts);
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, causal, ld);
     if (rc) return rc;
     if (lddo % 8 || ldo % 8 || lddq % 4) return TVTS_EINVAL;
+    if (q8out) {
+        if (ldq8 != lddq || lddq % 8 || !q8_scale) return TVTS_EINVAL;
+        g.q8_ref = (const bf16*)dqkv; g.q8 = (unsigned char*)q8out; g.q8_scale = q8_scale; g.q8_amax = q8_amax;
+    }
     const bool divided = mode == MODE_SPACE || mode == MODE_TIME;
     if (fused && use_tr && mode == MODE_FULL && S <= 32) {  // short sequences (text tower): one launch, D in registers
         const int MT = ceil_div(S, 16), groups = B * heads;
@@ -2621,10 +2695,11 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
         TVTS_LAUNCH_CHECK();
         const int total = B * heads * 3 * DH;  // CLS row of dqkv: dK, dV and dQ all come from the accumulators
         hipLaunchKernelGGL(attn_cls_finalize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, cls_acc, B, heads, S,
-                           heads * DH, 1, (bf16*)dqkv, lddq, g.cls_parts ? g.cls_parts : 1);
+                           heads * DH, 1, (bf16*)dqkv, lddq, g.cls_parts ? g.cls_parts : 1, g.q8, g.q8_scale, g.q8_amax);
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }
+    if (q8out) return TVTS_EINVAL;  // only the fused kernels write the copy
     rc = ABI(delta)(dO, lddo, O, ldo, B * S, heads, delta, stream);
     if (rc) return rc;
     rc = ABI(bwd_dq)(mode, qkv, ld, B, heads, S, T, n, causal, dO, lddo, lse2, delta, dqkv, lddq, opts, stream);
@@ -2638,18 +2713,39 @@ extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int
     }
     return rc;
 }
+extern "C" int ABI(bwd)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+                        const void* dO, int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv,
+                        int lddq, float* cls_acc, long cls_acc_elems, int opts, hipStream_t stream) {
+    return bwd_impl(mode, qkv, ld, B, heads, S, T, n, causal, dO, lddo, O, ldo, lse2, delta, dqkv, lddq, cls_acc, cls_acc_elems,
+                    nullptr, 0, nullptr, nullptr, opts, stream);
+}
+// the same, with the per-tensor e4m3 copy of dqkv written by the kernels themselves (the output gradient of the qkv projection's
+// input-gradient and weight-gradient GEMMs, BASELINE config 5); ldq8 == lddq; fused divided geometries only
+extern "C" int ABI(bwd_q8)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, int causal,
+                           const void* dO, int lddo, const void* O, int ldo, const float* lse2, float* delta, void* dqkv,
+                           int lddq, float* cls_acc, long cls_acc_elems, void* q8out, int ldq8, const float* q8_scale,
+                           float* q8_amax, int opts, hipStream_t stream) {
+    if (!q8out) return TVTS_EINVAL;
+    return bwd_impl(mode, qkv, ld, B, heads, S, T, n, causal, dO, lddo, O, ldo, lse2, delta, dqkv, lddq, cls_acc, cls_acc_elems,
+                    q8out, ldq8, q8_scale, q8_amax, opts, stream);
+}
 
 // Forward of one divided-attention site, patch rows AND the CLS row: fused single-pass kernels + the CLS merge where the
 // groups fit (SPACE n + 1 <= 112, TIME T + 1 <= 32), the streaming kernels + the CLS-query kernel otherwise.
 // cls_ws: fp32 scratch, at least B * heads * max(T, ceil(n / 28)) * (dh + 2) elements.
-extern "C" int ABI(fwd_divided)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
-                                float* lse2, float* cls_ws, long cls_ws_elems, int opts, hipStream_t stream) {
+static int fwd_divided_impl(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
+                            float* lse2, float* cls_ws, long cls_ws_elems, void* q8out, int ldq8, const float* q8_scale,
+                            float* q8_amax, int opts, hipStream_t stream) {
     if (mode != MODE_SPACE && mode != MODE_TIME) return TVTS_EINVAL;
     ATTN_OPTS(opts);
     AttnGeom g;
     int rc = make_geom(g, mode, B, heads, S, T, n, 0, ld);
     if (rc) return rc;
     if (ldo % 4) return TVTS_EINVAL;
+    if (q8out) {  // the e4m3 copy is addressed like the bf16 output: same leading dimension (in bytes), 8-byte pieces
+        if (ldq8 != ldo || ldo % 8 || !q8_scale) return TVTS_EINVAL;
+        g.q8_ref = (const bf16*)out; g.q8 = (unsigned char*)q8out; g.q8_scale = q8_scale; g.q8_amax = q8_amax;
+    }
     const bool fs = fused && use_tr && mode == MODE_SPACE && n + 1 <= FUSED_MAX_TILES * 16;
     const bool ft = fused && use_tr && mode == MODE_TIME && T + 1 <= 32;
     const int G = mode == MODE_SPACE ? T : ceil_div(n, TIME_CHUNK);
@@ -2679,11 +2775,25 @@ extern "C" int ABI(fwd_divided)(int mode, const void* qkv, int ld, int B, int he
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2, cls_ws);
         TVTS_LAUNCH_CHECK();
         hipLaunchKernelGGL(attn_cls_merge_kernel, dim3(B * heads), dim3(DH <= 64 ? 64 : 128), 0, stream, cls_ws, G, heads, S,
-                           (bf16*)out, ldo, lse2);
+                           (bf16*)out, ldo, lse2, g.q8, g.q8_scale, g.q8_amax);
         TVTS_LAUNCH_CHECK();
         return TVTS_OK;
     }
+    if (q8out) return TVTS_EINVAL;  // only the fused kernels write the copy
     rc = ABI(fwd)(mode, qkv, ld, B, heads, S, T, n, 0, out, ldo, lse2, opts, stream);
     if (rc) return rc;
     return ABI(fwd)(MODE_CLS, qkv, ld, B, heads, S, T, n, 0, out, ldo, lse2, opts, stream);
+}
+extern "C" int ABI(fwd_divided)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
+                                float* lse2, float* cls_ws, long cls_ws_elems, int opts, hipStream_t stream) {
+    return fwd_divided_impl(mode, qkv, ld, B, heads, S, T, n, out, ldo, lse2, cls_ws, cls_ws_elems, nullptr, 0, nullptr, nullptr, opts, stream);
+}
+// the same, with the per-tensor e4m3 copy of the output written by the kernels themselves (BASELINE config 5: the attention output is
+// the operand of the projection's forward and weight-gradient GEMMs): q8out[r, c] = e4m3(out[r, c] / q8_scale[0]), ldq8 == ldo,
+// q8_amax = max(q8_amax, max |out|).  Fused geometries only (-22 otherwise).
+extern "C" int ABI(fwd_divided_q8)(int mode, const void* qkv, int ld, int B, int heads, int S, int T, int n, void* out, int ldo,
+                                   float* lse2, float* cls_ws, long cls_ws_elems, void* q8out, int ldq8, const float* q8_scale,
+                                   float* q8_amax, int opts, hipStream_t stream) {
+    if (!q8out) return TVTS_EINVAL;
+    return fwd_divided_impl(mode, qkv, ld, B, heads, S, T, n, out, ldo, lse2, cls_ws, cls_ws_elems, q8out, ldq8, q8_scale, q8_amax, opts, stream);
 }

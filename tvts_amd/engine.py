@@ -565,19 +565,37 @@ class Engine:
                              N=N, L=L, tok_sort=tok_sort)
 
     # ------------------------------------------------------------------ video tower
-    def _st_attention_fwd(self, qkv, att, lse, mode, B, T, n):
+    def _attn_q8(self, M, W, name, T, n, persistent=False):
+        """the divided-attention kernels write the per-tensor e4m3 copy of their result themselves (tensor mode, fused geometries;
+        arch["fp8_attn_copies"] = False keeps the quantiser pass: same bytes, tests/test_model_gpu.py::test_fp8_wgrad_path)"""
+        if not (self.fp8_wgrad and self._f8_tensor_mode and self.arch.get("fp8_attn_copies", True)) or n + 1 > 112 or T + 1 > 32:
+            return {}, None
+        q, sc, kw = self._q8(M, W, name, persistent=persistent)
+        return dict(q8out=q, q8_scale=sc, q8_amax=kw["amax"]), (q, sc)
+
+    def _st_attention_fwd(self, qkv, att, lse, mode, B, T, n, q8_for=None):
         h, S = self.arch["heads"], 1 + T * n
         ws = self._f("vit.clsws", (B * h * max(T, -(-n // 28)) * (self.dh + 2),))
-        K.attn_fwd_divided(mode, qkv, att, lse, ws, B=B, heads=h, S=S, T=T, n=n, head_dim=self.dh)
+        kw8 = {}
+        if q8_for is not None and q8_for in self.P.w8:
+            kw8, nxt = self._attn_q8(B * S, att.shape[1], "x." + q8_for, T, n, persistent=True)
+            if nxt is not None:
+                self._x8_ready[q8_for] = nxt
+        K.attn_fwd_divided(mode, qkv, att, lse, ws, B=B, heads=h, S=S, T=T, n=n, head_dim=self.dh, **kw8)
 
-    def _st_attention_bwd(self, qkv, att, datt, lse, dqkv, mode, B, T, n, scr):
+    def _st_attention_bwd(self, qkv, att, datt, lse, dqkv, mode, B, T, n, scr, q8_for=None):
         h, S = self.arch["heads"], 1 + T * n
         M = B * S
+        kw8 = {}
+        if q8_for is not None and q8_for in self.P.w8t:
+            kw8, nxt = self._attn_q8(M, dqkv.shape[1], "dy." + q8_for, T, n)
+            if nxt is not None:
+                self._dy8_ready[q8_for] = nxt
         delta = self._f(scr + ".delta", (M, h))
         hd = self.dh
         # one partial of the CLS token's dK / dV / dQ per block of the fused kernels, added in order (no atomics)
         cls_acc = self._f(scr + ".clsacc", (B, h, max(T, -(-n // 28)), 3, hd))
-        K.attn_bwd(mode, qkv, datt, att, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, cls_acc=cls_acc, head_dim=hd)
+        K.attn_bwd(mode, qkv, datt, att, lse, delta, dqkv, B=B, heads=h, S=S, T=T, n=n, cls_acc=cls_acc, head_dim=hd, **kw8)
 
     def video_forward(self, video, keep_dev, B, T, vid_rows=None):
         a = self.arch
@@ -607,7 +625,7 @@ class Engine:
             qkv_t = self._b(tg + ".qkv_t", (M, 3 * W))
             self._lin(ln3, pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", qkv_t, M, a8=a8)
             att_t, lse_t = self._b(tg + ".att_t", (M, W)), self._f(tg + ".lse_t", (M, a["heads"]))
-            self._st_attention_fwd(qkv_t, att_t, lse_t, "time", B, T, n)
+            self._st_attention_fwd(qkv_t, att_t, lse_t, "time", B, T, n, q8_for=pre + "timeattn.proj.weight")
             # the time residual only feeds ln_1 (the space branch restarts from x, video_encoder_ViT_B_16.py:121): bf16
             t_res = self._b(tg + ".t_res", (M, W))
             self._lin(att_t, pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", t_res, M, residual=x)
@@ -616,7 +634,7 @@ class Engine:
             qkv_s = self._b(tg + ".qkv_s", (M, 3 * W))
             self._lin(ln1, pre + "attn.qkv.weight", pre + "attn.qkv.bias", qkv_s, M, a8=a8)
             att_s, lse_s = self._b(tg + ".att_s", (M, W)), self._f(tg + ".lse_s", (M, a["heads"]))
-            self._st_attention_fwd(qkv_s, att_s, lse_s, "space", B, T, n)
+            self._st_attention_fwd(qkv_s, att_s, lse_s, "space", B, T, n, q8_for=pre + "attn.proj.weight")
             s_res = xbuf(tg + ".s_res", (M, W))  # residual from the block INPUT x (video_encoder_ViT_B_16.py:121)
             self._lin(att_s, pre + "attn.proj.weight", pre + "attn.proj.bias", s_res, M, residual=x)
             ln2 = self._b(tg + ".ln2", (M, W))
@@ -731,7 +749,8 @@ class Engine:
             # spatial attention branch
             self._lin_bwd(dsrb, B_[tg + ".att_s"], pre + "attn.proj.weight", pre + "attn.proj.bias", datt, M, dy8=dsrb8, side=side,
                           defer=defer)
-            self._st_attention_bwd(B_[tg + ".qkv_s"], B_[tg + ".att_s"], datt, B_[tg + ".lse_s"], dqkv, "space", B, T, n, "vit.s")
+            self._st_attention_bwd(B_[tg + ".qkv_s"], B_[tg + ".att_s"], datt, B_[tg + ".lse_s"], dqkv, "space", B, T, n, "vit.s",
+                                   q8_for=pre + "attn.qkv.weight")
             self._lin_bwd(dqkv, B_[tg + ".ln1"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", dln, M, side=side, defer=defer)
             # the time-residual gradient is a side branch (t_res only feeds ln_1): it lives in bf16 only -- as the operand of
             # the timeattn.proj GEMMs and as the bf16 residual term of the ln_3 backward
@@ -740,7 +759,8 @@ class Engine:
             # temporal attention branch
             self._lin_bwd(dtrb, B_[tg + ".att_t"], pre + "timeattn.proj.weight", pre + "timeattn.proj.bias", datt, M, dy8=dtrb8,
                           side=side, defer=defer)
-            self._st_attention_bwd(B_[tg + ".qkv_t"], B_[tg + ".att_t"], datt, B_[tg + ".lse_t"], dqkv_t, "time", B, T, n, "vit.s")
+            self._st_attention_bwd(B_[tg + ".qkv_t"], B_[tg + ".att_t"], datt, B_[tg + ".lse_t"], dqkv_t, "time", B, T, n, "vit.s",
+                                   q8_for=pre + "timeattn.qkv.weight")
             self._lin_bwd(dqkv_t, B_[tg + ".ln3"], pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", dln, M, side=side, defer=defer)
             if grouped:  # the block's six weight gradients (+ bias gradients) in one launch, their partials in one reduce launch:
                 self._tn_group_run(l, defer)  # every output gradient they read is still intact (dqkv of the two branches apart)

@@ -608,20 +608,36 @@ def attn_bwd_dkv(mode, qkv, dO, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, cau
     _chk(rc, "tvts_attn_bwd_dkv")
 
 
-def attn_fwd_divided(mode, qkv, out, lse2, cls_ws, *, B, heads, S, T, n, head_dim=64, **opt):
-    """Forward of one divided-attention site (patch rows + CLS row); cls_ws is fp32 scratch."""
+def attn_fwd_divided(mode, qkv, out, lse2, cls_ws, *, B, heads, S, T, n, head_dim=64, q8out=None, q8_scale=None, q8_amax=None, **opt):
+    """Forward of one divided-attention site (patch rows + CLS row); cls_ws is fp32 scratch.  q8out (uint8, out's shape and row
+    stride) + q8_scale / q8_amax: the kernels also write the per-tensor e4m3 copy of the output."""
     lib = _lib.load()
     M = B * S
-    with _hbm("attn_fwd_" + mode, _nb((qkv, M), (out, M)) + 8 * M * heads):  # (launches its CLS merge kernel as well)
-        rc = _attn_fn(lib, "fwd_divided", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, _p(out), _ld(out), _p(lse2),
-                                                    _p(cls_ws), cls_ws.numel(), attn_opts(**opt), _stream())
+    with _hbm("attn_fwd_" + mode, _nb((qkv, M), (out, M), (q8out, M)) + 8 * M * heads):  # (launches its CLS merge kernel as well)
+        if q8out is not None:
+            rc = _attn_fn(lib, "fwd_divided_q8", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, _p(out), _ld(out), _p(lse2),
+                                                           _p(cls_ws), cls_ws.numel(), _p(q8out), q8out.stride(0), _p(q8_scale),
+                                                           _p(q8_amax), attn_opts(**opt), _stream())
+        else:
+            rc = _attn_fn(lib, "fwd_divided", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, _p(out), _ld(out), _p(lse2),
+                                                        _p(cls_ws), cls_ws.numel(), attn_opts(**opt), _stream())
     _chk(rc, "tvts_attn_fwd_divided")
 
 
-def attn_bwd(mode, qkv, dO, O, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None, head_dim=64, **opt):
-    """Whole backward of one attention site into dqkv (delta / cls_acc are scratch)."""
+def attn_bwd(mode, qkv, dO, O, lse2, delta, dqkv, *, B, heads, S, T=0, n=0, causal=False, cls_acc=None, head_dim=64, q8out=None,
+             q8_scale=None, q8_amax=None, **opt):
+    """Whole backward of one attention site into dqkv (delta / cls_acc are scratch).  q8out (uint8, dqkv's shape and row stride): the
+    kernels also write the per-tensor e4m3 copy of dqkv (fused divided geometries)."""
     lib = _lib.load()
     M = B * S
+    if q8out is not None:
+        with _hbm("attn_bwd_" + mode, _nb((qkv, M), (dO, M), (O, M), (dqkv, M), (q8out, M)) + 8 * M * heads):
+            rc = _attn_fn(lib, "bwd_q8", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO), _p(O),
+                                                   _ld(O), _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc),
+                                                   cls_acc.numel() if cls_acc is not None else 0, _p(q8out), q8out.stride(0),
+                                                   _p(q8_scale), _p(q8_amax), attn_opts(**opt), _stream())
+        _chk(rc, "tvts_attn_bwd_q8")
+        return
     with _hbm("attn_bwd_" + mode, _nb((qkv, M), (dO, M), (O, M), (dqkv, M)) + 8 * M * heads):  # (delta / CLS finalize kernels included)
         rc = _attn_fn(lib, "bwd", head_dim)(MODE[mode], _p(qkv), _ld(qkv), B, heads, S, T, n, int(causal), _p(dO), _ld(dO), _p(O),
                                             _ld(O), _p(lse2), _p(delta), _p(dqkv), _ld(dqkv), _p(cls_acc),
