@@ -363,12 +363,14 @@ class Engine:
             return
         K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
 
-    TN_GROUPED_MAX_ROWS = 12000  # measured (profiles/r04_tn_grouped.txt): +1.5 % at 12 pairs (M = 9 420), -0.4 % at 24, -2 % at 48
+    # measured (profiles/r04_tn_grouped.txt): B/16 +1.5 % at 12 pairs (M = 9 420), -0.4 % at 24, -2 % at 48; B/32 +1.2 % at its 24 pairs
+    # (M = 9 432); H/14 at its 2 pairs (M = 2 434, 1 600 tiles of 128 x 128 per block of the model) -9 %: the window is where it pays
+    TN_GROUPED_MIN_ROWS, TN_GROUPED_MAX_ROWS = 6000, 12000
 
     def _tn_grouped_on(self, M) -> bool:
         on = self.tn_grouped
         if on is None:
-            on = M <= self.TN_GROUPED_MAX_ROWS
+            on = self.TN_GROUPED_MIN_ROWS <= M <= self.TN_GROUPED_MAX_ROWS
         return bool(on) and not self.fp8_wgrad and not self.wgrad_stream
 
     def _tn_group_run(self, key, problems):
