@@ -428,8 +428,11 @@ def main():
         stale = traffic.get("stale") if traffic else None
         if stale:
             traffic = None
+        # every launch priced against the dense peak of ITS operand type (bf16 2.5, e4m3 through the K = 128 scaled MFMA 5 PFLOP/s): the
+        # fraction is the time the launches would take at their own peaks over the time they took (= achieved / peak on a pure bf16 step)
+        ideal_ms = sum(v[1] / ((PEAK_FP8_TFLOPS if k.endswith("fp8") else PEAK_BF16_TFLOPS) * 1e12) * 1e3 for k, v in by.items())
         line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / PEAK_BF16_TFLOPS,
+                            "frac": ideal_ms / tot_ms,
                             "frac_of": "the MFMA GEMM launches alone (summed 2MNK over summed launch durations); the WHOLE step on its "
                                        "executed FLOPs is step_mfma_frac",
                             "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
