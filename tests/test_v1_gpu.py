@@ -397,3 +397,65 @@ def test_v1_training_curve_tracks_oracle(K):
     curve, ref = np.array(curve), np.array(ref)
     assert ref[-1] < ref[0] - 0.02, ref
     assert np.all(np.abs(curve - ref) < 0.02 * np.abs(ref) + 1e-2), (curve, ref)
+
+
+class _V1Loader(list):
+    def __init__(self, batches):
+        super().__init__(batches)
+        self.dataset_name, self.batch_size, self.n_samples = "YTTemporal", 4, 4 * len(batches)
+
+
+class _V1Config(dict):  # (module level: the checkpoint pickles the config object)
+    resume = None
+
+    def __init__(self, save_dir, epochs):
+        super().__init__(trainer=dict(epochs=epochs, save_period=1, verbosity=2, monitor="off", init_val=False),
+                         arch=dict(type="TVTS", args={}), optimizer=dict(type="AdamW", args=dict(lr=1e-4)))
+        self.save_dir = save_dir
+
+    def get_logger(self, name, verbosity=2):
+        import logging
+        return logging.getLogger(name)
+
+
+def test_v1_resumed_run_draws_the_masks_of_the_uninterrupted_run(K, tmp_path):
+    """Trainer_TVTS keeps the dropout generator's seed in the checkpoint (beside the reference's six keys): two epochs in one go and
+    one epoch + checkpoint + resume + one epoch end in the same parameters bit for bit, with the training-mode DistilBERT dropout on.
+    The seed of a data-parallel rank is mixed with the rank, so that ranks draw different masks like the reference's do."""
+    from tvts_amd.model.loss import NormSoftmaxLoss
+    from tvts_amd.optim import FusedHFAdamW
+    from tvts_amd.trainer.trainer import Trainer_TVTS
+    a, oa = small()
+
+    def make(save_dir, epochs, resume=None):
+        m = build(a, V.synth_params(oa, seed=7), dropout=0.1)
+        opt = FusedHFAdamW([dict(params=list(m.parameters()), lr=3e-4, weight_decay=0.0)], m.store, model=m)
+        cfg = _V1Config(str(save_dir), epochs)
+        cfg.resume = resume
+        dl = _V1Loader([V.synth_batch(oa, B=4, T=4, seed=40 + i, caption_len=9) for i in range(3)])
+        args = types.SimpleNamespace(local_rank=0, rank=0, world_size=1, schedule=[])
+        return Trainer_TVTS(args, m, NormSoftmaxLoss(), [], opt, config=cfg, data_loader=[dl], valid_data_loader=None), m
+
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    tr_a, m_a = make(tmp_path / "a", 2)
+    seed0 = int(m_a.engine.drop_seed.item())
+    tr_a.train()
+    assert int(m_a.engine.drop_seed.item()) != seed0
+    tr_b, m_b = make(tmp_path / "b", 1)
+    tr_b.train()
+    ck = torch.load(tmp_path / "b" / "checkpoint-epoch1.pth", map_location="cpu", weights_only=False)
+    assert ck["tvts_amd"]["drop_seed"] == int(m_b.engine.drop_seed.item())
+    assert list(ck.keys())[:6] == ["arch", "epoch", "state_dict", "optimizer", "monitor_best", "config"]
+    tr_c, m_c = make(tmp_path / "b", 2, resume=tmp_path / "b" / "checkpoint-epoch1.pth")
+    assert int(m_c.engine.drop_seed.item()) == int(m_b.engine.drop_seed.item())
+    tr_c.train()
+    assert torch.equal(m_c.store.flat, m_a.store.flat) and torch.equal(m_c.store.m, m_a.store.m)
+    # rank mixing: the same arch on "rank 3" starts from another seed
+    import tvts_amd.dist as D
+    orig = D.world
+    try:
+        D.world = lambda: (8, 3)
+        m_r = build(a, V.synth_params(oa, seed=7), dropout=0.1)
+    finally:
+        D.world = orig
+    assert int(m_r.engine.drop_seed.item()) != seed0
