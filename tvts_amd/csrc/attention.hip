@@ -174,9 +174,11 @@ __device__ __forceinline__ void ld_frags(const bf16* p, int gq, bf16x8 (&f)[KS])
 }
 
 // k-contiguous fragment of tile row `row` (d = ks*32 + gq*8 ..); slots past DH are zero
-__device__ __forceinline__ bf16x8 frag_row(const char* tile, int row, int ks, int gq) {
+// rs: rows the tile actually stores (rows >= rs read as zeros without touching LDS: the TIME kernels of ViT-H/14 keep 20 rows of
+// their 32-row MFMA geometry, 17 of them real, and fit two blocks on a CU instead of one)
+__device__ __forceinline__ bf16x8 frag_row(const char* tile, int row, int ks, int gq, int rs = 1 << 30) {
     const int d0 = ks * 32 + gq * 8;
-    return (d0 + 8 <= DH) ? *(const bf16x8*)(tile + row * VSTRIDE + d0 * 2) : zero8();
+    return (d0 + 8 <= DH && row < rs) ? *(const bf16x8*)(tile + row * VSTRIDE + d0 * 2) : zero8();
 }
 
 // stage `nrows` (<= 64, multiple of 16) rows x 64 bf16 (rows given by a functor) into a wave-private LDS tile;
@@ -1196,22 +1198,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_time_kernel(AttnGeom g, cons
 #define FUSED_MAX_TILES 7
 #define FUSED_THREADS 512  // 8 waves: one query tile and one key tile each; 2 blocks per CU (LDS) = 4 waves per SIMD
 template <bool TR>
-__device__ __forceinline__ bf16x8 frag_T_lim(const char* tile, int u, int dt, int lane, int lim) {
+__device__ __forceinline__ bf16x8 frag_T_lim(const char* tile, int u, int dt, int lane, int lim, int rs = 1 << 30) {
     const int gq = lane >> 4, i = lane & 15;
     bf16x8 out;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        const int row0 = u * 32 + half * 16 + gq * 4;
+        const int row_real = u * 32 + half * 16 + gq * 4;
+        // rows >= rs (a multiple of 4) are not stored: the lane group reads a stored 4-row group instead and zeroes what it got
+        const int row0 = row_real < rs ? row_real : rs - 4;
         if (u * 32 + half * 16 < lim) {  // wave-uniform: tiles past `lim` rows are not allocated, their P / dS are zero
             if (TR) {
                 const char* p = tile + (row0 + (i >> 2)) * VSTRIDE + dt * 32 + (i & 3) * 8;
                 const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))p);
                 const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) out[half * 4 + e] = tb[e];
+                for (int e = 0; e < 4; ++e) out[half * 4 + e] = row_real < rs ? tb[e] : (bf16)0.f;
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) out[half * 4 + e] = *(const bf16*)(tile + (row0 + e) * VSTRIDE + (dt * 16 + i) * 2);
+                for (int e = 0; e < 4; ++e)
+                    out[half * 4 + e] = row_real < rs ? *(const bf16*)(tile + (row0 + e) * VSTRIDE + (dt * 16 + i) * 2) : (bf16)0.f;
             }
         } else {
 #pragma unroll
@@ -1426,15 +1431,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void attn_bwd_space_fused_kernel(
 // a group: its Q / K / V / dO rows live in wave-private LDS tiles (the next group's rows are already in flight in
 // registers while the current one is computed), phase A and phase B run back to back in the same wave, and the three
 // CLS-token sums (dK, dV, dQ) stay in registers over the block's chunk of patch slots -> one set of atomics per block.
-template <int MT, bool TR>
+template <int MT, bool TR, int RS_ = 0>
 __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kernel(AttnGeom g, const bf16* __restrict__ qkv,
                                                                   const bf16* __restrict__ dO, int lddo,
                                                                   const float* __restrict__ lse2, const float* __restrict__ delta,
                                                                   bf16* __restrict__ dqkv, int lddq, float* __restrict__ cls_acc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int RA = MT * 16, TB = RA * VSTRIDE, NU = (MT + 1) / 2;
+    constexpr int RA = MT * 16, RS = RS_ ? RS_ : RA, TB = RS * VSTRIDE, NU = (MT + 1) / 2;  // RS rows of the RA-row geometry are stored
     constexpr int WB = 4 * TB + 2 * RA * 4 + 3 * DH * 4 + 1024;  // bytes of one wave's region: tiles, stats, CLS sums, output patch
-    constexpr int PT = (RA * NCH + 63) / 64;         // 16-byte chunks per lane per tile
+    constexpr int PT = (RS * NCH + 63) / 64;         // 16-byte chunks per lane per tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char* base = smem + wave * WB;
     char* Qs = base;
@@ -1485,7 +1490,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
 #pragma unroll
             for (int i = 0; i < PT; ++i) {
                 const int cc = lane + 64 * i, row = cc / NCH, ch = cc % NCH;
-                if (row < RA) *(bf16x8*)(base + t * TB + row * VSTRIDE + ch * 16) = stg[t][i];
+                if (row < RS) *(bf16x8*)(base + t * TB + row * VSTRIDE + ch * 16) = stg[t][i];
             }
         if (lane < RA) {
             st_lse[lane] = lane == 0 ? lse_c : (lane < m ? lse_pf : 0.f);
@@ -1501,7 +1506,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
             const int qj = qt * 16 + li;
             bf16x8 qf[KS], dof[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { qf[ks] = frag_row(Qs, qj, ks, gq); dof[ks] = frag_row(Ds, qj, ks, gq); }
+            for (int ks = 0; ks < KS; ++ks) { qf[ks] = frag_row(Qs, qj, ks, gq, RS); dof[ks] = frag_row(Ds, qj, ks, gq, RS); }
             const float lse = st_lse[qj];
             f32x4 P[2 * NU], dP[2 * NU];
             float part = 0.f;
@@ -1513,8 +1518,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
                     f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
-                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, t * 16 + li, ks, gq), qf[ks], sc, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Vs, t * 16 + li, ks, gq), dof[ks], dp, 0, 0, 0);
+                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, t * 16 + li, ks, gq, RS), qf[ks], sc, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Vs, t * 16 + li, ks, gq, RS), dof[ks], dp, 0, 0, 0);
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -1543,7 +1548,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
                 }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
-                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ks, u, dt, lane, RA), dsf, acc[dt], 0, 0, 0);
+                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ks, u, dt, lane, RA, RS), dsf, acc[dt], 0, 0, 0);
             }
             store_tile_rows(opatch, acc, lane, [&](int rr) -> bf16* {
                 const int j = qt * 16 + rr;
@@ -1564,7 +1569,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
             const int kj = kt * 16 + li;
             bf16x8 kb[KS], vb[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { kb[ks] = frag_row(Ks, kj, ks, gq); vb[ks] = frag_row(Vs, kj, ks, gq); }
+            for (int ks = 0; ks < KS; ++ks) { kb[ks] = frag_row(Ks, kj, ks, gq, RS); vb[ks] = frag_row(Vs, kj, ks, gq, RS); }
             f32x4 dv[DT], dk[DT];
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) { dv[dt] = (f32x4){0, 0, 0, 0}; dk[dt] = (f32x4){0, 0, 0, 0}; }
@@ -1579,8 +1584,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
                         f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks) {
-                            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, tile * 16 + li, ks, gq), kb[ks], sc, 0, 0, 0);
-                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ds, tile * 16 + li, ks, gq), vb[ks], dp, 0, 0, 0);
+                            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, tile * 16 + li, ks, gq, RS), kb[ks], sc, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ds, tile * 16 + li, ks, gq, RS), vb[ks], dp, 0, 0, 0);
                         }
                         const f32x4 l4 = *(const f32x4*)(st_lse + tile * 16 + gq * 4);
                         const f32x4 d4 = *(const f32x4*)(st_dl + tile * 16 + gq * 4);
@@ -1600,8 +1605,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void attn_bwd_time_fused_kern
                 }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ds, u, dt, lane, RA), pf, dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Qs, u, dt, lane, RA), dsf, dk[dt], 0, 0, 0);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Ds, u, dt, lane, RA, RS), pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Qs, u, dt, lane, RA, RS), dsf, dk[dt], 0, 0, 0);
                 }
             }
             if (kt == 0 && li == 0) {  // column 0 = the CLS key / value
@@ -1755,14 +1760,14 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_space_fused_kernel(AttnGeom g
     q8o.finish(g, lane);
 }
 
-template <int MT, bool TR>
+template <int MT, bool TR, int RS_ = 0>
 __global__ __launch_bounds__(256) void attn_fwd_time_fused_kernel(AttnGeom g, const bf16* __restrict__ qkv,
                                                                   bf16* __restrict__ out, int ldo, float* __restrict__ lse2,
                                                                   float* __restrict__ cls_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // per wave: V tile | CLS state [DH + 2]
-    constexpr int RA = MT * 16, TB = RA * VSTRIDE, NU = (MT + 1) / 2;
+    constexpr int RA = MT * 16, RS = RS_ ? RS_ : RA, TB = RS * VSTRIDE, NU = (MT + 1) / 2;  // RS rows of the RA-row geometry are stored
     constexpr int WB = TB + (DH + 2 + 2) * 4 + 1024;
-    constexpr int PT = (RA * NCH + 63) / 64;
+    constexpr int PT = (RS * NCH + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char* Vs = smem + wave * WB;
     char* opatch = Vs + TB + (DH + 4) * 4;  // output-staging patch (behind the V tile and the CLS state)
@@ -1804,7 +1809,7 @@ __global__ __launch_bounds__(256) void attn_fwd_time_fused_kernel(AttnGeom g, co
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
             const int cc = lane + 64 * i, row = cc / NCH, ch = cc % NCH;
-            if (row < RA) *(bf16x8*)(Vs + row * VSTRIDE + ch * 16) = vst[i];
+            if (row < RS) *(bf16x8*)(Vs + row * VSTRIDE + ch * 16) = vst[i];
         }
         bf16x8 qc[MT][KS], kc[MT][KS];
 #pragma unroll
@@ -1857,7 +1862,7 @@ __global__ __launch_bounds__(256) void attn_fwd_time_fused_kernel(AttnGeom g, co
                 for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[2 * u + (j >> 2)][j & 3];
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Vs, u, dt, lane, RA), pf, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_T_lim<TR>(Vs, u, dt, lane, RA, RS), pf, o[dt], 0, 0, 0);
             }
             {
                 const float inv = 1.0f / l;
@@ -2683,8 +2688,10 @@ static int bwd_impl(int mode, const void* qkv, int ld, int B, int heads, int S, 
             blocks = B * heads * T; threads = FUSED_THREADS; slot = MT;
         } else {
             const int MT = (T + 1 + 15) / 16, RA = MT * 16;
-            lds_bytes = 4 * (4 * RA * VSTRIDE + 2 * RA * 4 + 3 * DH * 4 + 1024);
-            kern = MT == 1 ? attn_bwd_time_fused_kernel<1, true> : attn_bwd_time_fused_kernel<2, true>;
+            // 17 .. 20 rows (ViT-H/14: 16 frames + CLS): 20 of the 32 rows are stored, two blocks fit a CU instead of one
+            const int RS = (MT == 2 && T + 1 <= 20) ? 20 : RA;
+            lds_bytes = 4 * (4 * RS * VSTRIDE + 2 * RA * 4 + 3 * DH * 4 + 1024);
+            kern = MT == 1 ? attn_bwd_time_fused_kernel<1, true> : RS == 20 ? attn_bwd_time_fused_kernel<2, true, 20> : attn_bwd_time_fused_kernel<2, true>;
             blocks = B * heads * ceil_div(n, TIME_CHUNK); threads = 256; slot = FUSED_MAX_TILES + MT;
         }
         (void)slot;  // (no memo of the attribute call: the library keeps no mutable state; the call is a host-side table write)
@@ -2768,8 +2775,9 @@ static int fwd_divided_impl(int mode, const void* qkv, int ld, int B, int heads,
             blocks = B * heads * T;
         } else {
             const int MT = (T + 1 + 15) / 16;
-            kern = MT == 1 ? attn_fwd_time_fused_kernel<1, true> : attn_fwd_time_fused_kernel<2, true>;
-            lds_bytes = 4 * (MT * 16 * VSTRIDE + (DH + 4) * 4 + 1024);
+            const int RS = (MT == 2 && T + 1 <= 20) ? 20 : MT * 16;
+            kern = MT == 1 ? attn_fwd_time_fused_kernel<1, true> : RS == 20 ? attn_fwd_time_fused_kernel<2, true, 20> : attn_fwd_time_fused_kernel<2, true>;
+            lds_bytes = 4 * (RS * VSTRIDE + (DH + 4) * 4 + 1024);
             blocks = B * heads * G;
         }
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, stream, g, (const bf16*)qkv, (bf16*)out, ldo, lse2, cls_ws);
