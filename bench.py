@@ -144,7 +144,7 @@ def gemm_bytes(kind, shp):
     return b
 
 
-GEMM_SOURCES = ("gemm.hip", "gemm_nt256.h", "gemm_tn256.h", "gemm_tn8.h", "common.h")
+GEMM_SOURCES = ("gemm.hip", "gemm_nt256.h", "gemm_nt_ring.h", "gemm_tn256.h", "gemm_tn8.h", "common.h")
 
 
 def gemm_source_id():

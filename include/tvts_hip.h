@@ -32,8 +32,14 @@ enum {
     TVTS_TN_AFAST_1 = 16,       /* ... or a-dimension fastest (default: the shorter one) */
     TVTS_GEMM_STREAMK = 32,     /* tvts_gemm_nt_bf16 / tvts_gemm_tn_bf16: force the stream-K walk (work split by K stage, ordered sum of the
                                    partial tiles in the block that arrives last); -22 without a workspace or on a shape it cannot take */
-    TVTS_GEMM_NO_STREAMK = 64   /* ... never take it */
+    TVTS_GEMM_NO_STREAMK = 64,  /* ... never take it */
+    TVTS_GEMM_RING = 128,       /* tvts_gemm_nt_bf16: force the ring form of the 128-column kernel (one block per CU, three 64-deep stages
+                                   in flight: the small-batch kernel; same bits as TVTS_GEMM_TILE_128); -22 if an operand is too large
+                                   for its 32-bit offsets.  Automatic where its cost model wins (csrc/gemm.hip, nt_use_ring) */
+    TVTS_GEMM_NO_RING = 16384   /* ... never take it */
 };
+/* measurement hook: tile rows of the forced ring kernel, 128 / 192 / 256 (0 = its own choice between 128 and 192) */
+#define TVTS_GEMM_RING_ROWS(r) ((r) == 128 ? (1 << 16) : (r) == 192 ? (2 << 16) : (r) == 256 ? (3 << 16) : 0)
 /* persistent grid of the 256x256 NT kernels (bf16 and fp8): at most n blocks, one per CU (8 .. 256, multiple of 8; 0 = the whole
  * chip) -- leaves CUs to kernels of other streams (the RCCL kernels of the side stream when world > 1), and a measurement
  * hook (tools/gemm_cus.py) */
@@ -63,8 +69,9 @@ int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int
                       int gate_act, void* out, int ldc, int out_f32, void* workspace, long workspace_bytes, int opts,
                       hipStream_t stream);
 long tvts_gemm_nt_workspace_bytes(void);
-/* the output tile (128 or 256) tvts_gemm_nt_bf16 picks for an [M, N] result under `opts`: lets a parity test assert that the
- * kernel it means to exercise is the one that ran */
+/* the kernel tvts_gemm_nt_bf16 picks for an [M, N] result under `opts` -- 256 / 128 = the output tile of the pipelined / the
+ * double-buffered kernel, 1128 / 1192 = the ring kernel (TVTS_GEMM_RING) with 128 / 192 tile rows: lets a parity test assert that
+ * the kernel it means to exercise is the one that ran */
 int tvts_gemm_nt_select(int M, int N, int opts);
 /* weight gradient: out[Na,Nb] (+)= P[M,Na]^T . Q[M,Nb], bf16 in, fp32 out (autograd of the Linear sites above) */
 /* colsum (optional): colsum[a] += sum_m P[m,a] -- the bias gradient, fused into the same pass.

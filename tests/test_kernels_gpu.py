@@ -186,6 +186,63 @@ def test_gemm_nt_streamk(K, M, N, K_):
     assert int(ws[:65536].view(torch.int32).abs().sum()) == 0
 
 
+@pytest.mark.parametrize("ring", ["ring2", "ring3", "ring4", "ring"])
+@pytest.mark.parametrize("M,N,K_", [(5856, 768, 768), (5856, 768, 3072), (1536, 512, 2048), (976, 2304, 768), (1537, 520, 64), (100, 132, 128),
+                                    (12001, 768, 192), (3072, 2048, 512), (64, 4, 64)])
+def test_gemm_nt_ring_gives_the_bits_of_the_128_kernel(K, M, N, K_, ring):
+    """The small-batch form of the 128-column NT kernel (TVTS_GEMM_RING; round 4): one block of 8 waves per CU, a ring of 64-deep
+    stages with three of them in flight, epilogue inputs requested ahead by hand-counted loads, 128 / 192 / 256 tile rows.  Same
+    tile walk, same k order and the same epilogue arithmetic as the double-buffered 128 kernel: every epilogue form gives the same
+    bits, on the step's shapes at 2 / 12 / 24 pairs per GPU, on ragged shapes (rows / columns sticking out of the last tile, K of
+    one and two stages -- shorter than the ring) and launch after launch."""
+    a, b = bf(rnd(M, K_, seed=81)).to(DEV), bf(rnd(N, K_, seed=82) * K_ ** -0.5).to(DEV)
+    bias = rnd(N, seed=83).to(DEV)
+    res = rnd(M, N, seed=84).to(DEV)
+    gh = bf(rnd(M, N, seed=85)).to(DEV)
+    def run(tile):
+        outs = []
+        o = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        K.gemm_nt(a, b, o, bias=bias, residual=res, tile=tile); outs.append(o)                      # fp32 + residual
+        o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt(a, b, o, tile=tile); outs.append(o)                                                # plain bf16, no bias
+        o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt(a, b, o, bias=bias, residual=res, tile=tile); outs.append(o)                      # bf16 + fp32 residual
+        o, pre = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV), torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt(a, b, o, bias=bias, act="quick_gelu", preact=pre, tile=tile); outs += [o, pre]     # activation + pre-activation
+        o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt(a, b, o, bias=bias, act="gelu", tile=tile); outs.append(o)
+        for ga in ("quick_gelu", "gelu", "add"):                                                      # activation-gradient gates, bf16 residual
+            o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            K.gemm_nt(a, b, o, gate_h=gh, gate_act=ga, tile=tile); outs.append(o)
+        torch.cuda.synchronize()
+        return outs
+    ref = run("128noring")
+    got = run(ring)
+    again = run(ring)
+    for i, (x, y, z) in enumerate(zip(ref, got, again)):
+        assert not torch.isnan(x.float()).any()
+        assert torch.equal(y, z)
+        if i == 7:  # the erf-GELU gate: hipcc contracts the derivative's polynomial differently in the two kernels -- a handful of
+            # elements in a million land on the other side of a bf16 rounding boundary (one ulp); every other form is the same bits
+            assert int((x != y).sum()) <= max(4, x.numel() // 100000) and rel(x.float(), y.float()) < 1e-4
+        else:
+            assert torch.equal(x, y), i
+    exact = a.double() @ b.double().t() + bias.double() + res.double()
+    assert rel(got[0], exact) < 2e-5
+
+
+def test_gemm_nt_ring_is_what_the_small_batches_take(K):
+    """The dispatcher's choice (tvts_gemm_nt_select): the N = 768 GEMMs of the video tower at the reference's 12 pairs per GPU and the
+    text tower up to 24 pairs run on the ring kernel, the wide outputs and every shape of the 192-pair step keep the 256 kernel, a
+    forced tile size or TVTS_GEMM_NO_RING means the old kernels."""
+    assert K.gemm_nt_select(5856, 768) == 1192 and K.gemm_nt_select(1536, 512) == 1128 and K.gemm_nt_select(3072, 2048) == 1192
+    assert K.gemm_nt_select(5856, 2304) == 256 and K.gemm_nt_select(11712, 768) == 256
+    assert K.gemm_nt_select(9420, 768) == 128  # the bench's 12 pairs x 785 rows: 444 tiles fill the 128 kernel's 512 slots
+    assert K.gemm_nt_select(93696, 768) == 256 and K.gemm_nt_select(24576, 512) == 256
+    assert K.gemm_nt_select(5856, 768, tile=128) == 128 and K.gemm_nt_select(5856, 768, tile="noring") == 128
+    assert K.gemm_nt_select(93696, 768, tile="ring") == 1128 + 64 * (K.gemm_nt_select(93696, 768, tile="ring") == 1192)
+
+
 @pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("M,Na,Nb", [(9420, 768, 768), (9420, 2304, 768), (18840, 768, 3072), (4097, 1280, 640), (40001, 768, 768), (3000, 248, 264)])
 def test_gemm_tn_fused_reduce_gives_the_bits_of_the_reduce_pass(K, M, Na, Nb, tile):

@@ -151,6 +151,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNT g) {
     }
 }
 
+#include "gemm_nt_ring.h"
+
 // ---- dispatch.  Tile choice: the pipelined 256x256 kernel when N is a multiple of 256 and the output has at least
 // NT_MIN_TILES_256 of its tiles (the text tower of a 192-pair step has 192 of them, M = 24 576, N = 512, and runs ~10 % faster
 // on it), else the persistent 128x128 kernel.  The per-call `opts` word (include/tvts_hip.h, TVTS_GEMM_*) overrides for benches and
@@ -177,7 +179,6 @@ static bool nt_use_256(int M, int N, int K, bool has_ws, int opts) {
     // tower at 24 pairs, M = 18 936 x N = 512: 54 vs 72 us at K = 2048, profiles/r03_gemm_tile_choice_small_m.txt)
     return (long)ceil_div(M, 256) * (N / 256) >= NT_MIN_TILES_256 || (long)ceil_div(M, 128) * (N / 128) > 512;
 }
-extern "C" int tvts_gemm_nt_select(int M, int N, int opts) { return nt_use_256(M, N, 0, false, opts) ? 256 : 128; }
 
 // Wide outputs (>= 10 tile columns: the MLP's 4x expansion): walk the tiles in column groups of 6 or 5.  An XCD's 32
 // co-resident tiles then span 5-6 weight panels x 5-6 row panels instead of all 12-20 weight panels x 2-3 row panels
@@ -317,6 +318,81 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
     return TVTS_OK;
 }
 
+// The ring form of the 128-column kernel (gemm_nt_ring.h: one block per CU, 3 stages in flight, tile rows 128 / 192).  Measured
+// per 64-deep stage with HBM-cold operands (tools/gemm_ring.py, profiles/r04_gemm_ring.txt): the double-buffered 128 kernel 1.25 us
+// per round of its 512 block slots (one or two blocks per CU, one stage in flight each), the ring 0.68 us (128 rows) / 0.88 us (192
+// rows) per round of 256 blocks.  Taken where that model says the ring is at least 5 % faster, i.e. where the 128 kernel would run
+// about one block per CU: the text tower up to 24 pairs per GPU (fc2 43 -> 27 us, proj 15 -> 11 at 12 pairs), every GEMM of the
+// 2-pair step.  TVTS_GEMM_RING forces it, TVTS_GEMM_NO_RING forbids.
+static const double NT_RING_STAGE_US[5] = {0., 0., 0.68, 0.88, 1.32};
+static int nt_ring_rm(int M, int N, int opts, double* t_out = nullptr) {
+    const int forced = (opts >> 16) & 3;
+    int best = 2;
+    double best_t = 1e30;
+    for (int rm = 2; rm <= 3; ++rm) {
+        const long tiles = (long)ceil_div(M, 64 * rm) * ceil_div(N, BN);
+        const double t = (double)((tiles + 255) / 256) * NT_RING_STAGE_US[rm];
+        if (t < best_t - 1e-9) { best_t = t; best = rm; }
+    }
+    if (t_out) *t_out = best_t;
+    return forced ? forced + 1 : best;
+}
+static bool nt_use_ring(int M, int N, int K, int opts) {
+    (void)K;
+    if (opts & 16384) return false;
+    if (opts & 128) return true;
+    if (opt_tile(opts)) return false;  // a forced tile size means that kernel
+    double t_ring;
+    nt_ring_rm(M, N, opts, &t_ring);
+    const long tiles128 = (long)ceil_div(M, BM) * ceil_div(N, BN);
+    const double t128 = (double)((tiles128 + 511) / 512) * 1.25;
+    return t_ring < 0.95 * t128;
+}
+// which kernel a bf16 NT call of this shape takes: 256 (pipelined 256 x 256), 128 (double-buffered 128 x 128), or the ring kernel,
+// reported as 1000 + its tile rows (1128 / 1192)
+extern "C" int tvts_gemm_nt_select(int M, int N, int opts) {
+    if (nt_use_256(M, N, 0, false, opts)) return 256;
+    return nt_use_ring(M, N, 0, opts) ? 1000 + 64 * nt_ring_rm(M, N, opts) : 128;
+}
+// 32-bit byte offsets: operand rows from the tile's first row, side inputs from the matrix base; one side input at most
+static bool nt_ring_fits(const GemmNT& g) {
+    const unsigned long long lim = 1ull << 32, Mu = (unsigned long long)g.M;
+    return (unsigned long long)g.lda * 2ull * 128ull < lim && (unsigned long long)g.ldb * 2ull * 128ull < lim &&
+           !(g.gate_h && g.residual) && (!g.residual || Mu * (unsigned long long)g.ldr * 4ull < lim) &&
+           (!g.gate_h || Mu * (unsigned long long)g.ldh * 2ull < lim) && (unsigned long long)g.N * 4ull < lim;
+}
+template <int RM, int NS>
+static int launch_nt_ring_rm(GemmNT& g, int act, int gate_act, bool gated, hipStream_t stream) {
+    g.tiles_m = ceil_div(g.M, 64 * RM);
+    g.tiles_n = ceil_div(g.N, BN);
+    const int total_tiles = g.tiles_m * g.tiles_n;
+    const int grid = total_tiles < 256 ? ((total_tiles + 7) / 8) * 8 : 256;
+    void (*kern)(GemmNT) = nullptr;
+    if (gated) {
+        if (act != ACT_NONE) return TVTS_EINVAL;
+        kern = gate_act == ACT_QUICK_GELU ? gemm_nt_ring_kernel<0, 1, RM, NS> : gate_act == ACT_GELU_ERF ? gemm_nt_ring_kernel<0, 2, RM, NS>
+             : gate_act == ACT_ADD_BF16 ? gemm_nt_ring_kernel<0, 3, RM, NS> : nullptr;
+    } else {
+        kern = act == ACT_NONE ? gemm_nt_ring_kernel<0, 0, RM, NS> : act == ACT_QUICK_GELU ? gemm_nt_ring_kernel<1, 0, RM, NS>
+             : act == ACT_GELU_ERF ? gemm_nt_ring_kernel<2, 0, RM, NS> : nullptr;
+    }
+    if (!kern) return TVTS_EINVAL;
+    constexpr int lds_bytes = NS * (64 * RM * 128 + 16384);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, stream, g);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+static int launch_nt_ring(GemmNT& g, int act, int gate_act, bool gated, int opts, hipStream_t stream) {
+    if (!nt_ring_fits(g)) return TVTS_EINVAL;
+    switch (nt_ring_rm(g.M, g.N, opts)) {
+        case 2: return launch_nt_ring_rm<2, 4>(g, act, gate_act, gated, stream);
+        case 3: return launch_nt_ring_rm<3, 4>(g, act, gate_act, gated, stream);
+        default: return launch_nt_ring_rm<4, 3>(g, act, gate_act, gated, stream);
+    }
+}
+
 extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                                  const float* bias, const float* residual, int ldr, int act, void* preact,
                                  int ldp, const void* gate_h, int ldh, int gate_act, void* out, int ldc,
@@ -340,6 +416,7 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     g.tiles_n = ceil_div(N, BN);
     g.tiles_m = ceil_div(M, BM);
     const int total_tiles = g.tiles_m * g.tiles_n;
+    if (nt_use_ring(M, N, K, opts) && (nt_ring_fits(g) || (opts & 128))) return launch_nt_ring(g, act, gate_act, gate_h != nullptr, opts, stream);
     int tiles = total_tiles < 512 ? ((total_tiles + 7) / 8) * 8 : 512;  // persistent grid: 2 blocks x 256 CUs, multiple of 8
     void (*kern)(GemmNT) = nullptr;
     if (gate_h) {

@@ -108,7 +108,9 @@ def set_default(**kw):
 
 
 def _tile_bits(t):
-    return {0: 0, None: 0, 128: 1, 256: 2}[t]
+    # "ring" (/ "ring2" "ring3" "ring4"): the one-block-per-CU ring form of the 128-column NT kernel (/ 128, 192, 256 tile rows), "noring": never take it
+    return {0: 0, None: 0, 128: 1, 256: 2, "ring": 1 | 128, "ring2": 1 | 128 | (1 << 16), "ring3": 1 | 128 | (2 << 16), "ring4": 1 | 128 | (3 << 16), "noring": 16384,
+            "128noring": 1 | 16384}[t]
 
 
 def _sk_bits(sk):
