@@ -435,11 +435,6 @@ def main():
                             "frac": ideal_ms / tot_ms,
                             "frac_of": "the MFMA GEMM launches alone (summed 2MNK over summed launch durations); the WHOLE step on its "
                                        "executed FLOPs is step_mfma_frac",
-                            # measured ceiling of the tile design (profiles/r04_gemm_ring.txt): a CU takes in ~24 B per clock
-                            # (57 GB/s; 14.7 TB/s over 256 CUs) whatever asks -- a 256 x 256 bf16 tile streams 1 operand byte per 128 flop
-                            "cu_fill_bound": {"bytes_per_clock_per_cu": 24, "TFLOPs_256x256_bf16_tiles": 1880.0,
-                                              "achieved_over_bound": ach / 1880.0 if not any(k.endswith("fp8") for k in by) else None,
-                                              "source": "profiles/r04_gemm_ring.txt"},
                             "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
                             "traffic_unit": "HBM bytes per step over the same launches (rocprofv3 --pmc FETCH_SIZE x2 + "
                                             "WRITE_SIZE, tools/pmc_traffic.sh)" if traffic else None,

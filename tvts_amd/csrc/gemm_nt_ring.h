@@ -10,13 +10,15 @@
 // epilogue), and an epilogue whose bias / residual / gate inputs are requested 3 stages ahead by inline asm and retired by count -- a
 // tracked load would wait for every DMA in flight.  Tile rows 128 or 192 (RM = 2 / 3), whichever needs fewer one-block-per-CU rounds.
 //
-// What it reaches, and why not more (profiles/r04_gemm_ring.txt): 0.65 - 0.70 us per stage of a 128 x 128 tile, hot or cold, three
-// or four stages in flight, LDS-DMA or plain loads into registers alike, with or without the MFMAs (0.55 us without) -- a CU takes
-// in about 24 B per clock (57 GB/s), whatever asks.  A 64-deep stage of a 128 x 128 tile is 32 KiB for 2.1 MFLOP: the fill rate
-// bounds it at 0.55 us, 2.6x the stage's MFMA time (and a 256 x 256 tile's 64 KiB at 1.1 us for 8.4 MFLOP: the same limit the
-// big kernel's K loop sits at, 1250 - 1380 TF without epilogue).  So the ring brings ONE block per CU to the rate the old kernel
-// needs TWO co-resident blocks for, which is what the small batches lack -- and no further: where the 128 kernel fills its 512
-// slots (the N = 768 GEMMs of the video tower at 12 pairs: 444 tiles) or the 256 kernel its 256 (24 pairs), they stay.
+// What it reaches, and why not more (profiles/r04_gemm_ring.txt, profiles/r04_cu_intake_probe.txt): 0.65 - 0.70 us per stage of a
+// 128 x 128 tile, hot or cold, three or four stages in flight, 0.55 us with the MFMAs switched off.  A CU alone can take 64 B/clk from
+// L2 with this very access pattern, and the bare stage loop (pieces, counted waits, barrier) runs 0.27 - 0.36 us per stage on 48 CUs:
+// the kernel's stage is the fragment reads + MFMAs (660 - 800 clocks per wave) plus the ISSUE of the wave's four LDS-DMA pieces
+// (90 - 140 clocks each beside the partner wave's MFMAs), which a wave cannot overlap with its own MFMAs.  With all 256 CUs on cold
+// panels the chip delivers 14.5 TB/s past L2 (56 GB/s per CU): 0.55 - 0.6 us per 32 KiB stage whatever the kernel does.  So the ring
+// brings ONE block per CU to the rate the old kernel needs TWO co-resident blocks for, which is what the small batches lack; where
+// the 128 kernel fills its 512 slots (the N = 768 GEMMs of the video tower at 12 pairs: 444 tiles) or the 256 kernel its 256 (24
+// pairs), they stay.  Dedicated loader waves would be the next step.
 //
 // Same tile walk (XCD x owns a contiguous tile range, n fastest), same k order and the same epilogue arithmetic as
 // gemm_nt_kernel: bit-identical results (tests/test_kernels_gpu.py::test_gemm_nt_ring_*; the erf-GELU gate alone may differ by one
