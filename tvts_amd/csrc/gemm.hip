@@ -320,11 +320,11 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
 
 // The ring form of the 128-column kernel (gemm_nt_ring.h: one block per CU, 3 stages in flight, tile rows 128 / 192).  Measured
 // per 64-deep stage with HBM-cold operands (tools/gemm_ring.py, profiles/r04_gemm_ring.txt): the double-buffered 128 kernel 1.25 us
-// per round of its 512 block slots (one or two blocks per CU, one stage in flight each), the ring 0.68 us (128 rows) / 0.88 us (192
-// rows) per round of 256 blocks.  Taken where that model says the ring is at least 5 % faster, i.e. where the 128 kernel would run
-// about one block per CU: the text tower up to 24 pairs per GPU (fc2 43 -> 27 us, proj 15 -> 11 at 12 pairs), every GEMM of the
+// per round of its 512 block slots (one or two blocks per CU, one stage in flight each), the ring 0.58 us (128 rows, loader waves) / 0.88 us
+// (192 rows) per round of 256 blocks.  Taken where that model says the ring is at least 10 % faster, i.e. where the 128 kernel would run
+// about one block per CU: the text tower up to 24 pairs per GPU (fc2 43 -> 24 us, proj 15 -> 9.5 at 12 pairs), every GEMM of the
 // 2-pair step.  TVTS_GEMM_RING forces it, TVTS_GEMM_NO_RING forbids.
-static const double NT_RING_STAGE_US[5] = {0., 0., 0.68, 0.88, 1.32};
+static const double NT_RING_STAGE_US[5] = {0., 0., 0.58, 0.88, 1.32};
 static int nt_ring_rm(int M, int N, int opts, double* t_out = nullptr) {
     const int forced = (opts >> 16) & 3;
     int best = 2;
@@ -346,7 +346,7 @@ static bool nt_use_ring(int M, int N, int K, int opts) {
     nt_ring_rm(M, N, opts, &t_ring);
     const long tiles128 = (long)ceil_div(M, BM) * ceil_div(N, BN);
     const double t128 = (double)((tiles128 + 511) / 512) * 1.25;
-    return t_ring < 0.95 * t128;
+    return t_ring < 0.9 * t128;
 }
 // which kernel a bf16 NT call of this shape takes: 256 (pipelined 256 x 256), 128 (double-buffered 128 x 128), or the ring kernel,
 // reported as 1000 + its tile rows (1128 / 1192)
@@ -360,6 +360,29 @@ static bool nt_ring_fits(const GemmNT& g) {
     return (unsigned long long)g.lda * 2ull * 128ull < lim && (unsigned long long)g.ldb * 2ull * 128ull < lim &&
            !(g.gate_h && g.residual) && (!g.residual || Mu * (unsigned long long)g.ldr * 4ull < lim) &&
            (!g.gate_h || Mu * (unsigned long long)g.ldh * 2ull < lim) && (unsigned long long)g.N * 4ull < lim;
+}
+template <int RM, int NS>
+static int launch_nt_ringl_rm(GemmNT& g, int act, int gate_act, bool gated, hipStream_t stream) {
+    g.tiles_m = ceil_div(g.M, 64 * RM);
+    g.tiles_n = ceil_div(g.N, BN);
+    const int total_tiles = g.tiles_m * g.tiles_n;
+    const int grid = total_tiles < 256 ? ((total_tiles + 7) / 8) * 8 : 256;
+    void (*kern)(GemmNT) = nullptr;
+    if (gated) {
+        if (act != ACT_NONE) return TVTS_EINVAL;
+        kern = gate_act == ACT_QUICK_GELU ? gemm_nt_ringl_kernel<0, 1, RM, NS> : gate_act == ACT_GELU_ERF ? gemm_nt_ringl_kernel<0, 2, RM, NS>
+             : gate_act == ACT_ADD_BF16 ? gemm_nt_ringl_kernel<0, 3, RM, NS> : nullptr;
+    } else {
+        kern = act == ACT_NONE ? gemm_nt_ringl_kernel<0, 0, RM, NS> : act == ACT_QUICK_GELU ? gemm_nt_ringl_kernel<1, 0, RM, NS>
+             : act == ACT_GELU_ERF ? gemm_nt_ringl_kernel<2, 0, RM, NS> : nullptr;
+    }
+    if (!kern) return TVTS_EINVAL;
+    constexpr int lds_bytes = NS * (64 * RM * 128 + 16384);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds_bytes, stream, g);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
 }
 template <int RM, int NS>
 static int launch_nt_ring_rm(GemmNT& g, int act, int gate_act, bool gated, hipStream_t stream) {
@@ -387,8 +410,8 @@ static int launch_nt_ring_rm(GemmNT& g, int act, int gate_act, bool gated, hipSt
 static int launch_nt_ring(GemmNT& g, int act, int gate_act, bool gated, int opts, hipStream_t stream) {
     if (!nt_ring_fits(g)) return TVTS_EINVAL;
     switch (nt_ring_rm(g.M, g.N, opts)) {
-        case 2: return launch_nt_ring_rm<2, 4>(g, act, gate_act, gated, stream);
-        case 3: return launch_nt_ring_rm<3, 4>(g, act, gate_act, gated, stream);
+        case 2: return launch_nt_ringl_rm<2, 4>(g, act, gate_act, gated, stream);  // 128 rows: 8 multiplying + 4 loader waves
+        case 3: return launch_nt_ring_rm<3, 4>(g, act, gate_act, gated, stream);   // 192 rows: 8 waves that load for themselves (the 12-wave form would spill at 168 registers)
         default: return launch_nt_ring_rm<4, 3>(g, act, gate_act, gated, stream);
     }
 }
