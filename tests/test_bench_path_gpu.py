@@ -435,6 +435,57 @@ def test_wgrad_side_stream_gives_the_same_bits(K, lib, arch_name, B, T):
     assert float(res[True].abs().max()) > 0 and torch.equal(res[False], res[True])
 
 
+@pytest.mark.parametrize("arch_name,B,T", [("B_16", 2, 8), ("B_16", 12, 8), ("B_32", 24, 8)])
+def test_ring_kernels_leave_the_bits_of_the_old_small_batch_kernel(K, lib, arch_name, B, T):
+    """The reference's per-GPU batches once more: with the ring forms of the 128-column NT kernel (the dispatcher's choice for the text
+    tower at these sizes and for every GEMM of the 2-pair step) the step's losses and EVERY gradient are the bits of the step that
+    forbids them (TVTS_GEMM_NO_RING through the engine's options: the double-buffered 128 kernel) -- same tile walk, k order and
+    epilogue arithmetic -- and the captured step replays them."""
+    from tvts_amd import arch as A
+    from tvts_amd.data_loader import synth_batch
+    from tvts_amd.model._common import TVTSv2Base
+    assert K.gemm_nt_select(B * 4 * 32, 512) in (1128, 1192) and K.gemm_nt_select(B * 4 * 32, 512, tile="noring") in (128, 256)
+    res = {}
+    for tile in ("noring", None):
+        a = dict(A.ARCHS[arch_name])
+        a["num_frames"] = max(a["num_frames"], T)
+        m = TVTSv2Base(ARGS, arch=a, init_seed=0)
+        for name, p in m.named_parameters():
+            p.requires_grad = A.param_group_of(name, a) >= 0
+        _, _, run = _runner_of(m, a)
+        eng = m.engine
+        batch = synth_batch(a, B, T, seed=5, caption_len=32)
+        m._fresh_shadows(); m._sync_requires_grad()
+        pb = eng.prepare_batch(batch)
+        lab = batch["label"].reshape(-1).to(torch.int32).to(DEV)
+
+        def grads():
+            m.store.grad.zero_()
+            eng.embeds_ready = run.gather.start
+            try:
+                te, ve, pred = eng.forward(pb)
+            finally:
+                eng.embeds_ready = None
+            l1, l2, dte, dve, dpred = run.losses_and_grads(pb, te, ve, pred, lab)
+            eng.backward(dte, dve, dpred)
+            return l1, l2
+        with K.options(nt_tile=tile):
+            grads()
+            l1, l2 = grads()
+            torch.cuda.synchronize()
+            eager = m.store.grad.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                grads()
+            for _ in range(2):
+                g.replay()
+            torch.cuda.synchronize()
+        assert torch.equal(eager, m.store.grad), f"captured backward differs from the eager one (nt_tile {tile})"
+        res[tile] = (eager, float(l1), float(l2))
+        del g, m
+    assert float(res[None][0].abs().max()) > 0 and torch.equal(res["noring"][0], res[None][0]) and res["noring"][1:] == res[None][1:]
+
+
 def test_grouped_weight_gradients_match_the_single_launches(K, lib):
     """At the reference's per-GPU batch (B/16, 12 pairs: M = 9 420) the six weight gradients of a ViT block leave in one grouped launch
     (arch["tn_grouped"], the automatic choice up to 12 000 token rows).  Same products, same ordered partial sums per problem -- only the

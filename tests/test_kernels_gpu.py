@@ -222,11 +222,7 @@ def test_gemm_nt_ring_gives_the_bits_of_the_128_kernel(K, M, N, K_, ring):
     for i, (x, y, z) in enumerate(zip(ref, got, again)):
         assert not torch.isnan(x.float()).any()
         assert torch.equal(y, z)
-        if i == 7:  # the erf-GELU gate: hipcc contracts the derivative's polynomial differently in the two kernels -- a handful of
-            # elements in a million land on the other side of a bf16 rounding boundary (one ulp); every other form is the same bits
-            assert int((x != y).sum()) <= max(4, x.numel() // 100000) and rel(x.float(), y.float()) < 1e-4
-        else:
-            assert torch.equal(x, y), i
+        assert torch.equal(x, y), i  # (the erf-GELU forms too: their fp contraction is pinned by hand in common.h)
     exact = a.double() @ b.double().t() + bias.double() + res.double()
     assert rel(got[0], exact) < 2e-5
 

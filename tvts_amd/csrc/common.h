@@ -47,21 +47,25 @@ __device__ __forceinline__ float fast_sigmoid(float z) {
 //   erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5) e^{-z^2},  t = 1 / (1 + p z),  z >= 0,  |error| <= 1.5e-7,
 // i.e. <= 7.5e-8 absolute in Phi -- five orders below the bf16 rounding of the outputs these epilogues write.  The tail
 // q = 1 - Phi(|x|) is formed without cancellation; e^{-z^2} = e^{-x^2 / 2} is also the Gaussian of the derivative.
+// (fp contraction is pinned by hand in the erf forms: left to hipcc, the derivative's polynomial was contracted differently in
+// different kernels -- the ring and the double-buffered NT kernel disagreed by one bf16 ulp in a few elements per million)
 __device__ __forceinline__ void gelu_erf_parts(float x, float& cdf, float& gauss) {
+#pragma clang fp contract(off)
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    gauss = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    gauss = __builtin_amdgcn_exp2f((-0.72134752044448170f * x) * x);
     float poly = 1.061405429f;
-    poly = poly * t - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
-    const float q = 0.5f * poly * t * gauss;  // 1 - Phi(|x|)
+    poly = __builtin_fmaf(poly, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    const float q = ((0.5f * poly) * t) * gauss;  // 1 - Phi(|x|)
     cdf = x >= 0.f ? 1.0f - q : q;
 }
 __device__ __forceinline__ float act_fwd(float x, int act) {
     if (act == ACT_QUICK_GELU) return x * fast_sigmoid(1.702f * x);
     if (act == ACT_GELU_ERF) {
+#pragma clang fp contract(off)
         float cdf, gs;
         gelu_erf_parts(x, cdf, gs);
         return x * cdf;
@@ -75,9 +79,10 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
         return s * (1.0f + 1.702f * x * (1.0f - s));
     }
     if (act == ACT_GELU_ERF) {
+#pragma clang fp contract(off)
         float cdf, gs;
         gelu_erf_parts(x, cdf, gs);
-        return cdf + x * 0.3989422804014327f * gs;
+        return __builtin_fmaf(x * 0.3989422804014327f, gs, cdf);
     }
     return 1.0f;
 }

@@ -21,8 +21,8 @@
 // pairs), they stay.  Dedicated loader waves would be the next step.
 //
 // Same tile walk (XCD x owns a contiguous tile range, n fastest), same k order and the same epilogue arithmetic as
-// gemm_nt_kernel: bit-identical results (tests/test_kernels_gpu.py::test_gemm_nt_ring_*; the erf-GELU gate alone may differ by one
-// bf16 ulp in a few elements per million, where hipcc contracts the derivative's polynomial differently in the two kernels).
+// gemm_nt_kernel: bit-identical results in every epilogue form (tests/test_kernels_gpu.py::test_gemm_nt_ring_*; the erf-GELU forms since
+// their fp contraction is pinned by hand in common.h -- left to hipcc, the two kernels disagreed by one bf16 ulp in a few elements per million).
 #pragma once
 
 template <int RM> struct RingOff { unsigned a[RM], b[2]; };
