@@ -84,6 +84,29 @@ def cpu_baseline_worker(arch_name, T, caption_len, pairs, max_seconds, threads, 
         oarch = O.ARCHS[arch_name]
         P = O.synth_params(oarch, seed=0)
         batch = O.synth_batch(oarch, B=pairs, T=T, seed=0, caption_len=caption_len, n_trans=n_trans)
+    # a short thread sweep ON THIS HOST picks the thread count (one step each at half the timed batch, after one warm-up step): the
+    # oracle's CPU step is memory-bound and gets SLOWER with too many torch threads, and the best count depends on the host
+    host = host_threads()
+    cands = sorted({max(1, threads // 2), threads, min(host, threads * 2)})
+    sweep = {}
+    if len(cands) > 1 and max_seconds >= 10:
+        if arch_name == "v1":
+            small = V.synth_batch(oarch, B=max(1, pairs // 2), T=T, seed=1, caption_len=caption_len, n_trans=n_trans)
+        else:
+            small = O.synth_batch(oarch, B=max(1, pairs // 2), T=T, seed=1, caption_len=caption_len, n_trans=n_trans)
+        Ps, st = {k: v.clone() for k, v in P.items()}, {}
+        torch.set_num_threads(threads)
+        O.train_step(Ps, small, oarch, st)  # allocator / thread-pool warm-up
+        for c in cands:
+            torch.set_num_threads(c)
+            t0 = time.time()
+            O.train_step(Ps, small, oarch, st)
+            sweep[c] = max(1, pairs // 2) / (time.time() - t0)
+            if time.time() - t0 > max_seconds / 2:
+                break  # a count that slow is not going to win; keep the sweep bounded
+        threads = max(sweep, key=sweep.get)
+        del Ps, st, small
+    torch.set_num_threads(threads)
     state = {}
     t0 = time.time()
     O.train_step(P, batch, oarch, state)  # first step (includes allocator warm-up)
@@ -95,11 +118,13 @@ def cpu_baseline_worker(arch_name, T, caption_len, pairs, max_seconds, threads, 
             O.train_step(P, batch, oarch, state)
             n += 1
         dt = (time.time() - t0) / n
+    swept = ("thread sweep on this host (pairs/s at %d pairs per step): " % max(1, pairs // 2)
+             + ", ".join(f"{c} threads {v:.2f}" for c, v in sweep.items()) + f" -> {threads}") if sweep else "no thread sweep"
     return {"value": pairs / dt, "unit": "pairs/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+            "thread_sweep": {str(c): v for c, v in sweep.items()},
             "sample": f"{n} full step(s) (fwd+bwd+HF-AdamW) of the fp32 torch-CPU oracle, {arch_name}, T={T}, "
                       f"{pairs} pairs/step, {caption_len}-token captions x{n_trans}, {threads} torch threads on a host with "
-                      f"{os.cpu_count()} logical CPUs (not all of them: 32 threads measured best on the 256-CPU host -- 0.98 pairs/s "
-                      f"against 0.52 with 64 and 0.25 with 128; 256 time out)"}
+                      f"{os.cpu_count()} logical CPUs ({host} usable by this process); {swept}"}
 
 
 def host_threads():
@@ -113,7 +138,8 @@ def host_threads():
 def cpu_baseline(arch_name, T, caption_len, pairs, max_seconds, n_trans=4):
     """Runs the worker in a child process with a hard wall-clock limit, so a slow host cannot stall the bench."""
     import subprocess
-    # 32 torch threads: measured best on the 256-CPU host (0.98 pairs/s; 64 threads 0.52, 128 threads 0.25, 256 time out)
+    # starting point of the worker's own thread sweep (it also tries half and twice this count): 32 was best on the 256-CPU hosts
+    # of rounds 2-4 (0.98 pairs/s; 64 threads 0.52, 128 threads 0.25, 256 timed out), fewer CPUs -> all of them
     threads = min(host_threads(), 32)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--arch", arch_name, "--frames", str(T),
            "--caption-len", str(caption_len), "--cpu-pairs", str(pairs), "--cpu-seconds", str(max_seconds),
@@ -196,14 +222,15 @@ def main():
                     "default: +1 %% throughput, 2.4x the error of the embedding-side gradients; opt-in since round 4)")
     ap.add_argument("--fp8-wgrad", action="store_true", help="BASELINE config 5 in full: e4m3 weight gradients as well (implies --fp8-dgrad); every "
                     "e4m3 operand copy under one delayed scale per tensor, tvts_gemm_tn_fp8")
-    ap.add_argument("--fp32-streams", action="store_true", help="carry the gradient of the ViT blocks' residual stream in fp32 as in rounds "
-                    "1-2 (default since round 3: bf16; profiles/r03_bf16_streams_ab.txt)")
+    ap.add_argument("--fp32-streams", action="store_true", help="deprecated no-op: the fp32 residual stream and its fp32 gradient are the default "
+                    "again since round 4 (--bf16-grad-stream / --bf16-residual opt in; profiles/r03_bf16_streams_ab.txt)")
     ap.add_argument("--bf16-residual", action="store_true", help="also carry the residual stream itself in bf16 (opt-in: +5 %% throughput, "
                     "but the |d loss| <= 1e-2 gate of SURVEY 8d fails on one small configuration; profiles/r03_bf16_streams_ab.txt)")
     ap.add_argument("--wgrad-stream", choices=("auto", "on", "off"), default="auto", help="weight gradients of the ViT blocks on a side "
                     "stream beside the input-gradient chain (auto = off: measured slower, profiles/r04_wgrad_side_stream.txt)")
     ap.add_argument("--tn-grouped", choices=("auto", "on", "off"), default="auto", help="the six weight gradients of a ViT block in one grouped "
-                    "launch (auto: below 40 000 token rows per GPU)")
+                    "launch (auto: from 6 000 to 12 000 token rows per GPU, Engine.TN_GROUPED_MIN_ROWS / MAX_ROWS -- the reference's 12 pairs; "
+                    "profiles/r04_tn_grouped.txt)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
@@ -434,7 +461,10 @@ def main():
         line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": ideal_ms / tot_ms,
                             "frac_of": "the MFMA GEMM launches alone (summed 2MNK over summed launch durations); the WHOLE step on its "
-                                       "executed FLOPs is step_mfma_frac",
+                                       "executed FLOPs is step_frac (= step_mfma_frac)",
+                            # the fraction BASELINE.md section 3 defines: executed matmul FLOPs of the whole step (every kernel's
+                            # time in the denominator, not only the GEMMs') over the dense bf16 peak, from the TIMED replayed steps
+                            "step_frac": line["step_mfma_frac"],
                             "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
                             "traffic_unit": "HBM bytes per step over the same launches (rocprofv3 --pmc FETCH_SIZE x2 + "
                                             "WRITE_SIZE, tools/pmc_traffic.sh)" if traffic else None,

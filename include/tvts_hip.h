@@ -87,11 +87,14 @@ int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq, int M, int
 /* Several weight gradients in ONE launch + ONE ordered reduce launch (the six of a ViT block at the reference's per-GPU batches, where
  * each alone fills a fraction of a round): problems = HOST array of n records
  *   struct { const void* P; int ldp; const void* Q; int ldq; int M, Na, Nb; float* out; int ldo; int accumulate; float* colsum; }
- * (the arguments of tvts_gemm_tn_bf16); table_dev = device memory for the plan (tvts_gemm_tn_grouped_table_bytes(n)).  upload != 0
- * writes the plan (a synchronous copy: not during a stream capture); upload == 0 re-uses the plan a previous call with the SAME
- * problems and workspace left there.  Every problem's result has the bits of tvts_gemm_tn_bf16 called with the same range count. */
-int tvts_gemm_tn_bf16_grouped(const void* problems, int n, void* table_dev, long table_bytes, int upload, float* workspace,
-                              long workspace_elems, int opts, hipStream_t stream);
+ * (the arguments of tvts_gemm_tn_bf16); table_dev = device memory for the plan (tvts_gemm_tn_grouped_table_bytes(n)), table_host = HOST
+ * staging memory of the same size, owned by the caller (page-locked, so that the copy is truly asynchronous) and left untouched until
+ * the stream has passed this call.  upload != 0 builds the plan in table_host and copies it with ONE hipMemcpyAsync on `stream`, in
+ * front of the kernels that read it -- no host wait, ordered on whatever stream the caller launches on; upload == 0 re-uses the plan a
+ * previous call with the SAME problems and workspace left in table_dev (table_host may be NULL).  Every problem's result has the bits
+ * of tvts_gemm_tn_bf16 called with the same range count. */
+int tvts_gemm_tn_bf16_grouped(const void* problems, int n, void* table_dev, void* table_host, long table_bytes, int upload,
+                              float* workspace, long workspace_elems, int opts, hipStream_t stream);
 long tvts_gemm_tn_grouped_table_bytes(int n);
 /* the tile (128: 128x128 kernel, two blocks per CU; 256: pipelined 256x256 kernel) tvts_gemm_tn_bf16 picks for M rows into an
  * [Na, Nb] output under `opts` */

@@ -624,27 +624,42 @@ def hf_adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: flo
         p.add_(p, alpha=-lr * wd)
 
 
-def train_step(P: Params, batch: dict, arch, opt_state: dict, truncate_text: bool = True):
+def train_step(P: Params, batch: dict, arch, opt_state: dict, truncate_text: bool = True, none_grad: str = "zero"):
     """Full single-rank step on leaf copies of P: losses, grads, HF-AdamW update (in place on P).
 
-    opt_state: {'step': int, 'm': {name: Tensor}, 'v': {name: Tensor}}."""
+    opt_state: {'steps': {name: int}, 'm': {name: Tensor}, 'v': {name: Tensor}}.
+
+    A tensor that took no part in this step's loss -- every `pred_model.*` tensor in a WebVid step (NT = 1,
+    model_dist_TVTSv2_ViT_B_16.py:87-90, trainer.py:494) -- follows the reference's loop under its PINNED torch 1.11
+    (v2/requirement.txt:142): `self.optimizer.zero_grad()` (trainer.py:477, no argument) leaves a ZERO TENSOR in `.grad`
+    once a gradient has existed (set_to_none became the default in torch 2.0), HF AdamW only skips `p.grad is None`, so the
+    tensor is updated with g = 0: both moments decay, the weights move by -step_size * m / (sqrt(v) + eps) and by the
+    decoupled decay.  A tensor that has NEVER had a gradient is skipped and its per-parameter step count does not advance
+    (none arises in the kept configs: loader 0 is YT-Temporal in all three, so the first step reaches every trainable tensor).
+    Pinned by tests/golden/alternating_steps.npz (the reference's modules driven through YT / WebVid / YT ... steps).
+    none_grad="skip" is modern torch's set_to_none behaviour, kept as the negative control of that test."""
     groups, frozen = param_groups(list(P.keys()), arch)
     leaves = {k: t.detach().clone().requires_grad_(k not in frozen) for k, t in P.items()}
     loss1, loss2, *_ = step_losses(leaves, batch, arch, truncate_text)
     (loss1 + loss2).backward()
-    opt_state["step"] = opt_state.get("step", 0) + 1
+    steps = opt_state.setdefault("steps", {})
     grads = {}
     for gi, names in enumerate(groups):
         lr, wd = GROUP_HPARAMS[gi]
         for k in names:
             g = leaves[k].grad
             if g is None:
-                continue
-            grads[k] = g
+                if none_grad == "skip" or k not in steps:
+                    continue
+                g = torch.zeros_like(P[k])
+            else:
+                grads[k] = g
             m = opt_state.setdefault("m", {}).setdefault(k, torch.zeros_like(P[k]))
             v = opt_state.setdefault("v", {}).setdefault(k, torch.zeros_like(P[k]))
-            hf_adamw_step(P[k], g, m, v, opt_state["step"], lr, wd)
-    return float(loss1), float(loss2), grads
+            steps[k] = steps.get(k, 0) + 1
+            hf_adamw_step(P[k], g, m, v, steps[k], lr, wd)
+    opt_state["step"] = opt_state.get("step", 0) + 1
+    return float(loss1.detach()), float(loss2.detach()), grads
 
 
 # --------------------------------------------------------------------------------------

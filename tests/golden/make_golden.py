@@ -781,8 +781,97 @@ def gen_ddp2():
          **{"g_" + k: v for k, v in g0.items()})
 
 
+class _PinnedHFAdamW(torch.optim.Optimizer):
+    """transformers==4.10.2 `AdamW` (v2/requirement.txt:148; the package is absent here and the installed 5.x dropped the
+    class), restated from its published algorithm as a torch.optim.Optimizer so that the REFERENCE's loop statements
+    (`optimizer.zero_grad()`, `optimizer.step()`) drive it: a parameter whose `.grad` is None is skipped, one whose `.grad`
+    is a zero tensor is updated (moments decay, the weights move by m / (sqrt(v) + eps) and by the decoupled decay);
+    `state['step']` is per parameter."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self):
+        for g in self.param_groups:
+            b1, b2 = g["betas"]
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st.update(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+                st["step"] += 1
+                st["exp_avg"].mul_(b1).add_(p.grad, alpha=1.0 - b1)
+                st["exp_avg_sq"].mul_(b2).addcmul_(p.grad, p.grad, value=1.0 - b2)
+                size = g["lr"] * (1.0 - b2 ** st["step"]) ** 0.5 / (1.0 - b1 ** st["step"])
+                p.addcdiv_(st["exp_avg"], st["exp_avg_sq"].sqrt().add_(g["eps"]), value=-size)
+                if g["weight_decay"] > 0.0:
+                    p.add_(p, alpha=-g["lr"] * g["weight_decay"])
+
+
+def alternating_arch():
+    """the GPU tests' reduced architecture with the reference's text depth, so that the entrypoint's hard-coded
+    `resblocks.9 .. 11` tuning rule (train_dist_TVTSv2_ViT_B_16.py:69) applies as written"""
+    return O.tiny_arch(name="small", image=64, patch=16, width=256, heads=4, layers=2, embed=128, text_width=128,
+                       text_heads=2, text_layers=12, text_tune_from=9, vocab=512, context=16)
+
+
+def gen_alternating():
+    """trainer.py:451-512 as the kept configs run it: loader 0 = YT-Temporal (NT = 4, sorting loss), loader 1 = WebVid
+    (NT = 1, `pred_order is None`, loss2 = 0), ONE optimizer step per loader and loop iteration, `optimizer.zero_grad()` with
+    no argument in front of each.  Under the pinned torch 1.11 (requirement.txt:142) zero_grad() keeps ZERO TENSORS
+    (set_to_none=False was the default until 2.0), so in a WebVid step every `pred_model.*` tensor has g = 0, not None, and
+    HF AdamW updates it.  Real reference modules, forward wiring, losses and autograd; parameter groups by executing the
+    entrypoint's own grouping statements on the module; 3 loop iterations = 6 optimizer steps."""
+    ns = import_reference()
+    arch = alternating_arch()
+    P = O.synth_params(arch, seed=21)
+    m = TinyRefModel(ns, arch, P)
+    src = open(os.path.join(REF, "train_dist_TVTSv2_ViT_B_16.py")).read().splitlines()
+    start = next(i for i, l in enumerate(src) if "no_decay_names = [" in l)
+    stop = next(i for i, l in enumerate(src) if "optimizer = transformers.AdamW" in l)
+    body = "\n".join(l[4:] if l.startswith("    ") else l for l in src[start:stop])
+    env = {"model": m}
+    exec(compile(body, "<reference grouping>", "exec"), env)
+    opt = _PinnedHFAdamW(env["optimizer_grouped_parameters"])
+    assert [g["lr"] for g in opt.param_groups] == [1e-4, 1e-4, 1e-7, 1e-7]
+    yt = [O.synth_batch(arch, B=4, T=2, seed=40 + i, caption_len=9) for i in range(3)]
+    wv = [O.synth_batch(arch, B=4, T=3, seed=50 + i, n_trans=1, caption_len=9) for i in range(3)]
+    ce = torch.nn.CrossEntropyLoss()
+    l1s, l2s, none_after_first = [], [], None
+    for it in range(3):
+        for dl_idx, data in enumerate((yt[it], wv[it])):
+            opt.zero_grad(set_to_none=False)  # == torch 1.11's optimizer.zero_grad()
+            te, ve, pred = m(data)
+            loss1 = ns.loss.NormSoftmaxLoss()(ns.m32.sim_matrix(ve, te))
+            if pred is not None:
+                loss2 = ce(pred.reshape(-1, pred.shape[-1]), data["label"].reshape(-1)) * 2
+            else:
+                loss2 = torch.Tensor([0])
+            (loss1 + loss2).backward()
+            opt.step()
+            l1s.append(float(loss1.detach())); l2s.append(float(loss2.detach()))
+            if none_after_first is None:
+                none_after_first = [k for k, p in m.named_parameters() if p.requires_grad and p.grad is None]
+    assert none_after_first == [], none_after_first  # the first step is a YT step: no trainable tensor is ever skipped
+    pd = dict(m.named_parameters())
+    assert all(opt.state[p]["step"] == 6 for g in opt.param_groups for p in g["params"])
+    keep = ["pred_model.head.weight", "pred_model.head.bias", "pred_model.blocks.1.mlp.fc2.weight", "pred_model.type_embed",
+            "video_model.transformer.resblocks.0.timeattn.proj.weight", "video_model.transformer.resblocks.1.ln_3.weight",
+            "text_projection"]
+    out = {}
+    for k in keep:  # (matrices beyond the head: their leading 16 x 32 corner)
+        cut = (lambda t: t[:16, :32]) if pd[k].dim() == 2 and pd[k].numel() > 4096 else (lambda t: t)
+        out["p_" + k] = cut(pd[k])
+        out["m_" + k] = cut(opt.state[pd[k]]["exp_avg"])
+        out["v_" + k] = cut(opt.state[pd[k]]["exp_avg_sq"])
+    save("alternating_steps", loss1=np.array(l1s), loss2=np.array(l2s), seed=21, yt_seeds=np.array([40, 41, 42]),
+         wv_seeds=np.array([50, 51, 52]), B=4, T_yt=2, T_wv=3, caption_len=9, names=np.array(keep), **out)
+
+
 GENS = {"block": gen_block, "vit": gen_vit, "text": gen_text, "sort": gen_sort, "model_tiny": gen_model_tiny,
-        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream, "transform": gen_transform, "transform_resize": gen_transform_resize, "tokenize": gen_tokenize, "downstream_more": gen_downstream_more, "model_b16": gen_model_b16, "ctor_init": gen_ctor_init}
+        "model_b32": gen_model_b32, "groups": gen_groups, "ddp2": gen_ddp2, "model_h_tiny": gen_model_h_tiny, "model_h14": gen_model_h14, "metrics": gen_metrics, "downstream": gen_downstream, "transform": gen_transform, "transform_resize": gen_transform_resize, "tokenize": gen_tokenize, "downstream_more": gen_downstream_more, "model_b16": gen_model_b16, "ctor_init": gen_ctor_init, "alternating": gen_alternating}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

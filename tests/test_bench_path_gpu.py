@@ -531,6 +531,19 @@ def test_grouped_weight_gradients_match_the_single_launches(K, lib):
         assert (len(eng._tn_groups) == a["layers"]) == grouped
         res[grouped] = (g1, m.store)
         del gr
+        if grouped:
+            # the reference's loop alternates two loaders of different clip lengths: a block keeps ONE plan per problem signature
+            # instead of rebuilding (and re-uploading) it at every step, and going back to the first loader re-uses its plan
+            pb_first = pb
+            pb = eng.prepare_batch(synth_batch(a, 12, 4, seed=6, caption_len=32))
+            step()
+            plans_mid = {k: list(v.values()) for k, v in eng._tn_groups.items()}
+            pb = pb_first
+            step()
+            torch.cuda.synchronize()
+            assert torch.equal(g1, m.store.grad)
+            assert all(len(v) == 2 for v in eng._tn_groups.values())
+            assert all(list(v.values())[:len(plans_mid[k])] == plans_mid[k] for k, v in eng._tn_groups.items())  # nothing was rebuilt
     g0, g1 = res[False][0], res[True][0]
     assert not torch.equal(g0, g1)
     st = res[True][1]

@@ -306,6 +306,30 @@ def test_gemm_tn_grouped_gives_the_bits_of_the_single_launches(K):
     for i in range(len(shapes)):
         ref = base[i].cpu().double() + ps[i].cpu().float().t().double() @ qs[i].cpu().float().double()
         assert rel(outs2[i], ref) < 3e-5, (i, rel(outs2[i], ref))
+    # the FIRST run of a plan on a non-default, non-blocking stream (the side-stream warm-up in front of a graph capture): the plan's
+    # upload is a copy ON THAT STREAM (round 4: a synchronous copy on the legacy stream, ordered only against torch's default stream
+    # -- an empty plan on another stream skips every weight gradient silently); and on that stream inside a capture
+    side = torch.cuda.Stream()
+    outs3 = [b.clone() for b in base]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        busy = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+        for _ in range(8):
+            busy.zero_()  # work queued in front of the upload on the same stream
+        g3 = K.TnGroup(problems(outs3, [None] * 6), ws, splits=4)
+        g3.run()
+    side.synchronize()
+    for i in range(len(shapes)):
+        assert torch.equal(outs3[i], outs[i]), i
+    outs4 = [b.clone() for b in base]
+    g4 = K.TnGroup(problems(outs4, [None] * 6), ws, splits=4)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g4.run()  # first run = upload, captured as a copy node from the plan's page-locked staging memory
+    graph.replay()
+    torch.cuda.synchronize()
+    for i in range(len(shapes)):
+        assert torch.equal(outs4[i], outs[i]), i
 
 
 def test_gemm_tn_tile_selection(K):

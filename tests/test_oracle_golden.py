@@ -341,3 +341,64 @@ def test_model_b16_config2(golden):
     for k, (name, idx) in sl.items():
         assert relerr(f[k], P[name].grad[idx]) < 2e-4, k
     assert relerr(f["g_conv"], P["video_model.conv1.weight"].grad[:4].reshape(4, -1)) < 2e-4
+
+
+def _alternating_arch():
+    return O.tiny_arch(name="small", image=64, patch=16, width=256, heads=4, layers=2, embed=128, text_width=128,
+                       text_heads=2, text_layers=12, text_tune_from=9, vocab=512, context=16)
+
+
+def _alternating_oracle(f, none_grad):
+    arch = _alternating_arch()
+    P = {k: v.clone() for k, v in O.synth_params(arch, seed=int(f["seed"])).items()}
+    state, l1s, l2s = {}, [], []
+    for it in range(3):
+        yt = O.synth_batch(arch, B=int(f["B"]), T=int(f["T_yt"]), seed=int(f["yt_seeds"][it]), caption_len=int(f["caption_len"]))
+        wv = O.synth_batch(arch, B=int(f["B"]), T=int(f["T_wv"]), seed=int(f["wv_seeds"][it]), n_trans=1,
+                           caption_len=int(f["caption_len"]))
+        for data in (yt, wv):
+            l1, l2, _ = O.train_step(P, data, arch, state, none_grad=none_grad)
+            l1s.append(l1); l2s.append(l2)
+    return P, state, np.array(l1s), np.array(l2s)
+
+
+def _cut(f, key, t):
+    ref = f[key]
+    return t[:ref.shape[0], :ref.shape[1]] if (t.dim() == 2 and tuple(t.shape) != ref.shape) else t
+
+
+def test_alternating_yt_webvid_steps(golden):
+    """trainer.py:463-499 over YT (NT = 4) / WebVid (NT = 1) / YT ... : six optimizer steps of the reference's own modules under
+    `optimizer.zero_grad()` as the pinned torch 1.11 executes it (zero tensors, not None) and HF AdamW.  In the three WebVid
+    steps every `pred_model.*` tensor takes a g = 0 update: moments decay, weights keep moving along m / sqrt(v) and decay."""
+    f = golden("alternating_steps")
+    P, state, l1s, l2s = _alternating_oracle(f, "zero")
+    assert np.allclose(l1s, f["loss1"], atol=2e-5) and np.allclose(l2s, f["loss2"], atol=2e-5), (l1s, f["loss1"], l2s, f["loss2"])
+    assert all(s == 6 for s in state["steps"].values())
+    for k in f["names"]:
+        k = str(k)
+        for tag, src in (("p_", P), ("m_", state["m"]), ("v_", state["v"])):
+            # parameters are held by their DISPLACEMENT from the initial values (lr 1e-4 / 1e-7 against weights of order 0.1:
+            # the values themselves would agree to 1e-5 whatever the optimizer did); measured 3e-7 .. 5e-5, moments 5e-7 .. 2e-6
+            got, ref = _cut(f, tag + k, src[k]).detach(), torch.from_numpy(f[tag + k])
+            if tag == "p_":
+                P0 = _cut(f, tag + k, O.synth_params(_alternating_arch(), seed=int(f["seed"]))[k])
+                d_got, d_ref = (got - P0).double(), (ref - P0).double()
+                assert float((d_got - d_ref).norm()) <= 5e-4 * float(d_ref.norm()) + 1e-12, (k, float((d_got - d_ref).norm()), float(d_ref.norm()))
+            else:
+                assert relerr(ref, got) < GTOL, (tag, k, relerr(ref, got))
+
+
+def test_alternating_steps_fixture_rejects_the_set_to_none_rule(golden):
+    """negative control: modern torch's zero_grad(set_to_none=True) -- `pred_model.*` skipped in WebVid steps -- is a different
+    trajectory, and the fixture tells them apart by a wide margin (the sort head's first moment is 0.9^-1 too large per skipped
+    step, its weights stop moving)."""
+    f = golden("alternating_steps")
+    P, state, l1s, l2s = _alternating_oracle(f, "skip")
+    k = "pred_model.head.weight"
+    assert state["steps"][k] == 3
+    assert relerr(torch.from_numpy(f["m_" + k]), state["m"][k]) > 0.05
+    P0 = O.synth_params(_alternating_arch(), seed=int(f["seed"]))[k]
+    d_got, d_ref = (P[k] - P0).double(), (torch.from_numpy(f["p_" + k]) - P0).double()
+    assert float((d_got - d_ref).norm()) > 0.2 * float(d_ref.norm())
+    assert not np.allclose(l2s, f["loss2"], atol=2e-5)  # the later YT steps see a different sort head

@@ -444,7 +444,7 @@ def test_v1_resumed_run_draws_the_masks_of_the_uninterrupted_run(K, tmp_path):
     tr_b, m_b = make(tmp_path / "b", 1)
     tr_b.train()
     ck = torch.load(tmp_path / "b" / "checkpoint-epoch1.pth", map_location="cpu", weights_only=False)
-    assert ck["tvts_amd"]["drop_seed"] == int(m_b.engine.drop_seed.item())
+    assert ck["tvts_amd"]["drop_seed_base"] == int(m_b.engine.drop_seed.item()) & ((1 << 64) - 1)  # rank 0: offset 0
     assert list(ck.keys())[:6] == ["arch", "epoch", "state_dict", "optimizer", "monitor_best", "config"]
     tr_c, m_c = make(tmp_path / "b", 2, resume=tmp_path / "b" / "checkpoint-epoch1.pth")
     assert int(m_c.engine.drop_seed.item()) == int(m_b.engine.drop_seed.item())
@@ -456,6 +456,12 @@ def test_v1_resumed_run_draws_the_masks_of_the_uninterrupted_run(K, tmp_path):
     try:
         D.world = lambda: (8, 3)
         m_r = build(a, V.synth_params(oa, seed=7), dropout=0.1)
+        assert int(m_r.engine.drop_seed.item()) != seed0
+        # a resume on "rank 3" of the file rank 0 wrote continues rank 3's OWN sequence: base + 3 strides, not rank 0's seed
+        base = ck["tvts_amd"]["drop_seed_base"]
+        tr_r, m_r2 = make(tmp_path / "b", 2, resume=tmp_path / "b" / "checkpoint-epoch1.pth")
+        got = int(m_r2.engine.drop_seed.item()) & ((1 << 64) - 1)
+        assert got == (base + 3 * m_r2.engine.DROP_RANK_STRIDE) & ((1 << 64) - 1) != base
+        assert m_r2.engine.drop_seed_base() == base
     finally:
         D.world = orig
-    assert int(m_r.engine.drop_seed.item()) != seed0

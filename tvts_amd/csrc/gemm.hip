@@ -989,12 +989,17 @@ extern "C" int tvts_gemm_tn_bf16(const void* P, int ldp, const void* Q, int ldq,
 // problems (same pointers, shapes, workspace) from an earlier call, only the launches are enqueued -- the form a captured step uses.
 struct tvts_tn_problem_ { const void* P; int ldp; const void* Q; int ldq; int M, Na, Nb; float* out; int ldo; int accumulate; float* colsum; };
 extern "C" long tvts_gemm_tn_grouped_table_bytes(int n) { return (long)n * (long)sizeof(GemmTN) + (long)(n + 1) * 4 + 64; }
-extern "C" int tvts_gemm_tn_bf16_grouped(const void* problems, int n, void* table_dev, long table_bytes, int upload, float* workspace,
-                                         long workspace_elems, int opts, hipStream_t stream) {
+extern "C" int tvts_gemm_tn_bf16_grouped(const void* problems, int n, void* table_dev, void* table_host, long table_bytes, int upload,
+                                         float* workspace, long workspace_elems, int opts, hipStream_t stream) {
     if (n <= 0 || n > 64 || !problems || !table_dev || !workspace || table_bytes < tvts_gemm_tn_grouped_table_bytes(n)) return TVTS_EINVAL;
+    if (upload && !table_host) return TVTS_EINVAL;
     const tvts_tn_problem_* pr = (const tvts_tn_problem_*)problems;
-    GemmTN tab[64];
-    int prefix[65];
+    // the plan is built in the CALLER's staging memory when it is uploaded (it has to outlive this call: the copy is asynchronous),
+    // on the stack when only the launch geometry is needed
+    GemmTN tab_local[64];
+    int prefix_local[65];
+    GemmTN* tab = upload ? (GemmTN*)table_host : tab_local;
+    int* prefix = upload ? (int*)((char*)table_host + (size_t)n * sizeof(GemmTN)) : prefix_local;
     long tiles_total = 0, out_total = 0;
     int Mmax = 0;
     for (int i = 0; i < n; ++i) {
@@ -1050,9 +1055,9 @@ extern "C" int tvts_gemm_tn_bf16_grouped(const void* problems, int n, void* tabl
     }
     char* td = (char*)table_dev;
     if (upload) {
-        hipError_t e = hipMemcpy(td, tab, (size_t)n * sizeof(GemmTN), hipMemcpyHostToDevice);
-        if (e != hipSuccess) return (int)e;
-        e = hipMemcpy(td + (size_t)n * sizeof(GemmTN), prefix, (size_t)(n + 1) * 4, hipMemcpyHostToDevice);
+        // ONE copy, ordered on the launch stream in front of the kernels that read the plan: no host-side wait, no legacy-stream
+        // ordering assumption (round 4 used two synchronous hipMemcpy calls, ordered only against torch's default stream)
+        hipError_t e = hipMemcpyAsync(td, table_host, (size_t)n * sizeof(GemmTN) + (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return (int)e;
     }
     TnGroup grp;

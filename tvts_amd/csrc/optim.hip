@@ -381,12 +381,16 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16* __restr
     amax_publish(amax_acc, run_amax, lane);
 }
 // next step's scales from this step's amax values, for n tensors at once: scale[i] = amax[i] / 448 (unchanged while amax[i] == 0:
-// a tensor that was not produced this step keeps its scale), amax[i] = 0
+// a tensor that was not produced this step keeps its scale), amax[i] = 0.  A scale slot never stays 0: a tensor whose maximum was 0
+// in the calibration step (the time branch's attention output under the reference's zero-initialised timeattn.qkv) gets the scale
+// 1.0 -- the value q8_scale() quantises under when it meets a zero scale -- so that producer and consumers agree (the GEMMs
+// dequantise with the slot's value: a raw 0 there would force the tensor's products to zero for one step)
 __global__ void fp8_update_scales_kernel(float* __restrict__ amax, float* __restrict__ scale, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float a = amax[i];
     if (a > 0.f) scale[i] = a / 448.0f;
+    else if (!(scale[i] > 0.f)) scale[i] = 1.0f;
     amax[i] = 0.f;
 }
 extern "C" int tvts_fp8_update_scales(float* amax, float* scale, int n, hipStream_t stream) {

@@ -15,6 +15,8 @@ Two transports, same semantics:
              the compute stream, no host synchronisation anywhere in the step.  OPT-IN (``TVTS_COMM=native``) since round 4:
              never run on more than one GPU, and its bring-up can hang instead of falling back (see transport());
   ``torch``  torch.distributed collectives (backend nccl = RCCL on the GPUs, gloo on CPU tensors in the tests): the default.
+``TVTS_COMM`` is read ONCE, by the first call of transport(); the result is cached for the process and later changes of the
+environment variable are ignored (every rank has to stay on the transport the ranks agreed on).
 
 CU reservation (``TVTS_NT_CUS``, default none): the persistent 256x256 GEMM blocks fill a CU completely, so an RCCL kernel only
 gets CUs at a GEMM kernel boundary or on CUs the persistent grid leaves free.  tools/overlap_probe.py (profiles/r03_overlap_probe.txt)

@@ -374,17 +374,24 @@ class Engine:
         return bool(on) and not self.fp8_wgrad and not self.wgrad_stream
 
     def _tn_group_run(self, key, problems):
-        """launch the deferred weight gradients of one block together; the plan is cached per block while the buffers stay the same"""
+        """launch the deferred weight gradients of one block together.  Plans are cached per (block, problem signature): the
+        reference's loop alternates two loaders with different clip lengths (trainer.py:463), so a block sees two signatures in
+        turn -- replacing the plan would rebuild and re-upload it twelve times per step; a bounded number is kept per block."""
         if not problems:
             return
-        grp = self._tn_groups.get(key)
         sig = tuple((pr["p"].data_ptr(), pr["q"].data_ptr(), pr["out"].data_ptr(), pr["M"],
                      pr["colsum"].data_ptr() if pr["colsum"] is not None else 0) for pr in problems)
-        if grp is None or grp[0] != sig:
+        plans = self._tn_groups.setdefault(key, {})
+        grp = plans.get(sig)
+        if grp is None:
             if self._tn_group_ws is None:
                 self._tn_group_ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.dev)
-            grp = self._tn_groups[key] = (sig, K.TnGroup(problems, self._tn_group_ws, splits=int(self.arch.get("tn_group_splits", 0))))
-        grp[1].run()
+            if len(plans) >= self.TN_GROUP_PLANS_PER_BLOCK:
+                plans.pop(next(iter(plans)))  # the oldest (a last partial batch, a loader that is gone)
+            grp = plans[sig] = K.TnGroup(problems, self._tn_group_ws, splits=int(self.arch.get("tn_group_splits", 0)))
+        grp.run()
+
+    TN_GROUP_PLANS_PER_BLOCK = 4
 
     def _lin_bwd(self, dy, a_in, wname, bname, d_in, M, dy8=None, side=False, q8_for=None, defer=None, **epi):
         """dW += dy^T a_in, db += colsum(dy) (if trainable); d_in = dy W (optional, with epilogue).  dy8: the e4m3 copy of dy
@@ -728,10 +735,13 @@ class Engine:
         # the time branch, dtrb, and the block's own dxb) then live in buffers of the layer's parity, and the chain joins the side
         # stream's work of layer l + 1 before layer l overwrites the first of them (its ln_3 backward writes the dxb that layer
         # l + 1 read) -- the side stream may lag one layer behind, never two
-        side = self._wgrad_side(M)
+        # (not with e4m3 weight gradients in tensor mode: those never take the side branch of _lin_bwd)
+        side = self._wgrad_side(M) and not (self.fp8_wgrad and self._f8_tensor_mode)
         grouped = self._tn_grouped_on(M)
         side_done = {}
         cur = torch.cuda.current_stream(self.dev)
+        if side:
+            self._side()  # the stream exists before anything records on it or joins it (all weights frozen: no launch creates it)
         for l in reversed(range(a["layers"])):
             pre, tg = f"video_model.transformer.resblocks.{l}.", f"vit{l}"
             x_in = B_[f"vit.x{l}"]

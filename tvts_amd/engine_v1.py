@@ -49,6 +49,23 @@ class EngineV1(Engine):
     DROP_STEP_STRIDE = 0x51ED270B7F4A7C15  # added to the seed (mod 2^64) once per training forward
     DROP_RANK_STRIDE = 0x9E3779B97F4A7C15  # ... and once per rank below this one
 
+    @classmethod
+    def _rank_offset(cls, rank):
+        return (rank * cls.DROP_RANK_STRIDE) & ((1 << 64) - 1)
+
+    def drop_seed_base(self) -> int:
+        """the rank-independent part of the seed (configured seed + step advances, unsigned 64-bit): what a checkpoint stores --
+        rank 0 writes the file, every rank reads it"""
+        from .dist import world
+        return ((int(self.drop_seed.item()) & ((1 << 64) - 1)) - self._rank_offset(world()[1])) & ((1 << 64) - 1)
+
+    def set_drop_seed_base(self, base: int):
+        """resume: this rank's seed = stored base + this rank's offset (mod 2^64), so that every rank continues ITS OWN mask
+        sequence -- loading rank 0's seed verbatim would give all ranks the same masks"""
+        from .dist import world
+        seed = ((int(base) & ((1 << 64) - 1)) + self._rank_offset(world()[1])) & ((1 << 64) - 1)
+        self.drop_seed.fill_(seed - (1 << 64) if seed >= (1 << 63) else seed)
+
     def _advance_drop_seed(self):
         """new masks for this step (a device op: a captured graph advances the seed on every replay)"""
         self._drop_active = self.text_drop_p if self.training else 0.0

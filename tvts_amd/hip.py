@@ -354,8 +354,9 @@ def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True, 
 
 class TnGroup:
     """The weight gradients of one group (a ViT block's six) launched together: tvts_gemm_tn_bf16_grouped.  Build it once with the
-    problems -- dicts of the gemm_tn arguments p, q, out, M, accumulate, colsum -- and call run(); the device plan is uploaded on the
-    first run outside a stream capture and re-used while the problems stay the same tensors (the engine's buffers are persistent)."""
+    problems -- dicts of the gemm_tn arguments p, q, out, M, accumulate, colsum -- and call run(); the device plan is uploaded by the
+    first run -- one asynchronous copy from page-locked staging memory ON THE LAUNCH STREAM, in front of the kernels that read it --
+    and re-used while the problems stay the same tensors (the engine's buffers are persistent)."""
 
     class _Rec(ctypes.Structure):
         _fields_ = [("P", ctypes.c_void_p), ("ldp", ctypes.c_int), ("Q", ctypes.c_void_p), ("ldq", ctypes.c_int), ("M", ctypes.c_int),
@@ -376,21 +377,20 @@ class TnGroup:
             r.colsum = pr["colsum"].data_ptr() if pr.get("colsum") is not None else None
         self.key = tuple((r.P, r.Q, r.out, r.colsum, r.M, r.Na, r.Nb, r.ldp, r.ldq, r.ldo, r.accumulate) for r in self.recs)
         self.ws = workspace
-        self.table = torch.zeros(lib.tvts_gemm_tn_grouped_table_bytes(self.n), dtype=torch.uint8, device=workspace.device)
+        nbytes = lib.tvts_gemm_tn_grouped_table_bytes(self.n)
+        self.table = torch.empty(nbytes, dtype=torch.uint8, device=workspace.device)  # (no fill: a fill on another stream could land after the upload)
+        self.table_host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)    # stays alive and untouched with the plan
         self.uploaded = False
         self.opts = int(splits) << 8
         self.flops = sum(2.0 * r.M * r.Na * r.Nb for r in self.recs)
 
     def run(self):
         lib = _lib.load()
-        capturing = torch.cuda.is_current_stream_capturing()
-        if not self.uploaded and capturing:
-            raise HipError("TnGroup: the plan must be uploaded by one eager run before the step is captured")
         if GEMM_PROFILE is not None:
             ev0, ev1 = Event(), Event()
             ev0.record()
-        rc = lib.tvts_gemm_tn_bf16_grouped(ctypes.cast(self.recs, ctypes.c_void_p), self.n, _p(self.table), self.table.numel(),
-                                           0 if self.uploaded else 1, _p(self.ws), self.ws.numel(), self.opts, _stream())
+        rc = lib.tvts_gemm_tn_bf16_grouped(ctypes.cast(self.recs, ctypes.c_void_p), self.n, _p(self.table), _p(self.table_host),
+                                           self.table.numel(), 0 if self.uploaded else 1, _p(self.ws), self.ws.numel(), self.opts, _stream())
         _chk(rc, "tvts_gemm_tn_bf16_grouped")
         self.uploaded = True
         if GEMM_PROFILE is not None:

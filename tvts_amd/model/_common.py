@@ -99,6 +99,8 @@ class _ModelFn(torch.autograd.Function):
         foreign = m._prepare_grad_buffer()
         dp = d_pred.reshape(-1, d_pred.shape[-1]).contiguous().float() if ctx.has_pred else None
         m.engine.backward(d_te.contiguous().float(), d_ve.contiguous().float(), dp)
+        if hasattr(m.engine, "end_step"):
+            m.engine.end_step()  # e4m3 weight gradients: without it the autograd path would stay in its calibration step forever
         m._install_grads()
         for p, name in foreign:  # .grad tensors that are not views of the flat buffer: ordinary accumulation
             p.grad.add_(m.store.g(name))

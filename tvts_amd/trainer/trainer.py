@@ -266,14 +266,20 @@ class Trainer_TVTS(_TrainerBase):
                          writer, visualizer, tokenizer, max_samples_per_epoch)
         self.base_lr = optimizer.state_dict()["param_groups"][0]["lr"]  # v1/base/base_trainer.py:30
 
-    # the dropout generator's state travels with the checkpoint: a resumed run draws the masks the uninterrupted run would have
+    # the dropout generator's state travels with the checkpoint: a resumed run draws the masks the uninterrupted run would have,
+    # on EVERY rank -- the file (written by rank 0) holds the rank-independent part of the seed, each rank adds its own offset back
     def _extra_state(self):
         eng = self.model.engine
-        return {"drop_seed": int(eng.drop_seed.item())} if hasattr(eng, "drop_seed") else None
+        return {"drop_seed_base": eng.drop_seed_base()} if hasattr(eng, "drop_seed") else None
 
     def _load_extra_state(self, state):
-        if state and "drop_seed" in state and hasattr(self.model.engine, "drop_seed"):
-            self.model.engine.drop_seed.fill_(int(state["drop_seed"]))
+        eng = self.model.engine
+        if not state or not hasattr(eng, "drop_seed"):
+            return
+        if "drop_seed_base" in state:
+            eng.set_drop_seed_base(int(state["drop_seed_base"]))
+        elif "drop_seed" in state:  # a round-4 checkpoint: rank 0's full seed (its rank offset is 0, so this IS the base)
+            eng.set_drop_seed_base(int(state["drop_seed"]))
 
     def _adjust_learning_rate(self, optimizer, epoch, args):
         lr = self.base_lr
