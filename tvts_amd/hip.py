@@ -389,7 +389,7 @@ class TnGroup:
         if GEMM_PROFILE is not None:
             ev0, ev1 = Event(), Event()
             ev0.record()
-        rc = lib.tvts_gemm_tn_bf16_grouped(ctypes.cast(self.recs, ctypes.c_void_p), self.n, _p(self.table), _p(self.table_host),
+        rc = lib.tvts_gemm_tn_bf16_grouped(ctypes.cast(self.recs, ctypes.c_void_p), self.n, _p(self.table), ctypes.c_void_p(self.table_host.data_ptr()),
                                            self.table.numel(), 0 if self.uploaded else 1, _p(self.ws), self.ws.numel(), self.opts, _stream())
         _chk(rc, "tvts_gemm_tn_bf16_grouped")
         self.uploaded = True
