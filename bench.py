@@ -218,14 +218,14 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 4: e4m3 forward GEMMs in the ViT blocks")
     ap.add_argument("--fp8-dgrad", action="store_true", help="... and e4m3 input-gradient GEMMs (output gradient one scale per token, "
                     "transposed e4m3 weight copies); the weight gradients stay bf16")
-    ap.add_argument("--bf16-grad-stream", action="store_true", help="carry the GRADIENT of the ViT blocks' residual stream in bf16 (round 3's "
-                    "default: +1 %% throughput, 2.4x the error of the embedding-side gradients; opt-in since round 4)")
+    ap.add_argument("--bf16-grad-stream", action="store_true", help="carry the GRADIENT of the ViT blocks' residual stream in bf16 on EVERY row, the "
+                    "forward stream in fp32 (round 3's default: 2.4x the error of the embedding-side gradients; switches the hybrid stream off)")
     ap.add_argument("--fp8-wgrad", action="store_true", help="BASELINE config 5 in full: e4m3 weight gradients as well (implies --fp8-dgrad); every "
                     "e4m3 operand copy under one delayed scale per tensor, tvts_gemm_tn_fp8")
-    ap.add_argument("--fp32-streams", action="store_true", help="deprecated no-op: the fp32 residual stream and its fp32 gradient are the default "
-                    "again since round 4 (--bf16-grad-stream / --bf16-residual opt in; profiles/r03_bf16_streams_ab.txt)")
-    ap.add_argument("--bf16-residual", action="store_true", help="also carry the residual stream itself in bf16 (opt-in: +5 %% throughput, "
-                    "but the |d loss| <= 1e-2 gate of SURVEY 8d fails on one small configuration; profiles/r03_bf16_streams_ab.txt)")
+    ap.add_argument("--fp32-streams", action="store_true", help="the space-time blocks' residual stream and its gradient in fp32 on every row "
+                    "(rounds 1, 2, 4) instead of the hybrid stream (round 5 default: bf16 rows, the CLS row of every clip in fp32)")
+    ap.add_argument("--bf16-residual", action="store_true", help="both streams in bf16 on EVERY row, CLS rows included (round 3's opt-in; "
+                    "the |d loss| <= 1e-2 gate of SURVEY 8d fails on one small configuration; switches the hybrid stream off)")
     ap.add_argument("--wgrad-stream", choices=("auto", "on", "off"), default="auto", help="weight gradients of the ViT blocks on a side "
                     "stream beside the input-gradient chain (auto = off: measured slower, profiles/r04_wgrad_side_stream.txt)")
     ap.add_argument("--tn-grouped", choices=("auto", "on", "off"), default="auto", help="the six weight gradients of a ViT block in one grouped "
@@ -287,7 +287,7 @@ def main():
     if args.dense_sort_head:
         a["sort_used_rows_only"] = False
     if args.fp32_streams:
-        a["bf16_grad_stream"] = False
+        a["hybrid_stream"] = False
     if args.bf16_grad_stream:
         a["bf16_grad_stream"] = True
     if args.bf16_residual:

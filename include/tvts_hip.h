@@ -176,6 +176,24 @@ int tvts_layernorm_bwd_fp8(const void* dy, int lddy, const void* x, int ldx, int
                            const float* gamma, const void* res1, int res1_bf16, int ldr, const void* res2_bf16, int ldr2, int M, int W, float* dx,
                            int lddx, void* dx_bf16, int lddxb, void* q8, int ldq, float* row_scale, const float* tscale, float* amax_acc,
                            float* dgamma, float* dbeta, float* workspace, long workspace_elems, hipStream_t stream);
+/* The HYBRID residual stream of the space-time blocks (round 5; replaces the fp32 activations `x + ...` of
+ * video_encoder_ViT_B_16.py:113-124 byte for byte except one row per clip): the stream x [M, W] is bf16, but the row of each clip's CLS
+ * token (rows r % cls_period == 0) -- the row the video embedding is read from, and the one row whose rounding error reaches every
+ * other token through the attention -- is carried in fp32 in a compact side array cls_x [M / cls_period, W].  Forward: those rows are
+ * normalised from cls_x (their stream rows are stale) and x_refresh (normally x itself, optional) receives their bf16 rounding, so that
+ * later readers of the stream see the exact value rounded once.  q8 .. amax_acc optional, as in tvts_layernorm_fwd_fp8. */
+int tvts_layernorm_fwd_cls(const void* x, int ldx, const float* cls_x, int cls_period, void* x_refresh, const float* gamma,
+                           const float* beta, float eps, int M, int W, void* y, int ldy, void* q8, int ldq, float* row_scale,
+                           const float* tscale, float* amax_acc, float* mean, float* rstd, hipStream_t stream);
+/* Backward on the hybrid stream: bf16 dy, bf16 x, every row; res1_bf16 (optional) the bf16 stream gradient, res2_bf16 (optional, with
+ * res1) a bf16 side branch; dx_bf16 required.  Rows r % cls_period == 0: input from cls_x (optional), stream gradient from cls_res1
+ * (optional, fp32 [M / cls_period, W]) instead of res1's row, result ALSO to cls_dx (optional, fp32) -- the CLS token's gradient chain
+ * never passes through a bf16 rounding.  q8 .. amax_acc optional, as in tvts_layernorm_bwd_fp8. */
+int tvts_layernorm_bwd_cls(const void* dy, int lddy, const void* x, int ldx, const float* cls_x, const float* cls_res1, float* cls_dx,
+                           int cls_period, const float* mean, const float* rstd, const float* gamma, const void* res1_bf16, int ldr,
+                           const void* res2_bf16, int ldr2, int M, int W, void* dx_bf16, int lddxb, void* q8, int ldq, float* row_scale,
+                           const float* tscale, float* amax_acc, float* dgamma, float* dbeta, float* workspace, long workspace_elems,
+                           hipStream_t stream);
 
 /* ---- attention (attention.hip), head dim 64, packed qkv [rows, 3*heads*64]:
  *      divided space-time attention video_encoder_ViT_B_16.py:11-15,38-76; causal text attention

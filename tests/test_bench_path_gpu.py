@@ -335,7 +335,8 @@ def test_full_size_step_properties(K, lib, arch_name, B, T, nsub):
 
 
 @pytest.mark.parametrize("arch_name,B,T,flags", [("B_16", 48, 8, ()), ("B_32", 48, 8, ()), ("H_14", 8, 16, ()), ("H_14", 8, 16, ("fp8", "fp8_dgrad")),
-                                                 ("B_16", 48, 8, ("bf16_residual",)), ("v1", 48, 4, ())])
+                                                 ("B_16", 48, 8, ("bf16_residual",)), ("B_16", 48, 8, ("hybrid_stream=False",)),
+                                                 ("H_14", 8, 16, ("hybrid_stream=False",)), ("v1", 48, 4, ())])
 def test_every_gradient_is_bit_reproducible(K, lib, arch_name, B, T, flags):
     """Two identical steps (the training step's parameter groups, v1 with its dropout masks pinned) leave the same bits in EVERY
     parameter gradient and both losses: all reductions of the step are ordered sums -- none is a scatter of fp32 atomics whose
@@ -348,7 +349,7 @@ def test_every_gradient_is_bit_reproducible(K, lib, arch_name, B, T, flags):
     a = dict(A.ARCHS[arch_name])
     a["num_frames"] = max(a["num_frames"], T)
     for f in flags:
-        a[f] = True
+        a[f.split("=")[0]] = not f.endswith("=False")
     v1 = a.get("family") == "v1"
     m = (TVTS if v1 else TVTSv2Base)(ARGS, arch=a, init_seed=0)
     for name, p in m.named_parameters():

@@ -436,6 +436,77 @@ def test_layernorm(K, W, eps):
         assert torch.equal(dg4, dg) and torch.equal(db4, db)
 
 
+@pytest.mark.parametrize("W,period,q8", [(768, 7, False), (1280, 5, False), (256, 3, False), (768, 7, True)])
+def test_layernorm_on_the_hybrid_stream(K, W, period, q8):
+    """tvts_layernorm_{fwd,bwd}_cls: the stream is bf16, the rows r % period == 0 (a clip's CLS token) are carried in fp32 side
+    arrays.  Those rows are normalised from the side array (their stream rows are stale garbage here) and receive their bf16
+    rounding; in the backward their input comes from the side array, their residual-stream gradient from cls_res1 (fp32) and their
+    result also goes to cls_dx in fp32; every other row behaves exactly like the plain bf16-stream kernels (same bits)."""
+    Bc = 9
+    M = Bc * period
+    g, b = (1 + 0.1 * rnd(W, seed=17)).to(DEV), (0.1 * rnd(W, seed=18)).to(DEV)
+    x_exact = rnd(M, W, seed=16) * 2 + 0.3                       # what the stream "is": fp32 on the CLS rows, bf16 elsewhere
+    cls_rows = torch.arange(Bc) * period
+    xs = bf(x_exact)
+    xs[cls_rows] = 777.0                                          # stale stream rows: must never be read
+    cls_x = x_exact[cls_rows].contiguous().to(DEV)
+    truth = bf(x_exact).float()
+    truth[cls_rows] = x_exact[cls_rows]
+    xr = truth.clone().requires_grad_(True)
+    gr, br = g.cpu().clone().requires_grad_(True), b.cpu().clone().requires_grad_(True)
+    y_ref = O.layer_norm(xr, gr, br, 1e-5)
+    dy = bf(rnd(M, W, seed=19))
+    y_ref.backward(dy.float())
+    x_dev = xs.to(DEV)
+    y = torch.empty(M, W, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    kw = {}
+    if q8:
+        kw = dict(q8=torch.empty(M, W, dtype=torch.uint8, device=DEV), row_scale=torch.empty(M, device=DEV))
+    K.layernorm_fwd(x_dev, g, b, 1e-5, y, mean, rstd, cls_x=cls_x, cls_period=period, **kw)
+    assert rel(y.float(), y_ref) < 4e-3
+    assert torch.equal(x_dev[cls_rows.to(DEV)].view(torch.int16), cls_x.bfloat16().view(torch.int16))  # refreshed: rounded once
+    # non-CLS rows: the bits of the plain bf16-input kernel
+    y0 = torch.empty_like(y)
+    m0, r0 = torch.empty_like(mean), torch.empty_like(rstd)
+    K.layernorm_fwd(x_dev, g, b, 1e-5, y0, m0, r0)
+    other = torch.ones(M, dtype=torch.bool); other[cls_rows] = False
+    assert torch.equal(y[other.to(DEV)].view(torch.int16), y0[other.to(DEV)].view(torch.int16))
+    if q8:
+        q0, rs0 = K.quantize_fp8_rows(y)
+        assert torch.equal(q0, kw["q8"]) and torch.equal(rs0[:M], kw["row_scale"][:M])
+    # backward: stream gradient bf16, CLS rows of it fp32
+    res1_exact = rnd(M, W, seed=20)
+    res1 = bf(res1_exact); res1[cls_rows] = -555.0
+    cls_res1 = res1_exact[cls_rows].contiguous().to(DEV)
+    res2 = bf(rnd(M, W, seed=21))
+    for form in ("res12", "res1", "none"):
+        r1 = res1.to(DEV) if form != "none" else None
+        r2 = res2.to(DEV) if form == "res12" else None
+        dxb = torch.full((M, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        cls_dx = torch.full((Bc, W), float("nan"), device=DEV)
+        dg, db = torch.zeros(W, device=DEV), torch.zeros(W, device=DEV)
+        kwb = {}
+        if q8:
+            kwb = dict(q8=torch.empty(M, W, dtype=torch.uint8, device=DEV), row_scale=torch.empty(M, device=DEV))
+        K.layernorm_bwd(dy.to(DEV), x_dev, mean, rstd, g, None, dx_bf16=dxb, res1=r1, res2=r2, dgamma=dg, dbeta=db,
+                        cls_period=period, cls_x=cls_x, cls_res1=cls_res1 if form != "none" else None, cls_dx=cls_dx, **kwb)
+        want = xr.grad.clone()
+        if form != "none":
+            r = bf(res1_exact).float(); r[cls_rows] = res1_exact[cls_rows]
+            want = want + r
+        if form == "res12":
+            want = want + res2.float()
+        assert rel(cls_dx, want[cls_rows]) < 1e-5, form
+        assert rel(dxb.float(), want) < 4e-3, form
+        assert torch.equal(dxb[cls_rows.to(DEV)].view(torch.int16), cls_dx.bfloat16().view(torch.int16)), form
+        # (dgamma sums dy * xhat over every row in the plain launch, where a CLS row's xhat comes from its bf16-rounded stream row)
+        assert rel(dg, gr.grad) < 1e-3 and rel(db, br.grad) < 1e-4, form
+        if q8:
+            q0, rs0 = K.quantize_fp8_rows(dxb)
+            assert torch.equal(q0, kwb["q8"]) and torch.equal(rs0[:M], kwb["row_scale"][:M]), form
+
+
 def test_layernorm_rows(K):
     """Gathered rows (ln_final on the EOT rows, sort-head norm on the caption rows) and the scatter in backward."""
     M, W, R = 40, 128, 6

@@ -33,14 +33,20 @@ __device__ __forceinline__ void store4(bf16* p, f32x4 v) {
 // Q8: additionally write the row as OCP e4m3 bytes with ONE scale per row (amax of the bf16-rounded outputs / 448): the fp8
 // operand of the next GEMM (BASELINE config 4) leaves the LayerNorm that produced it, bit-identical to tvts_quant_fp8_rows
 // run on y, without another pass over the activation.
-template <typename TO, int IT, typename TX = float, bool Q8 = false>
+template <typename TO, int IT, typename TX = float, bool Q8 = false, bool CLS = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, int ldx, const int* __restrict__ rows,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, int M, int W, TO* __restrict__ y, int ldy,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      unsigned char* __restrict__ q8 = nullptr, int ldq = 0,
                                                      float* __restrict__ row_scale = nullptr,
-                                                     const float* __restrict__ tscale = nullptr, float* __restrict__ amax_acc = nullptr) {
+                                                     const float* __restrict__ tscale = nullptr, float* __restrict__ amax_acc = nullptr,
+                                                     const float* __restrict__ cls_x = nullptr, int cls_period = 0,
+                                                     TX* x_refresh = nullptr) {
+    // cls_x / cls_period (the hybrid residual stream, round 5): row r with r % cls_period == 0 is the CLS token of clip
+    // r / cls_period; its value is carried in fp32 in the compact side array cls_x[M / cls_period][W] and read from THERE (the
+    // stream's own row r is stale), and x_refresh row r receives its rounding, so that every later reader of the stream (the
+    // residual epilogues, the backward) sees the exact value rounded once instead of an accumulated bf16 sum
     const int lane = threadIdx.x & 63;
     const int stride = gridDim.x * 4;
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -56,6 +62,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
     const float invW = 1.0f / (float)W;
     f32x4 v[IT], nx[IT];
     auto load_row = [&](int rr, f32x4 (&d)[IT]) {
+        if (CLS && rr % cls_period == 0) {  // (wave-uniform: a wave owns the row)
+            const float* cp = cls_x + (size_t)(rr / cls_period) * W;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = lane * 4 + it * 256;
+                d[it] = c < W ? load4<float>(cp + c) : (f32x4){0, 0, 0, 0};
+            }
+            return;
+        }
         const TX* xp = x + (size_t)(rows ? rows[rr] : rr) * ldx;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
@@ -86,6 +101,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
         const float rstd = rsqrtf(wave_sum(q) * invW + eps);
         f32x4 ob[Q8 ? IT : 1];
         float am = 0.f;
+        const bool refresh = CLS && x_refresh && r % cls_period == 0;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int c = lane * 4 + it * 256;
@@ -94,6 +110,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd * gm[it][e] + bt[it][e];
                 store4(y + (size_t)r * ldy + c, o);
+                if (refresh) store4(x_refresh + (size_t)r * ldx + c, v[it]);
                 if (Q8) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -135,19 +152,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
     if (Q8) amax_publish(amax_acc, run_amax, lane);
 }
 
-template <typename TO, typename TX>
+template <typename TO, typename TX, bool CLS = false>
 static void launch_ln_fwd(int it, dim3 grid, hipStream_t stream, const TX* x, int ldx, const int* rows, const float* gamma,
-                          const float* beta, float eps, int M, int W, TO* y, int ldy, float* mean, float* rstd) {
-#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<TO, N, TX>), grid, dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd); break;
+                          const float* beta, float eps, int M, int W, TO* y, int ldy, float* mean, float* rstd,
+                          const float* cls_x = nullptr, int cls_period = 0, TX* x_refresh = nullptr) {
+#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<TO, N, TX, false, CLS>), grid, dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd, (unsigned char*)nullptr, 0, (float*)nullptr, (const float*)nullptr, (float*)nullptr, cls_x, cls_period, x_refresh); break;
     switch (it) { LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) default: LN_FWD_CASE(5) }
 #undef LN_FWD_CASE
 }
 
-template <typename TX>
+template <typename TX, bool CLS = false>
 static void launch_ln_fwd_q8(int it, dim3 grid, hipStream_t stream, const TX* x, int ldx, const int* rows, const float* gamma,
                              const float* beta, float eps, int M, int W, bf16* y, int ldy, float* mean, float* rstd,
-                             unsigned char* q8, int ldq, float* row_scale, const float* tscale, float* amax_acc) {
-#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<bf16, N, TX, true>), grid, dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd, q8, ldq, row_scale, tscale, amax_acc); break;
+                             unsigned char* q8, int ldq, float* row_scale, const float* tscale, float* amax_acc,
+                             const float* cls_x = nullptr, int cls_period = 0, TX* x_refresh = nullptr) {
+#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL((ln_fwd_kernel<bf16, N, TX, true, CLS>), grid, dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd, q8, ldq, row_scale, tscale, amax_acc, cls_x, cls_period, x_refresh); break;
     switch (it) { LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) default: LN_FWD_CASE(5) }
 #undef LN_FWD_CASE
 }
@@ -182,6 +201,26 @@ extern "C" int tvts_layernorm_fwd(const void* x, int ldx, int x_bf16, const int*
     return TVTS_OK;
 }
 
+// The hybrid residual stream (round 5): the stream is bf16, the CLS token's row of every clip -- the row the video embedding is read
+// from, and the one row whose rounding error reaches every other token through the attention -- is carried in fp32 in a compact side
+// array.  x bf16 [M, W] (rows r % cls_period == 0 stale), cls_x fp32 [M / cls_period, W]; those rows are normalised from cls_x and
+// x_refresh (normally x itself; optional) receives their bf16 rounding.  q8 (optional) as in tvts_layernorm_fwd_fp8.
+extern "C" int tvts_layernorm_fwd_cls(const void* x, int ldx, const float* cls_x, int cls_period, void* x_refresh, const float* gamma,
+                                      const float* beta, float eps, int M, int W, void* y, int ldy, void* q8, int ldq, float* row_scale,
+                                      const float* tscale, float* amax_acc, float* mean, float* rstd, hipStream_t stream) {
+    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || ldy % 4 || !cls_x || cls_period <= 0 || M % cls_period) return TVTS_EINVAL;
+    if (q8 && (ldq % 4 || (!row_scale && !tscale))) return TVTS_EINVAL;
+    int blocks = ceil_div(M, 4);
+    if (blocks > 2048) blocks = 2048;
+    const int it = ceil_div(W, 256);
+    if (q8) launch_ln_fwd_q8<bf16, true>(it, dim3(blocks), stream, (const bf16*)x, ldx, nullptr, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd,
+                                   (unsigned char*)q8, ldq, row_scale, tscale, amax_acc, cls_x, cls_period, (bf16*)x_refresh);
+    else launch_ln_fwd<bf16, bf16, true>(it, dim3(blocks), stream, (const bf16*)x, ldx, nullptr, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd,
+                                   cls_x, cls_period, (bf16*)x_refresh);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
 template <typename TDY> struct RawDy;
 template <> struct RawDy<float> { typedef f32x4 T; };
 template <> struct RawDy<bf16> { typedef bf16x4 T; };
@@ -190,7 +229,7 @@ __device__ __forceinline__ f32x4 widen(bf16x4 v) { return (f32x4){(float)v[0], (
 
 // Q8: additionally write the bf16 copy of dx as OCP e4m3 bytes with one scale per row (amax of the bf16-rounded values / 448) -- the
 // output gradient of the e4m3 input-gradient GEMM that consumes dx_bf16 (same bytes as tvts_quant_fp8_rows of dx_bf16)
-template <typename TDY, int IT, bool R1, bool R2, typename TX = float, bool Q8 = false, typename TR1 = float>
+template <typename TDY, int IT, bool R1, bool R2, typename TX = float, bool Q8 = false, typename TR1 = float, bool CLS = false>
 __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3)) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const TX* __restrict__ x,
                                                         int ldx, const int* __restrict__ rows,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -201,7 +240,14 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
                                                         float* __restrict__ partial,
                                                         unsigned char* __restrict__ q8 = nullptr, int ldq = 0,
                                                         float* __restrict__ row_scale = nullptr,
-                                                        const float* __restrict__ tscale = nullptr, float* __restrict__ amax_acc = nullptr) {
+                                                        const float* __restrict__ tscale = nullptr, float* __restrict__ amax_acc = nullptr,
+                                                        const float* __restrict__ cls_x = nullptr, const float* __restrict__ cls_res1 = nullptr,
+                                                        float* __restrict__ cls_dx = nullptr, int cls_period = 0) {
+    // CLS (the hybrid residual stream): this instantiation walks ONLY the rows r % cls_period == 0, behind a plain launch that has
+    // done every row (and dgamma / dbeta): for them the LayerNorm input comes from cls_x (fp32, what the forward normalised), the
+    // residual-stream gradient res1 from cls_res1 (fp32) instead of the bf16 stream row, and the result -- which replaces the
+    // plain launch's in dx_bf16 (and q8) -- is ALSO stored in fp32 to cls_dx: the CLS token's gradient chain never passes through
+    // a bf16 rounding.  (One kernel for both kinds of rows ran the 784 other rows of a clip at half speed: 14 spilled registers.)
     typedef typename RawDy<TDY>::T DyV;
     float run_amax = 0.f;
     __shared__ float red[2][4][IT * 256];  // [gamma|beta][wave][column slot]
@@ -215,25 +261,27 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
         gm[it] = c < W ? load4<float>(gamma + c) : (f32x4){0, 0, 0, 0};
     }
     const float invW = 1.0f / (float)W;
-    const int stride = gridDim.x * 4;
+    const int stride = gridDim.x * 4 * (CLS ? cls_period : 1);
     struct Row { f32x4 x[IT]; DyV d[IT]; f32x4 r1[R1 ? IT : 1]; bf16x4 r2[R2 ? IT : 1]; float mu, rs; int xr; };
     auto load_row = [&](int rr, Row& w) {
         w.xr = rows ? rows[rr] : rr;
         w.mu = mean[rr];
         w.rs = rstd[rr];
+        const bool cls = CLS;
+        const size_t ci = cls ? (size_t)(rr / cls_period) * W : 0;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int c = lane * 4 + it * 256;
             if (c < W) {
-                w.x[it] = load4<TX>(x + (size_t)w.xr * ldx + c);
+                w.x[it] = (cls && cls_x) ? load4<float>(cls_x + ci + c) : load4<TX>(x + (size_t)w.xr * ldx + c);
                 w.d[it] = *(const DyV*)(dy + (size_t)rr * lddy + c);
-                if (R1) w.r1[it] = load4<TR1>(res1 + (size_t)w.xr * ldr + c);
+                if (R1) w.r1[it] = (cls && cls_res1) ? load4<float>(cls_res1 + ci + c) : load4<TR1>(res1 + (size_t)w.xr * ldr + c);
                 if (R2) w.r2[it] = *(const bf16x4*)(res2 + (size_t)w.xr * ldr2 + c);
             }
         }
     };
-    constexpr bool PF = IT <= 3;  // wider rows (1024, 1280 columns) do not have the registers for a second row in flight
-    int r = blockIdx.x * 4 + wave;
+    constexpr bool PF = IT <= 3 && !CLS;  // wider rows (1024, 1280 columns) do not have the registers for a second row in flight
+    int r = (blockIdx.x * 4 + wave) * (CLS ? cls_period : 1);
     Row cur, nxt;
     if (PF && r < M) load_row(r, cur);
     for (; r < M; r += stride) {
@@ -280,6 +328,7 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
                 const f32x4 o = out_of(it);
                 if (dx) store4(dx + (size_t)cur.xr * lddx + c, o);
                 if (dx_bf16) store4(dx_bf16 + (size_t)cur.xr * lddxb + c, o);
+                if (CLS && cls_dx) store4(cls_dx + (size_t)(r / cls_period) * W + c, o);
                 if (Q8) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -370,19 +419,21 @@ __global__ __launch_bounds__(1024) void ln_dgamma_reduce_kernel(const float* __r
     }
 }
 
-template <typename TDY, bool R1, bool R2, typename TX = float, bool Q8 = false, typename TR1 = float>
+template <typename TDY, bool R1, bool R2, typename TX = float, bool Q8 = false, typename TR1 = float, bool CLS = false>
 static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int lddy, const TX* x, int ldx, const int* rows,
                           const float* mean, const float* rstd, const float* gamma, const TR1* res1, const bf16* res2,
                           int ldr2, int ldr, int W, float* dx, int lddx, bf16* dxb, int lddxb, float* dgamma, float* dbeta,
                           float* ws, long ws_elems, unsigned char* q8 = nullptr, int ldq = 0, float* row_scale = nullptr,
-                          const float* tscale = nullptr, float* amax_acc = nullptr) {
+                          const float* tscale = nullptr, float* amax_acc = nullptr, const float* cls_x = nullptr,
+                          const float* cls_res1 = nullptr, float* cls_dx = nullptr, int cls_period = 0) {
     // persistent grid: as many blocks per CU as the variant's registers allow (see __launch_bounds__ above)
     const int per_cu = it <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3);
-    int blocks = ceil_div(M, 4);
+    int blocks = ceil_div(CLS ? M / cls_period : M, 4);
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     const dim3 grid(blocks);
+    if (CLS) dgamma = dbeta = nullptr;  // the plain launch in front of this one has accumulated them over every row
     float* partial = (dgamma && ws && ws_elems >= (long)blocks * 2 * W) ? ws : nullptr;
-#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N, R1, R2, TX, Q8, TR1>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta, partial, q8, ldq, row_scale, tscale, amax_acc); break;
+#define LN_BWD_CASE(N) case N: hipLaunchKernelGGL((ln_bwd_kernel<TDY, N, R1, R2, TX, Q8, TR1, CLS>), grid, dim3(256), 0, stream, dy, lddy, x, ldx, rows, mean, rstd, gamma, res1, res2, ldr2, ldr, M, W, dx, lddx, dxb, lddxb, dgamma, dbeta, partial, q8, ldq, row_scale, tscale, amax_acc, cls_x, cls_res1, cls_dx, cls_period); break;
     switch (it) { LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) default: LN_BWD_CASE(5) }
 #undef LN_BWD_CASE
     if (partial)
@@ -482,6 +533,39 @@ extern "C" int tvts_layernorm_bwd_fp8(const void* dy, int lddy, const void* x_, 
         else launch_ln_bwd<bf16, false, false, float, true>(Q8_ARGS);
     }
 #undef Q8_ARGS
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// LayerNorm backward on the hybrid residual stream (tvts_layernorm_fwd_cls): bf16 dy, bf16 x [M, W], every row; res1 (optional) the
+// bf16 stream gradient, res2 (optional, only with res1) a bf16 side branch; dx_bf16 required.  For the rows r % cls_period == 0:
+// input from cls_x (optional), residual-stream gradient from cls_res1 (optional; fp32 [M / cls_period, W]) instead of res1's row,
+// result also to cls_dx (optional, fp32).  q8 (optional) as in tvts_layernorm_bwd_fp8.
+extern "C" int tvts_layernorm_bwd_cls(const void* dy, int lddy, const void* x_, int ldx, const float* cls_x, const float* cls_res1,
+                                      float* cls_dx, int cls_period, const float* mean, const float* rstd, const float* gamma,
+                                      const void* res1_bf16, int ldr, const void* res2_bf16, int ldr2, int M, int W, void* dx_bf16,
+                                      int lddxb, void* q8, int ldq, float* row_scale, const float* tscale, float* amax_acc,
+                                      float* dgamma, float* dbeta, float* workspace, long workspace_elems, hipStream_t stream) {
+    if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || lddy % 4 || !dx_bf16 || lddxb % 4) return TVTS_EINVAL;
+    if (cls_period <= 0 || M % cls_period || (cls_res1 && !res1_bf16) || (res2_bf16 && !res1_bf16)) return TVTS_EINVAL;
+    if ((res1_bf16 && ldr % 4) || (res2_bf16 && ldr2 % 4) || (q8 && (ldq % 4 || (!row_scale && !tscale)))) return TVTS_EINVAL;
+    const bf16* x = (const bf16*)x_;
+    const bf16* res1 = (const bf16*)res1_bf16;
+    const bf16* res2 = (const bf16*)res2_bf16;
+    const int it = ceil_div(W, 256);
+#define CLS_ARGS(c) it, M, stream, (const bf16*)dy, lddy, x, ldx, (const int*)nullptr, mean, rstd, gamma, res1, res2, ldr2, ldr, W, (float*)nullptr, 0, (bf16*)dx_bf16, lddxb, dgamma, dbeta, workspace, workspace_elems, (unsigned char*)q8, ldq, row_scale, tscale, amax_acc, c ? cls_x : nullptr, c ? cls_res1 : nullptr, c ? cls_dx : nullptr, c ? cls_period : 0
+    // every row through the plain bf16-stream kernel (the CLS rows' results there come from the stream's bf16 rows: close, and
+    // replaced below), then the CLS rows alone from the fp32 side arrays
+    if (q8) {
+        if (res1 && res2) { launch_ln_bwd<bf16, true, true, bf16, true, bf16>(CLS_ARGS(0)); launch_ln_bwd<bf16, true, true, bf16, true, bf16, true>(CLS_ARGS(1)); }
+        else if (res1) { launch_ln_bwd<bf16, true, false, bf16, true, bf16>(CLS_ARGS(0)); launch_ln_bwd<bf16, true, false, bf16, true, bf16, true>(CLS_ARGS(1)); }
+        else { launch_ln_bwd<bf16, false, false, bf16, true, bf16>(CLS_ARGS(0)); launch_ln_bwd<bf16, false, false, bf16, true, bf16, true>(CLS_ARGS(1)); }
+    } else {
+        if (res1 && res2) { launch_ln_bwd<bf16, true, true, bf16, false, bf16>(CLS_ARGS(0)); launch_ln_bwd<bf16, true, true, bf16, false, bf16, true>(CLS_ARGS(1)); }
+        else if (res1) { launch_ln_bwd<bf16, true, false, bf16, false, bf16>(CLS_ARGS(0)); launch_ln_bwd<bf16, true, false, bf16, false, bf16, true>(CLS_ARGS(1)); }
+        else { launch_ln_bwd<bf16, false, false, bf16, false, bf16>(CLS_ARGS(0)); launch_ln_bwd<bf16, false, false, bf16, false, bf16, true>(CLS_ARGS(1)); }
+    }
+#undef CLS_ARGS
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }

@@ -192,7 +192,20 @@ class Engine:
         #     pairs/s); video embedding rel-L2 0.89 % (gate 2 %; 0.39 % in fp32), row cosine 0.99995 (gate 0.9995), but the
         #     |d loss| <= 1e-2 gate fails on one small 3-pair NT = 1 configuration (0.0155) -- parity is the first gate, so it
         #     is not the default.
-        self.bf16_residual = bool(a.get("bf16_residual", False)) and a.get("family") != "v1"
+        # Round 5, the HYBRID stream (arch["hybrid_stream"], the default for v2): both streams bf16, EXCEPT the CLS token's row of
+        # every clip, which is carried in fp32 in compact [B, W] side arrays.  experiments/dbg/bf16_residual_rows.py (the fp32 oracle
+        # with bf16 roundings at the engine's stream points) shows where the error of a bf16 stream comes from: rounding the 784
+        # patch rows of a clip costs |d loss1| 2e-4 ... 1.7e-3 (2 ... 12 blocks), rounding the ONE CLS row 3.4e-3 ... 5e-3 -- the video
+        # embedding is read from that row, and its error reaches every other token through the attention, while the patch rows'
+        # independent errors average out in it; for the gradient stream likewise (positional-embedding gradient rel-L2 1e-4 ... 1.3e-3
+        # with the CLS row exact against 2 ... 3.7e-2 with every row rounded).  So 784 of 785 rows take the bf16 bytes and the loss /
+        # gradient errors stay at the fp32 streams' level: the forward CLS rows through two [B, K] GEMMs per block with fp32 residual
+        # (`_cls_lin`), the LayerNorms read / write them beside the stream (tvts_layernorm_{fwd,bwd}_cls).
+        hybrid = a.get("hybrid_stream", None)
+        if hybrid is None:  # default: on, unless one of the older stream options is asked for explicitly
+            hybrid = a.get("family") != "v1" and "bf16_residual" not in a and "bf16_grad_stream" not in a
+        self.cls32 = bool(hybrid) and a.get("family") != "v1"
+        self.bf16_residual = (bool(a.get("bf16_residual", False)) or self.cls32) and a.get("family") != "v1"
         self.bf16_grad_stream = bool(a.get("bf16_grad_stream", False)) or self.bf16_residual
         # Weight gradients of the space-time blocks on a SIDE STREAM (round 4).  dW = dY^T X depends on dY only, not on the
         # input-gradient chain that continues from dY, so the weight-gradient kernels can run beside the chain's NT GEMMs,
@@ -223,6 +236,9 @@ class Engine:
         self._wg_ws = None
         self.dev = store.device
         self.buf: Dict[str, torch.Tensor] = {}
+        self._back: Dict[str, torch.Tensor] = {}  # the allocations behind buf (grow-only, see _b)
+        self._seen: Dict[str, int] = {}           # name -> the forward() count at which its shape last changed
+        self._tick = 0
         self.requires_grad = {name: True for name in store.shapes}
         self.ctx: dict = {}
         self.grad_ready = None  # optional callback(start, end): flat grad range is final (GradSync.reduce_range)
@@ -265,12 +281,29 @@ class Engine:
 
     # ------------------------------------------------------------------ workspace
     def _b(self, name, shape, dtype=torch.bfloat16, zero=False):
+        """A named workspace tensor.  Its storage only ever GROWS: a smaller shape is a view of the first elements of the same
+        allocation, so a loop that alternates batches of two sizes (the reference's YT / WebVid loaders, trainer.py:463) keeps
+        every buffer's address -- no allocator traffic after the first pass over both, and plans keyed by buffer addresses (the
+        grouped weight gradients) stay valid."""
         t = self.buf.get(name)
         shape = tuple(int(s) for s in shape)
-        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
-            t = torch.zeros(shape, dtype=dtype, device=self.dev) if zero else torch.empty(shape, dtype=dtype, device=self.dev)
-            self.buf[name] = t
-        elif zero:
+        if t is not None and tuple(t.shape) == shape and t.dtype == dtype:
+            if zero:
+                t.zero_()
+            return t
+        n = 1
+        for s in shape:
+            n *= s
+        seen, self._seen[name] = self._seen.get(name), self._tick
+        if seen == self._tick:
+            # the name changes shape WITHIN one forward / backward pair: both tensors may be live, so they must not share memory
+            t = self.buf[name] = torch.empty(shape, dtype=dtype, device=self.dev)
+        else:
+            back = self._back.get(name)
+            if back is None or back.dtype != dtype or back.numel() < n:
+                back = self._back[name] = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
+            t = self.buf[name] = back[:n].view(shape)
+        if zero:
             t.zero_()
         return t
 
@@ -363,6 +396,15 @@ class Engine:
             return
         K.gemm_nt(a, self.P.w(wname), out, M=M, bias=self.P.p(bname) if bname else None, **epi)
 
+    def _cls_lin(self, a, S, wname, bname, res_c, out_c):
+        """The CLS rows of the hybrid stream through a residual-adding linear layer: out_c [B, N] = res_c + a[b * S, :] @ W^T + bias,
+        fp32 result and fp32 residual (the stream's own rows take the bf16 residual epilogue).  a: the [B * S, K] bf16 operand of the
+        block's GEMM; its CLS rows are addressed as a [B, K] matrix with the row stride S * K -- the same operand bytes and the same
+        bf16 weight shadow, always on the bf16 MFMA path (also when the block's GEMMs multiply e4m3 copies)."""
+        Bc = out_c.shape[0]
+        a_c = a.view(Bc, -1)[:, :a.shape[1]] if a.shape[0] == Bc * S else a[:Bc * S].view(Bc, -1)[:, :a.shape[1]]
+        K.gemm_nt(a_c, self.P.w(wname), out_c, M=Bc, bias=self.P.p(bname) if bname else None, residual=res_c)
+
     # measured (profiles/r04_tn_grouped.txt): B/16 +1.5 % at 12 pairs (M = 9 420), -0.4 % at 24, -2 % at 48; B/32 +1.2 % at its 24 pairs
     # (M = 9 432); H/14 at its 2 pairs (M = 2 434, 1 600 tiles of 128 x 128 per block of the model) -9 %: the window is where it pays
     TN_GROUPED_MIN_ROWS, TN_GROUPED_MAX_ROWS = 6000, 12000
@@ -436,27 +478,37 @@ class Engine:
                 return
             K.gemm_nt(dy, self.P.wt(wname), d_in, M=M, **epi)
 
-    def _ln(self, x, name, eps, y, tag, rows=None, M=None, fp8_for=None):
+    def _ln(self, x, name, eps, y, tag, rows=None, M=None, fp8_for=None, cls_x=None):
         """fp8_for: name of the weight the output feeds; when that GEMM runs in fp8 the LayerNorm also emits the e4m3 copy
-        (returned, to be handed to _lin as a8)."""
+        (returned, to be handed to _lin as a8).  cls_x: the fp32 CLS rows of the hybrid stream x (read instead of x's own CLS
+        rows, which receive their bf16 rounding)."""
         M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
+        if cls_x is not None:
+            kw_cls = dict(cls_x=cls_x, cls_period=M // cls_x.shape[0])
+        else:
+            kw_cls = {}
         mean, rstd = self._f(tag + ".mean", (M,)), self._f(tag + ".rstd", (M,))
         a8, kw = None, {}
         if fp8_for is not None and fp8_for in self.P.w8:
             q, sa, kw = self._q8(M, y.shape[1], "x." + fp8_for, persistent=True)
             a8, kw = (q, sa), dict(kw, q8=q)
-        K.layernorm_fwd(x, self.P.p(name + ".weight"), self.P.p(name + ".bias"), eps, y, mean, rstd, rows=rows, M=M, **kw)
+        K.layernorm_fwd(x, self.P.p(name + ".weight"), self.P.p(name + ".bias"), eps, y, mean, rstd, rows=rows, M=M, **kw, **kw_cls)
         return a8
 
-    def _ln_bwd(self, dy, x, name, tag, dx, dx_bf16=None, res1=None, res2=None, rows=None, M=None, fp8_for=None):
+    def _ln_bwd(self, dy, x, name, tag, dx, dx_bf16=None, res1=None, res2=None, rows=None, M=None, fp8_for=None,
+                cls_x=None, cls_res1=None, cls_dx=None):
         """fp8_for: name of the weight whose input-gradient GEMM consumes dx_bf16; when that GEMM runs on e4m3 operands the
-        LayerNorm backward also emits the e4m3 copy (returned, to be handed to _lin_bwd as dy8)."""
+        LayerNorm backward also emits the e4m3 copy (returned, to be handed to _lin_bwd as dy8).  cls_*: the fp32 CLS rows of the
+        hybrid stream (input, incoming stream gradient, outgoing stream gradient)."""
         tr = self.requires_grad[name + ".weight"]
         d8, kw = None, {}
+        if cls_x is not None or cls_res1 is not None or cls_dx is not None:
+            nc = (cls_x if cls_x is not None else cls_dx if cls_dx is not None else cls_res1).shape[0]
+            kw = dict(cls_period=(x.shape[0] if M is None else M) // nc, cls_x=cls_x, cls_res1=cls_res1, cls_dx=cls_dx)
         if (fp8_for is not None and fp8_for in self.P.w8t and rows is None and dx_bf16 is not None and dy.dtype == torch.bfloat16
                 and not (res2 is not None and res1 is None)):
-            q, sa, kw = self._q8(dx_bf16.shape[0] if M is None else M, dx_bf16.shape[1], "dy." + fp8_for)
-            d8, kw = (q, sa), dict(kw, q8=q)
+            q, sa, kw8 = self._q8(dx_bf16.shape[0] if M is None else M, dx_bf16.shape[1], "dy." + fp8_for)
+            d8, kw = (q, sa), dict(kw, q8=q, **kw8)
         K.layernorm_bwd(dy, x, self.buf[tag + ".mean"], self.buf[tag + ".rstd"], self.P.p(name + ".weight"), dx,
                         dx_bf16=dx_bf16, res1=res1, res2=res2, dgamma=self.P.g(name + ".weight") if tr else None,
                         dbeta=self.P.g(name + ".bias") if tr else None, rows=rows, M=M, **kw)
@@ -627,10 +679,17 @@ class Engine:
         xbuf = self._b if lowres else self._f   # the residual stream's buffers: bf16 or fp32
         x = xbuf("vit.x0", (M, W))
         self._ln(tok, "video_model.ln_pre", 1e-5, x, "vit.lnpre")
+        cls = self.cls32
+        if vid_rows is None:
+            vid_rows = (torch.arange(B, device=self.dev) * S).to(torch.int32)
+        xc = None
+        if cls:  # the hybrid stream's CLS rows start as ln_pre's fp32 output on those rows
+            xc = self._f("vit.xc0", (B, W))
+            self._ln(tok, "video_model.ln_pre", 1e-5, xc, "vit.lnpre_c", rows=vid_rows)
         for l in range(a["layers"]):
             pre, tg = f"video_model.transformer.resblocks.{l}.", f"vit{l}"
             ln3 = self._b(tg + ".ln3", (M, W))
-            a8 = self._ln(x, pre + "ln_3", 1e-5, ln3, tg + ".ln3", fp8_for=pre + "timeattn.qkv.weight")
+            a8 = self._ln(x, pre + "ln_3", 1e-5, ln3, tg + ".ln3", fp8_for=pre + "timeattn.qkv.weight", cls_x=xc)
             qkv_t = self._b(tg + ".qkv_t", (M, 3 * W))
             self._lin(ln3, pre + "timeattn.qkv.weight", pre + "timeattn.qkv.bias", qkv_t, M, a8=a8)
             att_t, lse_t = self._b(tg + ".att_t", (M, W)), self._f(tg + ".lse_t", (M, a["heads"]))
@@ -646,18 +705,26 @@ class Engine:
             self._st_attention_fwd(qkv_s, att_s, lse_s, "space", B, T, n, q8_for=pre + "attn.proj.weight")
             s_res = xbuf(tg + ".s_res", (M, W))  # residual from the block INPUT x (video_encoder_ViT_B_16.py:121)
             self._lin(att_s, pre + "attn.proj.weight", pre + "attn.proj.bias", s_res, M, residual=x)
+            s_res_c = None
+            if cls:
+                s_res_c = self._f(tg + ".s_res_c", (B, W))
+                self._cls_lin(att_s, S, pre + "attn.proj.weight", pre + "attn.proj.bias", xc, s_res_c)
             ln2 = self._b(tg + ".ln2", (M, W))
-            a8 = self._ln(s_res, pre + "ln_2", 1e-5, ln2, tg + ".ln2", fp8_for=pre + "mlp.c_fc.weight")
+            a8 = self._ln(s_res, pre + "ln_2", 1e-5, ln2, tg + ".ln2", fp8_for=pre + "mlp.c_fc.weight", cls_x=s_res_c)
             h, act = self._b(tg + ".h", (M, 4 * W)), self._b(tg + ".a", (M, 4 * W))
             self._lin(ln2, pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", act, M, act=a["act"], preact=h, a8=a8,
                       q8_for=pre + "mlp.c_proj.weight")
             xo = xbuf(f"vit.x{l + 1}", (M, W))
             self._lin(act, pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", xo, M, residual=s_res)
+            if cls:
+                xcn = self._f(f"vit.xc{l + 1}", (B, W))
+                self._cls_lin(act, S, pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", s_res_c, xcn)
+                xc = xcn
             x = xo
         out = self._f("vit.out", (M, E))
         if not self.pooled_tail:  # B models: ln_post on every token, all S projected rows feed the sort head
             lnp = self._b("vit.lnpost", (M, W))
-            self._ln(x, "video_model.ln_post", 1e-5, lnp, "vit.lnpost")
+            self._ln(x, "video_model.ln_post", 1e-5, lnp, "vit.lnpost", cls_x=xc)
             K.gemm_nt(lnp, self.P.wt("video_model.proj"), out, M=M)  # x @ proj, proj stored [W,E]
             return out, None
         # H/14 (video_encoder_ViT_H_14.py:472-484): pooled = ln_post(CLS) @ proj in fp32; the patch tokens are projected
@@ -669,9 +736,10 @@ class Engine:
             K.cast_f32_bf16(x, xb)
         K.gemm_nt(xb, self.P.wt("video_model.proj"), out, M=M)
         lnc = self._f("vit.lnpost_cls", (B, W))
-        if vid_rows is None:
-            vid_rows = (torch.arange(B, device=self.dev) * S).to(torch.int32)
-        if lowres:  # ln_post on the B CLS rows in fp32: an fp32 copy of those rows (plumbing on [B, W])
+        if cls:  # ln_post on the exact CLS rows of the hybrid stream
+            self.buf["vit.xcls32"] = xc
+            self._ln(xc, "video_model.ln_post", 1e-5, lnc, "vit.lnpost")
+        elif lowres:  # ln_post on the B CLS rows in fp32: an fp32 copy of those rows (plumbing on [B, W])
             xc, xcb = self._f("vit.xcls32", (B, W)), self._b("vit.xcls16", (B, W))
             vr64 = self.ctx.get("vid_rows64") if isinstance(self.ctx, dict) else None
             torch.index_select(x, 0, vr64 if vr64 is not None else vid_rows.long(), out=xcb)
@@ -698,14 +766,19 @@ class Engine:
         # ln_pre's cancellation (5.8 % instead of 2.4 % rel-L2; profiles/r03_bf16_streams_ab.txt)
         lowp = self.bf16_grad_stream
         lowres = self.bf16_residual
+        cls = self.cls32   # hybrid stream: the CLS rows of the gradient chain in fp32 side arrays dxc / dsrc [B, W]
+        dxc = dsrc = None
         dxb = self._b("vit.dxbA", (M, W))
         dx = None if (lowp and not self.pooled_tail) else self._f("vit.dxA", (M, W))
         if not self.pooled_tail:
             if rg["video_model.proj"]:  # dproj[W,E] += lnpost^T dout
                 K.gemm_tn(B_["vit.lnpost"], dout_b, self.P.g("video_model.proj"), M=M, accumulate=True)
             K.gemm_nt(dout_b, self.P.w("video_model.proj"), dln, M=M)
+            if cls:
+                dxc = self._f("vit.dxcA", (B, W))
             dxb8 = self._ln_bwd(dln, B_[f"vit.x{a['layers']}"], "video_model.ln_post", "vit.lnpost", dx, dx_bf16=dxb,
-                                fp8_for=f"video_model.transformer.resblocks.{a['layers'] - 1}.mlp.c_proj.weight")
+                                fp8_for=f"video_model.transformer.resblocks.{a['layers'] - 1}.mlp.c_proj.weight",
+                                cls_x=B_[f"vit.xc{a['layers']}"] if cls else None, cls_dx=dxc)
         else:
             dxb8 = None
             # patch-token branch (no LN): dproj += x^T dout, dx = dout proj^T (CLS rows of dout are zero)
@@ -722,7 +795,9 @@ class Engine:
             dlnc = self._f("vit.s.dlnc", (B, W))
             K.gemm_small(d_pooled, self.P.p("video_model.proj"), dlnc, M=B, N=W, K=E, sa=(E, 1), sb=(1, E))
             if lowres:  # ln_post backward on the fp32 copy of the CLS rows, added into those rows of dx
-                dxc = self._f("vit.s.dxcls", (B, W))
+                # (hybrid stream: those rows of dx are zero -- no gradient enters the CLS rows through the patch-token branch -- so
+                # the LayerNorm's result IS the fp32 CLS chain's first value)
+                dxc = self._f("vit.dxcA" if cls else "vit.s.dxcls", (B, W))
                 self._ln_bwd(dlnc, B_["vit.xcls32"], "video_model.ln_post", "vit.lnpost", dxc)
                 dx.index_add_(0, self.ctx["vid_rows64"] if "vid_rows64" in self.ctx else self.ctx["vid_rows"].long(), dxc)
             else:
@@ -756,8 +831,11 @@ class Engine:
             self._lin_bwd(dxb, B_[tg + ".a"], pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", dh, M, dy8=dxb8, side=side, defer=defer,
                           q8_for=pre + "mlp.c_fc.weight", gate_h=B_[tg + ".h"], gate_act=a["act"])
             self._lin_bwd(dh, B_[tg + ".ln2"], pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", dln, M, side=side, defer=defer)
+            if cls:
+                dsrc = self._f("vit.s.dsrc", (B, W))
             dsrb8 = self._ln_bwd(dln, B_[tg + ".s_res"], pre + "ln_2", tg + ".ln2", dsr, dx_bf16=dsrb, res1=dxb if lowp else dx,
-                                 fp8_for=pre + "attn.proj.weight")
+                                 fp8_for=pre + "attn.proj.weight", cls_x=B_[tg + ".s_res_c"] if cls else None,
+                                 cls_res1=dxc if cls else None, cls_dx=dsrc)
             # spatial attention branch
             self._lin_bwd(dsrb, B_[tg + ".att_s"], pre + "attn.proj.weight", pre + "attn.proj.bias", datt, M, dy8=dsrb8, side=side,
                           defer=defer)
@@ -786,9 +864,11 @@ class Engine:
             dxbi = self._b("vit.dxb" + nx, (M, W))
             dxi = None if lowp else self._f("vit.dx" + nx, (M, W))
             # x feeds ln_3, the time residual and the space residual
+            dxci = self._f("vit.dxc" + nx, (B, W)) if cls else None
             dxb8 = self._ln_bwd(dln, x_in, pre + "ln_3", tg + ".ln3", dxi, dx_bf16=dxbi, res1=dsrb if lowp else dsr, res2=dtrb,
-                                fp8_for=f"video_model.transformer.resblocks.{l - 1}.mlp.c_proj.weight" if l > 0 else None)
-            dx, dxb = dxi, dxbi
+                                fp8_for=f"video_model.transformer.resblocks.{l - 1}.mlp.c_proj.weight" if l > 0 else None,
+                                cls_x=B_[f"vit.xc{l}"] if cls else None, cls_res1=dsrc, cls_dx=dxci)
+            dx, dxb, dxc = dxi, dxbi, dxci
             if not side:
                 self._ready(pre)
         if side:
@@ -1037,6 +1117,7 @@ class Engine:
         """-> (text_emb [B,E], video_emb [B,E], pred [B*NT, n_trans] | None); all fp32 workspace tensors."""
         a = self.arch
         self.ctx = pb
+        self._tick += 1  # (workspace: a buffer whose shape changes from here on belongs to a new step, see _b)
         B, T, N, NT, L, S, E = pb["B"], pb["T"], pb["N"], pb["NT"], pb["L"], pb["S"], a["embed"]
         t = self.text_forward(pb["ids"], pb["eot_rows"], N, L, eot_index=pb.get("eot_index"))
         text_emb = self._f("mdl.text_emb", (B, E))

@@ -275,6 +275,7 @@ class EngineV1(Engine):
     def forward(self, pb: dict):
         a = self.arch
         self.ctx = pb
+        self._tick += 1  # (workspace: a buffer whose shape changes from here on belongs to a new step, see _b)
         B, N, NT, L, S, E = pb["B"], pb["N"], pb["NT"], pb["L"], pb["S"], a["embed"]
         before, t = self.text_forward_v1(pb["ids"], pb["kv_len"], pb["txt_cls_rows"], N, L)
         text_emb = self._f("mdl.text_emb", (B, E))

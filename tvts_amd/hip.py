@@ -433,11 +433,23 @@ def colsum(x, out, *, M=None):
     _chk(lib.tvts_colsum_bf16(_p(x), _ld(x), M, x.shape[1], _p(out), _p(ws), ws.numel(), _stream()), "tvts_colsum_bf16")
 
 
-def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=None, q8=None, row_scale=None, tscale=None, amax=None):
-    """q8 (uint8 [M, W]) + row_scale (float32 [>= M]): also write the bf16 output as e4m3 bytes with one scale per row."""
+def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=None, q8=None, row_scale=None, tscale=None, amax=None,
+                  cls_x=None, cls_period=0, refresh=True):
+    """q8 (uint8 [M, W]) + row_scale (float32 [>= M]): also write the bf16 output as e4m3 bytes with one scale per row.
+    cls_x (float32 [M / cls_period, W]) + cls_period: the hybrid residual stream -- x bf16, the rows r % cls_period == 0 are read
+    from cls_x and (refresh) their bf16 rounding is written back into x."""
     lib = _lib.load()
     M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
     fam = "ln_fwd" if M >= 4096 else "ln_fwd_small"
+    if cls_x is not None:
+        assert rows is None and x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and cls_x.dtype == torch.float32
+        assert cls_x.is_contiguous() and cls_x.shape[1] == x.shape[1] and cls_x.shape[0] * cls_period == M
+        with _hbm(fam, _nb((x, M), (y, M), (q8, M)) + 8 * M):
+            rc = lib.tvts_layernorm_fwd_cls(_p(x), _ld(x), _p(cls_x), cls_period, _p(x) if refresh else None, _p(gamma), _p(beta), eps, M,
+                                            x.shape[1], _p(y), _ld(y), _p(q8), q8.stride(0) if q8 is not None else 0, _p(row_scale), _p(tscale),
+                                            _p(amax), _p(mean), _p(rstd), _stream())
+        _chk(rc, "tvts_layernorm_fwd_cls")
+        return
     if q8 is not None:
         assert y.dtype == torch.bfloat16 and q8.dtype == torch.uint8 and (tscale is not None or (row_scale.dtype == torch.float32 and row_scale.numel() >= M))
         with _hbm(fam, _nb((x, M), (y, M), (q8, M)) + 12 * M):
@@ -462,16 +474,32 @@ def _ln_workspace(dev):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2=None, dgamma=None, dbeta=None,
-                  rows=None, M=None, workspace=True, q8=None, row_scale=None, tscale=None, amax=None):
+                  rows=None, M=None, workspace=True, q8=None, row_scale=None, tscale=None, amax=None,
+                  cls_period=0, cls_x=None, cls_res1=None, cls_dx=None):
     """dx (fp32, may be None when only the bf16 copy is wanted) = LN backward [+ res1 (fp32 or bf16) + res2 (bf16)];
     dgamma / dbeta are ACCUMULATED (+=) from per-block partials in a shared scratch buffer.  q8 / row_scale: also the e4m3
-    copy of dx_bf16 with one scale per row (bf16 dy, every row)."""
+    copy of dx_bf16 with one scale per row (bf16 dy, every row).
+    cls_period > 0: the hybrid residual stream (bf16 dy / x / res1, bf16 output only) -- for the rows r % cls_period == 0 the input
+    comes from cls_x, the stream gradient from cls_res1 (both float32 [M / cls_period, W], optional) and the result also goes to
+    cls_dx in fp32 (optional)."""
     lib = _lib.load()
     ws = _ln_workspace(x.device) if (workspace and dgamma is not None) else None
     M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
     assert res2 is None or res2.dtype == torch.bfloat16
     fam = "ln_bwd" if M >= 4096 else "ln_bwd_small"
     nbytes = _nb((dy, M), (x, M), (res1, M), (res2, M), (dx, M), (dx_bf16, M), (q8, M)) + 8 * M
+    if cls_period:
+        assert rows is None and dx is None and dx_bf16 is not None and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+        assert res1 is None or res1.dtype == torch.bfloat16
+        for t in (cls_x, cls_res1, cls_dx):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] * cls_period == M and t.shape[1] == x.shape[1])
+        with _hbm(fam, nbytes):
+            rc = lib.tvts_layernorm_bwd_cls(_p(dy), _ld(dy), _p(x), _ld(x), _p(cls_x), _p(cls_res1), _p(cls_dx), cls_period, _p(mean), _p(rstd),
+                                            _p(gamma), _p(res1), _ld(res1) if res1 is not None else 0, _p(res2), _ld(res2) if res2 is not None else 0,
+                                            M, x.shape[1], _p(dx_bf16), _ld(dx_bf16), _p(q8), q8.stride(0) if q8 is not None else 0, _p(row_scale),
+                                            _p(tscale), _p(amax), _p(dgamma), _p(dbeta), _p(ws), ws.numel() if ws is not None else 0, _stream())
+        _chk(rc, "tvts_layernorm_bwd_cls")
+        return
     if q8 is not None:
         assert rows is None and dx_bf16 is not None and dy.dtype == torch.bfloat16 and (tscale is not None or (row_scale is not None and row_scale.numel() >= M))
         with _hbm(fam, nbytes):
