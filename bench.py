@@ -231,6 +231,8 @@ def main():
     ap.add_argument("--tn-grouped", choices=("auto", "on", "off"), default="auto", help="the six weight gradients of a ViT block in one grouped "
                     "launch (auto: from 6 000 to 12 000 token rows per GPU, Engine.TN_GROUPED_MIN_ROWS / MAX_ROWS -- the reference's 12 pairs; "
                     "profiles/r04_tn_grouped.txt)")
+    ap.add_argument("--text-side", choices=("on", "off"), default="on", help="the text tower on its own stream beside the ViT (round 5 default; "
+                    "off = in line in front of it)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
@@ -292,6 +294,7 @@ def main():
         a["bf16_grad_stream"] = True
     if args.bf16_residual:
         a["bf16_residual"] = True
+    a["text_side"] = args.text_side == "on"
     if args.tn_grouped != "auto":
         a["tn_grouped"] = args.tn_grouped == "on"
     if os.environ.get("TVTS_TN_GROUP_SPLITS"):

@@ -387,6 +387,58 @@ def test_every_gradient_is_bit_reproducible(K, lib, arch_name, B, T, flags):
             raise AssertionError(f"gradients differ between identical steps: max |d| {float(diff.max()):.3e} in {int((diff > 0).sum())} elements")
         assert (l1, l2) == (l1b, l2b)
 
+@pytest.mark.parametrize("arch_name,B,T,NT", [("B_16", 12, 8, 4), ("B_16", 6, 4, 1), ("H_14", 2, 16, 4)])
+def test_text_tower_on_its_own_stream_gives_the_same_bits(K, lib, arch_name, B, T, NT):
+    """arch["text_side"] (the default): the text tower's forward and backward run on a second stream beside the ViT -- one fork and one
+    join per direction, scratch buffers of their own (hip.lane).  The towers share nothing until the loss, so every embedding, both
+    losses and every gradient have the bits of the in-line order, eagerly and through a captured hipGraph (whose replays keep the
+    two chains side by side)."""
+    from tvts_amd import arch as A
+    from tvts_amd.data_loader import synth_batch
+    from tvts_amd.model._common import TVTSv2Base
+    res = {}
+    for side in (False, True):
+        a = dict(A.ARCHS[arch_name], text_side=side)
+        a["num_frames"] = max(a["num_frames"], T)
+        m = TVTSv2Base(ARGS, arch=a, init_seed=0)
+        for name, p in m.named_parameters():
+            p.requires_grad = A.param_group_of(name, a) >= 0
+        _, _, run = _runner_of(m, a)
+        eng = m.engine
+        assert eng.text_side == side
+        batch = synth_batch(a, B, T, seed=5, caption_len=32, n_trans=NT)
+        m._fresh_shadows(); m._sync_requires_grad()
+        pb = eng.prepare_batch(batch)
+        lab = batch["label"].reshape(-1).to(torch.int32).to(DEV) if NT != 1 else None
+        out = {}
+
+        def grads():
+            m.store.grad.zero_()
+            eng.embeds_ready = run.gather.start
+            try:
+                te, ve, pred = eng.forward(pb)
+            finally:
+                eng.embeds_ready = None
+            l1, l2, dte, dve, dpred = run.losses_and_grads(pb, te, ve, pred, lab)
+            eng.backward(dte, dve, dpred)
+            out.update(te=te, ve=ve, l1=l1)
+        grads(); grads()
+        torch.cuda.synchronize()
+        eager = (m.store.grad.clone(), out["te"].clone(), out["ve"].clone(), out["l1"].clone())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            grads()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(eager[0], m.store.grad), f"captured step differs from the eager one (text_side {side})"
+        assert torch.equal(eager[1], out["te"]) and torch.equal(eager[3], out["l1"])
+        res[side] = eager
+        del g, m
+    assert float(res[True][0].abs().max()) > 0
+    for x, y in zip(res[False], res[True]):
+        assert torch.equal(x, y)
+
 
 @pytest.mark.parametrize("arch_name,B,T", [("B_16", 12, 8), ("B_32", 24, 8), ("H_14", 2, 16)])
 def test_wgrad_side_stream_gives_the_same_bits(K, lib, arch_name, B, T):

@@ -20,6 +20,8 @@ from collections import OrderedDict
 from typing import Dict, Optional
 
 import numpy as np
+import os
+
 import torch
 
 from . import hip as K
@@ -202,6 +204,8 @@ class Engine:
         # gradient errors stay at the fp32 streams' level: the forward CLS rows through two [B, K] GEMMs per block with fp32 residual
         # (`_cls_lin`), the LayerNorms read / write them beside the stream (tvts_layernorm_{fwd,bwd}_cls).
         hybrid = a.get("hybrid_stream", None)
+        if hybrid is None and os.environ.get("TVTS_HYBRID_STREAM"):
+            hybrid = os.environ["TVTS_HYBRID_STREAM"] != "0"
         if hybrid is None:  # default: on, unless one of the older stream options is asked for explicitly
             hybrid = a.get("family") != "v1" and "bf16_residual" not in a and "bf16_grad_stream" not in a
         self.cls32 = bool(hybrid) and a.get("family") != "v1"
@@ -218,6 +222,17 @@ class Engine:
         # 692.9 / 958.5 / 1154 / 1351 without.  arch["wgrad_stream"] = True switches it on (bit-identical gradients,
         # tests/test_bench_path_gpu.py::test_wgrad_side_stream_gives_the_same_bits).
         self.wgrad_stream = a.get("wgrad_stream", False)
+        # The text tower on its own stream beside the ViT (round 5).  The two towers share nothing until the loss (the sort head reads
+        # DETACHED caption embeddings, model_dist_TVTSv2_ViT_B_16.py:61-95): the text tower's forward (12 blocks of 5-25 us kernels
+        # on <= 48 tiles) and its three trainable blocks' backward are latency-bound chains -- in the replayed 12-pair step every one
+        # of their ~150 kernels waits 10-20 us for its predecessor's completion signal (profiles/r04_timeline_b12.txt) -- that fit
+        # beside the ViT's kernels: ONE fork and ONE join per direction, scratch buffers of their own (hip.lane).
+        # arch["text_side"]: True / False, None = on
+        ts = a.get("text_side", None)
+        if ts is None and os.environ.get("TVTS_TEXT_SIDE"):  # (A/B runs of whole test files / tools without touching their arch dicts)
+            ts = os.environ["TVTS_TEXT_SIDE"] != "0"
+        self.text_side = (True if ts is None else bool(ts)) and a.get("family") != "v1"
+        self._txt_stream = None
         # The six weight gradients of a ViT block in ONE grouped launch + one reduce launch (round 4, tvts_gemm_tn_bf16_grouped):
         # arch["tn_grouped"] True / False, None = automatic (up to TN_GROUPED_MAX_ROWS token rows per GPU, where a single weight
         # gradient fills a fraction of a round of the chip and its launch ramp is a third of its time)
@@ -235,6 +250,8 @@ class Engine:
         self._wg_stream = None
         self._wg_ws = None
         self.dev = store.device
+        if self.dev.type == "cuda":
+            K.warm_scratch(self.dev)
         self.buf: Dict[str, torch.Tensor] = {}
         self._back: Dict[str, torch.Tensor] = {}  # the allocations behind buf (grow-only, see _b)
         self._seen: Dict[str, int] = {}           # name -> the forward() count at which its shape last changed
@@ -1119,20 +1136,56 @@ class Engine:
         self.ctx = pb
         self._tick += 1  # (workspace: a buffer whose shape changes from here on belongs to a new step, see _b)
         B, T, N, NT, L, S, E = pb["B"], pb["T"], pb["N"], pb["NT"], pb["L"], pb["S"], a["embed"]
-        t = self.text_forward(pb["ids"], pb["eot_rows"], N, L, eot_index=pb.get("eot_index"))
         text_emb = self._f("mdl.text_emb", (B, E))
         text_before = self._f("mdl.text_before", (B, NT, E))
-        K.text_mean(t, text_emb, text_before, NT=NT, B=B)
+        with self._text_lane():  # (the text tower beside the ViT when self.text_side, in line otherwise)
+            t = self.text_forward(pb["ids"], pb["eot_rows"], N, L, eot_index=pb.get("eot_index"))
+            K.text_mean(t, text_emb, text_before, NT=NT, B=B)
         out, pooled = self.video_forward(pb["video"], pb["keep"], B, T, vid_rows=pb["vid_rows"])
         if pooled is None:
             video_emb = self._f("mdl.video_emb", (B, E))
             K.rows_gather(out, pb["vid_rows"], video_emb)
         else:
             video_emb = pooled
+        self._text_join()
         if self.embeds_ready is not None:  # the embedding all-gather starts here and travels under the sort head's forward
             self.embeds_ready(text_emb, video_emb)
         pred = self.sort_forward(out, text_before, B, S, NT) if (NT != 1 and self.has_sort_head) else None
         return text_emb, video_emb, pred
+
+    class _TextLane:
+        """`with` block whose launches go to the text tower's stream (forked from the current stream's position) and use the side
+        scratch lane; a no-op when the text tower runs in line"""
+
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            e = self.eng
+            if not e.text_side:
+                return
+            if e._txt_stream is None:
+                e._txt_stream = torch.cuda.Stream(device=e.dev)
+            cur = torch.cuda.current_stream(e.dev)
+            e._txt_stream.wait_stream(cur)
+            self.sc, self.ln = torch.cuda.stream(e._txt_stream), K.lane(1)
+            self.sc.__enter__()
+            self.ln.__enter__()
+            e._txt_open = True
+
+        def __exit__(self, *exc):
+            if self.eng.text_side:
+                self.ln.__exit__(*exc)
+                self.sc.__exit__(*exc)
+
+    def _text_lane(self):
+        return Engine._TextLane(self)
+
+    def _text_join(self):
+        """the current stream waits for what the text lane has queued"""
+        if self.text_side and getattr(self, "_txt_open", False):
+            torch.cuda.current_stream(self.dev).wait_stream(self._txt_stream)
+            self._txt_open = False
 
     def backward(self, d_text, d_video, d_pred):
         """Accumulates parameter gradients into the flat grad buffer (+=).  d_* are fp32 GPU tensors (or None)."""
@@ -1143,9 +1196,10 @@ class Engine:
         # all-reduce of the step -- issued here it travels under the whole video backward instead of after it
         if d_text is not None:
             dt = self._f("mdl.dt", (N, E))
-            K.text_mean_bwd(d_text, dt, NT=NT, B=B)
-            self.text_backward(dt, pb["ids"], pb["eot_rows"], N, L, tok_sort=pb.get("tok_sort"))
-            self._ready("text_")
+            with self._text_lane():  # beside the sort head's and the ViT's backward when self.text_side; joined at the end
+                K.text_mean_bwd(d_text, dt, NT=NT, B=B)
+                self.text_backward(dt, pb["ids"], pb["eot_rows"], N, L, tok_sort=pb.get("tok_sort"))
+                self._ready("text_")
         dout = self._b("mdl.dout", (B * S, E))
         off = 1 if self.pooled_tail else 0
         dv_cls = None if self.pooled_tail else d_video  # B models: the embedding IS the CLS row of the projected tokens
@@ -1159,6 +1213,7 @@ class Engine:
         else:
             dout = None
         self.video_backward(dout, pb["keep"], B, T, d_pooled=d_video if self.pooled_tail else None)
+        self._text_join()
 
 
 class LossHead:

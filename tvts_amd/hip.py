@@ -156,15 +156,16 @@ def gemm_tn_select(M, Na, Nb, tile=None):
 
 
 STREAMK_TAKEN = [0]  # launches that took the stream-K walk / the fused reduce under a forcing option (tests assert the path ran)
-NT_WORKSPACE = None  # scratch of the stream-K walk of gemm_nt (arrival counters + fp32 partial tiles), one per process = one stream
+NT_WORKSPACE = {}  # per (device, lane): scratch of the stream-K walk of gemm_nt (arrival counters + fp32 partial tiles)
 
 
 def _nt_workspace(dev):
     """zeroed once: every launch leaves the arrival counters at zero again (include/tvts_hip.h)"""
-    global NT_WORKSPACE
-    if NT_WORKSPACE is None or NT_WORKSPACE.device != dev:
-        NT_WORKSPACE = torch.zeros(_lib.load().tvts_gemm_nt_workspace_bytes(), dtype=torch.uint8, device=dev)
-    return NT_WORKSPACE
+    key = (dev, current_lane())
+    ws = NT_WORKSPACE.get(key)
+    if ws is None:
+        ws = NT_WORKSPACE[key] = torch.zeros(_lib.load().tvts_gemm_nt_workspace_bytes(), dtype=torch.uint8, device=dev)
+    return ws
 
 
 def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None, tile=None, cus=None,
@@ -302,14 +303,49 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
         GEMM_PROFILE.append(("gemm_nt_fp8", 2.0 * M * N * Kd, ev0, ev1, (M, N, Kd, "fp8", "res" if residual is not None else "", str(act or ""), "")))
 
 
-TN_WORKSPACE = None  # fp32 scratch tensor for the split partials of gemm_tn (allocated lazily, 256 MiB: 8 partials of the largest weight, H/14 mlp 1280 x 5120)
+# Scratch LANES: the shared scratch buffers of this module (split partials of the weight gradients, LayerNorm dgamma / dbeta partials,
+# stream-K workspace) belong to ONE stream's launch order.  A second stream that runs kernels beside it (the text tower next to the
+# ViT, Engine.text_side) selects its own set with `with K.lane(1):` -- per host thread, like torch's current stream.
+import threading
+
+_LANE = threading.local()
+
+
+def current_lane() -> int:
+    return getattr(_LANE, "i", 0)
+
+
+class lane:
+    def __init__(self, i: int):
+        self.i = int(i)
+
+    def __enter__(self):
+        self.prev = current_lane()
+        _LANE.i = self.i
+
+    def __exit__(self, *exc):
+        _LANE.i = self.prev
+
+
+TN_WORKSPACE = {}  # per (device, lane): fp32 scratch tensor for the split partials of gemm_tn (allocated lazily, 256 MiB: 8 partials of the largest weight, H/14 mlp 1280 x 5120)
 
 
 def _tn_workspace(dev):
-    global TN_WORKSPACE
-    if TN_WORKSPACE is None or TN_WORKSPACE.device != dev:
-        TN_WORKSPACE = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev)
-    return TN_WORKSPACE
+    key = (dev, current_lane())
+    ws = TN_WORKSPACE.get(key)
+    if ws is None:
+        ws = TN_WORKSPACE[key] = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev)  # (every lane the same size: the split plan depends on it)
+    return ws
+
+
+def warm_scratch(dev, lanes=(0, 1)):
+    """allocate every lane's shared scratch NOW (Engine.__init__): a buffer that is first touched inside a hipGraph capture would live
+    in that graph's private pool and die with it, while this module keeps handing it out"""
+    for i in lanes:
+        with lane(i):
+            _tn_counters(_tn_workspace(dev))
+            _ln_workspace(dev)
+            _nt_workspace(dev)
 
 
 TN_COUNTERS = {}  # per workspace: zeroed arrival counters of the fused reduce (every launch leaves them at zero again)
@@ -463,14 +499,15 @@ def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=Non
     _chk(rc, "tvts_layernorm_fwd")
 
 
-LN_WORKSPACE = None  # fp32 scratch for the per-block dgamma/dbeta partials of layernorm_bwd (1024 blocks x 2 x 1280)
+LN_WORKSPACE = {}  # per (device, lane): fp32 scratch for the per-block dgamma/dbeta partials of layernorm_bwd (1024 blocks x 2 x 1280)
 
 
 def _ln_workspace(dev):
-    global LN_WORKSPACE
-    if LN_WORKSPACE is None or LN_WORKSPACE.device != dev:
-        LN_WORKSPACE = torch.empty(1024 * 2 * 1280, dtype=torch.float32, device=dev)
-    return LN_WORKSPACE
+    key = (dev, current_lane())
+    ws = LN_WORKSPACE.get(key)
+    if ws is None:
+        ws = LN_WORKSPACE[key] = torch.empty(1024 * 2 * 1280, dtype=torch.float32, device=dev)
+    return ws
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, *, dx_bf16=None, res1=None, res2=None, dgamma=None, dbeta=None,
