@@ -231,6 +231,8 @@ def main():
     ap.add_argument("--tn-grouped", choices=("auto", "on", "off"), default="auto", help="the six weight gradients of a ViT block in one grouped "
                     "launch (auto: from 6 000 to 12 000 token rows per GPU, Engine.TN_GROUPED_MIN_ROWS / MAX_ROWS -- the reference's 12 pairs; "
                     "profiles/r04_tn_grouped.txt)")
+    ap.add_argument("--fp8-q8-only", choices=("on", "off"), default="on", help="with --fp8-wgrad: the MLP's GELU output and gated hidden gradient "
+                    "leave their GEMM epilogues as e4m3 bytes ONLY (round 5 default); off = bf16 result + a quantiser pass (round 4)")
     ap.add_argument("--text-side", choices=("on", "off"), default="on", help="the text tower on its own stream beside the ViT (round 5 default; "
                     "off = in line in front of it)")
     ap.add_argument("--no-graph", action="store_true")
@@ -295,6 +297,8 @@ def main():
     if args.bf16_residual:
         a["bf16_residual"] = True
     a["text_side"] = args.text_side == "on"
+    if args.fp8_q8_only == "off":
+        a["fp8_q8_only"] = False
     if args.tn_grouped != "auto":
         a["tn_grouped"] = args.tn_grouped == "on"
     if os.environ.get("TVTS_TN_GROUP_SPLITS"):

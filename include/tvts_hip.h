@@ -108,7 +108,8 @@ int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int 
                      hipStream_t stream);
 /* q8out (optional; activation forms with a bf16 result, here and in tvts_gemm_nt_fp8_gate): the epilogue also writes
  * q8out[m, n] = e4m3(out[m, n] / q8_scale[0]) and folds max |out| into q8_amax -- the per-tensor copy the next GEMMs of
- * BASELINE config 5 read (the following layer's forward and weight gradient), without a quantiser pass over the result */
+ * BASELINE config 5 read (the following layer's forward and weight gradient), without a quantiser pass over the result.  With q8out,
+ * `out` may be NULL: the e4m3 copy is then the only result (round 5: in the per-tensor regime nothing reads the bf16 tensor) */
 /* input gradient of such a layer (autograd of nn.Linear + the GELU of video_encoder_ViT_H_14.py's Mlp): out[M,N] (bf16) =
  * gate_act'(gate_h[M,N]) * (scale_a[m] * scale_b * (A[M,K] B[N,K]^T)), A = e4m3 copy of the output gradient (per-token scales),
  * B = e4m3 copy of the transposed weight; the un-gated input gradients take tvts_gemm_nt_fp8 itself */

@@ -465,7 +465,7 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
                                 int scale_a_rows, const float* scale_b, const float* bias, const float* residual, int ldr, int act, void* preact,
                                 int ldp, void* out, int ldc, int out_f32, void* q8out, int ldq8, const float* q8_scale, float* q8_amax,
                                 int opts, hipStream_t stream) {
-    if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b || (q8out && !q8_scale)) return TVTS_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b || (q8out && !q8_scale) || (!out && !q8out)) return TVTS_EINVAL;
     if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || (residual && ldr % 4) || (preact && ldp % 8)) return TVTS_EINVAL;
     GemmNT g;
     g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;  // byte-identical bf16 view, half as wide
@@ -484,7 +484,7 @@ extern "C" int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int 
                                      int scale_a_rows, const float* scale_b, const float* bias, const void* gate_h, int ldh,
                                      int gate_act, void* out, int ldc, void* q8out, int ldq8, const float* q8_scale, float* q8_amax,
                                      int opts, hipStream_t stream) {
-    if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b || !gate_h || (q8out && !q8_scale)) return TVTS_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || !scale_a || !scale_b || !gate_h || (q8out && !q8_scale) || (!out && !q8out)) return TVTS_EINVAL;
     if (K % 128 || N % 8 || lda % 16 || ldb % 16 || ldc % 8 || ldh % 8) return TVTS_EINVAL;
     GemmNT g;
     g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;

@@ -308,7 +308,9 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-            if (!(ABL & 4) || v[0] == 1.2345e33f) store16<ABL>((bf16*)g.out + (size_t)m * g.ldc + n, o);
+            // (q8 forms: out == nullptr -> the e4m3 copy is the ONLY result -- in the per-tensor regime every consumer of the MLP's
+            // GELU output / gated gradient multiplies the e4m3 bytes, the bf16 tensor would be written and never read)
+            if ((!(ABL & 4) || v[0] == 1.2345e33f) && (!Q8OUT || g.out != nullptr)) store16<ABL>((bf16*)g.out + (size_t)m * g.ldc + n, o);
             if constexpr (Q8OUT) {  // the same 8 values as e4m3 bytes under the tensor's scale (what the bf16 consumers see, quantised)
                 float f[8];
                 float am = *q8am;

@@ -241,6 +241,8 @@ class Engine:
         self._tn_group_ws = None
         # e4m3 weight gradients (BASELINE config 5): per-tensor delayed scaling of every e4m3 operand copy, see _q8 below
         self.fp8_wgrad = bool(a.get("fp8_wgrad", False))
+        self.fp8_q8_only = self.fp8_wgrad and bool(a.get("fp8_q8_only", True))
+        self._x8_only = set()
         self._f8_ids: Dict[str, int] = {}
         self._f8_scale = self._f8_amax = None
         self._f8_tensor_mode = False
@@ -387,7 +389,11 @@ class Engine:
         # the two quantiser passes it removes are worth 8.6 ms per step, the two epilogues that take their work over get 105 / 120 us
         # slower per launch (7.2 ms: they are the epilogue-bound GELU / gate forms, and the extra stores spill 30-40 bytes more) --
         # 295.3 against 295.8 ms per step, not worth a second path by default
-        if not (self.fp8_wgrad and self._f8_tensor_mode and self.arch.get("fp8_epilogue_copies")):
+        # Round 5, arch["fp8_q8_only"] (default with fp8_wgrad): the epilogue writes the e4m3 copy INSTEAD of the bf16 result -- in the
+        # per-tensor regime every consumer of the MLP's GELU output (fc2 forward, fc2 weight gradient) and of the gated hidden gradient
+        # (fc1 input and weight gradient, bias gradient on the matrix pipe) multiplies the e4m3 bytes: one byte per element leaves
+        # the epilogue where round 4 wrote two and a quantiser pass read them again
+        if not (self.fp8_wgrad and self._f8_tensor_mode and (self.arch.get("fp8_epilogue_copies") or self.fp8_q8_only)):
             return {}, None
         q, sc, kw = self._q8(M, W, name, persistent=persistent)
         return dict(q8out=q, q8_scale=sc, q8_amax=kw["amax"]), (q, sc)
@@ -404,6 +410,9 @@ class Engine:
                 epi = dict(epi, **kw8)
                 if nxt is not None:
                     self._x8_ready[q8_for] = nxt
+                    if self.fp8_q8_only and self.requires_grad[q8_for]:
+                        epi["store_out"] = False       # `out` (bf16) is not written: its consumers read nxt
+                        self._x8_only.add(q8_for)
             if a8 is None:  # activations that do not come out of a LayerNorm: one pass
                 q, sa, kw = self._q8(M, a.shape[1], "x." + wname, persistent=True)
                 K.quantize_fp8_rows(a[:M], q=q, **kw)
@@ -419,7 +428,12 @@ class Engine:
         block's GEMM; its CLS rows are addressed as a [B, K] matrix with the row stride S * K -- the same operand bytes and the same
         bf16 weight shadow, always on the bf16 MFMA path (also when the block's GEMMs multiply e4m3 copies)."""
         Bc = out_c.shape[0]
-        a_c = a.view(Bc, -1)[:, :a.shape[1]] if a.shape[0] == Bc * S else a[:Bc * S].view(Bc, -1)[:, :a.shape[1]]
+        if wname in self._x8_only:  # the operand only exists as e4m3 bytes (arch["fp8_q8_only"]): the same rows of that copy
+            q, sa = self._x8[wname]
+            w8, ws, _ = self.P.w8[wname]
+            K.gemm_nt_fp8(q[:Bc * S].view(Bc, -1)[:, :q.shape[1]], sa, w8, ws, out_c, bias=self.P.p(bname) if bname else None, residual=res_c)
+            return
+        a_c = a[:Bc * S].view(Bc, -1)[:, :a.shape[1]]
         K.gemm_nt(a_c, self.P.w(wname), out_c, M=Bc, bias=self.P.p(bname) if bname else None, residual=res_c)
 
     # measured (profiles/r04_tn_grouped.txt): B/16 +1.5 % at 12 pairs (M = 9 420), -0.4 % at 24, -2 % at 48; B/32 +1.2 % at its 24 pairs
@@ -491,6 +505,8 @@ class Engine:
                     epi = dict(epi, **kw8)
                     if nxt is not None:
                         self._dy8_ready[q8_for] = nxt
+                        if self.fp8_q8_only and self.requires_grad[q8_for] and q8_for in self._x8:
+                            epi["store_out"] = False   # the gated gradient exists as e4m3 bytes only
                 K.gemm_nt_fp8(dy8[0], dy8[1], w8t, wst, d_in[:M], **epi)
                 return
             K.gemm_nt(dy, self.P.wt(wname), d_in, M=M, **epi)

@@ -264,12 +264,15 @@ def fp8_update_scales(amax, scale):
 
 
 def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None, k32=None,
-                cus=None, q8out=None, q8_scale=None, q8_amax=None):
+                cus=None, q8out=None, q8_scale=None, q8_amax=None, store_out=True):
     """out[M,N] = act(sa*sb * (a8[M,K] @ b8[N,K]^T) + bias) [+ residual]; a8 / b8 uint8 e4m3 bit patterns; sb float32[1]; sa
     float32[1] (one scale for the tensor) or float32[>= M] (one per row, quantize_fp8_rows); preact receives the bf16
     pre-activation like gemm_nt.  gate_h / gate_act: the input-gradient form, out = gate_act'(gate_h) * (sa*sb * (a8 @ b8^T)).
-    k32: the 16x16x32 fp8 main loop instead of the K = 128 scaled MFMA (same products, same fp32 accumulation)."""
+    k32: the 16x16x32 fp8 main loop instead of the K = 128 scaled MFMA (same products, same fp32 accumulation).
+    store_out=False (with q8out): the bf16 result is not written, the e4m3 copy is the only output."""
     lib = _lib.load()
+    assert store_out or q8out is not None
+    po = _p(out) if store_out else None
     M, Kd = a8.shape
     N = b8.shape[0]
     assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and b8.shape[1] == Kd
@@ -285,7 +288,7 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
         assert residual is None and act is None and preact is None and out.dtype == torch.bfloat16
         assert bias is None or gate_act == "add"
         rc = lib.tvts_gemm_nt_fp8_gate(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(bias), _p(gate_h),
-                                       _ld(gate_h), ACT[gate_act], _p(out), _ld(out), _p(q8out), q8out.stride(0) if q8out is not None else 0, _p(q8_scale),
+                                       _ld(gate_h), ACT[gate_act], po, _ld(out), _p(q8out), q8out.stride(0) if q8out is not None else 0, _p(q8_scale),
                                        _p(q8_amax), nt_opts(None, cus, k32), _stream())
         _chk(rc, "tvts_gemm_nt_fp8_gate")
         if GEMM_PROFILE is not None:
@@ -294,7 +297,7 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
         return
     rc = lib.tvts_gemm_nt_fp8(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(bias), _p(residual),
                               _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
-                              _ld(preact) if preact is not None else 0, _p(out), _ld(out),
+                              _ld(preact) if preact is not None else 0, po, _ld(out),
                               1 if out.dtype == torch.float32 else 0, _p(q8out), q8out.stride(0) if q8out is not None else 0,
                               _p(q8_scale), _p(q8_amax), nt_opts(None, cus, k32), _stream())
     _chk(rc, "tvts_gemm_nt_fp8")
