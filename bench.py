@@ -434,11 +434,15 @@ def main():
         # dominant kernel family = the bf16 MFMA GEMMs (gemm_nt_kernel / gemm_tn_kernel): one instrumented eager
         # step with a HIP event pair around every GEMM launch on the launch stream.  EVERY rank runs the step (it
         # contains the all-gather / all-reduce of the data-parallel path); rank 0 records.
+        # The text tower runs IN LINE in this one step (in the timed steps it runs on its own stream beside the ViT, same kernels,
+        # same bits): a launch's event pair then brackets that launch alone, not the other stream's kernels it shared the chip with.
         if rank == 0:
             K.GEMM_PROFILE = []
             K.HBM_PROFILE = []
+        eng_ts, model.engine.text_side = model.engine.text_side, False
         one_step(0, device_step=False)
         torch.cuda.synchronize()
+        model.engine.text_side = eng_ts
         if world > 1:
             dist.barrier()
     if rank == 0 and not args.no_roofline:

@@ -23,12 +23,22 @@ extern "C" {
 #endif
 
 enum { TVTS_COMM_F32 = 0, TVTS_COMM_BF16 = 1 };
+#define TVTS_COMM_ETIMEDOUT (-110)
 
 /* 128-byte RCCL unique id, created on rank 0 and handed to every rank by the host side (torch.distributed broadcast) */
 int tvts_comm_unique_id(void* id128);
 /* collective over all ranks: creates the communicator for the CURRENT HIP device plus the side stream and its events */
 int tvts_comm_create(const void* id128, int rank, int world, void** comm_out);
+/* the same with a deadline on the rendezvous (round 5): ncclCommInitRank runs on a helper thread; if it has not returned after
+ * timeout_ms (> 0) the call gives up with TVTS_COMM_ETIMEDOUT and *comm_out = NULL -- a peer that died after the id broadcast costs
+ * the survivors the deadline, not the job: they are free to agree on the torch.distributed transport.  (The helper thread stays
+ * parked inside RCCL; should its call ever return it aborts the communicator itself.)  timeout_ms <= 0: tvts_comm_create. */
+int tvts_comm_create_deadline(const void* id128, int rank, int world, int timeout_ms, void** comm_out);
 int tvts_comm_destroy(void* comm);
+/* tear-down that does NOT wait for outstanding collectives (ncclCommAbort): for a communicator whose peer is gone */
+int tvts_comm_abort(void* comm);
+/* poll: 1 = every collective issued so far has completed, 0 = not yet, < 0 = error; never blocks */
+int tvts_comm_idle(void* comm);
 int tvts_comm_world(void* comm, int* rank, int* world);
 /* video_all[W*B, E] and text_all[W*B, E] <- all ranks' video[B, E] / text[B, E] (fp32), rank r owns rows r*B..r*B+B-1 */
 int tvts_comm_allgather_embeds(void* comm, const float* video, const float* text, int B, int E, float* video_all,

@@ -46,7 +46,8 @@ def test_kernel_library_has_no_process_global_switches():
 def test_comm_library_exports_every_declared_symbol():
     protos = _lib.parse_header(_lib.COMM_HEADER_PATH)
     assert set(protos) == {"tvts_comm_unique_id", "tvts_comm_create", "tvts_comm_destroy", "tvts_comm_world",
-                           "tvts_comm_allgather_embeds", "tvts_comm_allreduce_bucket", "tvts_comm_wait"}
+                           "tvts_comm_allgather_embeds", "tvts_comm_allreduce_bucket", "tvts_comm_wait",
+                           "tvts_comm_create_deadline", "tvts_comm_abort", "tvts_comm_idle"}
     lib = _lib.load_comm()
     for name in protos:
         assert hasattr(lib, name), name

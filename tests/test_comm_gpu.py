@@ -171,3 +171,36 @@ def test_captured_step_through_the_native_transport(comm):
     assert run.sync.bytes_sent > 0
     assert replayed == eager, (replayed, eager)
     assert float((m.store.flat - p_eager).abs().max()) < 1e-7
+
+
+def test_bring_up_has_a_deadline_and_a_dead_peer_does_not_hang_the_survivor(comm):
+    """tvts_comm_create_deadline: the rendezvous of a 2-rank communicator whose second rank never arrives (a peer that died after
+    the id broadcast) returns TVTS_COMM_ETIMEDOUT after the deadline instead of blocking inside ncclCommInitRank for ever -- the
+    survivor is free to agree on the torch.distributed transport (dist.transport()).  tvts_comm_idle polls the side stream
+    without blocking; tvts_comm_abort tears a communicator down without waiting for its collectives."""
+    import ctypes
+    import time
+    lib = comm.lib
+    raw = (ctypes.c_ubyte * 128)()
+    assert lib.tvts_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)) == 0
+    h = ctypes.c_void_p()
+    t0 = time.time()
+    rc = lib.tvts_comm_create_deadline(ctypes.cast(raw, ctypes.c_void_p), 0, 2, 1500, ctypes.byref(h))
+    dt = time.time() - t0
+    assert rc == -110 and not h.value, (rc, h.value)
+    assert 1.0 < dt < 20.0, dt
+    # the device and the existing communicator are unharmed by the parked helper thread
+    x = torch.ones(1 << 16, device=DEV)
+    comm.allreduce(x)
+    assert comm.drain(30.0)
+    comm.wait()
+    torch.cuda.synchronize()
+    assert float(x.sum()) == float(1 << 16)
+    assert lib.tvts_comm_idle(comm.h) == 1
+    # a second communicator of one rank, with a deadline that is met, then aborted instead of destroyed
+    raw2 = (ctypes.c_ubyte * 128)()
+    assert lib.tvts_comm_unique_id(ctypes.cast(raw2, ctypes.c_void_p)) == 0
+    h2 = ctypes.c_void_p()
+    assert lib.tvts_comm_create_deadline(ctypes.cast(raw2, ctypes.c_void_p), 0, 1, 60000, ctypes.byref(h2)) == 0 and h2.value
+    assert lib.tvts_comm_idle(h2) == 1
+    assert lib.tvts_comm_abort(h2) == 0

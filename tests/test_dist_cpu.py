@@ -76,3 +76,15 @@ def test_two_rank_exchange_matches_reference_ddp():
         for k, g in res[r][4].items():
             ref = f["g_" + k]
             assert np.linalg.norm(g - ref) < 1e-4 * np.linalg.norm(ref), k
+
+
+def test_cu_reservation_rule():
+    """dist.auto_cu_reservation: what the persistent GEMM grids leave to the RCCL kernels, from the per-GPU token rows and the
+    world size (DESIGN.md section 6 records the model and the prediction the first multi-GPU run has to confirm)."""
+    from tvts_amd.dist import auto_cu_reservation as rule
+    assert rule(150720, 1) == 0 and rule(9420, 1) == 0      # one GPU: nothing to overlap with
+    assert rule(9420, 8) == 0                                 # 12 pairs: 128 x 128 kernels, RCCL's workgroups co-reside
+    assert rule(18840, 8) == 8 and rule(37680, 8) == 8        # 24 / 48 pairs: every CU held by a persistent block, traffic 10-25 % of the backward
+    assert rule(150720, 8) == 0                               # 192 pairs: the all-reduce is a few per cent of the backward
+    assert rule(18840, 2) in (0, 8)                           # two ranks move half of it: either side of the threshold is fine
+    assert rule(37680, 8, grad_bytes=312 << 20) in (0, 8)

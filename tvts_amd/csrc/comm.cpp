@@ -4,6 +4,12 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+
 #include "tvts_comm.h"
 
 #define TVTS_EINVAL (-22)
@@ -43,7 +49,51 @@ static void comm_free(TvtsComm* c) {
     delete c;
 }
 
+// ncclCommInitRank is a rendezvous of every rank: a peer that died after the id broadcast leaves the others inside it forever.
+// The bring-up therefore runs on a helper thread and the caller waits for it with a deadline.  On a timeout the caller gets
+// TVTS_COMM_ETIMEDOUT and is free again (to agree with the other ranks on the fallback transport over ITS OWN channel); the helper
+// stays parked in RCCL and, should the call ever return, aborts the communicator it was given itself.
+struct InitJob {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false, abandoned = false;
+    ncclResult_t res = ncclSuccess;
+    ncclComm_t comm = nullptr;
+};
+
+static int init_rank_deadline(ncclComm_t* out, int world, ncclUniqueId id, int rank, int device, int timeout_ms) {
+    if (timeout_ms <= 0) {
+        ncclResult_t r = ncclCommInitRank(out, world, id, rank);
+        return r == ncclSuccess ? 0 : -(1000 + (int)r);
+    }
+    auto job = std::make_shared<InitJob>();
+    std::thread([job, world, id, rank, device]() {
+        ncclComm_t c = nullptr;
+        ncclResult_t r = hipSetDevice(device) == hipSuccess ? ncclCommInitRank(&c, world, id, rank) : ncclUnhandledCudaError;
+        std::unique_lock<std::mutex> lk(job->mu);
+        if (job->abandoned) {  // nobody is waiting any more
+            lk.unlock();
+            if (r == ncclSuccess && c) ncclCommAbort(c);
+            return;
+        }
+        job->res = r; job->comm = c; job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->mu);
+    if (!job->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return job->done; })) {
+        job->abandoned = true;
+        return TVTS_COMM_ETIMEDOUT;
+    }
+    if (job->res != ncclSuccess) return -(1000 + (int)job->res);
+    *out = job->comm;
+    return 0;
+}
+
 extern "C" int tvts_comm_create(const void* id128, int rank, int world, void** comm_out) {
+    return tvts_comm_create_deadline(id128, rank, world, 0, comm_out);
+}
+
+extern "C" int tvts_comm_create_deadline(const void* id128, int rank, int world, int timeout_ms, void** comm_out) {
     if (!id128 || !comm_out || world < 1 || rank < 0 || rank >= world) return TVTS_EINVAL;
     *comm_out = nullptr;
     TvtsComm* c = new TvtsComm();
@@ -54,7 +104,12 @@ extern "C" int tvts_comm_create(const void* id128, int rank, int world, void** c
     // every early return releases what exists so far (communicator, stream, events) and leaves *comm_out NULL
 #define CREATE_TRY_NCCL(x) do { ncclResult_t r__ = (x); if (r__ != ncclSuccess) { comm_free(c); return -(1000 + (int)r__); } } while (0)
 #define CREATE_TRY_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { comm_free(c); return (int)e__; } } while (0)
-    CREATE_TRY_NCCL(ncclCommInitRank(&c->nccl, world, id, rank));
+    int device = 0;
+    CREATE_TRY_HIP(hipGetDevice(&device));
+    {
+        const int rc = init_rank_deadline(&c->nccl, world, id, rank, device, timeout_ms);
+        if (rc) { c->nccl = nullptr; comm_free(c); return rc; }
+    }
     // a high-priority side stream: its (few, short) kernels should not queue behind the persistent GEMM blocks
     int lo = 0, hi = 0;
     CREATE_TRY_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -82,6 +137,32 @@ extern "C" int tvts_comm_destroy(void* comm) {
     e = hipStreamDestroy(c->side); if (e != hipSuccess && !rc) rc = (int)e;
     delete c;
     return rc;
+}
+
+// Tears a communicator down WITHOUT waiting for its outstanding work: a collective whose peer is gone never completes, and
+// with it neither would tvts_comm_destroy's stream synchronisation.  ncclCommAbort ends the kernels in flight.
+extern "C" int tvts_comm_abort(void* comm) {
+    if (!comm) return TVTS_EINVAL;
+    TvtsComm* c = (TvtsComm*)comm;
+    int rc = 0;
+    ncclResult_t r = ncclCommAbort(c->nccl);
+    if (r != ncclSuccess) rc = -(1000 + (int)r);
+    c->nccl = nullptr;
+    hipEventDestroy(c->fork);
+    hipEventDestroy(c->join);
+    hipStreamDestroy(c->side);
+    delete c;
+    return rc;
+}
+
+// 1 when everything issued on the side stream so far has completed, 0 when not (a poll: never blocks), < 0 on an error
+extern "C" int tvts_comm_idle(void* comm) {
+    if (!comm) return TVTS_EINVAL;
+    TvtsComm* c = (TvtsComm*)comm;
+    hipError_t e = hipStreamQuery(c->side);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return -(int)e;
 }
 
 extern "C" int tvts_comm_world(void* comm, int* rank, int* world) {

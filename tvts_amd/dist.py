@@ -84,10 +84,36 @@ class NativeComm:
             raise RuntimeError("tvts_comm_unique_id failed on rank 0")
         raw = (ctypes.c_ubyte * 128)(*idbuf.tolist())
         h = ctypes.c_void_p()
-        self._chk(self.lib.tvts_comm_create(ctypes.cast(raw, ctypes.c_void_p), r, W, ctypes.byref(h)), "tvts_comm_create")
+        # the rendezvous has a deadline (TVTS_COMM_TIMEOUT_S, default 60 s): a rank that died after the id broadcast costs the others
+        # the deadline, then they are back here with an error and reach transport()'s agreement instead of hanging in RCCL
+        self.timeout_s = float(os.environ.get("TVTS_COMM_TIMEOUT_S", "60"))
+        self._chk(self.lib.tvts_comm_create_deadline(ctypes.cast(raw, ctypes.c_void_p), r, W, int(self.timeout_s * 1000), ctypes.byref(h)),
+                  "tvts_comm_create_deadline")
         self.h, self.W, self.rank = h, W, r
         import atexit
         atexit.register(self.close)  # before torch.distributed tears its own RCCL communicators down at interpreter exit
+
+    def abort(self):
+        """Tears the communicator down without waiting for its outstanding collectives (a peer is gone): ncclCommAbort."""
+        h, self.h = self.h, None
+        if h is not None:
+            self.lib.tvts_comm_abort(h)
+            if NativeComm._inst is self:
+                NativeComm._inst = None
+
+    def drain(self, timeout_s: float) -> bool:
+        """Polls (never blocks inside the driver) until every collective issued so far has completed; False after timeout_s."""
+        import time
+        t0 = time.time()
+        while True:
+            st = self.lib.tvts_comm_idle(self.h)
+            if st == 1:
+                return True
+            if st < 0:
+                raise RuntimeError(f"tvts_comm_idle failed with code {st}")
+            if time.time() - t0 > timeout_s:
+                return False
+            time.sleep(0.002)
 
     def close(self):
         """Destroys the communicator, the side stream and its events (idempotent)."""
@@ -141,6 +167,11 @@ class NativeComm:
         v_all, t_all = torch.zeros(2 * W, 8, device=dev), torch.zeros(2 * W, 8, device=dev)
         self.allreduce(x)
         self.allgather_embeds(v, t, v_all, t_all)
+        # NOT tvts_comm_wait + synchronize: with a dead peer the collectives never complete and the compute stream would be wedged
+        # behind them.  The side stream is polled with a deadline; on a timeout the communicator is aborted (ends the kernels).
+        if not self.drain(self.timeout_s):
+            self.abort()
+            raise RuntimeError(f"native transport self-test: collectives did not complete within {self.timeout_s:.0f} s (communicator aborted)")
         self.wait()
         torch.cuda.synchronize()
         want = torch.arange(1, W + 1, device=dev, dtype=torch.float32).repeat_interleave(2)[:, None].expand(2 * W, 8)
@@ -151,17 +182,49 @@ class NativeComm:
 _TRANSPORT: Optional[str] = None
 
 
+def auto_cu_reservation(rows_per_gpu: int, world_size: int, grad_bytes: int = 624 << 20) -> int:
+    """CUs the persistent GEMM grids leave to the RCCL kernels (0 = none), from the per-GPU token rows and the world size --
+    the rule that replaces the TVTS_NT_CUS environment variable nobody sets (TVTS_NT_CUS still overrides it).
+
+    Measured on one GPU (tools/overlap_probe.py, profiles/r03_overlap_probe.txt): a side-stream kernel forked under the dgrad chain
+    starts within one GEMM launch either way; on 8 reserved CUs it streams 0.27 TB/s, and reserving 8 / 16 CUs costs the GEMM chain
+    4.3 % / 8.7 %.  Model: the gradient all-reduce moves 2 (W - 1) / W x grad_bytes per GPU at ~300 GB/s of bus bandwidth (xGMI ring,
+    8 GPUs), the backward lasts ~0.62 us per token row (93 ms at 150 720 rows, 9.5 ms at 9 420 with its fixed part); a reservation
+    pays when the traffic it keeps moving is worth more than the 4.3 % it takes:
+      * rows < 15 000 (the reference's 12 pairs): the ViT's GEMMs run on the 128 x 128 kernels (two blocks per CU, 128 of 160 KiB of
+        LDS, half the registers) -- RCCL's workgroups co-reside, nothing to reserve;
+      * 15 000 <= rows < 60 000 (24 ... 72 pairs): every CU is held by a persistent 256 x 256 block and the all-reduce is 8 ... 25 %
+        of the backward -- 8 CUs;
+      * rows >= 60 000: the all-reduce is < 7 % of the backward and hides at the kernel boundaries -- nothing.
+    PREDICTION to be checked by the first multi-GPU run."""
+    if world_size <= 1:
+        return 0
+    comm_ms = 2.0 * (world_size - 1) / world_size * grad_bytes / 300e9 * 1e3
+    bwd_ms = 3.7 + 0.62e-3 * rows_per_gpu
+    if rows_per_gpu < 15000:
+        return 0
+    return 8 if comm_ms > 0.07 * bwd_ms else 0
+
+
 _NT_CUS_APPLIED = False
 
 
-def _apply_cu_reservation():
-    """TVTS_NT_CUS (the persistent GEMM grid leaves CUs to the RCCL kernels): applied once, whenever the resolved transport is
-    native -- forced by TVTS_COMM=native or not"""
+def _apply_cu_reservation(rows_per_gpu: Optional[int] = None):
+    """The persistent GEMM grids leave CUs to the RCCL kernels: TVTS_NT_CUS (the grid size, e.g. 248) when set, else
+    auto_cu_reservation() once the per-GPU token rows are known (StepRunner's first step at world > 1).  Applied once."""
     global _NT_CUS_APPLIED
     if _NT_CUS_APPLIED:
         return
+    env = os.environ.get("TVTS_NT_CUS")
+    if env is None and rows_per_gpu is None:
+        return  # nothing to decide yet
     _NT_CUS_APPLIED = True
-    cus = int(os.environ.get("TVTS_NT_CUS", "0"))
+    if env is not None:
+        cus = int(env)
+    else:
+        W, _ = world()
+        keep = auto_cu_reservation(rows_per_gpu, W)
+        cus = (256 - keep) if keep else 0
     if cus:
         from . import hip as K
         K.set_default(nt_cus=cus)
@@ -207,7 +270,8 @@ def transport() -> str:
             if agree(err is None):
                 _TRANSPORT = "native"
             elif NativeComm._inst is not None:
-                NativeComm._inst.close()
+                # another rank failed: this rank's communicator may have collectives in flight towards it -> abort, do not wait
+                NativeComm._inst.abort()
         if _TRANSPORT != "native":
             import warnings
             why = f"{type(err).__name__}: {err}" if err is not None else "another rank failed"

@@ -46,6 +46,8 @@ class StepRunner:
 
     def run(self, pb, labels, device_step=False):
         """The device-side part of the step (capturable in a hipGraph when world == 1)."""
+        if self.sync.W > 1:
+            D._apply_cu_reservation(pb["B"] * pb["S"])  # (decided once, from the first batch's token rows per GPU)
         self.store.grad.zero_()
         self.sync.bytes_sent = 0
         self.eng.embeds_ready = self.gather.start  # only the training step gathers; eval / autograd forwards do not
