@@ -810,3 +810,24 @@ def test_captured_step_follows_the_learning_rate_schedule(K, lib):
     w1 = m.store.p(key).clone()
     g.replay(); torch.cuda.synchronize()
     assert d1 > 0 and torch.equal(m.store.p(key), w1)
+
+
+def test_range_wise_adamw_gives_the_bits_of_the_single_launch(K, lib):
+    """arch["adamw_ranges"] (opt-in, measured slower): the fused AdamW launched range by range on its own stream as the backward
+    finishes each parameter range, the rest by step() -- three steps leave the parameters, both moments and the transposed shadows
+    of the single launch behind the backward, bit for bit, eagerly and replayed."""
+    from tvts_amd import arch as A
+    oarch = O.tiny_arch(**A.small_arch())
+    P = O.synth_params(oarch, seed=21)
+    batch = O.synth_batch(oarch, B=4, T=3, seed=22, caption_len=9)
+    res = {}
+    for ranged in (False, True):
+        a = dict(A.small_arch(), adamw_ranges=ranged)
+        for mode in ("eager", "graph"):
+            m, opt, losses, gn = _three_steps(a, P, batch, mode)
+            res[(ranged, mode)] = (m.store.flat.clone(), m.store.m.clone(), m.store.v.clone(), m.store.shadow_t.clone(), losses)
+    ref = res[(False, "eager")]
+    for k, v in res.items():
+        for x, y in zip(ref[:4], v[:4]):
+            assert torch.equal(x, y), k
+        assert v[4] == ref[4], k

@@ -365,9 +365,12 @@ class GradSync:
             dst.copy_(src)
 
     def reduce_range(self, start: int, end: int):
-        """Called once the backward no longer writes grad[start:end]."""
+        """Called once the backward no longer writes grad[start:end].  Returns None, or a callable that makes the CURRENT stream
+        wait for this range's reductions (and casts a bf16 payload back): the optimizer's range-wise update calls it on its own
+        stream in front of the range's AdamW launch; ranges nobody waited for are waited for by finish()."""
         if (self.W == 1 and not self.native) or end <= start:
-            return
+            return None
+        first = len(self.handles)
         for s in range(start, end, self.bucket_elems):
             e = min(end, s + self.bucket_elems)
             if self.stage is not None:
@@ -381,6 +384,20 @@ class GradSync:
                 self.handles.append((None, s, e))
             else:
                 self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), s, e))
+        mine = self.handles[first:]
+
+        def wait():
+            if self.native:
+                NativeComm.get().wait()  # (the current stream waits for everything the side stream has been given so far)
+            for ent in mine:
+                h, s, e = ent
+                if ent in self.handles:
+                    self.handles.remove(ent)
+                    if h is not None:
+                        h.wait()
+                    if self.stage is not None:
+                        self._cast(self.stage[s:e], self.g[s:e])
+        return wait
 
     def finish(self) -> float:
         """Wait for outstanding reductions; returns the scale (1/W) still to be applied to the sum."""

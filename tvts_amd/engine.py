@@ -69,6 +69,7 @@ class ParamStore:
         for i, t in enumerate(tiles):
             rec[i] = t
         self.n_tiles = len(tiles)
+        self.tile_src = [t[0] for t in tiles]  # (ascending: parameter order) -> tiles of a flat range by bisection
         self.tile_table = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
         # patch-embedding GEMM: K = 3*p*p must be a multiple of 64 for the MFMA kernel; H/14 (588) gets a zero-padded copy
         self.conv_name = "video_model.patch_embed.proj.weight" if arch.get("family") == "v1" else "video_model.conv1.weight"
@@ -119,12 +120,19 @@ class ParamStore:
         o, s = self.toff[name], self.shapes[name]
         return self.shadow_t[o:o + self._n(name)].view(-1, s[0])
 
-    def refresh_shadows(self, cast: bool = True):
+    def refresh_transposed(self, s: int, e: int):
+        """the transposed shadows of the MFMA weights inside the flat element range [s, e) (tiles are stored in parameter order)"""
+        import bisect
+        lo, hi = bisect.bisect_left(self.tile_src, s), bisect.bisect_left(self.tile_src, e)
+        if hi > lo:
+            K.transpose_batched(self.shadow, self.shadow_t, self.tile_table[lo * 32:hi * 32], hi - lo)
+
+    def refresh_shadows(self, cast: bool = True, transposed: bool = True):
         """fp32 master -> bf16 shadow (+ transposed copies).  cast=False when the fused AdamW kernel
-        already wrote the plain shadow."""
+        already wrote the plain shadow; transposed=False when refresh_transposed has covered every range."""
         if cast:
             K.cast_f32_bf16(self.flat, self.shadow)
-        if self.n_tiles:
+        if self.n_tiles and transposed:
             K.transpose_batched(self.shadow, self.shadow_t, self.tile_table, self.n_tiles)
         if self.conv_pad is not None:
             K.pad_rows_bf16(self.w(self.conv_name), self.conv_pad)
@@ -260,7 +268,8 @@ class Engine:
         self._tick = 0
         self.requires_grad = {name: True for name in store.shapes}
         self.ctx: dict = {}
-        self.grad_ready = None  # optional callback(start, end): flat grad range is final (GradSync.reduce_range)
+        self.grad_ready = None  # optional callback(start, end): flat grad range is final (GradSync.reduce_range); may return a wait()
+        self.param_ready = None  # optional callback(start, end, wait): the range may be stepped (FusedHFAdamW.step_range)
         self.embeds_ready = None  # optional callback(text_emb, video_emb): both embeddings exist, the sort head has not run yet
         self._ranges: dict = {}
 
@@ -269,10 +278,12 @@ class Engine:
         (contiguous in state-dict order, whichever registration order the architecture uses) to the gradient sync --
         maximal runs of TRAINABLE tensors only: the frozen text layers below the tune range (train_dist..:89-96, ~28 M
         parameters of all-zero gradient for ViT-B/16) never travel."""
-        if self.grad_ready is None:
+        if self.grad_ready is None and self.param_ready is None:
             return
         for lo, hi in self.trainable_runs(prefixes):
-            self.grad_ready(lo, hi)
+            wait = self.grad_ready(lo, hi) if self.grad_ready is not None else None
+            if self.param_ready is not None:  # the optimizer's update of the range, beside the remaining backward
+                self.param_ready(lo, hi, wait)
 
     def trainable_runs(self, prefixes):
         P = self.P

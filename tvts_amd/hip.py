@@ -937,7 +937,7 @@ def add_rows_f32(dst, src):
 
 def transpose_batched(src, dst, tiles, ntiles):
     lib = _lib.load()
-    with _hbm("weight_transpose", 4.0 * dst.numel()):
+    with _hbm("weight_transpose", 4.0 * 64 * 64 * ntiles):
         rc = lib.tvts_transpose_bf16_batched(_p(src), _p(dst), _p(tiles), ntiles, _stream())
     _chk(rc, "tvts_transpose_bf16_batched")
 

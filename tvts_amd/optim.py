@@ -51,6 +51,8 @@ class FusedHFAdamW(torch.optim.Optimizer):
         self.hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)  # lr[4] | wd[4] for captured launches
         self._hyper_host = None
         self.grad_scale = 1.0
+        self._ranged = None      # (hyper-parameters, device_step, [chunk ranges done]) between begin_ranges() and step()
+        self._opt_stream = None
 
     def _hyper(self):
         b1, b2 = self.param_groups[0]["betas"]
@@ -87,9 +89,8 @@ class FusedHFAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         self.store.grad.zero_()
 
-    @torch.no_grad()
-    def step(self, closure=None, device_step: bool = False):
-        """device_step=True keeps the step counter in device memory (hipGraph replay)."""
+    def _begin(self, device_step: bool):
+        """counters of a new optimizer step (once per step, in front of its first launch)"""
         b1, b2, eps, lr4, wd4 = self._hyper()
         capturing = torch.cuda.is_current_stream_capturing()
         if device_step and not capturing:
@@ -101,15 +102,69 @@ class FusedHFAdamW(torch.optim.Optimizer):
             self.step_dev.add_(1)
         else:
             self.step_dev.fill_(self.global_step)  # keeps the device counter in step when eager and captured steps mix
-        K.adamw_hf(self.store.flat, self.store.grad, self.store.m, self.store.v, self.store.shadow, self.chunk_group,
+        return b1, b2, eps, lr4, wd4
+
+    def _launch(self, lo: int, hi: int, hp, device_step: bool):
+        """the update of the chunks [lo, hi) of the flat buffers + the transposed shadows of the weights inside them"""
+        b1, b2, eps, lr4, wd4 = hp
+        st = self.store
+        s, e = lo * CH, hi * CH
+        K.adamw_hf(st.flat[s:e], st.grad[s:e], st.m[s:e], st.v[s:e], st.shadow[s:e], self.chunk_group[lo:hi],
                    lr4, wd4, self.global_step, b1, b2, eps, self.grad_scale, step_dev=self.step_dev if device_step else None,
                    hyper_dev=self.hyper_dev if device_step else None)
-        self.store.refresh_shadows(cast=False)
+        st.refresh_transposed(s, e)
+
+    @torch.no_grad()
+    def step(self, closure=None, device_step: bool = False):
+        """device_step=True keeps the step counter in device memory (hipGraph replay).  After begin_ranges() / step_range() calls
+        this finishes the step: the chunks no range has covered yet."""
+        nch = self.chunk_group.numel()
+        if self._ranged is None:
+            hp = self._begin(device_step)
+            K.adamw_hf(self.store.flat, self.store.grad, self.store.m, self.store.v, self.store.shadow, self.chunk_group,
+                       hp[3], hp[4], self.global_step, hp[0], hp[1], hp[2], self.grad_scale, step_dev=self.step_dev if device_step else None,
+                       hyper_dev=self.hyper_dev if device_step else None)
+            self.store.refresh_shadows(cast=False)
+        else:
+            hp, dstep, done = self._ranged
+            self._ranged = None
+            cur = torch.cuda.current_stream(self.store.device)
+            if self._opt_stream is not None and done:
+                cur.wait_stream(self._opt_stream)  # every range launched beside the backward has landed
+            pos = 0
+            for lo, hi in sorted(done) + [(nch, nch)]:
+                if lo > pos:
+                    self._launch(pos, lo, hp, dstep)
+                pos = max(pos, hi)
+            self.store.refresh_shadows(cast=False, transposed=False)  # what is not per-range: K-padded conv weight, e4m3 copies
         if self.model is not None:
             self.model.mark_shadows_fresh()
         if not device_step:
             for st in self.state.values():
                 st["step"] = self.global_step
+
+    # ---- the update range by range, beside the backward (round 5).  The hand-written backward reports every parameter range whose
+    # gradient is final (Engine._ready -> param_ready); its update -- HBM-bound, 30 B per parameter -- then runs on a stream of its
+    # own under the remaining backward instead of behind it: the layer's weights are not read again before the next forward.
+    # begin_ranges() once per step in front of the backward, step_range(lo, hi) per finished range (elements of the flat buffers,
+    # chunk-aligned as Engine.trainable_runs hands them out), step() afterwards for whatever no range covered.
+    def begin_ranges(self, device_step: bool = False):
+        self._ranged = (self._begin(device_step), device_step, [])
+
+    def step_range(self, lo_elem: int, hi_elem: int, wait=None):
+        """wait: callable run on the optimizer stream in front of the launch (the range's all-reduce completing)"""
+        if self._ranged is None:
+            raise RuntimeError("FusedHFAdamW.step_range outside begin_ranges() ... step()")
+        hp, dstep, done = self._ranged
+        lo, hi = lo_elem // CH, -(-hi_elem // CH)
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.store.device)
+        self._opt_stream.wait_stream(torch.cuda.current_stream(self.store.device))
+        with torch.cuda.stream(self._opt_stream), K.lane(2):
+            if wait is not None:
+                wait()
+            self._launch(lo, hi, hp, dstep)
+        done.append((lo, hi))
 
     def load_state_dict(self, state_dict):
         """Accepts the HF-AdamW / torch layout: state keyed by the running parameter index."""

@@ -5,6 +5,7 @@ hand-written backward (gradients all-reduced range by range while it runs) -> fu
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -22,6 +23,13 @@ class StepRunner:
         self.fused = hasattr(optimizer, "chunk_group")
         self.eng.grad_ready = self.sync.reduce_range if (self.sync.W > 1 or self.sync.native) else None
         self.gather = D.EmbedGather()
+        # OPT-IN (arch["adamw_ranges"] / TVTS_ADAMW_RANGES=1): the fused optimizer's update range by range beside the backward
+        # (FusedHFAdamW.step_range), each range as soon as its gradient is final.  Built for the reference's per-GPU batches, where
+        # the single AdamW launch + the transposes are 1.0 of 15.6 ms, and MEASURED SLOWER at every batch (profiles/r05_adamw_ranges.txt:
+        # 12 / 24 / 192 pairs 757 / 987 / 1354 pairs/s with it against 774 / 1022 / 1363 without): an HBM-bound 4.7 GB pass takes the
+        # bandwidth and the CUs it runs on away from the backward it was meant to hide under, and its ~18 fork edges cost the replayed
+        # graph what the r04 side-stream experiments already showed.  Same bits either way (tests/test_bench_path_gpu.py).
+        self.ranged = self.fused and hasattr(optimizer, "step_range") and bool(self.eng.arch.get("adamw_ranges", os.environ.get("TVTS_ADAMW_RANGES", "0") == "1"))
 
     def losses_and_grads(self, pb, te, ve, pred, labels):
         B = pb["B"]
@@ -56,7 +64,14 @@ class StepRunner:
         finally:
             self.eng.embeds_ready = None
         loss1, loss2, d_te, d_ve, dpred = self.losses_and_grads(pb, te, ve, pred, labels)
-        self.eng.backward(d_te, d_ve, dpred)
+        if self.ranged:
+            self.opt.grad_scale = 1.0 / self.sync.W
+            self.opt.begin_ranges(device_step=device_step)
+            self.eng.param_ready = self.opt.step_range
+        try:
+            self.eng.backward(d_te, d_ve, dpred)
+        finally:
+            self.eng.param_ready = None
         if hasattr(self.eng, "end_step"):
             self.eng.end_step()  # (e4m3 weight gradients: this step's amax values become the next step's per-tensor scales)
         scale = self.sync.finish()
