@@ -82,6 +82,9 @@ def check_grads(store, grads, gn_tol=0.01, cos_tol=0.995):
     worst.sort()
     assert abs(tot - tot_ref) < gn_tol * tot_ref, (tot, tot_ref, worst[:5])
     assert worst[0][0] > cos_tol, worst[:8]
+    if gn_tol > 0.01:  # the e4m3 paths: report the margins their (wider) gates leave (pytest -s)
+        print(f"   [margins] gradient norm {tot / tot_ref - 1:+.3%} (gate {gn_tol:.0%}), worst tensor cosines "
+              + ", ".join(f"{c:.4f} {k.split('resblocks.')[-1]}" for c, k, *_ in worst[:3]) + f" (gate {cos_tol})")
     return tot, tot_ref, worst
 
 
@@ -559,7 +562,8 @@ def test_fp8_forward_path(gpu):
     """BASELINE config 4's weight / activation format on a small model: the six linear layers of every ViT block run their
     FORWARD product on per-tensor-scaled e4m3 copies (tvts_gemm_nt_fp8), the backward keeps the bf16 operands.  Checked
     against the oracle with the same quantise -> dequantise emulation (tight), and against the unquantised fp32 oracle
-    (the fp8 tolerance: cosine >= 0.995, |d loss| <= 5e-2, gradient direction >= 0.95 per tensor)."""
+    (the fp8 tolerance: cosine >= 0.995, |d loss| <= 5e-2, gradient direction >= 0.97 per tensor, gradient norm within 3 %;
+    every e4m3 gate of this file carries the margin measured on an MI355X beside it -- `pytest -s` prints the current ones)."""
     from tvts_amd import arch as A
     a = A.small_arch(fp8=True)
     m, oarch, P = build(arch=a, seed=3)
@@ -572,7 +576,8 @@ def test_fp8_forward_path(gpu):
     assert abs(l1 - r1) < 2e-2 and abs(l2 - r2) < 2e-2, (l1, r1, l2, r2)
     # rounding decisions differ between the bf16-fed kernel and the fp32-fed emulation for values near an e4m3 tie; the
     # temperature-0.05 softmax amplifies that into the text tower's gradients
-    tot, tot_ref, worst = check_grads(store, grads, gn_tol=0.05, cos_tol=0.9)
+    # measured (round 5, MI355X): gradient norm +0.5 %, worst tensor cosine 0.989 (text_ln_final.bias), ViT tensors >= 0.991
+    tot, tot_ref, worst = check_grads(store, grads, gn_tol=0.03, cos_tol=0.97)
     # and against the unquantised model: the price of e4m3
     oa32 = dict(oarch, fp8=False)
     f1, f2, fte, fve, fpred, fgrads = oracle_step(P, batch, oa32)
@@ -593,7 +598,8 @@ def test_fp8_forward_path_h14_structure(gpu):
     assert rel(te, rte) < 0.02
     assert min_cos(ve, rve) > 0.999 and rel(ve, rve) < 0.04, (min_cos(ve, rve), rel(ve, rve))
     assert abs(l1 - r1) < 2e-2 and abs(l2 - r2) < 2e-2, (l1, r1, l2, r2)
-    check_grads(store, grads, gn_tol=0.05, cos_tol=0.9)
+    # measured: gradient norm -0.8 %, worst tensor cosine 0.994 (block 1 mlp.c_proj.weight)
+    check_grads(store, grads, gn_tol=0.03, cos_tol=0.97)
     f1, f2, fte, fve, fpred, fgrads = oracle_step(P, batch, dict(oarch, fp8=False))
     assert min_cos(ve, fve) > 0.995 and abs(l1 - f1) < 5e-2 and abs(l2 - f2) < 5e-2, (min_cos(ve, fve), l1, f1, l2, f2)
 
@@ -615,7 +621,8 @@ def test_fp8_dgrad_path(gpu, h14):
     k1, k2, te1, ve1, pred1, store = engine_step(m1, batch)
     assert len(store.w8t) == len(store.w8) == 6 * oarch["layers"]
     assert torch.equal(ve1, ve) and torch.equal(te1, te) and k1 == l1 and k2 == l2   # same forward
-    check_grads(store, grads, gn_tol=0.05, cos_tol=0.9)
+    # measured (B-style / H/14-style): gradient norm -0.3 % / -0.8 %, worst tensor cosine 0.991 (mlp.c_fc.weight) / 0.991 (ln_2.weight)
+    check_grads(store, grads, gn_tol=0.03, cos_tol=0.97)
     g1 = store.grad
     cos = float(torch.nn.functional.cosine_similarity(g0.double().flatten(), g1.double().flatten(), dim=0))
     assert cos > 0.995 and abs(float(g1.double().norm()) / float(g0.double().norm()) - 1) < 0.02, cos
@@ -647,7 +654,9 @@ def test_fp8_wgrad_path(gpu, h14):
     assert bool((m1.engine._f8_scale[:n] > 0).all()) and float(m1.engine._f8_amax.abs().max()) == 0.0
     q1, q2, te2, ve2, pred2, store = engine_step(m1, batch)        # per-tensor scales, e4m3 weight gradients
     assert min_cos(ve2, rve) > 0.999 and min_cos(te2, rte) > 0.9995 and abs(q1 - r1) < 5e-2 and abs(q2 - r2) < 5e-2, (q1, r1, q2, r2)
-    check_grads(store, grads, gn_tol=0.05, cos_tol=0.9)
+    # measured (B-style / H/14-style): gradient norm +1.2 % / -0.8 %, worst tensor cosine 0.984 / 0.987 (the MLP weights, whose
+    # operands are e4m3 on both sides of all three products): the gates sit 1.5-2 % under what is measured, not at 0.9
+    check_grads(store, grads, gn_tol=0.03, cos_tol=0.97)
     g2 = store.grad.clone()
     cos = float(torch.nn.functional.cosine_similarity(g0.double().flatten(), g2.double().flatten(), dim=0))
     assert cos > 0.99 and abs(float(g2.double().norm()) / float(g0.double().norm()) - 1) < 0.03, cos

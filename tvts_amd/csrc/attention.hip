@@ -55,6 +55,8 @@ struct AttnGeom {
     int W;                  // heads * 64
     float scale2;           // dh^-0.5 * log2(e)
     float scale;            // dh^-0.5
+    int q8_only;            // fused divided kernels with a q8 copy: 1 = the patch rows' bf16 values are NOT stored (opts bit 7; the CLS
+                            // row, which the merge / finalize kernels write, keeps both forms)
     int ablate;             // dev knob (opts bits 4..6 of tvts_attn_bwd): 1 skip phase A, 2 skip phase B, 4 skip global loads
     const int* kv_len;      // FULL only, optional: valid keys per sequence (keys >= kv_len[b] are padding and masked)
     int cls_nq, cls_q0;     // CLS geometry generalised: cls_nq (<= 16) queries at tokens cls_q0 .. of the sequence (1, 0 = the CLS token)
@@ -75,8 +77,9 @@ struct AttnGeom {
 // per-thread state of that copy
 struct Q8Out {
     const bf16* ref; unsigned char* q8; float inv; float am;
+    bool only;  // the e4m3 copy is the ONLY output of the fused kernels' patch rows (g.q8_only): no bf16 row is stored
     __device__ __forceinline__ void init(const AttnGeom& g) {
-        ref = g.q8_ref; q8 = g.q8; am = 0.f; inv = 0.f;
+        ref = g.q8_ref; q8 = g.q8; am = 0.f; inv = 0.f; only = g.q8 && g.q8_only;
         if (q8) { const float sc = g.q8_scale[0]; inv = sc > 0.f ? 1.0f / sc : 1.0f; }
     }
     __device__ __forceinline__ void emit8(const bf16* dst8, const bf16x8& w) {  // the 8 values stored at dst8, as 8 e4m3 bytes
@@ -257,7 +260,7 @@ __device__ __forceinline__ void store_tile_rows(char* patch, const f32x4 (&v)[DT
         const bf16x8 w = *(const bf16x8*)(patch + rrow * 64 + ((rc ^ (rrow & 3)) << 4));
         asm volatile("" ::: "memory");
         if (dst && 2 * d2 + (rc >> 1) < DT) {
-            *(bf16x8*)(dst + d2 * 32 + rc * 8) = w;
+            if (!(q8o && q8o->only)) *(bf16x8*)(dst + d2 * 32 + rc * 8) = w;
             if (q8o && q8o->q8) q8o->emit8(dst + d2 * 32 + rc * 8, w);
         }
     }
@@ -2277,6 +2280,7 @@ static int make_geom(AttnGeom& g, int mode, int B, int heads, int S, int T, int 
     g.q8_ref = nullptr; g.q8 = nullptr; g.q8_scale = nullptr; g.q8_amax = nullptr;
     g.scale = 1.0f / sqrtf((float)DH);
     g.scale2 = g.scale * 1.4426950408889634f;
+    g.q8_only = 0;
     g.ablate = 0;  // timing-ablation bits of the fused backward (opts bits 4..6 of tvts_attn_bwd; results are wrong by construction)
     return TVTS_OK;
 }
@@ -2659,6 +2663,7 @@ static int bwd_impl(int mode, const void* qkv, int ld, int B, int heads, int S, 
     const bool parts_ok = want_parts > 0 && cls_acc && cls_acc_elems >= (long)B * heads * want_parts * 3 * DH;
     g.cls_parts = parts_ok ? want_parts : 0;
     g.ablate = (opts >> 4) & 7;
+    g.q8_only = (q8out && (opts & 128)) ? 1 : 0;
     if (divided && !parts_ok) {
         if (!cls_acc || cls_acc_elems < (long)B * heads * 3 * DH) return TVTS_EINVAL;
         // a kernel, not hipMemsetAsync: captured memset nodes did not reliably zero this buffer on hipGraph replay (ROCm 7.x:
@@ -2752,6 +2757,7 @@ static int fwd_divided_impl(int mode, const void* qkv, int ld, int B, int heads,
     if (q8out) {  // the e4m3 copy is addressed like the bf16 output: same leading dimension (in bytes), 8-byte pieces
         if (ldq8 != ldo || ldo % 8 || !q8_scale) return TVTS_EINVAL;
         g.q8_ref = (const bf16*)out; g.q8 = (unsigned char*)q8out; g.q8_scale = q8_scale; g.q8_amax = q8_amax;
+        g.q8_only = (opts & 128) ? 1 : 0;
     }
     const bool fs = fused && use_tr && mode == MODE_SPACE && n + 1 <= FUSED_MAX_TILES * 16;
     const bool ft = fused && use_tr && mode == MODE_TIME && T + 1 <= 32;

@@ -670,20 +670,27 @@ class Engine:
                              N=N, L=L, tok_sort=tok_sort)
 
     # ------------------------------------------------------------------ video tower
-    def _attn_q8(self, M, W, name, T, n, persistent=False):
+    def _attn_q8(self, M, W, name, T, n, persistent=False, consumer=None):
         """the divided-attention kernels write the per-tensor e4m3 copy of their result themselves (tensor mode, fused geometries;
         arch["fp8_attn_copies"] = False keeps the quantiser pass: same bytes, tests/test_model_gpu.py::test_fp8_wgrad_path)"""
         if not (self.fp8_wgrad and self._f8_tensor_mode and self.arch.get("fp8_attn_copies", True)) or n + 1 > 112 or T + 1 > 32:
             return {}, None
         q, sc, kw = self._q8(M, W, name, persistent=persistent)
-        return dict(q8out=q, q8_scale=sc, q8_amax=kw["amax"]), (q, sc)
+        out = dict(q8out=q, q8_scale=sc, q8_amax=kw["amax"])
+        # arch["fp8_q8_only"]: the e4m3 bytes are the kernels' only output for the patch rows -- every consumer of the attention
+        # output (projection forward / weight gradient) and of the attention input gradient (qkv input / weight / bias gradient)
+        # multiplies the e4m3 copy; the CLS rows, which the CLS-row delta, the hybrid stream's fix-up GEMM and the merge / finalize
+        # kernels touch, keep both forms
+        if self.fp8_q8_only and consumer is not None and self.requires_grad[consumer]:
+            out["q8_only"] = True
+        return out, (q, sc)
 
     def _st_attention_fwd(self, qkv, att, lse, mode, B, T, n, q8_for=None):
         h, S = self.arch["heads"], 1 + T * n
         ws = self._f("vit.clsws", (B * h * max(T, -(-n // 28)) * (self.dh + 2),))
         kw8 = {}
         if q8_for is not None and q8_for in self.P.w8:
-            kw8, nxt = self._attn_q8(B * S, att.shape[1], "x." + q8_for, T, n, persistent=True)
+            kw8, nxt = self._attn_q8(B * S, att.shape[1], "x." + q8_for, T, n, persistent=True, consumer=q8_for)
             if nxt is not None:
                 self._x8_ready[q8_for] = nxt
         K.attn_fwd_divided(mode, qkv, att, lse, ws, B=B, heads=h, S=S, T=T, n=n, head_dim=self.dh, **kw8)
@@ -693,7 +700,7 @@ class Engine:
         M = B * S
         kw8 = {}
         if q8_for is not None and q8_for in self.P.w8t:
-            kw8, nxt = self._attn_q8(M, dqkv.shape[1], "dy." + q8_for, T, n)
+            kw8, nxt = self._attn_q8(M, dqkv.shape[1], "dy." + q8_for, T, n, consumer=q8_for if q8_for in self._x8 else None)
             if nxt is not None:
                 self._dy8_ready[q8_for] = nxt
         delta = self._f(scr + ".delta", (M, h))

@@ -139,12 +139,13 @@ def tn_opts(tile=None, splits=None, early_dma=None, a_fast=None, streamk=None):
     return o
 
 
-def attn_opts(tr=None, shared=None, fused=None, ablate=None):
+def attn_opts(tr=None, shared=None, fused=None, ablate=None, q8_only=False):
     tr = _OPTS["attn_tr"] if tr is None else tr
     shared = _OPTS["attn_shared"] if shared is None else shared
     fused = _OPTS["attn_fused"] if fused is None else fused
     ablate = _OPTS["attn_ablate"] if ablate is None else ablate
-    return (0 if tr else 1) | (0 if shared else 2) | (0 if fused else 4) | ((int(ablate) & 7) << 4)
+    # bit 7: with a q8 copy, the fused divided kernels do not store the bf16 patch rows (the e4m3 bytes are their only output)
+    return (0 if tr else 1) | (0 if shared else 2) | (0 if fused else 4) | ((int(ablate) & 7) << 4) | (128 if q8_only else 0)
 
 
 def gemm_nt_select(M, N, tile=None):
