@@ -151,6 +151,11 @@ int tvts_fp8_update_scales(float* amax, float* scale, int n, hipStream_t stream)
  * sim_matrix model_dist..B_16.py:126): C[i,j] (+)= alpha * sum_k A[i*sai+k*sak] * B[k*sbk+j*sbj] + bias[j] */
 int tvts_gemm_small_f32(const float* A, long sai, long sak, const float* B, long sbk, long sbj, int M, int N, int K,
                         float alpha, const float* bias, float* C, long ldc, int accumulate, hipStream_t stream);
+/* a FEW rows through a linear layer with fp32 result and fp32 residual: out[r, n] = residual[r, n] + bias[n] + sum_k A[r * lda + k] W[n * ldw + k]
+ * (A, W bf16; N % 16 == 0, K % 32 == 0; bias / residual optional).  The CLS rows of the hybrid residual stream through the blocks'
+ * residual-adding projections (`x + attn(...)`, `x + mlp(...)`, video_encoder_ViT_B_16.py:121-124): one row per clip, lda = S * K. */
+int tvts_rows_linear_bf16(const void* A, long lda, const void* W, int ldw, int R, int N, int K, const float* bias, const float* residual,
+                          int ldr, float* out, int ldo, hipStream_t stream);
 /* bias gradient: out[n] += sum_m X[m,n].  workspace (optional): partial sums of row ranges, added in range order (deterministic, and
  * a grid over the rows as well as the columns); without it one block per 64 columns walks every row */
 int tvts_colsum_bf16(const void* X, int ld, int M, int N, float* out, float* workspace, long workspace_elems, hipStream_t stream);

@@ -332,6 +332,26 @@ def test_gemm_tn_grouped_gives_the_bits_of_the_single_launches(K):
         assert torch.equal(outs4[i], outs[i]), i
 
 
+@pytest.mark.parametrize("R,N,Kd,S", [(12, 768, 768, 785), (192, 768, 3072, 785), (2, 1280, 5120, 1217), (5, 64, 96, 3), (48, 1280, 1280, 7)])
+def test_rows_linear(K, R, N, Kd, S):
+    """tvts_rows_linear_bf16: a few STRIDED rows (the CLS token of every clip: row stride S * K of the block's [B * S, K] operand)
+    through a linear layer with fp32 result and fp32 residual -- the hybrid residual stream's fix-up of `x + proj(...)` -- against the
+    fp64 product of the same bf16 operands."""
+    a_all = bf(rnd(R * S, Kd, seed=70)).to(DEV)
+    w = bf(rnd(N, Kd, seed=71) * 0.05).to(DEV)
+    bias, res = rnd(N, seed=72).to(DEV), rnd(R, N, seed=73).to(DEV)
+    a = a_all.view(R, S * Kd)[:, :Kd]
+    out = torch.full((R, N), float("nan"), device=DEV)
+    K.rows_linear(a, w, out, bias=bias, residual=res)
+    ref = res.double().cpu() + bias.double().cpu() + a.float().cpu().double() @ w.float().cpu().double().t()
+    assert rel(out, ref) < 2e-6, rel(out, ref)
+    out2 = torch.full((R, N), float("nan"), device=DEV)
+    K.rows_linear(a, w, out2)
+    assert rel(out2, a.float().cpu().double() @ w.float().cpu().double().t()) < 2e-6
+    K.rows_linear(a, w, out2, bias=bias, residual=res)
+    assert torch.equal(out, out2)  # fixed summation order
+
+
 def test_gemm_tn_tile_selection(K):
     """The plan of the weight-gradient entry point (a cost model of tile and range count, csrc/gemm.hip; tools/tn_plan_check.py
     measures it against both tiles' best): the long contractions of the 192-pair step take the 256x256 kernel -- the text tower's

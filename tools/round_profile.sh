@@ -11,7 +11,9 @@ cd $GRAFT_REPO_ROOT
 python -c "import torch" > /dev/null 2>&1
 python bench.py --steps 20 --warmup 5 > $out/bench_default_b192.json 2> $out/bench_default.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dense-sort-head 2>/dev/null | grep '^{' > $out/bench_dense_sort_head.json
-tools/profile_step.sh ${tag}_default > $out/profile_step.log 2>&1
+# (the text tower in line: in the timed steps it runs on its own stream beside the ViT, and a kernel's traced duration would then
+#  include the time it shared the chip with the other stream's kernels -- same kernels, same bits either way)
+tools/profile_step.sh ${tag}_default --text-side off > $out/profile_step.log 2>&1
 cp gpurun_out/prof_${tag}_default/summary.txt $out/kernel_summary_default_b192.txt
 cp gpurun_out/prof_${tag}_default/kernel_stats.csv $out/kernel_stats_default_b192.csv
 tools/pmc_traffic.sh > $out/pmc_traffic.log 2>&1
@@ -28,13 +30,14 @@ python tools/pmc_join.py gpurun_out/gemm_order.json gpurun_out > $out/pmc_gemm_t
   python bench.py --arch H_14 --frames 16 --batch 48 --steps 8 --warmup 3 --no-cpu-baseline --fp8
   python bench.py --arch H_14 --frames 16 --batch 48 --steps 8 --warmup 3 --no-cpu-baseline --fp8-dgrad
   python bench.py --arch H_14 --frames 16 --batch 48 --steps 8 --warmup 3 --no-cpu-baseline --fp8-wgrad; } 2>/dev/null | grep '^{' > $out/bench_h14_t16_b48.jsonl
-tools/profile_step.sh ${tag}_h14fp8 --arch H_14 --frames 16 --batch 48 --fp8-wgrad > $out/profile_h14fp8.log 2>&1
+tools/profile_step.sh ${tag}_h14fp8 --arch H_14 --frames 16 --batch 48 --fp8-wgrad --text-side off > $out/profile_h14fp8.log 2>&1
 cp gpurun_out/prof_${tag}_h14fp8/summary.txt $out/kernel_summary_h14_b48_fp8_wgrad.txt
 python tools/tn_fp8_bench.py > $out/tn_fp8_bench.txt 2>&1
 PAIRS=48 python tools/gemm_fp8_cmp.py > $out/gemm_fp8_cmp.txt 2>&1
 PAIRS=192 python tools/attn_bench.py > $out/attn_bench.txt 2>&1
 { python bench.py --arch v1 --frames 4 --batch 256 --steps 20 --warmup 5 --cpu-pairs 8
   python bench.py --arch v1 --frames 16 --batch 64 --steps 20 --warmup 5 --no-cpu-baseline; } 2>/dev/null | grep '^{' > $out/bench_v1.jsonl
+PAIRS=192 python tools/attn_ablate.py > $out/attn_ablate.txt 2>&1
 tools/profile_step.sh ${tag}_v1 --arch v1 --frames 4 --batch 256 > $out/profile_v1.log 2>&1
 cp gpurun_out/prof_${tag}_v1/summary.txt $out/kernel_summary_v1_t4_b256.txt
 ls -la $out

@@ -14,7 +14,7 @@ python -c "import torch" > /dev/null 2>&1
 for b in 12 24; do
   d=$out/trace_b$b
   mkdir -p $d
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $d -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch $b --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-roofline > $d/run.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $d -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch $b --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --text-side off > $d/run.log 2>&1)
   db=$(find $d -name '*_results.db' | head -1)
   python tools/prof_summary.py $db $d/kernel_stats.csv 6 > $out/kernel_summary_b$b.txt 2>&1
   python tools/step_timeline.py $db > $out/timeline_b$b.txt 2>&1

@@ -1286,6 +1286,60 @@ extern "C" int tvts_gemm_small_f32(const float* A, long sai, long sak, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// A FEW rows through a linear layer with fp32 residual: out[r, n] = residual[r, n] + bias[n] + sum_k A[r * lda + k] * W[n * ldw + k]
+// (A, W bf16; out / residual fp32) -- the CLS rows of the hybrid residual stream (one row per clip, row stride S * K in the block's
+// [B * S, K] operand).  R is the per-GPU batch (2 ... 192): the tiled kernels would run it as ONE 128- or 256-row tile per output
+// column block -- 6 blocks walking K = 3072 in 48 dependent stages, 12-35 us per launch, 24 launches per step.  Here a block owns a
+// 16 x 16 output tile and its four waves split the contraction (wave w takes the 32-deep steps w, w + 4, ...), operands straight
+// from L2 into the MFMA fragments (a lane's 16 bytes are contiguous in both), partials summed through LDS in wave order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_linear_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ W, int ldw,
+                                                          int R, int N, int K, const float* __restrict__ bias,
+                                                          const float* __restrict__ residual, int ldr, float* __restrict__ out, int ldo) {
+    __shared__ float red[4][16][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, gq = lane >> 4;
+    const int n0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
+    const int row = r0 + li < R ? r0 + li : R - 1;
+    const bf16* ap = A + (size_t)row * lda + gq * 8;
+    const bf16* wp = W + (size_t)(n0 + li) * ldw + gq * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int k = wave * 32;
+    for (; k + 3 * 128 < K; k += 4 * 128) {  // four steps' loads in flight before their MFMAs
+        bf16x8 a[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = *(const bf16x8*)(ap + k + u * 128); w[u] = *(const bf16x8*)(wp + k + u * 128); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], w[u], acc, 0, 0, 0);
+    }
+    for (; k < K; k += 128) {
+        const bf16x8 a = *(const bf16x8*)(ap + k), w = *(const bf16x8*)(wp + k);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, acc, 0, 0, 0);
+    }
+    // lane holds D[m = 4 gq + e][n = li]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][gq * 4 + e][li] = acc[e];
+    __syncthreads();
+    const int m = threadIdx.x >> 4, n = threadIdx.x & 15;
+    if (r0 + m < R) {
+        float v = ((red[0][m][n] + red[1][m][n]) + red[2][m][n]) + red[3][m][n];
+        if (bias) v += bias[n0 + n];
+        if (residual) v += residual[(size_t)(r0 + m) * ldr + n0 + n];
+        out[(size_t)(r0 + m) * ldo + n0 + n] = v;
+    }
+}
+
+extern "C" int tvts_rows_linear_bf16(const void* A, long lda, const void* W, int ldw, int R, int N, int K, const float* bias,
+                                     const float* residual, int ldr, float* out, int ldo, hipStream_t stream) {
+    if (R <= 0 || N <= 0 || K <= 0 || !A || !W || !out) return TVTS_EINVAL;
+    if (N % 16 || K % 32 || lda % 8 || ldw % 8) return TVTS_EINVAL;
+    hipLaunchKernelGGL(rows_linear_kernel, dim3(N / 16, ceil_div(R, 16)), dim3(256), 0, stream, (const bf16*)A, lda, (const bf16*)W, ldw,
+                       R, N, K, bias, residual, ldr, out, ldo);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // bias gradient: out[n] += sum_m X[m,n]  (bf16 in).  A block owns 64 columns and one of gridDim.y row ranges: 8 column threads
 // (8 columns each) x 32 row lanes striding the range, merged through LDS in row-lane order.  With a workspace the row ranges'
 // sums go to partials [range][N] that colsum_ranges_kernel adds in range order -- no atomics, run-to-run reproducible, and

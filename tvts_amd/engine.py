@@ -445,7 +445,7 @@ class Engine:
             K.gemm_nt_fp8(q[:Bc * S].view(Bc, -1)[:, :q.shape[1]], sa, w8, ws, out_c, bias=self.P.p(bname) if bname else None, residual=res_c)
             return
         a_c = a[:Bc * S].view(Bc, -1)[:, :a.shape[1]]
-        K.gemm_nt(a_c, self.P.w(wname), out_c, M=Bc, bias=self.P.p(bname) if bname else None, residual=res_c)
+        K.rows_linear(a_c, self.P.w(wname), out_c, bias=self.P.p(bname) if bname else None, residual=res_c)
 
     # measured (profiles/r04_tn_grouped.txt): B/16 +1.5 % at 12 pairs (M = 9 420), -0.4 % at 24, -2 % at 48; B/32 +1.2 % at its 24 pairs
     # (M = 9 432); H/14 at its 2 pairs (M = 2 434, 1 600 tiles of 128 x 128 per block of the model) -9 %: the window is where it pays

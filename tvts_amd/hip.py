@@ -466,6 +466,16 @@ def gemm_small(a, b, out, *, M, N, K, sa, sb, alpha=1.0, bias=None, accumulate=F
     _chk(rc, "tvts_gemm_small_f32")
 
 
+def rows_linear(a, w, out, *, bias=None, residual=None):
+    """out[R, N] (fp32) = residual + bias + a[R, K] @ w[N, K]^T for a FEW rows (a may be a strided row view: one row per clip)"""
+    lib = _lib.load()
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and out.dtype == torch.float32 and a.stride(1) == 1
+    R, Kd = a.shape
+    N = w.shape[0]
+    _chk(lib.tvts_rows_linear_bf16(_p(a), a.stride(0), _p(w), _ld(w), R, N, Kd, _p(bias), _p(residual),
+                                   _ld(residual) if residual is not None else 0, _p(out), _ld(out), _stream()), "tvts_rows_linear_bf16")
+
+
 def colsum(x, out, *, M=None):
     lib = _lib.load()
     M = x.shape[0] if M is None else M
