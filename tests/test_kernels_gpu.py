@@ -491,7 +491,10 @@ def test_layernorm_on_the_hybrid_stream(K, W, period, q8):
     m0, r0 = torch.empty_like(mean), torch.empty_like(rstd)
     K.layernorm_fwd(x_dev, g, b, 1e-5, y0, m0, r0)
     other = torch.ones(M, dtype=torch.bool); other[cls_rows] = False
-    assert torch.equal(y[other.to(DEV)].view(torch.int16), y0[other.to(DEV)].view(torch.int16))
+    if not q8 and W % 8 == 0:  # (the fused-copy form is the 4-column kernel: same values, another summation order)
+        assert torch.equal(y[other.to(DEV)].view(torch.int16), y0[other.to(DEV)].view(torch.int16))
+    else:
+        assert float((y[other.to(DEV)].float() - y0[other.to(DEV)].float()).abs().max()) <= 2.0 ** -7 * float(y0.float().abs().max())
     if q8:
         q0, rs0 = K.quantize_fp8_rows(y)
         assert torch.equal(q0, kw["q8"]) and torch.equal(rs0[:M], kw["row_scale"][:M])
@@ -1385,15 +1388,19 @@ def test_layernorm_fwd_fp8_output(K, W, xdt):
     q = torch.full((M, W), 3, dtype=torch.uint8, device=DEV)
     rs = torch.empty(M, device=DEV)
     K.layernorm_fwd(x, g, b, 1e-5, y1, m1, r1, q8=q, row_scale=rs)
-    assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1)
-    q_ref, rs_ref = K.quantize_fp8_rows(y0)
+    if xdt == torch.float32:
+        assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    else:  # bf16 rows: the plain forward is the 8-columns-per-lane kernel (round 5), another summation order than the fused-copy form
+        assert torch.allclose(m0, m1, rtol=0, atol=1e-6) and torch.allclose(r0, r1, rtol=1e-6, atol=0)
+        assert float((y0.float() - y1.float()).abs().max()) <= 2.0 ** -7 * float(y0.float().abs().max())  # a last bf16 bit here and there
+    q_ref, rs_ref = K.quantize_fp8_rows(y1)
     assert torch.equal(q, q_ref) and torch.equal(rs, rs_ref)
     # gathered rows (the pooled tail's CLS rows)
     rows = torch.tensor([5, 0, 333, 516], dtype=torch.int32, device=DEV)
     y2 = torch.empty(4, W, dtype=torch.bfloat16, device=DEV)
     q2, rs2 = torch.empty(4, W, dtype=torch.uint8, device=DEV), torch.empty(4, device=DEV)
     K.layernorm_fwd(x, g, b, 1e-5, y2, torch.empty(4, device=DEV), torch.empty(4, device=DEV), rows=rows, q8=q2, row_scale=rs2)
-    assert torch.equal(y2, y0[rows.long()]) and torch.equal(q2, q_ref[rows.long()]) and torch.equal(rs2, rs_ref[rows.long()])
+    assert torch.equal(y2, y1[rows.long()]) and torch.equal(q2, q_ref[rows.long()]) and torch.equal(rs2, rs_ref[rows.long()])
 
 
 @pytest.mark.parametrize("M,Na,Nb", [(5000, 768, 3072), (4097, 256, 128), (12345, 1280, 640)])

@@ -29,3 +29,20 @@ for name, kw, byt in (("bwd ln_2 (res1)", dict(dx=dx, dx_bf16=dxb, res1=res1), 1
     print(f"{name:22s} {t:7.1f} us  {M*W*byt/t/1e6:6.2f} TB/s")
     t = timeit(lambda: K.layernorm_bwd(dy, x, mean, rstd, g, d, **kw))
     print(f"{name:22s} {t:7.1f} us  {M*W*byt/t/1e6:6.2f} TB/s   (no dgamma/dbeta)")
+
+# ---- the all-bf16 forms of the hybrid residual stream (round 5): bf16 x / y, bf16 dy / x / res1 / res2 / dx, CLS rows in fp32 side arrays
+S = 785
+Bc = M // S
+xb = x.bfloat16(); r1b = res1.bfloat16()
+cls = torch.randn(Bc, W, device=dev); cls_r1 = torch.randn(Bc, W, device=dev); cls_dx = torch.empty(Bc, W, device=dev)
+t = timeit(lambda: K.layernorm_fwd(xb, g, b, 1e-5, y, mean, rstd))
+print(f"ln_fwd bf16 rows              {t:7.1f} us  {M*W*4/t/1e6:6.2f} TB/s")
+t = timeit(lambda: K.layernorm_fwd(xb, g, b, 1e-5, y, mean, rstd, cls_x=cls, cls_period=S))
+print(f"ln_fwd bf16 rows + CLS        {t:7.1f} us  {M*W*4/t/1e6:6.2f} TB/s")
+for name, kw, byt in (("bwd ln_2 bf16 (res1)", dict(res1=r1b), 8), ("bwd ln_1 bf16", dict(), 6), ("bwd ln_3 bf16 (res1+res2)", dict(res1=r1b, res2=res2), 10)):
+    t = timeit(lambda: K.layernorm_bwd(dy, xb, mean, rstd, g, None, dx_bf16=dxb, dgamma=dg, dbeta=db, **kw))
+    print(f"{name:30s}{t:7.1f} us  {M*W*byt/t/1e6:6.2f} TB/s")
+    if kw:
+        t = timeit(lambda: K.layernorm_bwd(dy, xb, mean, rstd, g, None, dx_bf16=dxb, dgamma=dg, dbeta=db, cls_period=S, cls_x=cls, cls_res1=cls_r1,
+                                           cls_dx=cls_dx, **kw))
+        print(f"{name + ' + CLS':30s}{t:7.1f} us  {M*W*byt/t/1e6:6.2f} TB/s")

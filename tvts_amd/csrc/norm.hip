@@ -171,6 +171,125 @@ static void launch_ln_fwd_q8(int it, dim3 grid, hipStream_t stream, const TX* x,
 #undef LN_FWD_CASE
 }
 
+// ================================================================================================================================
+// bf16-row forms with EIGHT columns per lane (round 5).  The 4-column kernels above move a bf16 row in 8-byte pieces: the same
+// number of memory instructions as an fp32 row at half the bytes -- and the LayerNorm forward did not get faster when the hybrid
+// stream halved its input bytes (127 us for 0.46 GB at 150 720 x 768 where the fp32-input form took 136 us for 0.69 GB): the
+// kernels are bound by REQUESTS, not bytes.  Here a lane owns 8 consecutive columns (16-byte loads and stores, pair p of a row at
+// columns lane * 8 + p * 512), everything else as above: a wave per row, the next row's loads in flight, two-stage dgamma / dbeta.
+// Used for the bf16 -> bf16 FORWARD of the space-time blocks (W % 8 == 0): 127-134 -> 93-95 us at 150 720 x 768.  The backward forms
+// were built the same way and measured SLOWER than the 4-column kernels (ln_2 199 against 180 us, ln_1 151 against 134, ln_3 236
+// against 243: four input streams of two rows in flight need 180-200 registers, i.e. two blocks per CU instead of three) -- not kept.
+// ================================================================================================================================
+__device__ __forceinline__ void widen8(const bf16x8& t, f32x4& lo, f32x4& hi) {
+    lo = (f32x4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+    hi = (f32x4){(float)t[4], (float)t[5], (float)t[6], (float)t[7]};
+}
+__device__ __forceinline__ bf16x8 narrow8(const f32x4& lo, const f32x4& hi) {
+    return (bf16x8){(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
+}
+
+template <int NP, bool CLS>
+__global__ __launch_bounds__(256) void ln_fwd8_kernel(const bf16* __restrict__ x, int ldx, const int* __restrict__ rows,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                      int M, int W, bf16* __restrict__ y, int ldy, float* __restrict__ mean_out,
+                                                      float* __restrict__ rstd_out, const float* __restrict__ cls_x, int cls_period,
+                                                      bf16* x_refresh) {
+    const int lane = threadIdx.x & 63;
+    const int stride = gridDim.x * 4;
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    f32x4 gm[NP][2], bt[NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = lane * 8 + p * 512 + h * 4;
+            gm[p][h] = c < W ? load4<float>(gamma + c) : (f32x4){0, 0, 0, 0};
+            bt[p][h] = c < W ? load4<float>(beta + c) : (f32x4){0, 0, 0, 0};
+        }
+    const float invW = 1.0f / (float)W;
+    struct Row { bf16x8 raw[NP]; bool cls; };
+    auto load_row = [&](int rr, Row& w) {
+        w.cls = CLS && rr % cls_period == 0;  // (wave-uniform) its value comes from the fp32 side array below
+        if (w.cls) return;
+        const bf16* xp = x + (size_t)(rows ? rows[rr] : rr) * ldx;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int c = lane * 8 + p * 512;
+            if (c < W) w.raw[p] = *(const bf16x8*)(xp + c);
+        }
+    };
+    Row cur, nxt;
+    load_row(r, cur);
+    for (; r < M; r += stride) {
+        const bool more = r + stride < M;
+        if (more) load_row(r + stride, nxt);
+        f32x4 v[NP][2];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int c = lane * 8 + p * 512;
+            v[p][0] = (f32x4){0, 0, 0, 0}; v[p][1] = (f32x4){0, 0, 0, 0};
+            if (c < W) {
+                if (CLS && cur.cls) {
+                    const float* cp = cls_x + (size_t)(r / cls_period) * W + c;
+                    v[p][0] = load4<float>(cp); v[p][1] = load4<float>(cp + 4);
+                } else {
+                    widen8(cur.raw[p], v[p][0], v[p][1]);
+                }
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) s += v[p][h][0] + v[p][h][1] + v[p][h][2] + v[p][h][3];
+        const float mean = wave_sum(s) * invW;
+        float q = 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            if (lane * 8 + p * 512 < W) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[p][h][e] - mean; q += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum(q) * invW + eps);
+        const bool refresh = CLS && cur.cls && x_refresh;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int c = lane * 8 + p * 512;
+            if (c < W) {
+                f32x4 o[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[h][e] = (v[p][h][e] - mean) * rstd * gm[p][h][e] + bt[p][h][e];
+                *(bf16x8*)(y + (size_t)r * ldy + c) = narrow8(o[0], o[1]);
+                if (refresh) *(bf16x8*)(x_refresh + (size_t)r * ldx + c) = narrow8(v[p][0], v[p][1]);
+            }
+        }
+        if (lane == 0) {
+            if (mean_out) mean_out[r] = mean;
+            if (rstd_out) rstd_out[r] = rstd;
+        }
+        if (more) cur = nxt;
+    }
+}
+
+template <bool CLS>
+static void launch_ln_fwd8(hipStream_t stream, const bf16* x, int ldx, const int* rows, const float* gamma, const float* beta,
+                           float eps, int M, int W, bf16* y, int ldy, float* mean, float* rstd, const float* cls_x = nullptr,
+                           int cls_period = 0, bf16* x_refresh = nullptr) {
+    int blocks = ceil_div(M, 4);
+    if (blocks > 2048) blocks = 2048;
+    const int np = ceil_div(W, 512);
+#define LN8_CASE(N) case N: hipLaunchKernelGGL((ln_fwd8_kernel<N, CLS>), dim3(blocks), dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd, cls_x, cls_period, x_refresh); break;
+    switch (np) { LN8_CASE(1) LN8_CASE(2) default: LN8_CASE(3) }
+#undef LN8_CASE
+}
+static inline bool ln8_ok(int W, int ld_a, int ld_b) { return W % 8 == 0 && W <= 1536 && ld_a % 8 == 0 && ld_b % 8 == 0; }
+
 // LayerNorm forward that also emits the e4m3 copy of its bf16 output with per-row scales (see Q8 above)
 extern "C" int tvts_layernorm_fwd_fp8(const void* x, int ldx, int x_bf16, const int* rows, const float* gamma, const float* beta,
                                       float eps, int M, int W, void* y, int ldy, void* q8, int ldq, float* row_scale,
@@ -194,7 +313,8 @@ extern "C" int tvts_layernorm_fwd(const void* x, int ldx, int x_bf16, const int*
     int blocks = ceil_div(M, 4);
     if (blocks > 2048) blocks = 2048;  // 8 blocks x 4 waves per CU, two rows in flight per wave
     const int it = ceil_div(W, 256);
-    if (x_bf16) launch_ln_fwd<bf16, bf16>(it, dim3(blocks), stream, (const bf16*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd);
+    if (x_bf16 && ln8_ok(W, ldx, ldy)) launch_ln_fwd8<false>(stream, (const bf16*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd);
+    else if (x_bf16) launch_ln_fwd<bf16, bf16>(it, dim3(blocks), stream, (const bf16*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd);
     else if (y_f32) launch_ln_fwd<float, float>(it, dim3(blocks), stream, (const float*)x, ldx, rows, gamma, beta, eps, M, W, (float*)y, ldy, mean, rstd);
     else launch_ln_fwd<bf16, float>(it, dim3(blocks), stream, (const float*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd);
     TVTS_LAUNCH_CHECK();
@@ -215,8 +335,10 @@ extern "C" int tvts_layernorm_fwd_cls(const void* x, int ldx, const float* cls_x
     const int it = ceil_div(W, 256);
     if (q8) launch_ln_fwd_q8<bf16, true>(it, dim3(blocks), stream, (const bf16*)x, ldx, nullptr, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd,
                                    (unsigned char*)q8, ldq, row_scale, tscale, amax_acc, cls_x, cls_period, (bf16*)x_refresh);
+    else if (ln8_ok(W, ldx, ldy)) launch_ln_fwd8<true>(stream, (const bf16*)x, ldx, nullptr, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd,
+                                                        cls_x, cls_period, (bf16*)x_refresh);
     else launch_ln_fwd<bf16, bf16, true>(it, dim3(blocks), stream, (const bf16*)x, ldx, nullptr, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd,
-                                   cls_x, cls_period, (bf16*)x_refresh);
+                                         cls_x, cls_period, (bf16*)x_refresh);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
 }
