@@ -179,7 +179,8 @@ static void launch_ln_fwd_q8(int it, dim3 grid, hipStream_t stream, const TX* x,
 // columns lane * 8 + p * 512), everything else as above: a wave per row, the next row's loads in flight, two-stage dgamma / dbeta.
 // Used for the bf16 -> bf16 FORWARD of the space-time blocks (W % 8 == 0): 127-134 -> 93-95 us at 150 720 x 768.  The backward forms
 // were built the same way and measured SLOWER than the 4-column kernels (ln_2 199 against 180 us, ln_1 151 against 134, ln_3 236
-// against 243: four input streams of two rows in flight need 180-200 registers, i.e. two blocks per CU instead of three) -- not kept.
+// against 243: four input streams of two rows in flight need 180-200 registers, i.e. two blocks per CU instead of three; with ONE row
+// per wave at three blocks per CU 188 / 136 / 228 us) -- the backward streams ~5 TB/s either way: not kept.
 // ================================================================================================================================
 __device__ __forceinline__ void widen8(const bf16x8& t, f32x4& lo, f32x4& hi) {
     lo = (f32x4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
