@@ -36,7 +36,11 @@ enum {
     TVTS_GEMM_RING = 128,       /* tvts_gemm_nt_bf16: force the ring form of the 128-column kernel (one block per CU, three 64-deep stages
                                    in flight: the small-batch kernel; same bits as TVTS_GEMM_TILE_128); -22 if an operand is too large
                                    for its 32-bit offsets.  Automatic where its cost model wins (csrc/gemm.hip, nt_use_ring) */
-    TVTS_GEMM_NO_RING = 16384   /* ... never take it */
+    TVTS_GEMM_NO_RING = 16384,  /* ... never take it */
+    TVTS_GEMM_SIDE_DERIV = 1048576 /* tvts_gemm_nt_bf16 / _fp8 / _fp8_gate (round 5): the activation forms store act'(x) in `preact` instead of the
+                                   pre-activation x, the gate forms take `gate_h` as that derivative and multiply by it as is -- the forward
+                                   epilogue evaluates the sigmoid / erf parts anyway, the input-gradient epilogue then needs no
+                                   transcendental at all.  Both GEMMs of an MLP must agree on it (the stored tensor changes meaning). */
 };
 /* measurement hook: tile rows of the forced ring kernel, 128 / 192 / 256 (0 = its own choice between 128 and 192) */
 #define TVTS_GEMM_RING_ROWS(r) ((r) == 128 ? (1 << 16) : (r) == 192 ? (2 << 16) : (r) == 256 ? (3 << 16) : 0)

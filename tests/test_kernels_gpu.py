@@ -94,6 +94,21 @@ def test_gemm_nt_epilogues(K, act):
     g = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     K.gemm_nt(a.to(DEV), b.to(DEV), g, gate_h=hh.to(DEV), gate_act=act)
     assert rel(g.float(), (a.float() @ b.float().t()) * x.grad) < 5e-3
+    # TVTS_GEMM_SIDE_DERIV (round 5): the forward stores act'(x) in place of the pre-activation, the gate multiplies by it as is --
+    # on every tile kernel (256 x 256 with the generic and the hand-scheduled epilogue, 128 x 128, the ring forms)
+    xp = pre.clone().requires_grad_(True)
+    fn(xp).sum().backward()
+    for M2, tile in ((M, None), (M, 128), (1024, 256), (1024, None)):
+        a2 = bf(rnd(M2, K_, seed=9)).to(DEV)
+        pre2 = a2.float().cpu() @ b.float().t() + bias
+        xp2 = pre2.clone().requires_grad_(True)
+        fn(xp2).sum().backward()
+        o2, d2 = (torch.empty(M2, N, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+        K.gemm_nt(a2, b.to(DEV), o2, bias=bias.to(DEV), act=act, preact=d2, side_deriv=True, tile=tile)
+        assert rel(o2.float(), fn(pre2)) < 5e-3 and rel(d2.float(), xp2.grad) < 5e-3, (M2, tile)
+        g2 = torch.empty(M2, N, dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt(a2, b.to(DEV), g2, gate_h=d2, gate_act=act, side_deriv=True, tile=tile)
+        assert rel(g2.float(), (a2.float().cpu() @ b.float().t()) * d2.float().cpu()) < 5e-3, (M2, tile)
 
 
 @pytest.mark.parametrize("M,Na,Nb", [(64, 128, 128), (200, 256, 128), (1000, 768, 256), (9420, 768, 768), (37, 512, 128)])

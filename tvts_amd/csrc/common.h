@@ -87,10 +87,15 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
     return 1.0f;
 }
 
-// the GATE slot of a GEMM epilogue: v * act'(h) (input gradient through an activation) or v + h (bf16 residual)
-__device__ __forceinline__ float gate_apply(float v, float h, int gate) {
-    return gate == ACT_ADD_BF16 ? v + h : v * act_bwd(h, gate);
+// the GATE slot of a GEMM epilogue: v * act'(h) (input gradient through an activation) or v + h (bf16 residual).
+// deriv (TVTS_GEMM_SIDE_DERIV, round 5): h already IS act'(pre-activation) -- the forward's epilogue, which evaluates the sigmoid /
+// erf parts for the activation anyway, stored the derivative in place of the pre-activation -- so the gate is one multiply instead of
+// a second evaluation of the transcendentals (64 K of them per output tile while the matrix pipe waits)
+__device__ __forceinline__ float gate_apply(float v, float h, int gate, int deriv = 0) {
+    return gate == ACT_ADD_BF16 ? v + h : deriv ? v * h : v * act_bwd(h, gate);
 }
+// what the forward epilogue's side output stores for the pre-activation x: x itself, or (deriv) act'(x)
+__device__ __forceinline__ float act_side(float x, int act, int deriv) { return deriv ? act_bwd(x, act) : x; }
 
 // XCD-aware bijective remap of a 1-D block id: blocks that land on one XCD (bid % 8) get a
 // contiguous range of logical ids, so neighbouring tiles share that XCD's L2.

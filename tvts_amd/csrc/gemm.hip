@@ -122,7 +122,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNT g) {
                 }
                 if (ACT != ACT_NONE) {
                     if (g.preact) {
-                        bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        bf16x4 h = {(bf16)act_side(v[0], ACT, g.side_deriv), (bf16)act_side(v[1], ACT, g.side_deriv), (bf16)act_side(v[2], ACT, g.side_deriv), (bf16)act_side(v[3], ACT, g.side_deriv)};
                         *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = h;
                     }
 #pragma unroll
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNT g) {
                 if (GATE != ACT_NONE) {
                     const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)h[e], GATE);
+                    for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)h[e], GATE, g.side_deriv);
                 }
                 if (g.residual) {
                     const f32x4 r = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
@@ -427,6 +427,7 @@ extern "C" int tvts_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb,
     g.A = (const bf16*)A; g.lda = lda; g.B = (const bf16*)B; g.ldb = ldb;
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
+    g.side_deriv = (opts >> 20) & 1;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.sa = nullptr; g.sb = nullptr; g.sa_rows = 0; g.gc = 0;
     g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0; g.q8 = nullptr; g.ldq8 = 0; g.q8_scale = nullptr; g.q8_amax = nullptr;
     if (nt_use_256(M, N, K, workspace != nullptr, opts)) {
@@ -471,6 +472,7 @@ extern "C" int tvts_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, 
     g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;  // byte-identical bf16 view, half as wide
     g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = nullptr; g.ldh = 0; g.gate_act = ACT_NONE;
+    g.side_deriv = (opts >> 20) & 1;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
     g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0;
     g.q8 = (unsigned char*)q8out; g.ldq8 = ldq8; g.q8_scale = q8_scale; g.q8_amax = q8_amax;
@@ -490,6 +492,7 @@ extern "C" int tvts_gemm_nt_fp8_gate(const void* A, int lda, const void* B, int 
     g.A = (const bf16*)A; g.lda = lda / 2; g.B = (const bf16*)B; g.ldb = ldb / 2;
     g.M = M; g.N = N; g.K = K / 2; g.bias = bias; g.residual = nullptr; g.ldr = 0; g.act = ACT_NONE;
     g.preact = nullptr; g.ldp = 0; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
+    g.side_deriv = (opts >> 20) & 1;
     g.out = out; g.ldc = ldc; g.out_f32 = 0; g.gc = 0; g.sa = scale_a; g.sb = scale_b; g.sa_rows = scale_a_rows ? 1 : 0;
     g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0;
     g.q8 = (unsigned char*)q8out; g.ldq8 = ldq8; g.q8_scale = q8_scale; g.q8_amax = q8_amax;

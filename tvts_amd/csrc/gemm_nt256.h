@@ -15,6 +15,7 @@ struct GemmNT {
     int act;
     bf16* preact; int ldp;
     const bf16* gate_h; int ldh; int gate_act;
+    int side_deriv;  // TVTS_GEMM_SIDE_DERIV: preact receives act'(x) instead of x / gate_h holds act'(x) and is multiplied as is
     void* out; int ldc; int out_f32;
     int tiles_m, tiles_n;
     int sa_rows; // fp8: scale_a holds one scale per row of A (per-token activation scales) instead of one for the tensor
@@ -255,7 +256,7 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
             const int m = m_base + r, n = nb + c16 * 4;
             if (m >= g.M || n >= g.N) continue;
             if (ACT != ACT_NONE) {
-                if (g.preact && (!(ABL & 4) || v[0] == 1.2345e33f)) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                if (g.preact && (!(ABL & 4) || v[0] == 1.2345e33f)) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)act_side(v[0], ACT, g.side_deriv), (bf16)act_side(v[1], ACT, g.side_deriv), (bf16)act_side(v[2], ACT, g.side_deriv), (bf16)act_side(v[3], ACT, g.side_deriv)};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
             }
@@ -264,7 +265,7 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
                                : PF ? (bf16x4){side.gate[t >> 1][(t & 1) * 4], side.gate[t >> 1][(t & 1) * 4 + 1], side.gate[t >> 1][(t & 1) * 4 + 2], side.gate[t >> 1][(t & 1) * 4 + 3]}
                                     : side_load<ABL, bf16x4>(g.gate_h + (size_t)m * g.ldh + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)h[e], GATE);
+                for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)h[e], GATE, g.side_deriv);
             }
             if (g.residual && !(ABL & 2)) v += (PF && GATE == ACT_NONE) ? side.res[t] : side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
             if (!(ABL & 4) || v[0] == 1.2345e33f) store16<ABL>((float*)g.out + (size_t)m * g.ldc + n, v);
@@ -282,7 +283,7 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
                 if (g.preact && (!(ABL & 4) || v[0] == 1.2345e33f)) {
                     bf16x8 h;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) h[e] = (bf16)v[e];
+                    for (int e = 0; e < 8; ++e) h[e] = (bf16)act_side(v[e], ACT, g.side_deriv);
                     store16<ABL>(g.preact + (size_t)m * g.ldp + n, h);
                 }
 #pragma unroll
@@ -297,7 +298,7 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
                     h = PF ? side.gate[t] : side_load<ABL, bf16x8>(g.gate_h + (size_t)m * g.ldh + n);
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gate_apply(v[e], (float)h[e], GATE);
+                for (int e = 0; e < 8; ++e) v[e] = gate_apply(v[e], (float)h[e], GATE, g.side_deriv);
             }
             if (g.residual && !(ABL & 2)) {
                 const f32x4 r0 = (PF && GATE == ACT_NONE) ? side.res[2 * t] : side_load<ABL, f32x4>(g.residual + (size_t)m * g.ldr + n);
@@ -528,13 +529,13 @@ __device__ __forceinline__ void epilogue256_reg(const GemmNT& g, f32x4 (&acc)[4]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (ACT != ACT_NONE) {
-                    pre[j] = (bf16x4){(bf16)v[j][0], (bf16)v[j][1], (bf16)v[j][2], (bf16)v[j][3]};
+                    pre[j] = (bf16x4){(bf16)act_side(v[j][0], ACT, g.side_deriv), (bf16)act_side(v[j][1], ACT, g.side_deriv), (bf16)act_side(v[j][2], ACT, g.side_deriv), (bf16)act_side(v[j][3], ACT, g.side_deriv)};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[j][e] = act_fwd(v[j][e], ACT);
                 }
                 if (GATED) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[j][e] = gate_apply(v[j][e], (float)s.gate[j >> 1][(j & 1) * 4 + e], GATE);
+                    for (int e = 0; e < 4; ++e) v[j][e] = gate_apply(v[j][e], (float)s.gate[j >> 1][(j & 1) * 4 + e], GATE, g.side_deriv);
                 }
                 if (!GATED && has_res) v[j] += s.res[j];
             }
@@ -567,11 +568,11 @@ __device__ __forceinline__ void epilogue256_reg(const GemmNT& g, f32x4 (&acc)[4]
                 float w[8] = {v[2 * p][0], v[2 * p][1], v[2 * p][2], v[2 * p][3], v[2 * p + 1][0], v[2 * p + 1][1], v[2 * p + 1][2], v[2 * p + 1][3]};
                 if (ACT != ACT_NONE) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { pre[p][e] = (bf16)w[e]; w[e] = act_fwd(w[e], ACT); }
+                    for (int e = 0; e < 8; ++e) { pre[p][e] = (bf16)act_side(w[e], ACT, g.side_deriv); w[e] = act_fwd(w[e], ACT); }
                 }
                 if (GATED) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) w[e] = gate_apply(w[e], (float)s.gate[p][e], GATE);
+                    for (int e = 0; e < 8; ++e) w[e] = gate_apply(w[e], (float)s.gate[p][e], GATE, g.side_deriv);
                 }
                 if (!GATED && has_res) {
 #pragma unroll
@@ -723,11 +724,11 @@ __device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&a
                 float w[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 if constexpr (ACT != ACT_NONE) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { pre[t][e] = (bf16)w[e]; w[e] = act_fwd(w[e], ACT); }
+                    for (int e = 0; e < 8; ++e) { pre[t][e] = (bf16)act_side(w[e], ACT, g.side_deriv); w[e] = act_fwd(w[e], ACT); }
                 }
                 if constexpr (GATED) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) w[e] = gate_apply(w[e], (float)s.gate[t][e], GATE);
+                    for (int e = 0; e < 8; ++e) w[e] = gate_apply(w[e], (float)s.gate[t][e], GATE, g.side_deriv);
                 } else if constexpr (has_res) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { w[e] += s.res[2 * t][e]; w[4 + e] += s.res[2 * t + 1][e]; }

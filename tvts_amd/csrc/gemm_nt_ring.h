@@ -243,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ring_kernel(GemmNT g) {
                     if (has_bias) v += bias_r[j];
                     if (ACT != ACT_NONE) {
                         if (g.preact && ok) {
-                            bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                            bf16x4 h = {(bf16)act_side(v[0], ACT, g.side_deriv), (bf16)act_side(v[1], ACT, g.side_deriv), (bf16)act_side(v[2], ACT, g.side_deriv), (bf16)act_side(v[3], ACT, g.side_deriv)};
                             *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = h;
                         }
 #pragma unroll
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ring_kernel(GemmNT g) {
                     }
                     if (GATED) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)gate_r[j][i][e], GATE);
+                        for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)gate_r[j][i][e], GATE, g.side_deriv);
                     }
                     if (has_res) v += res_r[j][i];
                     if (ok) {
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(768, 1) void gemm_nt_ringl_kernel(GemmNT g) {
                     if (has_bias) v += bias_r[j];
                     if (ACT != ACT_NONE) {
                         if (g.preact && ok) {
-                            bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                            bf16x4 h = {(bf16)act_side(v[0], ACT, g.side_deriv), (bf16)act_side(v[1], ACT, g.side_deriv), (bf16)act_side(v[2], ACT, g.side_deriv), (bf16)act_side(v[3], ACT, g.side_deriv)};
                             *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = h;
                         }
 #pragma unroll
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(768, 1) void gemm_nt_ringl_kernel(GemmNT g) {
                     }
                     if (GATED) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)gate_r[j][i][e], GATE);
+                        for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)gate_r[j][i][e], GATE, g.side_deriv);
                     }
                     if (has_res) v += res_r[j][i];
                     if (ok) {

@@ -230,6 +230,11 @@ class Engine:
         # 692.9 / 958.5 / 1154 / 1351 without.  arch["wgrad_stream"] = True switches it on (bit-identical gradients,
         # tests/test_bench_path_gpu.py::test_wgrad_side_stream_gives_the_same_bits).
         self.wgrad_stream = a.get("wgrad_stream", False)
+        # The MLPs' saved tensor is act'(pre-activation), not the pre-activation (round 5, TVTS_GEMM_SIDE_DERIV; arch["gate_deriv"] =
+        # False stores the pre-activation as rounds 1-4 did): the forward epilogue evaluates the sigmoid / erf parts for the
+        # activation anyway and adds two multiply-adds for the derivative; the input gradient's gate epilogue then multiplies by the
+        # stored bf16 value instead of evaluating the transcendentals again.  Nothing else reads the tensor.
+        self.gate_deriv = bool(a.get("gate_deriv", os.environ.get("TVTS_GATE_DERIV", "1") != "0"))
         # The text tower on its own stream beside the ViT (round 5).  The two towers share nothing until the loss (the sort head reads
         # DETACHED caption embeddings, model_dist_TVTSv2_ViT_B_16.py:61-95): the text tower's forward (12 blocks of 5-25 us kernels
         # on <= 48 tiles) and its three trainable blocks' backward are latency-bound chains -- in the replayed 12-pair step every one
@@ -412,6 +417,8 @@ class Engine:
     def _lin(self, a, wname, bname, out, M, a8=None, q8_for=None, **epi):
         """q8_for: the weight whose GEMMs read `out` as their activation; in the per-tensor e4m3 regime the epilogue of this GEMM
         then writes that operand copy itself (the MLP's GELU output), instead of a quantiser pass over `out`."""
+        if epi.get("preact") is not None and self.gate_deriv:
+            epi["side_deriv"] = True  # the side output holds act'(x): the gate of the backward multiplies by it as is
         if wname in self.P.w8:  # fp8 weight/activation path (BASELINE config 4): forward GEMMs of the ViT blocks
             w8, ws, _ = self.P.w8[wname]
             if a8 is None:
@@ -483,6 +490,8 @@ class Engine:
         behind everything the current stream has queued so far (dy is complete there); the caller keeps dy and a_in untouched
         until it has joined the side stream."""
         want_b = bool(bname) and self.requires_grad[bname]
+        if epi.get("gate_h") is not None and epi.get("gate_act") not in (None, "add") and self.gate_deriv:
+            epi["side_deriv"] = True  # gate_h is the derivative the forward's epilogue stored (see _lin)
         f8w = self.fp8_wgrad and self._f8_tensor_mode and wname in self.P.w8t and wname in self._x8
         if dy8 is None:
             dy8 = self._dy8_ready.pop(wname, None)

@@ -117,12 +117,12 @@ def _sk_bits(sk):
     return 0 if sk is None else (32 if sk else 64)  # TVTS_GEMM_STREAMK / TVTS_GEMM_NO_STREAMK
 
 
-def nt_opts(tile=None, cus=None, fp8_k32=None, streamk=None):
+def nt_opts(tile=None, cus=None, fp8_k32=None, streamk=None, side_deriv=False):
     tile = _OPTS["nt_tile"] if tile is None else tile
     cus = _OPTS["nt_cus"] if cus is None else cus
     k32 = _OPTS["fp8_k32"] if fp8_k32 is None else fp8_k32
     streamk = _OPTS["nt_streamk"] if streamk is None else streamk
-    return _tile_bits(tile) | (4 if k32 else 0) | (((int(cus) // 8) & 63) << 8) | _sk_bits(streamk)
+    return _tile_bits(tile) | (4 if k32 else 0) | (((int(cus) // 8) & 63) << 8) | _sk_bits(streamk) | ((1 << 20) if side_deriv else 0)
 
 
 def tn_opts(tile=None, splits=None, early_dma=None, a_fast=None, streamk=None):
@@ -170,7 +170,7 @@ def _nt_workspace(dev):
 
 
 def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None, tile=None, cus=None,
-            streamk=None, workspace=True):
+            streamk=None, workspace=True, side_deriv=False):
     """out[M,N] = [act'(gate_h) *] act(a[M,K] @ b[N,K]^T + bias) [+ residual]; a, b bf16; out bf16 or fp32.
     streamk: None = the entry point's own choice, True / False force / forbid the stream-K walk (needs the workspace)."""
     lib = _lib.load()
@@ -191,7 +191,7 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
                                      _ld(preact) if preact is not None else 0, _p(gate_h),
                                      _ld(gate_h) if gate_h is not None else 0, ACT[gate_act], _p(out), _ld(out),
                                      1 if out.dtype == torch.float32 else 0, _p(ws), ws.numel() if ws is not None else 0,
-                                     nt_opts(tile, cus, streamk=sk), _stream())
+                                     nt_opts(tile, cus, streamk=sk, side_deriv=side_deriv), _stream())
     want_sk = _OPTS["nt_streamk"] if streamk is None else streamk
     rc = launch(streamk)
     if rc == -22 and want_sk and streamk is None:  # the process-wide option means "wherever the shape can take it"
@@ -265,7 +265,7 @@ def fp8_update_scales(amax, scale):
 
 
 def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, preact=None, gate_h=None, gate_act=None, k32=None,
-                cus=None, q8out=None, q8_scale=None, q8_amax=None, store_out=True):
+                cus=None, q8out=None, q8_scale=None, q8_amax=None, store_out=True, side_deriv=False):
     """out[M,N] = act(sa*sb * (a8[M,K] @ b8[N,K]^T) + bias) [+ residual]; a8 / b8 uint8 e4m3 bit patterns; sb float32[1]; sa
     float32[1] (one scale for the tensor) or float32[>= M] (one per row, quantize_fp8_rows); preact receives the bf16
     pre-activation like gemm_nt.  gate_h / gate_act: the input-gradient form, out = gate_act'(gate_h) * (sa*sb * (a8 @ b8^T)).
@@ -290,7 +290,7 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
         assert bias is None or gate_act == "add"
         rc = lib.tvts_gemm_nt_fp8_gate(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(bias), _p(gate_h),
                                        _ld(gate_h), ACT[gate_act], po, _ld(out), _p(q8out), q8out.stride(0) if q8out is not None else 0, _p(q8_scale),
-                                       _p(q8_amax), nt_opts(None, cus, k32), _stream())
+                                       _p(q8_amax), nt_opts(None, cus, k32, side_deriv=side_deriv), _stream())
         _chk(rc, "tvts_gemm_nt_fp8_gate")
         if GEMM_PROFILE is not None:
             ev1.record()
@@ -300,7 +300,7 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
                               _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
                               _ld(preact) if preact is not None else 0, po, _ld(out),
                               1 if out.dtype == torch.float32 else 0, _p(q8out), q8out.stride(0) if q8out is not None else 0,
-                              _p(q8_scale), _p(q8_amax), nt_opts(None, cus, k32), _stream())
+                              _p(q8_scale), _p(q8_amax), nt_opts(None, cus, k32, side_deriv=side_deriv), _stream())
     _chk(rc, "tvts_gemm_nt_fp8")
     if GEMM_PROFILE is not None:
         ev1.record()
