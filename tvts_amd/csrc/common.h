@@ -94,8 +94,24 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
 __device__ __forceinline__ float gate_apply(float v, float h, int gate, int deriv = 0) {
     return gate == ACT_ADD_BF16 ? v + h : deriv ? v * h : v * act_bwd(h, gate);
 }
-// what the forward epilogue's side output stores for the pre-activation x: x itself, or (deriv) act'(x)
-__device__ __forceinline__ float act_side(float x, int act, int deriv) { return deriv ? act_bwd(x, act) : x; }
+// act(x) and, in `side`, what the forward epilogue's side output stores for the pre-activation x: x itself, or (deriv) act'(x) --
+// from ONE evaluation of the sigmoid / erf parts (left to the compiler's CSE the erf form was evaluated twice: +64 us on the H/14 fc1)
+__device__ __forceinline__ float act_fwd_side(float x, int act, int deriv, float& side) {
+    if (act == ACT_QUICK_GELU) {
+        const float s = fast_sigmoid(1.702f * x);
+        side = deriv ? s * (1.0f + 1.702f * x * (1.0f - s)) : x;
+        return x * s;
+    }
+    if (act == ACT_GELU_ERF) {
+#pragma clang fp contract(off)
+        float cdf, gs;
+        gelu_erf_parts(x, cdf, gs);
+        side = deriv ? __builtin_fmaf(x * 0.3989422804014327f, gs, cdf) : x;
+        return x * cdf;
+    }
+    side = x;
+    return x;
+}
 
 // XCD-aware bijective remap of a 1-D block id: blocks that land on one XCD (bid % 8) get a
 // contiguous range of logical ids, so neighbouring tiles share that XCD's L2.

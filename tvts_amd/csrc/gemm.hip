@@ -121,12 +121,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNT g) {
                     v += b;
                 }
                 if (ACT != ACT_NONE) {
-                    if (g.preact) {
-                        bf16x4 h = {(bf16)act_side(v[0], ACT, g.side_deriv), (bf16)act_side(v[1], ACT, g.side_deriv), (bf16)act_side(v[2], ACT, g.side_deriv), (bf16)act_side(v[3], ACT, g.side_deriv)};
-                        *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = h;
-                    }
+                    f32x4 sd;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
+                    for (int e = 0; e < 4; ++e) { float t; v[e] = act_fwd_side(v[e], ACT, g.side_deriv, t); sd[e] = t; }
+                    if (g.preact) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)sd[0], (bf16)sd[1], (bf16)sd[2], (bf16)sd[3]};
                 }
                 if (GATE != ACT_NONE) {
                     const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);

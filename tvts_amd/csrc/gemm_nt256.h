@@ -256,9 +256,10 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
             const int m = m_base + r, n = nb + c16 * 4;
             if (m >= g.M || n >= g.N) continue;
             if (ACT != ACT_NONE) {
-                if (g.preact && (!(ABL & 4) || v[0] == 1.2345e33f)) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)act_side(v[0], ACT, g.side_deriv), (bf16)act_side(v[1], ACT, g.side_deriv), (bf16)act_side(v[2], ACT, g.side_deriv), (bf16)act_side(v[3], ACT, g.side_deriv)};
+                f32x4 sd;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
+                for (int e = 0; e < 4; ++e) { float t; v[e] = act_fwd_side(v[e], ACT, g.side_deriv, t); sd[e] = t; }
+                if (g.preact && (!(ABL & 4) || v[0] == 1.2345e33f)) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)sd[0], (bf16)sd[1], (bf16)sd[2], (bf16)sd[3]};
             }
             if (GATE != ACT_NONE) {
                 const bf16x4 h = (ABL & 2) ? (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}
@@ -280,14 +281,10 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
             const int m = m_base + r, n = nb + c8 * 8;
             if (m >= g.M || n >= g.N) continue;
             if (ACT != ACT_NONE) {
-                if (g.preact && (!(ABL & 4) || v[0] == 1.2345e33f)) {
-                    bf16x8 h;
+                bf16x8 h;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) h[e] = (bf16)act_side(v[e], ACT, g.side_deriv);
-                    store16<ABL>(g.preact + (size_t)m * g.ldp + n, h);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], ACT);
+                for (int e = 0; e < 8; ++e) { float t; v[e] = act_fwd_side(v[e], ACT, g.side_deriv, t); h[e] = (bf16)t; }
+                if (g.preact && (!(ABL & 4) || v[0] == 1.2345e33f)) store16<ABL>(g.preact + (size_t)m * g.ldp + n, h);
             }
             if (GATE != ACT_NONE) {
                 bf16x8 h;
@@ -529,9 +526,8 @@ __device__ __forceinline__ void epilogue256_reg(const GemmNT& g, f32x4 (&acc)[4]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (ACT != ACT_NONE) {
-                    pre[j] = (bf16x4){(bf16)act_side(v[j][0], ACT, g.side_deriv), (bf16)act_side(v[j][1], ACT, g.side_deriv), (bf16)act_side(v[j][2], ACT, g.side_deriv), (bf16)act_side(v[j][3], ACT, g.side_deriv)};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[j][e] = act_fwd(v[j][e], ACT);
+                    for (int e = 0; e < 4; ++e) { float t; v[j][e] = act_fwd_side(v[j][e], ACT, g.side_deriv, t); pre[j][e] = (bf16)t; }
                 }
                 if (GATED) {
 #pragma unroll
@@ -568,7 +564,7 @@ __device__ __forceinline__ void epilogue256_reg(const GemmNT& g, f32x4 (&acc)[4]
                 float w[8] = {v[2 * p][0], v[2 * p][1], v[2 * p][2], v[2 * p][3], v[2 * p + 1][0], v[2 * p + 1][1], v[2 * p + 1][2], v[2 * p + 1][3]};
                 if (ACT != ACT_NONE) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { pre[p][e] = (bf16)act_side(w[e], ACT, g.side_deriv); w[e] = act_fwd(w[e], ACT); }
+                    for (int e = 0; e < 8; ++e) { float t; w[e] = act_fwd_side(w[e], ACT, g.side_deriv, t); pre[p][e] = (bf16)t; }
                 }
                 if (GATED) {
 #pragma unroll
@@ -724,7 +720,7 @@ __device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&a
                 float w[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 if constexpr (ACT != ACT_NONE) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { pre[t][e] = (bf16)act_side(w[e], ACT, g.side_deriv); w[e] = act_fwd(w[e], ACT); }
+                    for (int e = 0; e < 8; ++e) { float sd_; w[e] = act_fwd_side(w[e], ACT, g.side_deriv, sd_); pre[t][e] = (bf16)sd_; }
                 }
                 if constexpr (GATED) {
 #pragma unroll
