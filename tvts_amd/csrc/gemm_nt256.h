@@ -303,20 +303,23 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
             }
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
             // (q8 forms: out == nullptr -> the e4m3 copy is the ONLY result -- in the per-tensor regime every consumer of the MLP's
             // GELU output / gated gradient multiplies the e4m3 bytes, the bf16 tensor would be written and never read)
-            if ((!(ABL & 4) || v[0] == 1.2345e33f) && (!Q8OUT || g.out != nullptr)) store16<ABL>((bf16*)g.out + (size_t)m * g.ldc + n, o);
-            if constexpr (Q8OUT) {  // the same 8 values as e4m3 bytes under the tensor's scale (what the bf16 consumers see, quantised)
+            const bool q8_alone = Q8OUT && g.out == nullptr;
+            if (!q8_alone) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; if (Q8OUT) v[e] = (float)o[e]; }  // (the copy quantises what the bf16 consumers see)
+                if (!(ABL & 4) || v[0] == 1.2345e33f) store16<ABL>((bf16*)g.out + (size_t)m * g.ldc + n, o);
+            }
+            if constexpr (Q8OUT) {  // the 8 values as e4m3 bytes under the tensor's scale; alone, straight from the fp32 results
                 float f[8];
                 float am = *q8am;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float w = (float)o[e];
+                    const float w = v[e];
                     am = fmaxf(am, fabsf(w));
-                    f[e] = fminf(fmaxf(w * q8inv, -448.0f), 448.0f);
+                    f[e] = __builtin_amdgcn_fmed3f(w * q8inv, -448.0f, 448.0f);
                 }
                 *q8am = am;
                 int p0 = 0, p1 = 0;
