@@ -47,6 +47,22 @@ def _worker(rank, world, port, q):
     assert sync16.bytes_sent * 2 == sync.bytes_sent == flat.numel() * 4
     err16 = float((flat16 - flat).norm() / flat.norm())
     assert 0 < err16 < 6e-3, err16
+    # reduce_range hands back a wait() for ITS range (the optimizer's range-wise update calls it on its own stream in front of that
+    # range's AdamW launch): waiting early completes and removes exactly those reductions, finish() takes the rest, same sums
+    flat_w = torch.cat([P[k].grad.reshape(-1) for k in names])
+    for payload in ("fp32", "bf16"):
+        fw = flat_w.clone()
+        sw = D.GradSync(fw, bucket_bytes=64 << 10, payload=payload)
+        w_hi = sw.reduce_range(cut, fw.numel())
+        n_hi = len(sw.handles)
+        w_lo = sw.reduce_range(0, cut)
+        assert callable(w_hi) and callable(w_lo) and len(sw.handles) > n_hi > 0
+        w_hi()
+        assert len(sw.handles) == len(sw.handles) and all(s < cut for _, s, _ in sw.handles)  # only the low range is left
+        w_hi()  # idempotent
+        fw.mul_(sw.finish())
+        assert not sw.handles
+        assert torch.equal(fw, flat if payload == "fp32" else flat16), payload
     # the embedding exchange through the preallocated EmbedGather gives what allgather_embeds gives
     eg = D.EmbedGather()
     eg.start(te.detach(), ve.detach())
