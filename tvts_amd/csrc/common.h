@@ -113,6 +113,43 @@ __device__ __forceinline__ float act_fwd_side(float x, int act, int deriv, float
     return x;
 }
 
+// The same two results for a PAIR of elements on the packed fp32 pipe (v_pk_mul / v_pk_add / v_pk_fma_f32 take two fp32 values per
+// lane in one full-rate issue; only the transcendentals and the sign select stay per element): the GEMM epilogues are bound by VALU
+// issue while the matrix pipe waits -- round 5 counted ~14 instructions per output element in the QuickGELU + derivative form.
+// Every operation and its order are those of the scalar form above, so the two produce the same bits.
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_ pk_fma(f32x2_ a, f32x2_ b, f32x2_ c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2_ act_fwd_side_pk(f32x2_ x, int act, int deriv, f32x2_& side) {
+    if (act == ACT_QUICK_GELU) {
+        const f32x2_ t = 1.702f * x;
+        const f32x2_ z = -1.4426950408889634f * t;
+        const f32x2_ d = 1.0f + (f32x2_){__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+        const f32x2_ s = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        side = deriv ? s * (1.0f + t * (1.0f - s)) : x;
+        return x * s;
+    }
+    if (act == ACT_GELU_ERF) {
+#pragma clang fp contract(off)
+        const f32x2_ z = __builtin_elementwise_abs(x) * 0.70710678118654752f;
+        const f32x2_ r = pk_fma((f32x2_){0.3275911f, 0.3275911f}, z, (f32x2_){1.0f, 1.0f});
+        const f32x2_ t = {__builtin_amdgcn_rcpf(r[0]), __builtin_amdgcn_rcpf(r[1])};
+        const f32x2_ a = (-0.72134752044448170f * x) * x;
+        const f32x2_ gauss = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        f32x2_ poly = {1.061405429f, 1.061405429f};
+        poly = pk_fma(poly, t, (f32x2_){-1.453152027f, -1.453152027f});
+        poly = pk_fma(poly, t, (f32x2_){1.421413741f, 1.421413741f});
+        poly = pk_fma(poly, t, (f32x2_){-0.284496736f, -0.284496736f});
+        poly = pk_fma(poly, t, (f32x2_){0.254829592f, 0.254829592f});
+        const f32x2_ q = ((0.5f * poly) * t) * gauss;
+        const f32x2_ p = 1.0f - q;
+        const f32x2_ cdf = {x[0] >= 0.f ? p[0] : q[0], x[1] >= 0.f ? p[1] : q[1]};
+        side = deriv ? pk_fma(x * 0.3989422804014327f, gauss, cdf) : x;
+        return x * cdf;
+    }
+    side = x;
+    return x;
+}
+
 // XCD-aware bijective remap of a 1-D block id: blocks that land on one XCD (bid % 8) get a
 // contiguous range of logical ids, so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

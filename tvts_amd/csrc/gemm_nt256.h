@@ -283,7 +283,12 @@ __device__ __forceinline__ void patch_readout(const GemmNT& g, const char* patch
             if (ACT != ACT_NONE) {
                 bf16x8 h;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float t; v[e] = act_fwd_side(v[e], ACT, g.side_deriv, t); h[e] = (bf16)t; }
+                for (int e = 0; e < 8; e += 2) {  // pairs on the packed fp32 pipe
+                    f32x2_ t;
+                    const f32x2_ y = act_fwd_side_pk((f32x2_){v[e], v[e + 1]}, ACT, g.side_deriv, t);
+                    v[e] = y[0]; v[e + 1] = y[1];
+                    h[e] = (bf16)t[0]; h[e + 1] = (bf16)t[1];
+                }
                 if (g.preact && (!(ABL & 4) || v[0] == 1.2345e33f)) store16<ABL>(g.preact + (size_t)m * g.ldp + n, h);
             }
             if (GATE != ACT_NONE) {
@@ -530,7 +535,12 @@ __device__ __forceinline__ void epilogue256_reg(const GemmNT& g, f32x4 (&acc)[4]
             for (int j = 0; j < 4; ++j) {
                 if (ACT != ACT_NONE) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { float t; v[j][e] = act_fwd_side(v[j][e], ACT, g.side_deriv, t); pre[j][e] = (bf16)t; }
+                    for (int e = 0; e < 4; e += 2) {
+                        f32x2_ t;
+                        const f32x2_ y = act_fwd_side_pk((f32x2_){v[j][e], v[j][e + 1]}, ACT, g.side_deriv, t);
+                        v[j][e] = y[0]; v[j][e + 1] = y[1];
+                        pre[j][e] = (bf16)t[0]; pre[j][e + 1] = (bf16)t[1];
+                    }
                 }
                 if (GATED) {
 #pragma unroll
@@ -567,7 +577,12 @@ __device__ __forceinline__ void epilogue256_reg(const GemmNT& g, f32x4 (&acc)[4]
                 float w[8] = {v[2 * p][0], v[2 * p][1], v[2 * p][2], v[2 * p][3], v[2 * p + 1][0], v[2 * p + 1][1], v[2 * p + 1][2], v[2 * p + 1][3]};
                 if (ACT != ACT_NONE) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { float t; w[e] = act_fwd_side(w[e], ACT, g.side_deriv, t); pre[p][e] = (bf16)t; }
+                    for (int e = 0; e < 8; e += 2) {  // pairs on the packed fp32 pipe
+                        f32x2_ t;
+                        const f32x2_ y = act_fwd_side_pk((f32x2_){w[e], w[e + 1]}, ACT, g.side_deriv, t);
+                        w[e] = y[0]; w[e + 1] = y[1];
+                        pre[p][e] = (bf16)t[0]; pre[p][e + 1] = (bf16)t[1];
+                    }
                 }
                 if (GATED) {
 #pragma unroll
@@ -723,7 +738,12 @@ __device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&a
                 float w[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 if constexpr (ACT != ACT_NONE) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { float sd_; w[e] = act_fwd_side(w[e], ACT, g.side_deriv, sd_); pre[t][e] = (bf16)sd_; }
+                    for (int e = 0; e < 8; e += 2) {  // pairs on the packed fp32 pipe
+                        f32x2_ sd_;
+                        const f32x2_ y = act_fwd_side_pk((f32x2_){w[e], w[e + 1]}, ACT, g.side_deriv, sd_);
+                        w[e] = y[0]; w[e + 1] = y[1];
+                        pre[t][e] = (bf16)sd_[0]; pre[t][e + 1] = (bf16)sd_[1];
+                    }
                 }
                 if constexpr (GATED) {
 #pragma unroll
@@ -824,8 +844,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     // s_waitcnt vmcnt(0) that waits for the LDS-DMA just issued
     auto fresh_lane = [&]() -> int {
         if constexpr (MX) {
-            int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            asm volatile("" : "+v"(l));
+            int l;  // (volatile asm: as builtins the two mbcnt are hoisted to the kernel's prologue and the RESULT is spilled)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
             return l;
         } else {
             return lane;
@@ -1019,9 +1039,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
             // step's DMA, so that the next step's vmcnt wait retires it and the epilogue starts without a memory wait
             if (kt == nk - 2) {
                 if (g.bias) {
+                    // (the lane's column group from a fresh mbcnt: kept live across the K loop it is spilled by the register-heavy
+                    // epilogue forms, and its reload here waits vmcnt(0) -- for the LDS-DMA in flight)
+                    int lb;  // (volatile asm: as builtins the two mbcnt are hoisted to the kernel's prologue and the RESULT is spilled)
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lb));
+                    const int gqb = lb >> 4;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        int n = n0 + wn * 64 + j * 16 + gq * 4;
+                        int n = n0 + wn * 64 + j * 16 + gqb * 4;
                         n = n < g.N ? n : g.N - 4;
                         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias4[j]) : "v"(g.bias + n) : "memory");
                     }
