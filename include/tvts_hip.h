@@ -169,7 +169,9 @@ int tvts_layernorm_fwd(const void* x, int ldx, int x_bf16, const int* rows, cons
                        int W, void* y, int ldy, int y_f32, float* mean, float* rstd, hipStream_t stream);
 /* the same, additionally writing the bf16 output as OCP e4m3 bytes q8[M, W] (ldq bytes per row) with one scale per row
  * (row_scale[M] = amax(row) / 448): the fp8 operand of the GEMM that follows (BASELINE config 4), identical to
- * tvts_quant_fp8_rows run on y */
+ * tvts_quant_fp8_rows run on y.  y may be NULL (bf16 x, W % 8 == 0, W <= 1536, ldx % 8 == ldq % 8 == 0): the e4m3 bytes are
+ * then the only output -- under per-tensor scales (tscale) the GEMMs that follow never read the bf16 tensor.  The same holds
+ * for tvts_layernorm_fwd_cls with q8. */
 int tvts_layernorm_fwd_fp8(const void* x, int ldx, int x_bf16, const int* rows, const float* gamma, const float* beta, float eps,
                            int M, int W, void* y, int ldy, void* q8, int ldq, float* row_scale, const float* tscale, float* amax_acc,
                            float* mean, float* rstd, hipStream_t stream);

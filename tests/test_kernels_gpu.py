@@ -513,6 +513,12 @@ def test_layernorm_on_the_hybrid_stream(K, W, period, q8):
     if q8:
         q0, rs0 = K.quantize_fp8_rows(y)
         assert torch.equal(q0, kw["q8"]) and torch.equal(rs0[:M], kw["row_scale"][:M])
+        # the e4m3 bytes as the only output: same bytes, the CLS rows still refreshed
+        x_dev2 = xs.to(DEV)
+        kw2 = dict(q8=torch.full((M, W), 9, dtype=torch.uint8, device=DEV), row_scale=torch.empty(M, device=DEV))
+        K.layernorm_fwd(x_dev2, g, b, 1e-5, None, torch.empty_like(mean), torch.empty_like(rstd), cls_x=cls_x, cls_period=period, **kw2)
+        assert torch.equal(kw2["q8"], kw["q8"]) and torch.equal(kw2["row_scale"][:M], kw["row_scale"][:M])
+        assert torch.equal(x_dev2.view(torch.int16), x_dev.view(torch.int16))
     # backward: stream gradient bf16, CLS rows of it fp32
     res1_exact = rnd(M, W, seed=20)
     res1 = bf(res1_exact); res1[cls_rows] = -555.0
@@ -1410,6 +1416,22 @@ def test_layernorm_fwd_fp8_output(K, W, xdt):
         assert float((y0.float() - y1.float()).abs().max()) <= 2.0 ** -7 * float(y0.float().abs().max())  # a last bf16 bit here and there
     q_ref, rs_ref = K.quantize_fp8_rows(y1)
     assert torch.equal(q, q_ref) and torch.equal(rs, rs_ref)
+    if xdt == torch.bfloat16:  # the e4m3 bytes as the ONLY output (arch["fp8_q8_only"]): the same bytes, per-row and per-tensor scales
+        assert torch.equal(y0, y1)  # (both are the 8-column kernel now)
+        q3, rs3, m3, r3 = torch.full_like(q, 5), torch.empty_like(rs), torch.empty_like(m1), torch.empty_like(r1)
+        K.layernorm_fwd(x, g, b, 1e-5, None, m3, r3, q8=q3, row_scale=rs3)
+        assert torch.equal(q3, q) and torch.equal(rs3, rs) and torch.equal(m3, m1) and torch.equal(r3, r1)
+        ts = torch.tensor([float(y1.float().abs().max()) / 448.0 * 0.9], device=DEV)  # (0.9: some values clamp at +-448)
+        q4, q5 = torch.full_like(q, 5), torch.full_like(q, 6)
+        am4, am5 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+        K.layernorm_fwd(x, g, b, 1e-5, torch.empty_like(y1), q8=q4, tscale=ts, amax=am4)
+        K.layernorm_fwd(x, g, b, 1e-5, None, q8=q5, tscale=ts, amax=am5)
+        assert torch.equal(q4, q5) and torch.equal(am4, am5) and float(am4) == float(y1.float().abs().max())
+        want = torch.clamp(y1.float() * (1.0 / ts), -448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        assert torch.equal(q5, want)
+    else:
+        with pytest.raises(K.HipError):  # fp32 rows have no e4m3-only form
+            K.layernorm_fwd(x, g, b, 1e-5, None, m1, r1, q8=q, row_scale=rs)
     # gathered rows (the pooled tail's CLS rows)
     rows = torch.tensor([5, 0, 333, 516], dtype=torch.int32, device=DEV)
     y2 = torch.empty(4, W, dtype=torch.bfloat16, device=DEV)

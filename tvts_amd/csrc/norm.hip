@@ -190,16 +190,22 @@ __device__ __forceinline__ bf16x8 narrow8(const f32x4& lo, const f32x4& hi) {
     return (bf16x8){(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
 }
 
-template <int NP, bool CLS>
+// Q8: the e4m3 copy of the output as in ln_fwd_kernel (the bf16-rounded values under the row's or the tensor's scale: the same
+// bytes); y may then be NULL -- under per-tensor scales every consumer of a space-time block's LayerNorm output multiplies the
+// e4m3 bytes (forward GEMM and weight gradient), the bf16 tensor would be written and never read.
+template <int NP, bool CLS, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd8_kernel(const bf16* __restrict__ x, int ldx, const int* __restrict__ rows,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                       int M, int W, bf16* __restrict__ y, int ldy, float* __restrict__ mean_out,
                                                       float* __restrict__ rstd_out, const float* __restrict__ cls_x, int cls_period,
-                                                      bf16* x_refresh) {
+                                                      bf16* x_refresh, unsigned char* __restrict__ q8 = nullptr, int ldq = 0,
+                                                      float* __restrict__ row_scale = nullptr, const float* __restrict__ tscale = nullptr,
+                                                      float* __restrict__ amax_acc = nullptr) {
     const int lane = threadIdx.x & 63;
     const int stride = gridDim.x * 4;
     int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
+    float run_amax = 0.f;
     f32x4 gm[NP][2], bt[NP][2];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -257,6 +263,8 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const bf16* __restrict__ x
             }
         const float rstd = rsqrtf(wave_sum(q) * invW + eps);
         const bool refresh = CLS && cur.cls && x_refresh;
+        bf16x8 ob[Q8 ? NP : 1];
+        float am = 0.f;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int c = lane * 8 + p * 512;
@@ -266,9 +274,38 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const bf16* __restrict__ x
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[h][e] = (v[p][h][e] - mean) * rstd * gm[p][h][e] + bt[p][h][e];
-                *(bf16x8*)(y + (size_t)r * ldy + c) = narrow8(o[0], o[1]);
+                const bf16x8 ob8 = narrow8(o[0], o[1]);
+                if (!Q8 || y) *(bf16x8*)(y + (size_t)r * ldy + c) = ob8;
                 if (refresh) *(bf16x8*)(x_refresh + (size_t)r * ldx + c) = narrow8(v[p][0], v[p][1]);
+                if (Q8) {
+                    ob[p] = ob8;  // the values a bf16 consumer would see
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf((float)ob8[e]));
+                }
             }
+        }
+        if (Q8) {
+            am = wave_max(am);
+            run_amax = fmaxf(run_amax, am);
+            const float scale = q8_scale(tscale, am);
+            const float inv = 1.0f / scale;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int c = lane * 8 + p * 512;
+                if (c < W) {
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf((float)ob[p][e] * inv, -448.0f), 448.0f);
+                    int p0 = 0, p1 = 0;
+                    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], p0, false);
+                    p0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], p0, true);
+                    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], p1, false);
+                    p1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], p1, true);
+                    typedef __attribute__((ext_vector_type(2))) int i32x2_;
+                    *(i32x2_*)(q8 + (size_t)r * ldq + c) = (i32x2_){p0, p1};
+                }
+            }
+            if (lane == 0 && row_scale) row_scale[r] = scale;
         }
         if (lane == 0) {
             if (mean_out) mean_out[r] = mean;
@@ -276,6 +313,7 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const bf16* __restrict__ x
         }
         if (more) cur = nxt;
     }
+    if (Q8) amax_publish(amax_acc, run_amax, lane);
 }
 
 template <bool CLS>
@@ -289,6 +327,18 @@ static void launch_ln_fwd8(hipStream_t stream, const bf16* x, int ldx, const int
     switch (np) { LN8_CASE(1) LN8_CASE(2) default: LN8_CASE(3) }
 #undef LN8_CASE
 }
+template <bool CLS>
+static void launch_ln_fwd8_q8(hipStream_t stream, const bf16* x, int ldx, const int* rows, const float* gamma, const float* beta,
+                              float eps, int M, int W, bf16* y, int ldy, float* mean, float* rstd, unsigned char* q8, int ldq,
+                              float* row_scale, const float* tscale, float* amax_acc, const float* cls_x = nullptr,
+                              int cls_period = 0, bf16* x_refresh = nullptr) {
+    int blocks = ceil_div(M, 4);
+    if (blocks > 2048) blocks = 2048;
+    const int np = ceil_div(W, 512);
+#define LN8_CASE(N) case N: hipLaunchKernelGGL((ln_fwd8_kernel<N, CLS, true>), dim3(blocks), dim3(256), 0, stream, x, ldx, rows, gamma, beta, eps, M, W, y, ldy, mean, rstd, cls_x, cls_period, x_refresh, q8, ldq, row_scale, tscale, amax_acc); break;
+    switch (np) { LN8_CASE(1) LN8_CASE(2) default: LN8_CASE(3) }
+#undef LN8_CASE
+}
 static inline bool ln8_ok(int W, int ld_a, int ld_b) { return W % 8 == 0 && W <= 1536 && ld_a % 8 == 0 && ld_b % 8 == 0; }
 
 // LayerNorm forward that also emits the e4m3 copy of its bf16 output with per-row scales (see Q8 above)
@@ -296,10 +346,13 @@ extern "C" int tvts_layernorm_fwd_fp8(const void* x, int ldx, int x_bf16, const 
                                       float eps, int M, int W, void* y, int ldy, void* q8, int ldq, float* row_scale,
                                       const float* tscale, float* amax_acc, float* mean, float* rstd, hipStream_t stream) {
     if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || ldy % 4 || ldq % 4 || !q8 || (!row_scale && !tscale)) return TVTS_EINVAL;
+    if (!y && !(x_bf16 && ln8_ok(W, ldx, 8) && ldq % 8 == 0)) return TVTS_EINVAL;  // e4m3-only: the 8-column bf16-row form
     int blocks = ceil_div(M, 4);
     if (blocks > 2048) blocks = 2048;
     const int it = ceil_div(W, 256);
-    if (x_bf16) launch_ln_fwd_q8<bf16>(it, dim3(blocks), stream, (const bf16*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd, (unsigned char*)q8, ldq, row_scale, tscale, amax_acc);
+    if (x_bf16 && ln8_ok(W, ldx, y ? ldy : 8) && ldq % 8 == 0)
+        launch_ln_fwd8_q8<false>(stream, (const bf16*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd, (unsigned char*)q8, ldq, row_scale, tscale, amax_acc);
+    else if (x_bf16) launch_ln_fwd_q8<bf16>(it, dim3(blocks), stream, (const bf16*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd, (unsigned char*)q8, ldq, row_scale, tscale, amax_acc);
     else launch_ln_fwd_q8<float>(it, dim3(blocks), stream, (const float*)x, ldx, rows, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd, (unsigned char*)q8, ldq, row_scale, tscale, amax_acc);
     TVTS_LAUNCH_CHECK();
     return TVTS_OK;
@@ -331,10 +384,14 @@ extern "C" int tvts_layernorm_fwd_cls(const void* x, int ldx, const float* cls_x
                                       const float* tscale, float* amax_acc, float* mean, float* rstd, hipStream_t stream) {
     if (M <= 0 || W <= 0 || W % 4 || W > 256 * LN_MAX_IT || ldx % 4 || ldy % 4 || !cls_x || cls_period <= 0 || M % cls_period) return TVTS_EINVAL;
     if (q8 && (ldq % 4 || (!row_scale && !tscale))) return TVTS_EINVAL;
+    if (!y && !(q8 && ln8_ok(W, ldx, 8) && ldq % 8 == 0)) return TVTS_EINVAL;  // e4m3-only: the 8-column form
     int blocks = ceil_div(M, 4);
     if (blocks > 2048) blocks = 2048;
     const int it = ceil_div(W, 256);
-    if (q8) launch_ln_fwd_q8<bf16, true>(it, dim3(blocks), stream, (const bf16*)x, ldx, nullptr, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd,
+    if (q8 && ln8_ok(W, ldx, y ? ldy : 8) && ldq % 8 == 0)
+        launch_ln_fwd8_q8<true>(stream, (const bf16*)x, ldx, nullptr, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd, (unsigned char*)q8, ldq,
+                                row_scale, tscale, amax_acc, cls_x, cls_period, (bf16*)x_refresh);
+    else if (q8) launch_ln_fwd_q8<bf16, true>(it, dim3(blocks), stream, (const bf16*)x, ldx, nullptr, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd,
                                    (unsigned char*)q8, ldq, row_scale, tscale, amax_acc, cls_x, cls_period, (bf16*)x_refresh);
     else if (ln8_ok(W, ldx, ldy)) launch_ln_fwd8<true>(stream, (const bf16*)x, ldx, nullptr, gamma, beta, eps, M, W, (bf16*)y, ldy, mean, rstd,
                                                         cls_x, cls_period, (bf16*)x_refresh);

@@ -545,6 +545,11 @@ class Engine:
         if fp8_for is not None and fp8_for in self.P.w8:
             q, sa, kw = self._q8(M, y.shape[1], "x." + fp8_for, persistent=True)
             a8, kw = (q, sa), dict(kw, q8=q)
+            # arch["fp8_q8_only"]: under per-tensor scales the forward GEMM and the weight gradient both multiply the e4m3 bytes,
+            # the bf16 output would be written and never read (8-column form of the kernel: bf16 rows, W % 8 == 0)
+            if (self.fp8_q8_only and self.fp8_wgrad and self._f8_tensor_mode and fp8_for in self.P.w8t and rows is None
+                    and x.dtype == torch.bfloat16 and y.shape[1] % 8 == 0 and y.shape[1] <= 1536 and q.stride(0) % 8 == 0):
+                y = None
         K.layernorm_fwd(x, self.P.p(name + ".weight"), self.P.p(name + ".bias"), eps, y, mean, rstd, rows=rows, M=M, **kw, **kw_cls)
         return a8
 

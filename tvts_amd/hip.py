@@ -486,25 +486,28 @@ def colsum(x, out, *, M=None):
 def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, rows=None, M=None, q8=None, row_scale=None, tscale=None, amax=None,
                   cls_x=None, cls_period=0, refresh=True):
     """q8 (uint8 [M, W]) + row_scale (float32 [>= M]): also write the bf16 output as e4m3 bytes with one scale per row.
+    y = None (with q8, bf16 x, W % 8 == 0, W <= 1536): the e4m3 bytes are the only output.
     cls_x (float32 [M / cls_period, W]) + cls_period: the hybrid residual stream -- x bf16, the rows r % cls_period == 0 are read
     from cls_x and (refresh) their bf16 rounding is written back into x."""
     lib = _lib.load()
     M = (rows.numel() if rows is not None else x.shape[0]) if M is None else M
     fam = "ln_fwd" if M >= 4096 else "ln_fwd_small"
+    assert y is not None or q8 is not None
+    ldy = _ld(y) if y is not None else 0
     if cls_x is not None:
-        assert rows is None and x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and cls_x.dtype == torch.float32
+        assert rows is None and x.dtype == torch.bfloat16 and (y is None or y.dtype == torch.bfloat16) and cls_x.dtype == torch.float32
         assert cls_x.is_contiguous() and cls_x.shape[1] == x.shape[1] and cls_x.shape[0] * cls_period == M
         with _hbm(fam, _nb((x, M), (y, M), (q8, M)) + 8 * M):
             rc = lib.tvts_layernorm_fwd_cls(_p(x), _ld(x), _p(cls_x), cls_period, _p(x) if refresh else None, _p(gamma), _p(beta), eps, M,
-                                            x.shape[1], _p(y), _ld(y), _p(q8), q8.stride(0) if q8 is not None else 0, _p(row_scale), _p(tscale),
+                                            x.shape[1], _p(y), ldy, _p(q8), q8.stride(0) if q8 is not None else 0, _p(row_scale), _p(tscale),
                                             _p(amax), _p(mean), _p(rstd), _stream())
         _chk(rc, "tvts_layernorm_fwd_cls")
         return
     if q8 is not None:
-        assert y.dtype == torch.bfloat16 and q8.dtype == torch.uint8 and (tscale is not None or (row_scale.dtype == torch.float32 and row_scale.numel() >= M))
+        assert (y is None or y.dtype == torch.bfloat16) and q8.dtype == torch.uint8 and (tscale is not None or (row_scale.dtype == torch.float32 and row_scale.numel() >= M))
         with _hbm(fam, _nb((x, M), (y, M), (q8, M)) + 12 * M):
             rc = lib.tvts_layernorm_fwd_fp8(_p(x), _ld(x), 1 if x.dtype == torch.bfloat16 else 0, _p(rows), _p(gamma), _p(beta), eps, M,
-                                            x.shape[1], _p(y), _ld(y), _p(q8), q8.stride(0), _p(row_scale), _p(tscale), _p(amax), _p(mean), _p(rstd), _stream())
+                                            x.shape[1], _p(y), ldy, _p(q8), q8.stride(0), _p(row_scale), _p(tscale), _p(amax), _p(mean), _p(rstd), _stream())
         _chk(rc, "tvts_layernorm_fwd_fp8")
         return
     with _hbm(fam, _nb((x, M), (y, M)) + 8 * M):
