@@ -384,7 +384,12 @@ __device__ __forceinline__ void epilogue256_patch(const GemmNT& g, f32x4 (&acc)[
             *(f32x4*)(patch + li * 256 + (((j * 4 + gq) ^ li) << 4)) = acc[j][i] * sc + bias4[j];
             acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        patch_readout<ACT, GATE, ABL>(g, patch, m0 + wm * 128 + i * 16, nb, lane, side, q8inv, &q8am);
+        // (an opaque copy of the lane id per slab: the read-out's lane-derived LDS / global offsets do not depend on the slab, so the
+        // compiler hoists them out of this loop -- and in the register-heavy forms (e4m3 operands, GELU, e4m3 copies) SPILLS them; every
+        // reload then waits vmcnt(0), i.e. for the previous slab's stores to be acknowledged: 8 store round trips per tile in series)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        patch_readout<ACT, GATE, ABL>(g, patch, m0 + wm * 128 + i * 16, nb, ln, side, q8inv, &q8am);
         if (PF && has_side && i + 1 < 8) side_prefetch<GATE, ABL>(g, m0 + wm * 128 + (i + 1) * 16, nb, lane, side);
     }
     if constexpr (Q8OUT) amax_publish(g.q8_amax, wave_max(q8am), lane);  // one conditional atomic per wave and tile
