@@ -985,8 +985,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
             if (++kt == nk) {
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results (16 passes) before the epilogue reads them
                 const int le = fresh_lane();
-                if (g.sa_rows) epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, le, patch, g.sb[0], g.sa);
-                else epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, le, patch, g.sa[0] * g.sb[0]);
+                // (ONE call: the epilogue is inlined, and two calls doubled the kernel's code -- the per-row and the per-tensor scale
+                // regimes differ in two scalars)
+                epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, le, patch, g.sa_rows ? g.sb[0] : g.sa[0] * g.sb[0],
+                                                  g.sa_rows ? g.sa : nullptr);
                 kt = 0; ++tl;
                 tile_origin256(g, tile_of(tl), gc, m0, n0);
                 if (more) {
@@ -1131,8 +1133,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                 if (full) epilogue256_reg<ACT, GATE, ABL, CFG, true>(g, acc, m0, n0, wm, wn, lane);
                 else epilogue256_reg<ACT, GATE, ABL, CFG, false>(g, acc, m0, n0, wm, wn, lane);
             } else {
-                if (FP8 && g.sa_rows) epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, g.sb[0], g.sa);
-                else epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, FP8 ? g.sa[0] * g.sb[0] : 1.0f);
+                if constexpr (FP8) epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, g.sa_rows ? g.sb[0] : g.sa[0] * g.sb[0],
+                                                                     g.sa_rows ? g.sa : nullptr);
+                else epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, 1.0f);
             }
             if constexpr ((ABL & 2048) != 0) {
                 if (wave == 0 && lane == 0 && tl < 32) {
