@@ -440,6 +440,46 @@ def test_text_tower_on_its_own_stream_gives_the_same_bits(K, lib, arch_name, B, 
         assert torch.equal(x, y)
 
 
+def test_cu_reservation_gives_the_same_bits(K, lib):
+    """dist.auto_cu_reservation reserves 8 CUs for the RCCL kernels at 24 ... 72 pairs per GPU when world > 1: the persistent 256 x 256
+    NT grids then run on 248 CUs (hip.set_default(nt_cus=248)).  A smaller grid changes which block walks which tile, never a tile's
+    arithmetic: embeddings, losses and every gradient of the 24-pair step keep their bits."""
+    from tvts_amd import arch as A
+    from tvts_amd.data_loader import synth_batch
+    from tvts_amd.dist import auto_cu_reservation
+    from tvts_amd.model._common import TVTSv2Base
+    B, T, NT = 24, 8, 4
+    a = dict(A.ARCHS["B_16"])
+    keep = auto_cu_reservation(B * (T * 98 + 1), 8)
+    assert keep == 8
+    res = {}
+    for cus in (0, 256 - keep):
+        m = TVTSv2Base(ARGS, arch=a, init_seed=0)
+        for name, p in m.named_parameters():
+            p.requires_grad = A.param_group_of(name, a) >= 0
+        _, _, run = _runner_of(m, a)
+        eng = m.engine
+        batch = synth_batch(a, B, T, seed=5, caption_len=32, n_trans=NT)
+        m._fresh_shadows(); m._sync_requires_grad()
+        pb = eng.prepare_batch(batch)
+        lab = batch["label"].reshape(-1).to(torch.int32).to(DEV)
+        with K.options(nt_cus=cus):
+            m.store.grad.zero_()
+            eng.embeds_ready = run.gather.start
+            try:
+                te, ve, pred = eng.forward(pb)
+            finally:
+                eng.embeds_ready = None
+            l1, l2, dte, dve, dpred = run.losses_and_grads(pb, te, ve, pred, lab)
+            eng.backward(dte, dve, dpred)
+            torch.cuda.synchronize()
+        res[cus] = (m.store.grad.clone(), te.clone(), ve.clone(), l1.clone(), l2.clone())
+        del m
+    assert float(res[0][0].abs().max()) > 0
+    for x, y in zip(res[0], res[248]):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("arch_name,B,T", [("B_16", 12, 8), ("B_32", 24, 8), ("H_14", 2, 16)])
 def test_wgrad_side_stream_gives_the_same_bits(K, lib, arch_name, B, T):
     """The reference's own per-GPU batches (v2/configs/dist-yt-web-pt-vit-b-16.json:21 = 12, ...b-32.json:21 = 24, ...h-14.json:21 = 2):
