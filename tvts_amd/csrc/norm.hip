@@ -10,6 +10,7 @@
 // Reference: nn.LayerNorm as used at v2/model/video_encoder_ViT_B_16.py:79-85 (eps 1e-5, fp32) and
 // v2/model/sort_transformer.py:99 (eps 1e-6).
 #include "common.h"
+#include <type_traits>
 
 #define LN_MAX_IT 5  // 5 * 256 = 1280 columns max
 
@@ -62,12 +63,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
     const float invW = 1.0f / (float)W;
     f32x4 v[IT], nx[IT];
     auto load_row = [&](int rr, f32x4 (&d)[IT]) {
+        // (unconditional loads, zeroed afterwards: see ln_bwd_kernel)
         if (CLS && rr % cls_period == 0) {  // (wave-uniform: a wave owns the row)
             const float* cp = cls_x + (size_t)(rr / cls_period) * W;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int c = lane * 4 + it * 256;
-                d[it] = c < W ? load4<float>(cp + c) : (f32x4){0, 0, 0, 0};
+                const f32x4 v = load4<float>(cp + (c < W ? c : 0));
+                d[it] = c < W ? v : (f32x4){0, 0, 0, 0};
             }
             return;
         }
@@ -75,7 +78,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int c = lane * 4 + it * 256;
-            d[it] = c < W ? load4<TX>(xp + c) : (f32x4){0, 0, 0, 0};
+            const f32x4 v = load4<TX>(xp + (c < W ? c : 0));
+            d[it] = c < W ? v : (f32x4){0, 0, 0, 0};
         }
     };
     load_row(r, v);
@@ -222,9 +226,9 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const bf16* __restrict__ x
         if (w.cls) return;
         const bf16* xp = x + (size_t)(rows ? rows[rr] : rr) * ldx;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
+        for (int p = 0; p < NP; ++p) {  // (unconditional loads: see ln_bwd_kernel)
             const int c = lane * 8 + p * 512;
-            if (c < W) w.raw[p] = *(const bf16x8*)(xp + c);
+            w.raw[p] = *(const bf16x8*)(xp + (c < W ? c : 0));
         }
     };
     Row cur, nxt;
@@ -409,8 +413,15 @@ __device__ __forceinline__ f32x4 widen(bf16x4 v) { return (f32x4){(float)v[0], (
 
 // Q8: additionally write the bf16 copy of dx as OCP e4m3 bytes with one scale per row (amax of the bf16-rounded values / 448) -- the
 // output gradient of the e4m3 input-gradient GEMM that consumes dx_bf16 (same bytes as tvts_quant_fp8_rows of dx_bf16)
+// blocks per CU of a variant (launch bound and persistent grid): rows of <= 768 columns 3 with a residual input, else 4; wider rows 2
+// with a residual input or with a second row in flight (all-bf16 streams), else 3
+template <typename TDY, int IT, bool R1, bool R2, typename TX, typename TR1>
+constexpr int ln_bwd_per_cu() {
+    return IT <= 3 ? ((R1 || R2) ? 3 : 4)
+                   : ((R1 || R2 || (sizeof(TDY) == 2 && sizeof(TX) == 2 && (!R1 || sizeof(TR1) == 2))) ? 2 : 3);
+}
 template <typename TDY, int IT, bool R1, bool R2, typename TX = float, bool Q8 = false, typename TR1 = float, bool CLS = false>
-__global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3)) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const TX* __restrict__ x,
+__global__ __launch_bounds__(256, (ln_bwd_per_cu<TDY, IT, R1, R2, TX, TR1>())) void ln_bwd_kernel(const TDY* __restrict__ dy, int lddy, const TX* __restrict__ x,
                                                         int ldx, const int* __restrict__ rows,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const TR1* __restrict__ res1,
@@ -429,6 +440,11 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
     // plain launch's in dx_bf16 (and q8) -- is ALSO stored in fp32 to cls_dx: the CLS token's gradient chain never passes through
     // a bf16 rounding.  (One kernel for both kinds of rows ran the 784 other rows of a clip at half speed: 14 spilled registers.)
     typedef typename RawDy<TDY>::T DyV;
+    // a row in flight keeps its inputs in their STORED type (bf16 rows: 2 registers per 4 columns instead of 4) and is widened where it
+    // is used; the CLS instantiation reads fp32 side rows and keeps f32x4
+    typedef typename std::conditional<CLS, f32x4, typename RawDy<TX>::T>::type XV;
+    typedef typename std::conditional<CLS, f32x4, typename RawDy<TR1>::T>::type R1V;
+    constexpr bool ALL16 = sizeof(TDY) == 2 && sizeof(TX) == 2 && (!R1 || sizeof(TR1) == 2);
     float run_amax = 0.f;
     __shared__ float red[2][4][IT * 256];  // [gamma|beta][wave][column slot]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -442,25 +458,40 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
     }
     const float invW = 1.0f / (float)W;
     const int stride = gridDim.x * 4 * (CLS ? cls_period : 1);
-    struct Row { f32x4 x[IT]; DyV d[IT]; f32x4 r1[R1 ? IT : 1]; bf16x4 r2[R2 ? IT : 1]; float mu, rs; int xr; };
+    struct Row { XV x[IT]; DyV d[IT]; R1V r1[R1 ? IT : 1]; bf16x4 r2[R2 ? IT : 1]; float mu, rs; int xr; };
     auto load_row = [&](int rr, Row& w) {
         w.xr = rows ? rows[rr] : rr;
         w.mu = mean[rr];
         w.rs = rstd[rr];
         const bool cls = CLS;
         const size_t ci = cls ? (size_t)(rr / cls_period) * W : 0;
+        // UNCONDITIONAL loads (lanes past the row's end re-read its first columns -- always inside the row; their values are never used): inside `if (c < W)`
+        // every column group is a basic block of its own, and hipcc's wait-count pass, which must assume that a group may have been
+        // skipped, makes each group wait for the loads of the one before it -- IT dependent round trips per row instead of one
+        // (the 1280-wide H/14 forms streamed 3.0 - 3.6 TB/s where the 768-wide ones stream ~5)
+        // The all-bf16 forms only: with fp32 streams every load in flight at once needs more registers than the launch bounds leave
+        // (24 - 40 spilled, and a spill reload in this loop waits for the prefetched row).
+        constexpr bool UNCOND = ALL16 && !CLS;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int c = lane * 4 + it * 256;
-            if (c < W) {
-                w.x[it] = (cls && cls_x) ? load4<float>(cls_x + ci + c) : load4<TX>(x + (size_t)w.xr * ldx + c);
+            const int c0 = lane * 4 + it * 256, c = c0 < W ? c0 : 0;
+            if (UNCOND || c0 < W) {
+                if constexpr (CLS) {
+                    w.x[it] = cls_x ? load4<float>(cls_x + ci + c) : load4<TX>(x + (size_t)w.xr * ldx + c);
+                    if (R1) w.r1[it] = cls_res1 ? load4<float>(cls_res1 + ci + c) : load4<TR1>(res1 + (size_t)w.xr * ldr + c);
+                } else {
+                    w.x[it] = *(const XV*)(x + (size_t)w.xr * ldx + c);
+                    if (R1) w.r1[it] = *(const R1V*)(res1 + (size_t)w.xr * ldr + c);
+                }
                 w.d[it] = *(const DyV*)(dy + (size_t)rr * lddy + c);
-                if (R1) w.r1[it] = (cls && cls_res1) ? load4<float>(cls_res1 + ci + c) : load4<TR1>(res1 + (size_t)w.xr * ldr + c);
                 if (R2) w.r2[it] = *(const bf16x4*)(res2 + (size_t)w.xr * ldr2 + c);
             }
         }
     };
-    constexpr bool PF = IT <= 3 && !CLS;  // wider rows (1024, 1280 columns) do not have the registers for a second row in flight
+    // a second row in flight: rows of <= 768 columns always; the wider rows (1024, 1280 columns) when every input stream is bf16 (the
+    // hybrid stream's forms: 40 instead of 60 - 80 registers per row in flight).  Without it a wave runs load -> reduce -> store round
+    // trips one at a time at 8 - 12 waves per CU: the H/14 backward forms streamed 3.0 - 3.6 TB/s where the B/16 forms stream ~5
+    constexpr bool PF = !CLS && (IT <= 3 || ALL16);
     int r = (blockIdx.x * 4 + wave) * (CLS ? cls_period : 1);
     Row cur, nxt;
     if (PF && r < M) load_row(r, cur);
@@ -474,10 +505,10 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
         for (int it = 0; it < IT; ++it) {
             const int c = lane * 4 + it * 256;
             if (c < W) {
-                const f32x4 d = widen(cur.d[it]);
+                const f32x4 d = widen(cur.d[it]), xv = widen(cur.x[it]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    xh[it][e] = (cur.x[it][e] - cur.mu) * cur.rs;
+                    xh[it][e] = (xv[e] - cur.mu) * cur.rs;
                     g[it][e] = d[e] * gm[it][e];
                     s1 += g[it][e];
                     s2 += g[it][e] * xh[it][e];
@@ -497,7 +528,7 @@ __global__ __launch_bounds__(256, IT <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ?
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = cur.rs * (g[it][e] - c1 - xh[it][e] * c2);
-            if (R1) o += cur.r1[it];
+            if (R1) o += widen(cur.r1[it]);
             if (R2) o += widen(cur.r2[it]);
             return o;
         };
@@ -607,7 +638,7 @@ static void launch_ln_bwd(int it, int M, hipStream_t stream, const TDY* dy, int 
                           const float* tscale = nullptr, float* amax_acc = nullptr, const float* cls_x = nullptr,
                           const float* cls_res1 = nullptr, float* cls_dx = nullptr, int cls_period = 0) {
     // persistent grid: as many blocks per CU as the variant's registers allow (see __launch_bounds__ above)
-    const int per_cu = it <= 3 ? ((R1 || R2) ? 3 : 4) : ((R1 || R2) ? 2 : 3);
+    const int per_cu = it <= 3 ? ln_bwd_per_cu<TDY, 3, R1, R2, TX, TR1>() : ln_bwd_per_cu<TDY, 5, R1, R2, TX, TR1>();
     int blocks = ceil_div(CLS ? M / cls_period : M, 4);
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     const dim3 grid(blocks);
