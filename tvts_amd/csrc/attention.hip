@@ -167,6 +167,13 @@ __device__ __forceinline__ bf16x8 zero8() {
     for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
     return z;
 }
+// A tile row that may lie past the group's last token: the LOAD is unconditional (row 0 of the group stands in -- always a valid
+// address) and the value is zeroed afterwards.  Written as `ok ? ldg8(p) : zero8()`, hipcc puts every such load into a conditional
+// block of its own and, the loaded register being merged with the zeros of the other arm, waits vmcnt(0) right behind it: loads
+// meant to be in flight together left one or two at a time (round 5, from the ISA of the fused SPACE kernels, which load a group and
+// stage it at once.  NOT for loads that are consumed an iteration later -- the TIME / sequence kernels' prefetch of the next group:
+// the selects then sit right behind the loads and the wait for them makes the prefetch synchronous; their conditional form is fine).
+__device__ __forceinline__ bf16x8 sel8(bool ok, const bf16x8& v) { return ok ? v : zero8(); }
 // KS k-contiguous fragments of one head row (d = ks*32 + gq*8 ..); slots past DH are zero
 __device__ __forceinline__ void ld_frags(const bf16* p, int gq, bf16x8 (&f)[KS]) {
 #pragma unroll
@@ -1266,13 +1273,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void attn_bwd_space_fused_kernel(
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int c = tid + FUSED_THREADS * i, row = c / NCH, ch = c % NCH;
-                stg[t][i] = (row < m && !(g.ablate & 4)) ? ldg8(base + (size_t)k_row<MODE_SPACE>(g, r, row) * ld + ch * 8) : zero8();
+                stg[t][i] = sel8(row < m && !(g.ablate & 4), ldg8(base + (size_t)k_row<MODE_SPACE>(g, r, row < m ? row : 0) * ld + ch * 8));
             }
         }
-        if (tid < RA) {
+        {   // (both statistics loaded unconditionally, by every thread, from a row that exists: no wait between them)
             const size_t o = (size_t)k_row<MODE_SPACE>(g, r, tid < m ? tid : 0) * g.heads + r.h;
-            st_lse[tid] = tid < m ? lse2[o] : 0.f;
-            st_dl[tid] = tid == 0 ? delta[o] : 0.f;  // CLS query: D from the delta pass over the CLS rows
+            const float lv = lse2[o], dv = delta[o];
+            if (tid < RA) {
+                st_lse[tid] = tid < m ? lv : 0.f;
+                st_dl[tid] = tid == 0 ? dv : 0.f;  // CLS query: D from the delta pass over the CLS rows
+            }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -1674,7 +1684,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_space_fused_kernel(AttnGeom g
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
-                stg[t][i] = row < m ? ldg8(qkv + (size_t)k_row<MODE_SPACE>(g, r, row) * g.ld + (1 + t) * g.W + hcol + ch * 8) : zero8();
+                stg[t][i] = sel8(row < m, ldg8(qkv + (size_t)k_row<MODE_SPACE>(g, r, row < m ? row : 0) * g.ld + (1 + t) * g.W + hcol + ch * 8));
             }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
