@@ -826,6 +826,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_grouped_kernel(TnGroup gr
     const GemmTN g = grp.tab[p];  // block-uniform
     tn128_item(g, item - grp.prefix[p], smem);
 }
+// The element pass of the two reduce kernels: out[a, b] = (accumulate ? out[a, b] : 0) + range 0 + range 1 + ... (that order: the fused
+// in-kernel reduce evaluates the same expression).  Partials of up to FOUR ranges are requested before the first is added (round 5:
+// the plain `for k: s += ws[k]` loop was a load -> vmcnt(0) -> add chain per range, and the row / column of an element cost a 64-bit
+// division, ~100 instructions).
+__device__ __forceinline__ void tn_reduce_elements(const float* __restrict__ ws, int splits, int Na, int Nb, float* __restrict__ out,
+                                                   int ldo, int accumulate) {
+    const size_t plane = (size_t)Na * Nb;
+    const size_t n4 = plane / 4;
+    const bool dense = ldo == Nb;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t e = i * 4;
+        size_t o = e;
+        if (!dense) {  // (Na * Nb < 2^32: the workspace holds `splits` planes of it)
+            const unsigned a = (unsigned)e / (unsigned)Nb;
+            o = (size_t)a * ldo + ((unsigned)e - a * (unsigned)Nb);
+        }
+        const float* p = ws + e;
+        // (the output is read also when it is overwritten -- it is valid memory, the value is dropped: no conditional load)
+        const f32x4 prev = *(const f32x4*)(out + o);
+        f32x4 s = accumulate ? prev : (f32x4){0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            const f32x4 v0 = *(const f32x4*)(p + (size_t)k * plane), v1 = *(const f32x4*)(p + (size_t)(k + 1) * plane);
+            const f32x4 v2 = *(const f32x4*)(p + (size_t)(k + 2) * plane), v3 = *(const f32x4*)(p + (size_t)(k + 3) * plane);
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        if (k + 2 <= splits) {
+            const f32x4 v0 = *(const f32x4*)(p + (size_t)k * plane), v1 = *(const f32x4*)(p + (size_t)(k + 1) * plane);
+            s += v0; s += v1;
+            k += 2;
+        }
+        if (k < splits) s += *(const f32x4*)(p + (size_t)k * plane);
+        *(f32x4*)(out + o) = s;
+    }
+}
 __global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnGroup grp) {
     const GemmTN g = grp.tab[blockIdx.y];
     if (!g.ws) return;  // one range: the kernel wrote the output itself
@@ -836,14 +871,7 @@ __global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnGroup grp) {
             g.colsum[a] = s;
         }
     }
-    const size_t n4 = (size_t)g.Na * g.Nb / 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const size_t e = i * 4;
-        const int a = (int)(e / g.Nb), b = (int)(e % g.Nb);
-        f32x4 s = g.accumulate ? *(const f32x4*)(g.out + (size_t)a * g.ldo + b) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < g.splits; ++k) s += *(const f32x4*)(g.ws + (size_t)k * g.Na * g.Nb + e);
-        *(f32x4*)(g.out + (size_t)a * g.ldo + b) = s;
-    }
+    tn_reduce_elements(g.ws, g.splits, g.Na, g.Nb, g.out, g.ldo, g.accumulate);
 }
 
 // out[a,b] = (accumulate ? out[a,b] : 0) + sum_s ws[s][a][b];  colsum[a] += sum_s cs_ws[s][a]  (both in split order)
@@ -857,14 +885,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
             colsum[a] = s;
         }
     }
-    const size_t n4 = (size_t)Na * Nb / 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const size_t e = i * 4;
-        const int a = (int)(e / Nb), b = (int)(e % Nb);
-        f32x4 s = accumulate ? *(const f32x4*)(out + (size_t)a * ldo + b) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < splits; ++k) s += *(const f32x4*)(ws + (size_t)k * Na * Nb + e);
-        *(f32x4*)(out + (size_t)a * ldo + b) = s;
-    }
+    tn_reduce_elements(ws, splits, Na, Nb, out, ldo, accumulate);
 }
 
 #include "gemm_tn256.h"
