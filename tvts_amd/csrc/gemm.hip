@@ -106,35 +106,67 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNT g) {
             if (kt + 1 < nk) __syncthreads();
         }
 
-        // epilogue: lane owns row m (column of the swapped MFMA) and 4 consecutive n
+        // epilogue: lane owns row m (column of the swapped MFMA) and 4 consecutive n.  Side inputs are loaded UNCONDITIONALLY (rows /
+        // columns past the matrix clamped to its last ones) and a row-tile's four at a time: with every load inside its own
+        // `if (g.bias) / if (m < M)` block hipcc waited vmcnt(0) behind each one -- up to three dependent memory round trips for each of
+        // the 16 sub-tiles, each of which also waited for the previous sub-tile's stores (round 5, from the ISA: the kernel of the
+        // reference's 12 / 24-pair batches, 36 us per launch of which the epilogue was a third)
+        f32x4 bias4[4];
+        int ncol[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            ncol[j] = n < g.N ? n : g.N - 4;
+            bias4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (g.bias) {  // (block-uniform: one block of four loads, one wait)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias4[j] = *(const f32x4*)(g.bias + ncol[j]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            const size_t mc = (size_t)(m < g.M ? m : g.M - 1);
+            bf16x4 h4[4];
+            f32x4 r4[4];
+            if (GATE != ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h4[j] = *(const bf16x4*)(g.gate_h + mc * g.ldh + ncol[j]);
+            }
+            if (g.residual) {  // (block-uniform)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r4[j] = *(const f32x4*)(g.residual + mc * g.ldr + ncol[j]);
+            }
+            // every value of the row-tile first, then its stores: a store between two uses of loaded side inputs makes the second
+            // use wait vmcnt(0), i.e. for that store's acknowledgement
+            f32x4 vv[4], sd4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[j][i];
+                if (g.bias) v += bias4[j];
+                if (ACT != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float t; v[e] = act_fwd_side(v[e], ACT, g.side_deriv, t); sd4[j][e] = t; }
+                }
+                if (GATE != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)h4[j][e], GATE, g.side_deriv);
+                }
+                if (g.residual) v += r4[j];
+                vv[j] = v;
+            }
+            // (pinned: left alone, hipcc sinks each value's arithmetic into the conditional block of its store, behind the previous
+            // store, and the wait for the loaded side inputs at that block's entry is vmcnt(0) again)
+            asm volatile("" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]));
+            if (ACT != ACT_NONE) asm volatile("" : "+v"(sd4[0]), "+v"(sd4[1]), "+v"(sd4[2]), "+v"(sd4[3]));
             if (m >= g.M) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
                 if (n >= g.N) continue;
-                f32x4 v = acc[j][i];
-                if (g.bias) {
-                    const f32x4 b = *(const f32x4*)(g.bias + n);
-                    v += b;
-                }
-                if (ACT != ACT_NONE) {
-                    f32x4 sd;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { float t; v[e] = act_fwd_side(v[e], ACT, g.side_deriv, t); sd[e] = t; }
-                    if (g.preact) *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)sd[0], (bf16)sd[1], (bf16)sd[2], (bf16)sd[3]};
-                }
-                if (GATE != ACT_NONE) {
-                    const bf16x4 h = *(const bf16x4*)(g.gate_h + (size_t)m * g.ldh + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)h[e], GATE, g.side_deriv);
-                }
-                if (g.residual) {
-                    const f32x4 r = *(const f32x4*)(g.residual + (size_t)m * g.ldr + n);
-                    v += r;
-                }
+                const f32x4 v = vv[j];
+                if (ACT != ACT_NONE && g.preact)
+                    *(bf16x4*)(g.preact + (size_t)m * g.ldp + n) = (bf16x4){(bf16)sd4[j][0], (bf16)sd4[j][1], (bf16)sd4[j][2], (bf16)sd4[j][3]};
                 if (g.out_f32) {
                     *(f32x4*)((float*)g.out + (size_t)m * g.ldc + n) = v;
                 } else {
