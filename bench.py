@@ -204,6 +204,29 @@ def pmc_traffic(args):
     return d
 
 
+def pmc_mfma_util(args):
+    """Matrix-pipe duty and clock under load of the step's GEMM launches from a committed counter pass of this exact workload
+    (tools/pmc_mfma_util.sh: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE; counters need rocprofv3's own passes).  Stamped and refused
+    like pmc_traffic."""
+    import glob
+    if args.fp8 or args.n_trans != 4:
+        return None
+    pat = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                       f"*pmc_mfma_util_{args.arch}_t{args.frames}_b{args.batch}.json")
+    hits = sorted(glob.glob(pat))
+    if not hits:
+        return None
+    d = json.load(open(hits[-1]))
+    src = "profiles/" + os.path.basename(hits[-1])
+    if d.get("gemm_source_id") != gemm_source_id():
+        return {"stale": f"{src} was measured on GEMM sources {d.get('gemm_source_id', '(unstamped)')}, this build is "
+                         f"{gemm_source_id()}: re-run tools/pmc_mfma_util.sh"}
+    a = d["all_gemm"]
+    return {"source": src, "mfma_busy": a["mfma_busy"], "clock_mhz_under_load": 1e3 * a["clock_ghz"],
+            "peak_at_clock": a["peak_tflops_at_clock"], "tflops_in_profiled_pass": a["tflops"],
+            "by_family": {k: {"mfma_busy": v["mfma_busy"], "clock_mhz": 1e3 * v["clock_ghz"]} for k, v in d.get("by_family", {}).items()}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -362,6 +385,8 @@ def main():
             graphs, use_graph = None, False
             torch.cuda.synchronize()
 
+    if world > 1 and graphs is None:
+        runner.diag = {}  # exchange diagnostics of the timed steps: where the compute stream waits for a collective (StepRunner._bracket)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -372,14 +397,37 @@ def main():
         else:
             out = one_step(i, device_step=False)
     torch.cuda.synchronize()
+    # this rank's own time for the K steps (before the closing barrier): the per-rank spread tells a slow rank from a slow collective
+    t_own = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    diag, runner.diag = runner.diag, None
+    exch_diag = {}
     if world > 1:
+        if diag is not None:
+            mine = [sum(a.elapsed_time(b) for a, b in diag.get(k, [])) / max(args.steps, 1) for k in ("gather", "allreduce")]
+        else:
+            mine = [float("nan"), float("nan")]
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank = torch.zeros(world, 3, dtype=torch.float64, device=dev)
+        per_rank[rank, 0], per_rank[rank, 1], per_rank[rank, 2] = 1e3 * t_own / args.steps, mine[0], mine[1]
+        dist.all_reduce(per_rank)
+        per_rank = per_rank.cpu()
         dt = float(t[0])
+        exch_diag = {
+            # ms per step the compute stream spent waiting where the loss needs the gathered embeddings / where AdamW needs the reduced
+            # gradient (HIP event pairs around EmbedGather.result / GradSync.finish in every timed step; mean over ranks, and the worst)
+            "gather_wait_ms": float(per_rank[:, 1].mean()), "gather_wait_ms_max_rank": float(per_rank[:, 1].max()),
+            "allreduce_exposed_ms": float(per_rank[:, 2].mean()), "allreduce_exposed_ms_max_rank": float(per_rank[:, 2].max()),
+            "step_ms_per_rank": [float(x) for x in per_rank[:, 0]],
+            "step_ms_rank_spread": float(per_rank[:, 0].max() - per_rank[:, 0].min()),
+            "diag": "HIP events on the compute stream, eager steps" if diag is not None else "not collected (captured multi-rank step)",
+            "cu_reservation": dict(D.CU_RESERVATION),
+            "text_range": "handed to the all-reduce at the join, behind the ViT ranges" if model.engine.text_side else "first (text tower in line)",
+        }
     loss = float(out["loss1"]) + (float(out["loss2"]) if out["loss2"] is not None else 0.0)
 
     fwd, bwd = (step_flops_per_pair_v1 if v1 else step_flops_per_pair)(a, T, args.caption_len, args.n_trans)
@@ -424,9 +472,12 @@ def main():
                    "executed_gflop_per_pair": (fwd + bwd - skipped) / 1e9,
                    "last_blocks": "dense" if args.dense_sort_head else "sort head / text tower last block on the rows the model reads (NT transcript rows / EOT row)",
                    "final_loss": loss,
+                   # peak of the caching allocator over the whole process (parameters + optimizer state + every saved activation + workspaces):
+                   # the "288 GB HBM sizing" figure of BASELINE configs[3]
+                   "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9, "hbm_reserved_gb": torch.cuda.max_memory_reserved() / 1e9,
                    "exchange": {"transport": D.transport() + (f" ({backend})" if world > 1 else ""),
                                 "ranks_seen": ranks_seen, "devices_seen": devices_seen, "native": native_ok,
-                                "grad_payload": runner.sync.payload, "grad_bytes_per_step": runner.sync.bytes_sent}},
+                                "grad_payload": runner.sync.payload, "grad_bytes_per_step": runner.sync.bytes_sent, **exch_diag}},
         "step_mfma_frac": pairs_per_s * (fwd + bwd - skipped) / (world * PEAK_BF16_TFLOPS * 1e12),
     }
 
@@ -439,7 +490,16 @@ def main():
         if rank == 0:
             K.GEMM_PROFILE = []
             K.HBM_PROFILE = []
+            # the shader clock the chip holds under this load: a ~10 us one-lane probe (tvts_clock_probe: s_memtime cycles over
+            # s_memrealtime ticks) behind every 8th GEMM launch of the instrumented step, outside the launches' event pairs
+            K.CLOCK_PROBE = dict(buf=torch.zeros(128, 2, dtype=torch.int64, device=dev), i=0, n=0, every=8, ticks=1000)
         eng_ts, model.engine.text_side = model.engine.text_side, False
+        # (a few un-instrumented steps first: the power management settles on the clock of the sustained step, not of the pause behind the timed loop)
+        for i in range(2):
+            one_step(i, device_step=False)
+        if rank == 0:
+            K.GEMM_PROFILE, K.HBM_PROFILE = [], []
+            K.CLOCK_PROBE.update(i=0, n=0)
         one_step(0, device_step=False)
         torch.cuda.synchronize()
         model.engine.text_side = eng_ts
@@ -448,6 +508,11 @@ def main():
     if rank == 0 and not args.no_roofline:
         recs, K.GEMM_PROFILE = K.GEMM_PROFILE, None
         hrecs, K.HBM_PROFILE = K.HBM_PROFILE, None
+        cp, K.CLOCK_PROBE = K.CLOCK_PROBE, None
+        wall_khz, n_cus, sheet_khz = K.device_clock_info(torch.cuda.current_device())
+        pr = cp["buf"][:cp["i"]].cpu().double()
+        pr = pr[pr[:, 1] > 0]
+        clk = (pr[:, 0] / pr[:, 1] * wall_khz / 1e3) if len(pr) else None   # MHz per probe
         tot_ms = sum(r[2].elapsed_ms(r[3]) for r in recs)
         tot_fl = sum(r[1] for r in recs)
         by = {}
@@ -488,6 +553,24 @@ def main():
                                               "peak": PEAK_FP8_TFLOPS if k.endswith("fp8") else PEAK_BF16_TFLOPS,
                                               "frac": v[1] / (v[2] * 1e-3) / 1e12 / (PEAK_FP8_TFLOPS if k.endswith("fp8") else PEAK_BF16_TFLOPS)}
                                           for k, v in by.items()}}
+        # matrix-pipe duty and the clock the GEMM launches actually ran at ("confirm the peak on the box"): a committed
+        # counter pass of this workload; frac_at_clock prices the live `achieved` against the dense peak AT THAT CLOCK
+        # (256 CUs x 4 SIMDs x 1024 FLOP per cycle) beside the sheet's 2.5 PFLOP/s at 2.4 GHz
+        util = pmc_mfma_util(args)
+        if clk is not None:
+            # LIVE: the clock probes of this very step; the peak at that clock = CUs x 4 SIMDs x 1024 FLOP per cycle (v_mfma_f32_16x16x32_bf16:
+            # 16 384 FLOP in 16 cycles per SIMD; 2.5 PFLOP/s is 256 CUs at the sheet's 2.4 GHz)
+            mhz = float(clk.mean())
+            peak_clk = n_cus * 4 * 1024 * mhz * 1e6 / 1e12
+            line["roofline"].update({"clock_mhz_under_load": mhz, "clock_mhz_min_max": [float(clk.min()), float(clk.max())],
+                                     "clock_probes": int(len(clk)), "sheet_clock_mhz": sheet_khz / 1e3, "cu_count": n_cus,
+                                     "peak_at_clock": peak_clk, "frac_at_clock": ach / peak_clk,
+                                     "clock_source": "tvts_clock_probe behind every 8th GEMM launch of the instrumented step (s_memtime / s_memrealtime)"})
+        if util and "stale" not in util:
+            line["roofline"].update({"mfma_busy": util["mfma_busy"], "mfma_busy_clock_mhz": util["clock_mhz_under_load"],
+                                     "mfma_util_by_family": util["by_family"], "mfma_util_source": util["source"]})
+        else:
+            line["roofline"].update({"mfma_busy": None, "mfma_util_source": util["stale"] if util else None})
         # the HBM-bound families of the same instrumented step (LayerNorm, attention, AdamW, weight transposes): algorithmic bytes
         # of every launch (each operand and result once) over its HIP-event duration, against the 8 TB/s peak of
         # MI355X_MICROARCH.md and against the ~6.3 TB/s a streaming kernel reaches on this part

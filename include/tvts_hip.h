@@ -399,6 +399,15 @@ int tvts_dropout_rows(const float* x, int ldx, int rows, int cols, float p, cons
 int tvts_relu(const float* x, const float* dy, float* out, long n, hipStream_t stream);
 int tvts_rows_gather(const float* src, int ld_src, const int* rows, int R, int W, float* dst, int ld_dst, int scatter_add,
                      hipStream_t stream);
+/* rows between a token-row matrix ("full") and a packed [R, W] matrix: the last block of the sort head (sort_transformer.py:131-141:
+   the model reads the NT transcript rows) and of the text tower (CLIP/clip/model.py:343-354: the EOT row) run on those R rows only.
+   mode 0 gather: packed[r] = full[rows[r]] (source full_f32 if given, else full_bf16; packed_f32 and / or packed_bf16 written);
+   mode 1 scatter: full[rows[r]] = packed[r] for every element type given on both sides; mode 2: full_f32[rows[r]] += packed_f32[r] and
+   full_bf16[rows[r]] = bf16(sum) when given.  rows must be distinct. */
+int tvts_rows_move(int mode, const int* rows, int R, int W, float* full_f32, int ld_full_f32, void* full_bf16, int ld_full_bf16,
+                   float* packed_f32, int ld_packed_f32, void* packed_bf16, int ld_packed_bf16, hipStream_t stream);
+/* x[r, 0:cols] = 0 of a bf16 matrix (cols, ld multiples of 8): dQ of the rows that are no queries in the used-rows attention backward */
+int tvts_zero_cols_bf16(void* x, int ld, long rows, int cols, hipStream_t stream);
 
 /* ---- losses (loss.hip): model_dist..B_16.py:119-127, loss.py:13-25, trainer.py:487-492 */
 int tvts_l2norm_rows(const float* x, int R, int E, float eps, float* xn, float* inv, hipStream_t stream);
@@ -432,6 +441,12 @@ int tvts_event_create(void** ev);
 int tvts_event_record(void* ev, hipStream_t stream);
 int tvts_event_elapsed_ms(void* start, void* stop, float* ms);
 int tvts_event_destroy(void* ev);
+/* clock under load (SURVEY.md 8d "confirm the peak on the box: clocks x CUs x MFMA rate"): a one-lane kernel that counts shader
+   cycles (s_memtime) over ref_ticks of the constant-rate counter (s_memrealtime); out2_u64[0] = cycles, [1] = ticks.  The rate of
+   the constant counter, the CU count and the sheet's maximum shader clock come from the device attributes.  No reference site: the
+   reference has no roofline accounting. */
+int tvts_clock_probe(void* out2_u64, int ref_ticks, hipStream_t stream);
+int tvts_device_clock_info(int device, int* wall_clock_khz, int* cu_count, int* max_shader_khz);
 
 #ifdef __cplusplus
 }

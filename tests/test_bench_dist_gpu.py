@@ -28,7 +28,15 @@ def test_two_rank_bench_line():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
     # (259 NT launches + the weight gradients: 94 one by one, or 12 grouped + the text / sort-head ones at this small batch)
     assert d["value"] > 0 and d["roofline"]["launches"] > 280 and "cpu_baseline" not in d
-    assert d["config"]["exchange"]["ranks_seen"] == 2 and len(d["config"]["exchange"]["devices_seen"]) == 2
+    ex = d["config"]["exchange"]
+    assert ex["ranks_seen"] == 2 and len(ex["devices_seen"]) == 2
+    # the diagnostics a first SCALE run is read with: where the compute stream waited for a collective, per-rank step times, the
+    # CU reservation in force (none unless TVTS_NT_CUS asks) and when the text tower's range was handed to the all-reduce
+    for k in ("gather_wait_ms", "allreduce_exposed_ms", "allreduce_exposed_ms_max_rank", "step_ms_rank_spread"):
+        assert isinstance(ex[k], float) and ex[k] >= 0.0 and ex[k] == ex[k], (k, ex[k])
+    assert len(ex["step_ms_per_rank"]) == 2 and min(ex["step_ms_per_rank"]) > 0
+    assert ex["cu_reservation"]["nt_cus"] is None and ex["grad_bytes_per_step"] > 0
+    assert ex["text_range"].startswith("handed to the all-reduce at the join")
 
 
 def _bench(extra, port):

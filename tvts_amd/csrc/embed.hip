@@ -663,6 +663,63 @@ extern "C" int tvts_rows_gather(const float* src, int ld_src, const int* rows, i
     return TVTS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- rows between a token-row matrix and a packed [R, W] one
+// (the "used rows" blocks: the last block of the sort head / the text tower runs on the R rows the model reads, engine.py::_used_rows_*)
+//   mode 0 gather        packed[r] = full[rows[r]]: source full_f32 if given else full_bf16; packed_f32 and / or packed_bf16 written
+//   mode 1 scatter       full[rows[r]] = packed[r], per element type given on BOTH sides
+//   mode 2 scatter-add   full_f32[rows[r]] += packed_f32[r]; full_bf16[rows[r]] = bf16(that sum) when given (the bf16 copy of the row)
+// rows are distinct (token rows of distinct captions / clips): no two blocks touch one row.
+__global__ __launch_bounds__(256) void rows_move_kernel(int mode, const int* __restrict__ rows, int W, float* full_f32, int ldf,
+                                                        bf16* full_bf16, int ldfb, float* packed_f32, int ldp, bf16* packed_bf16, int ldpb) {
+    const int r = blockIdx.x;
+    const size_t fr = (size_t)rows[r];
+    for (int c = threadIdx.x; c < W; c += 256) {
+        if (mode == 0) {
+            const float v = full_f32 ? full_f32[fr * ldf + c] : (float)full_bf16[fr * ldfb + c];
+            if (packed_f32) packed_f32[(size_t)r * ldp + c] = v;
+            if (packed_bf16) packed_bf16[(size_t)r * ldpb + c] = full_f32 ? (bf16)v : full_bf16[fr * ldfb + c];
+        } else if (mode == 1) {
+            if (full_f32 && packed_f32) full_f32[fr * ldf + c] = packed_f32[(size_t)r * ldp + c];
+            if (full_bf16 && packed_bf16) full_bf16[fr * ldfb + c] = packed_bf16[(size_t)r * ldpb + c];
+        } else {
+            const float v = full_f32[fr * ldf + c] + packed_f32[(size_t)r * ldp + c];
+            full_f32[fr * ldf + c] = v;
+            if (full_bf16) full_bf16[fr * ldfb + c] = (bf16)v;
+        }
+    }
+}
+extern "C" int tvts_rows_move(int mode, const int* rows, int R, int W, float* full_f32, int ld_full_f32, void* full_bf16, int ld_full_bf16,
+                              float* packed_f32, int ld_packed_f32, void* packed_bf16, int ld_packed_bf16, hipStream_t stream) {
+    if (!rows || R < 0 || W <= 0 || mode < 0 || mode > 2 || (!full_f32 && !full_bf16) || (!packed_f32 && !packed_bf16)) return TVTS_EINVAL;
+    if (mode == 2 && (!full_f32 || !packed_f32)) return TVTS_EINVAL;
+    if (mode == 1 && !((full_f32 && packed_f32) || (full_bf16 && packed_bf16))) return TVTS_EINVAL;
+    if (R == 0) return TVTS_OK;
+    hipLaunchKernelGGL(rows_move_kernel, dim3(R), dim3(256), 0, stream, mode, rows, W, full_f32, ld_full_f32, (bf16*)full_bf16, ld_full_bf16,
+                       packed_f32, ld_packed_f32, (bf16*)packed_bf16, ld_packed_bf16);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+// a column range of a bf16 row-major matrix set to zero (dQ of the rows that are no queries in the used-rows attention backward)
+__global__ __launch_bounds__(256) void zero_cols_bf16_kernel(bf16* x, int ld, long rows, int cols8) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+    const long n = rows * cols8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / cols8;
+        const int c = (int)(i - r * cols8);
+        *(u32x4_*)(x + (size_t)r * ld + c * 8) = (u32x4_){0u, 0u, 0u, 0u};
+    }
+}
+extern "C" int tvts_zero_cols_bf16(void* x, int ld, long rows, int cols, hipStream_t stream) {
+    if (!x || rows < 0 || cols <= 0 || (cols % 8) || (ld % 8) || ((size_t)x % 16)) return TVTS_EINVAL;
+    if (rows == 0) return TVTS_OK;
+    const long n = rows * (cols / 8);
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_cols_bf16_kernel, dim3((int)blocks), dim3(256), 0, stream, (bf16*)x, ld, rows, cols / 8);
+    TVTS_LAUNCH_CHECK();
+    return TVTS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- hidden-state dropout (v1 text tower)
 // out = x * m / (1 - p) (+ residual); m: element (r, c) is kept iff the upper 32 bits of splitmix64(seed + (r * cols + c) * phi)
 // are >= p * 2^32 -- the generator of the attention-probability dropout (attention.hip::drop_keep)

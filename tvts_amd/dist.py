@@ -19,7 +19,8 @@ Two transports, same semantics:
 environment variable are ignored (every rank has to stay on the transport the ranks agreed on).
 
 CU reservation (``TVTS_NT_CUS``, default none): the persistent 256x256 GEMM blocks fill a CU completely, so an RCCL kernel only
-gets CUs at a GEMM kernel boundary or on CUs the persistent grid leaves free.  tools/overlap_probe.py (profiles/r03_overlap_probe.txt)
+gets CUs at a GEMM kernel boundary or on CUs the persistent grid leaves free (``TVTS_NT_CUS=auto`` applies the rule of
+auto_cu_reservation, an unmeasured prediction, hence opt-in).  tools/overlap_probe.py (profiles/r03_overlap_probe.txt)
 measures both on one GPU: a side-stream kernel forked under the dgrad chain starts within one GEMM launch (<= 0.5 ms) either way;
 on 8 reserved CUs it streams at ~0.27 TB/s (128 MB in 480 us), on 32 at ~1.3 TB/s -- and reserving 8 / 16 CUs costs the GEMM chain
 4.3 % / 8.7 %.  At the bench's 192 pairs per GPU the whole gradient all-reduce (624 MB fp32) is ~5 ms of a 150 ms step, less
@@ -111,7 +112,9 @@ class NativeComm:
                 return True
             if st < 0:
                 raise RuntimeError(f"tvts_comm_idle failed with code {st}")
-            if time.time() - t0 > timeout_s:
+            # timeout_s <= 0 means "no deadline", as it does on the C side (tvts_comm_create_deadline falls through to a blocking
+            # create): poll until done instead of giving up at the first poll and aborting a healthy communicator
+            if timeout_s > 0 and time.time() - t0 > timeout_s:
                 return False
             time.sleep(0.002)
 
@@ -183,20 +186,21 @@ _TRANSPORT: Optional[str] = None
 
 
 def auto_cu_reservation(rows_per_gpu: int, world_size: int, grad_bytes: int = 624 << 20) -> int:
-    """CUs the persistent GEMM grids leave to the RCCL kernels (0 = none), from the per-GPU token rows and the world size --
-    the rule that replaces the TVTS_NT_CUS environment variable nobody sets (TVTS_NT_CUS still overrides it).
+    """CUs the persistent GEMM grids would leave to the RCCL kernels (0 = none), from the per-GPU token rows and the world size.
+    An UNMEASURED prediction (no multi-GPU box so far): it is applied only when asked for, TVTS_NT_CUS=auto; the default is no
+    reservation, a number in TVTS_NT_CUS is the grid size to use.
 
     Measured on one GPU (tools/overlap_probe.py, profiles/r03_overlap_probe.txt): a side-stream kernel forked under the dgrad chain
     starts within one GEMM launch either way; on 8 reserved CUs it streams 0.27 TB/s, and reserving 8 / 16 CUs costs the GEMM chain
-    4.3 % / 8.7 %.  Model: the gradient all-reduce moves 2 (W - 1) / W x grad_bytes per GPU at ~300 GB/s of bus bandwidth (xGMI ring,
-    8 GPUs), the backward lasts ~0.62 us per token row (93 ms at 150 720 rows, 9.5 ms at 9 420 with its fixed part); a reservation
-    pays when the traffic it keeps moving is worth more than the 4.3 % it takes:
+    4.3 % / 8.7 %.  Model: the gradient all-reduce moves 2 (W - 1) / W x grad_bytes per GPU at ~300 GB/s of bus bandwidth (xGMI ring),
+    the backward lasts 3.7 ms + 0.62 us per token row; a reservation pays when the traffic it keeps moving is worth more than the
+    4.3 % it takes, taken as comm > 7 % of the backward:
       * rows < 15 000 (the reference's 12 pairs): the ViT's GEMMs run on the 128 x 128 kernels (two blocks per CU, 128 of 160 KiB of
         LDS, half the registers) -- RCCL's workgroups co-reside, nothing to reserve;
-      * 15 000 <= rows < 60 000 (24 ... 72 pairs): every CU is held by a persistent 256 x 256 block and the all-reduce is 8 ... 25 %
-        of the backward -- 8 CUs;
-      * rows >= 60 000: the all-reduce is < 7 % of the backward and hides at the kernel boundaries -- nothing.
-    PREDICTION to be checked by the first multi-GPU run."""
+      * above that every CU is held by a persistent 256 x 256 block: 8 CUs while comm > 0.07 x backward, which with the model's
+        numbers is up to ~82 000 rows at W = 8 (3.6 ms of ring time; ~105 pairs of B/16) and up to ~44 000 rows at W = 2 (2.2 ms);
+      * beyond: the all-reduce hides at the kernel boundaries -- nothing.
+    The decision is taken ONCE, from the first batch's rows (a loop that alternates loaders of different clip lengths keeps it)."""
     if world_size <= 1:
         return 0
     comm_ms = 2.0 * (world_size - 1) / world_size * grad_bytes / 300e9 * 1e3
@@ -207,24 +211,31 @@ def auto_cu_reservation(rows_per_gpu: int, world_size: int, grad_bytes: int = 62
 
 
 _NT_CUS_APPLIED = False
+CU_RESERVATION = {"nt_cus": None, "source": "none (default: no reservation; TVTS_NT_CUS=<grid> or =auto)"}  # what the bench line reports
 
 
 def _apply_cu_reservation(rows_per_gpu: Optional[int] = None):
-    """The persistent GEMM grids leave CUs to the RCCL kernels: TVTS_NT_CUS (the grid size, e.g. 248) when set, else
-    auto_cu_reservation() once the per-GPU token rows are known (StepRunner's first step at world > 1).  Applied once."""
+    """The persistent GEMM grids leave CUs to the RCCL kernels ONLY when TVTS_NT_CUS asks for it: a number is the grid size
+    (e.g. 248 on the 256-CU part), `auto` applies auto_cu_reservation() once the per-GPU token rows are known (StepRunner's first
+    step at world > 1).  Applied once per process."""
     global _NT_CUS_APPLIED
     if _NT_CUS_APPLIED:
         return
     env = os.environ.get("TVTS_NT_CUS")
-    if env is None and rows_per_gpu is None:
+    if env is None:
+        return  # opt-in: nothing is reserved by default (the rule is a prediction until a multi-GPU run has measured it)
+    if env == "auto" and rows_per_gpu is None:
         return  # nothing to decide yet
     _NT_CUS_APPLIED = True
-    if env is not None:
-        cus = int(env)
-    else:
+    if env == "auto":
         W, _ = world()
         keep = auto_cu_reservation(rows_per_gpu, W)
-        cus = (256 - keep) if keep else 0
+        n_cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
+        cus = (n_cus - keep) if keep else 0
+        CU_RESERVATION.update(nt_cus=cus or None, source=f"TVTS_NT_CUS=auto: {keep} of {n_cus} CUs at {rows_per_gpu} rows per GPU, world {W}")
+    else:
+        cus = int(env)
+        CU_RESERVATION.update(nt_cus=cus or None, source=f"TVTS_NT_CUS={env}")
     if cus:
         from . import hip as K
         K.set_default(nt_cus=cus)

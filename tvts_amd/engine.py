@@ -323,6 +323,7 @@ class Engine:
         t = self.buf.get(name)
         shape = tuple(int(s) for s in shape)
         if t is not None and tuple(t.shape) == shape and t.dtype == dtype:
+            self._seen[name] = self._tick  # (live in this step: a later request for ANOTHER shape under this name must not alias it)
             if zero:
                 t.zero_()
             return t
@@ -478,7 +479,11 @@ class Engine:
             if self._tn_group_ws is None:
                 self._tn_group_ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=self.dev)
             if len(plans) >= self.TN_GROUP_PLANS_PER_BLOCK:
-                plans.pop(next(iter(plans)))  # the oldest (a last partial batch, a loader that is gone)
+                # the oldest plan no hipGraph refers to (a last partial batch, a loader that is gone); a captured plan's device table
+                # and staging memory are addresses inside the graph, so it stays
+                old = next((k for k, g in plans.items() if not g.captured), None)
+                if old is not None:
+                    plans.pop(old)
             grp = plans[sig] = K.TnGroup(problems, self._tn_group_ws, splits=int(self.arch.get("tn_group_splits", 0)))
         grp.run()
 
@@ -633,7 +638,7 @@ class Engine:
                 # the model reads the last block's output at the EOT token of every caption only (CLIP/clip/model.py:343-354)
                 ht, hd = a["text_heads"], Wt // a["text_heads"]
                 rows64, pos = self._text_eot = eot_index if eot_index is not None else self.eot_index(eot_rows, L)
-                xr = self._used_rows_fwd(f"text_model.resblocks.{l}.", _TEXT_NAMES, x, f"txt{l}", M, Wt, ht, rows64, a["act"], 1e-5,
+                xr = self._used_rows_fwd(f"text_model.resblocks.{l}.", _TEXT_NAMES, x, f"txt{l}", M, Wt, ht, eot_rows, a["act"], 1e-5,
                                          lambda qkv, att, lse: K.attn_fwd_rowq(qkv, pos, att, lse, B=N, heads=ht, S=L, head_dim=hd))
                 self._ln(xr, "text_ln_final", 1e-5, lnf, "txt.lnf")
                 break
@@ -671,7 +676,7 @@ class Engine:
                 ht, hd = a["text_heads"], Wt // a["text_heads"]
                 rows64, pos = self._text_eot  # the forward's tensors (the batch's when it came through prepare_batch)
                 self._used_rows_bwd(f"text_model.resblocks.{l}.", _TEXT_NAMES, self.buf[f"txt.x{l}"], dx, dxb, dxi, dxbi, f"txt{l}",
-                                    "txt.s", M, Wt, ht, rows64, a["act"],
+                                    "txt.s", M, Wt, ht, eot_rows, a["act"],
                                     lambda qkv, datt, att, lse, delta, dqkv: K.attn_bwd_rowq(
                                         qkv, pos, datt, att, lse, delta, dqkv, B=N, heads=ht, S=L, head_dim=hd))
                 dx, dxb = dxi, dxbi
@@ -807,8 +812,7 @@ class Engine:
         elif lowres:  # ln_post on the B CLS rows in fp32: an fp32 copy of those rows (plumbing on [B, W])
             xc, xcb = self._f("vit.xcls32", (B, W)), self._b("vit.xcls16", (B, W))
             vr64 = self.ctx.get("vid_rows64") if isinstance(self.ctx, dict) else None
-            torch.index_select(x, 0, vr64 if vr64 is not None else vid_rows.long(), out=xcb)
-            xc.copy_(xcb)
+            K.rows_move("gather", vid_rows, full_bf16=x, packed_f32=xc, packed_bf16=xcb)
             self._ln(xc, "video_model.ln_post", 1e-5, lnc, "vit.lnpost")
         else:
             self._ln(x, "video_model.ln_post", 1e-5, lnc, "vit.lnpost", rows=vid_rows)
@@ -864,7 +868,7 @@ class Engine:
                 # the LayerNorm's result IS the fp32 CLS chain's first value)
                 dxc = self._f("vit.dxcA" if cls else "vit.s.dxcls", (B, W))
                 self._ln_bwd(dlnc, B_["vit.xcls32"], "video_model.ln_post", "vit.lnpost", dxc)
-                dx.index_add_(0, self.ctx["vid_rows64"] if "vid_rows64" in self.ctx else self.ctx["vid_rows"].long(), dxc)
+                K.rows_move("scatter_add", self.ctx["vid_rows"], full_f32=dx, packed_f32=dxc)
             else:
                 self._ln_bwd(dlnc, B_[f"vit.x{a['layers']}"], "video_model.ln_post", "vit.lnpost", dx, res1=dx,
                              rows=self.ctx["vid_rows"])
@@ -996,14 +1000,14 @@ class Engine:
     # every parameter and every input row as the dense evaluation (tests/test_model_gpu.py::test_sort_head_used_rows_only);
     # arch["sort_used_rows_only"] = False evaluates the block densely like the reference does.
     def _sort_last_fwd(self, pre, x_in, tag, Mo, E, heads, B, So, NT):
-        return self._used_rows_fwd(pre, _SORT_NAMES, x_in, tag, Mo, E, heads, self.ctx["sort_rows64"], "gelu", 1e-6,
+        return self._used_rows_fwd(pre, _SORT_NAMES, x_in, tag, Mo, E, heads, self.ctx["sort_rows"], "gelu", 1e-6,
                                    lambda qkv, att, lse: K.attn_fwd_tail(qkv, att, lse, B=B, heads=heads, S=So, nq=NT, head_dim=E // heads))
 
     def _sort_last_bwd(self, pre, x_in, dxr, dxbr, dx_in, dxb_in, tag, Mo, E, heads, B, So, NT):
         def attn_bwd(qkv, datt, att, lse, delta, dqkv):
-            dqkv[:, :E].zero_()  # dQ of the rows that are no queries (dK / dV are written for every row)
+            K.zero_cols_bf16(dqkv, E)  # dQ of the rows that are no queries (dK / dV are written for every row)
             K.attn_bwd_tail(qkv, datt, att, lse, delta, dqkv, B=B, heads=heads, S=So, nq=NT, head_dim=E // heads)
-        self._used_rows_bwd(pre, _SORT_NAMES, x_in, dxr, dxbr, dx_in, dxb_in, tag, "srt.s", Mo, E, heads, self.ctx["sort_rows64"],
+        self._used_rows_bwd(pre, _SORT_NAMES, x_in, dxr, dxbr, dx_in, dxb_in, tag, "srt.s", Mo, E, heads, self.ctx["sort_rows"],
                             "gelu", attn_bwd)
 
     # A pre-LN block whose output the model reads at R rows only (rows64: their token rows), and into whose other output rows no
@@ -1011,8 +1015,8 @@ class Engine:
     # (attn_fwd: a query-restricted kernel writing the used rows of `att`), the output projection, the residual, LayerNorm 2 and the
     # MLP are computed for the R used rows; backward: dQ for those rows, dK / dV -- and through them the gradient of every input
     # row -- dense.  Returns the block output at the used rows, [R, Wd] fp32.
-    def _used_rows_fwd(self, pre, nm, x_in, tag, M, Wd, heads, rows64, act, eps, attn_fwd):
-        R = rows64.numel()
+    def _used_rows_fwd(self, pre, nm, x_in, tag, M, Wd, heads, rows32, act, eps, attn_fwd):
+        R = rows32.numel()
         ln1 = self._b(tag + ".ln1", (M, Wd))
         self._ln(x_in, pre + nm["ln1"], eps, ln1, tag + ".ln1")
         qkv = self._b(tag + ".qkv", (M, 3 * Wd))
@@ -1020,8 +1024,8 @@ class Engine:
         att, lse = self._b(tag + ".att", (M, Wd)), self._f(tag + ".lse", (M, heads))
         attn_fwd(qkv, att, lse)
         att_r, x_r = self._b(tag + ".att_r", (R, Wd)), self._f(tag + ".x_r", (R, Wd))
-        torch.index_select(att, 0, rows64, out=att_r)   # (row gathers of R x Wd elements: plumbing)
-        torch.index_select(x_in, 0, rows64, out=x_r)
+        K.rows_move("gather", rows32, full_bf16=att, packed_bf16=att_r)   # (row gathers of R x Wd elements)
+        K.rows_move("gather", rows32, full_f32=x_in, packed_f32=x_r)
         mid = self._f(tag + ".mid", (R, Wd))
         self._lin(att_r, pre + nm["o_w"], pre + nm["o_b"], mid, R, residual=x_r)
         ln2 = self._b(tag + ".ln2", (R, Wd))
@@ -1032,9 +1036,9 @@ class Engine:
         self._lin(hact, pre + nm["pj_w"], pre + nm["pj_b"], xo, R, residual=mid)
         return xo
 
-    def _used_rows_bwd(self, pre, nm, x_in, dxr, dxbr, dx_in, dxb_in, tag, scr, M, Wd, heads, rows64, act, attn_bwd):
+    def _used_rows_bwd(self, pre, nm, x_in, dxr, dxbr, dx_in, dxb_in, tag, scr, M, Wd, heads, rows32, act, attn_bwd):
         """dxr / dxbr: fp32 / bf16 gradient of the block output at the R used rows; writes the gradient of every input row."""
-        R, B_ = rows64.numel(), self.buf
+        R, B_ = rows32.numel(), self.buf
         dh, dln = self._b(scr + ".dh_r", (R, 4 * Wd)), self._b(scr + ".dln_r", (R, Wd))
         self._lin_bwd(dxbr, B_[tag + ".a"], pre + nm["pj_w"], pre + nm["pj_b"], dh, R, gate_h=B_[tag + ".h"], gate_act=act)
         self._lin_bwd(dh, B_[tag + ".ln2"], pre + nm["fc_w"], pre + nm["fc_b"], dln, R)
@@ -1043,7 +1047,7 @@ class Engine:
         datt_r = self._b(scr + ".datt_r", (R, Wd))
         self._lin_bwd(dmidb, B_[tag + ".att_r"], pre + nm["o_w"], pre + nm["o_b"], datt_r, R)
         datt = self._b(scr + ".datt", (M, Wd))            # token-row indexed like the attention output; only the R rows are read
-        datt.index_copy_(0, rows64, datt_r)
+        K.rows_move("scatter", rows32, full_bf16=datt, packed_bf16=datt_r)
         dqkv = self._b(scr + ".dqkv", (M, 3 * Wd))
         delta = self._f(scr + ".delta", (M, heads))
         attn_bwd(B_[tag + ".qkv"], datt, B_[tag + ".att"], B_[tag + ".lse"], delta, dqkv)
@@ -1051,11 +1055,7 @@ class Engine:
         self._lin_bwd(dqkv, B_[tag + ".ln1"], pre + nm["qkv_w"], pre + nm["qkv_b"], dlnf, M)
         self._ln_bwd(dlnf, x_in, pre + nm["ln1"], tag + ".ln1", dx_in, dx_bf16=dxb_in)
         # the residual path: + dmid at the used rows (fp32 sum, bf16 copy refreshed for those rows)
-        dx_in.index_add_(0, rows64, dmid)
-        tmp, tmpb = self._f(scr + ".tmp_r", (R, Wd)), self._b(scr + ".tmpb_r", (R, Wd))
-        torch.index_select(dx_in, 0, rows64, out=tmp)
-        tmpb.copy_(tmp)
-        dxb_in.index_copy_(0, rows64, tmpb)
+        K.rows_move("scatter_add", rows32, full_f32=dx_in, full_bf16=dxb_in, packed_f32=dmid)
 
     def sort_backward(self, dpred, B, S, NT):
         """-> fp32 grad of the sort-head input xs [B*So, E]."""
@@ -1065,8 +1065,9 @@ class Engine:
         Mo, R = B * So, B * NT
         nf = B_["srt.nf"]
         K.gemm_small(dpred, nf, self.P.g("pred_model.head.weight"), M=C, N=E, K=R, sa=(1, C), sb=(E, 1), accumulate=True)
-        ones = self._f("srt.ones", (R,))
-        ones.fill_(1.0)
+        ones = self.buf.get(("srt.ones", R))   # a constant: made once per row count, never written again
+        if ones is None:
+            ones = self.buf[("srt.ones", R)] = torch.ones(R, dtype=torch.float32, device=self.dev)
         K.gemm_small(ones, dpred, self.P.g("pred_model.head.bias").view(1, C), M=1, N=C, K=R, sa=(0, 1), sb=(C, 1),
                      accumulate=True)
         dnf = self._f("srt.dnf", (R, E))
@@ -1242,12 +1243,20 @@ class Engine:
         # the text tower first: it shares nothing with the video / sort-head backward (the sort head sees DETACHED caption
         # embeddings, model_dist..B_16.py:69), and its gradient range (token embedding included) is the largest single
         # all-reduce of the step -- issued here it travels under the whole video backward instead of after it
+        # ... which holds while the text tower runs IN LINE.  On its own stream (text_side) its backward finishes some 150 kernels after
+        # the fork, and an all-reduce issued from that lane would sit at the head of the single collective stream until then with every
+        # ViT range queued behind it: with an exchange step attached (world > 1 / range-wise optimizer) the text range is handed over
+        # at the join instead, from the main stream, behind the ViT ranges.
+        text_ready_at_join = False
         if d_text is not None:
             dt = self._f("mdl.dt", (N, E))
             with self._text_lane():  # beside the sort head's and the ViT's backward when self.text_side; joined at the end
                 K.text_mean_bwd(d_text, dt, NT=NT, B=B)
                 self.text_backward(dt, pb["ids"], pb["eot_rows"], N, L, tok_sort=pb.get("tok_sort"))
-                self._ready("text_")
+                if self.text_side and (self.grad_ready is not None or self.param_ready is not None):
+                    text_ready_at_join = True
+                else:
+                    self._ready("text_")
         dout = self._b("mdl.dout", (B * S, E))
         off = 1 if self.pooled_tail else 0
         dv_cls = None if self.pooled_tail else d_video  # B models: the embedding IS the CLS row of the projected tokens
@@ -1262,6 +1271,8 @@ class Engine:
             dout = None
         self.video_backward(dout, pb["keep"], B, T, d_pooled=d_video if self.pooled_tail else None)
         self._text_join()
+        if text_ready_at_join:
+            self._ready("text_")
 
 
 class LossHead:

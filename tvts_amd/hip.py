@@ -202,6 +202,7 @@ def gemm_nt(a, b, out, *, M=None, bias=None, residual=None, act=None, preact=Non
     if GEMM_PROFILE is not None:
         ev1.record()
         GEMM_PROFILE.append(("gemm_nt", 2.0 * M * N * K, ev0, ev1, (M, N, K, "f32" if out.dtype == torch.float32 else "bf16", "res" if residual is not None else "", str(act or ""), "gate" if gate_h is not None else "")))
+        _probe_clock()
 
 
 def quantize_fp8(x, q=None, scale=None, amax=None, amax_given=False):
@@ -295,6 +296,7 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
         if GEMM_PROFILE is not None:
             ev1.record()
             GEMM_PROFILE.append(("gemm_nt_fp8", 2.0 * M * N * Kd, ev0, ev1, (M, N, Kd, "fp8", "", "", "gate")))
+            _probe_clock()
         return
     rc = lib.tvts_gemm_nt_fp8(_p(a8), a8.stride(0), _p(b8), b8.stride(0), M, N, Kd, _p(sa), sa_rows, _p(sb), _p(bias), _p(residual),
                               _ld(residual) if residual is not None else 0, ACT[act], _p(preact),
@@ -305,6 +307,7 @@ def gemm_nt_fp8(a8, sa, b8, sb, out, *, bias=None, residual=None, act=None, prea
     if GEMM_PROFILE is not None:
         ev1.record()
         GEMM_PROFILE.append(("gemm_nt_fp8", 2.0 * M * N * Kd, ev0, ev1, (M, N, Kd, "fp8", "res" if residual is not None else "", str(act or ""), "")))
+        _probe_clock()
 
 
 # Scratch LANES: the shared scratch buffers of this module (split partials of the weight gradients, LayerNorm dgamma / dbeta partials,
@@ -390,6 +393,7 @@ def gemm_tn(p, q, out, *, M=None, accumulate=True, colsum=None, workspace=True, 
     if GEMM_PROFILE is not None:
         ev1.record()
         GEMM_PROFILE.append(("gemm_tn", 2.0 * M * p.shape[1] * q.shape[1], ev0, ev1, (M, p.shape[1], q.shape[1], "cs" if colsum is not None else "")))
+        _probe_clock()
 
 
 class TnGroup:
@@ -421,6 +425,7 @@ class TnGroup:
         self.table = torch.empty(nbytes, dtype=torch.uint8, device=workspace.device)  # (no fill: a fill on another stream could land after the upload)
         self.table_host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)    # stays alive and untouched with the plan
         self.uploaded = False
+        self.captured = False  # a hipGraph holds the addresses of table / table_host: the plan must outlive it (Engine never evicts it)
         self.opts = int(splits) << 8
         self.flops = sum(2.0 * r.M * r.Na * r.Nb for r in self.recs)
 
@@ -429,14 +434,21 @@ class TnGroup:
         if GEMM_PROFILE is not None:
             ev0, ev1 = Event(), Event()
             ev0.record()
+        # An upload issued while the stream is being captured becomes a memcpy NODE of the graph: it runs at every replay, not now.  The
+        # table then counts as uploaded for the replays only -- an eager run of the same plan (before or between replays) uploads again.
+        capturing = torch.cuda.is_current_stream_capturing()
         rc = lib.tvts_gemm_tn_bf16_grouped(ctypes.cast(self.recs, ctypes.c_void_p), self.n, _p(self.table), ctypes.c_void_p(self.table_host.data_ptr()),
-                                           self.table.numel(), 0 if self.uploaded else 1, _p(self.ws), self.ws.numel(), self.opts, _stream())
+                                           self.table.numel(), 0 if (self.uploaded and not capturing) else 1, _p(self.ws), self.ws.numel(), self.opts, _stream())
         _chk(rc, "tvts_gemm_tn_bf16_grouped")
-        self.uploaded = True
+        if capturing:
+            self.captured = True
+        else:
+            self.uploaded = True
         if GEMM_PROFILE is not None:
             ev1.record()
             r0 = self.recs[0]
             GEMM_PROFILE.append(("gemm_tn", self.flops, ev0, ev1, (r0.M, sum(r.Na * r.Nb for r in self.recs) // max(r0.Nb, 1), r0.Nb, "grouped")))
+            _probe_clock()
 
 
 def gemm_tn_fp8(p8, sp, q8, sq, out, *, M=None, accumulate=True, colsum=None, workspace=True, splits=None):
@@ -455,6 +467,7 @@ def gemm_tn_fp8(p8, sp, q8, sq, out, *, M=None, accumulate=True, colsum=None, wo
     if GEMM_PROFILE is not None:
         ev1.record()
         GEMM_PROFILE.append(("gemm_tn_fp8", 2.0 * M * p8.shape[1] * q8.shape[1], ev0, ev1, (M, p8.shape[1], q8.shape[1], "fp8")))
+        _probe_clock()
 
 
 def gemm_small(a, b, out, *, M, N, K, sa, sb, alpha=1.0, bias=None, accumulate=False):
@@ -876,6 +889,28 @@ def rows_gather(src, rows, dst, *, scatter_add=False):
                               int(scatter_add), _stream()), "tvts_rows_gather")
 
 
+def rows_move(mode, rows, *, full_f32=None, full_bf16=None, packed_f32=None, packed_bf16=None):
+    """mode "gather": packed[r] = full[rows[r]] (from full_f32 if given, else full_bf16); "scatter": full[rows[r]] = packed[r];
+    "scatter_add": full_f32[rows[r]] += packed_f32[r], full_bf16[rows[r]] = bf16(sum).  rows int32, distinct."""
+    lib = _lib.load()
+    assert rows.dtype == torch.int32
+    for t, dt in ((full_f32, torch.float32), (packed_f32, torch.float32), (full_bf16, torch.bfloat16), (packed_bf16, torch.bfloat16)):
+        assert t is None or (t.dtype == dt and t.stride(1) == 1)
+    ref = packed_f32 if packed_f32 is not None else packed_bf16
+    W = ref.shape[1]
+    ld = lambda t: _ld(t) if t is not None else 0  # noqa: E731
+    _chk(lib.tvts_rows_move({"gather": 0, "scatter": 1, "scatter_add": 2}[mode], _p(rows), rows.numel(), W, _p(full_f32), ld(full_f32),
+                            _p(full_bf16), ld(full_bf16), _p(packed_f32), ld(packed_f32), _p(packed_bf16), ld(packed_bf16), _stream()),
+         "tvts_rows_move")
+
+
+def zero_cols_bf16(x, cols):
+    """x[:, :cols] = 0 (bf16, row-major)"""
+    lib = _lib.load()
+    assert x.dtype == torch.bfloat16 and x.stride(1) == 1
+    _chk(lib.tvts_zero_cols_bf16(_p(x), _ld(x), x.shape[0], int(cols), _stream()), "tvts_zero_cols_bf16")
+
+
 def l2norm_rows(x, xn, inv, eps=1e-8):
     lib = _lib.load()
     _chk(lib.tvts_l2norm_rows(_p(x), x.shape[0], x.shape[1], eps, _p(xn), _p(inv), _stream()), "tvts_l2norm_rows")
@@ -959,6 +994,28 @@ def transpose_batched(src, dst, tiles, ntiles):
 def probe_tr16(inp, out):
     lib = _lib.load()
     _chk(lib.tvts_probe_tr16(_p(inp), _p(out), _stream()), "tvts_probe_tr16")
+
+
+CLOCK_PROBE = None  # bench.py: dict(buf=int64 [n, 2] device tensor, i=0, n=0, every=8, ticks=1000) while the instrumented step runs
+
+
+def _probe_clock():
+    """behind every `every`-th profiled GEMM launch: the shader clock the chip is holding under that load (tvts_clock_probe)"""
+    cp = CLOCK_PROBE
+    if cp is None:
+        return
+    cp["n"] += 1
+    if cp["n"] % cp["every"] or cp["i"] >= cp["buf"].shape[0]:
+        return
+    _chk(_lib.load().tvts_clock_probe(_p(cp["buf"][cp["i"]]), int(cp["ticks"]), _stream()), "tvts_clock_probe")
+    cp["i"] += 1
+
+
+def device_clock_info(device=0):
+    """-> (rate of the constant counter in kHz, CU count, the sheet's maximum shader clock in kHz)"""
+    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _chk(_lib.load().tvts_device_clock_info(int(device), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "tvts_device_clock_info")
+    return a.value, b.value, c.value
 
 
 class Event:

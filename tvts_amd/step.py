@@ -30,10 +30,25 @@ class StepRunner:
         # bandwidth and the CUs it runs on away from the backward it was meant to hide under, and its ~18 fork edges cost the replayed
         # graph what the r04 side-stream experiments already showed.  Same bits either way (tests/test_bench_path_gpu.py).
         self.ranged = self.fused and hasattr(optimizer, "step_range") and bool(self.eng.arch.get("adamw_ranges", os.environ.get("TVTS_ADAMW_RANGES", "0") == "1"))
+        # exchange diagnostics (bench.py at world > 1, eager launches only): event pairs on the compute stream around the two places where
+        # it waits for a collective -- {"gather": [...], "allreduce": [...]} when switched on, None otherwise
+        self.diag = None
+
+    def _bracket(self, key, fn):
+        """fn() between two events of the current stream when the diagnostics are on: the elapsed time is what the compute stream
+        spent WAITING there (the exposed part of the collective), since fn only enqueues waits and small copies"""
+        if self.diag is None or torch.cuda.is_current_stream_capturing():
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.diag.setdefault(key, []).append((e0, e1))
+        return out
 
     def losses_and_grads(self, pb, te, ve, pred, labels):
         B = pb["B"]
-        vg, tg = self.gather.result()  # started by the engine before the sort head ran
+        vg, tg = self._bracket("gather", self.gather.result)  # started by the engine before the sort head ran
         loss1, dv_all, dt_all = self.head.contrastive(vg, tg)
         if pred is not None:
             loss2, dpred = self.head.sorting(pred, labels)
@@ -74,7 +89,7 @@ class StepRunner:
             self.eng.param_ready = None
         if hasattr(self.eng, "end_step"):
             self.eng.end_step()  # (e4m3 weight gradients: this step's amax values become the next step's per-tensor scales)
-        scale = self.sync.finish()
+        scale = self._bracket("allreduce", self.sync.finish)
         if self.fused:
             self.opt.grad_scale = scale
             self.opt.step(device_step=device_step)
