@@ -490,16 +490,16 @@ def main():
         if rank == 0:
             K.GEMM_PROFILE = []
             K.HBM_PROFILE = []
-            # the shader clock the chip holds under this load: a ~10 us one-lane probe (tvts_clock_probe: s_memtime cycles over
-            # s_memrealtime ticks) behind every 8th GEMM launch of the instrumented step, outside the launches' event pairs
-            K.CLOCK_PROBE = dict(buf=torch.zeros(128, 2, dtype=torch.int64, device=dev), i=0, n=0, every=8, ticks=1000)
+            # the shader clock the chip holds under this load, sampled INSIDE the plain bf16 launches of the 256 x 256 kernel (qkv forward,
+            # input gradients): block 0 reads s_memtime (shader cycles) and s_memrealtime (constant rate) at its start and end
+            K.CLOCK_PROBE = dict(buf=torch.zeros(256, 4, dtype=torch.int64, device=dev), i=0, shape=[])
         eng_ts, model.engine.text_side = model.engine.text_side, False
         # (a few un-instrumented steps first: the power management settles on the clock of the sustained step, not of the pause behind the timed loop)
         for i in range(2):
             one_step(i, device_step=False)
         if rank == 0:
             K.GEMM_PROFILE, K.HBM_PROFILE = [], []
-            K.CLOCK_PROBE.update(i=0, n=0)
+            K.CLOCK_PROBE.update(i=0, shape=[])
         one_step(0, device_step=False)
         torch.cuda.synchronize()
         model.engine.text_side = eng_ts
@@ -511,8 +511,10 @@ def main():
         cp, K.CLOCK_PROBE = K.CLOCK_PROBE, None
         wall_khz, n_cus, sheet_khz = K.device_clock_info(torch.cuda.current_device())
         pr = cp["buf"][:cp["i"]].cpu().double()
-        pr = pr[pr[:, 1] > 0]
-        clk = (pr[:, 0] / pr[:, 1] * wall_khz / 1e3) if len(pr) else None   # MHz per probe
+        cyc, tk = pr[:, 2] - pr[:, 0], pr[:, 3] - pr[:, 1]
+        ok = (pr[:, 0] > 0) & (pr[:, 2] > 0) & (tk > 0)          # launches that took the sampling instantiation
+        clk = (cyc[ok] / tk[ok] * wall_khz / 1e3) if bool(ok.any()) else None   # MHz per sampled launch
+        clk_w = tk[ok] if clk is not None else None               # weights: the launches' durations
         tot_ms = sum(r[2].elapsed_ms(r[3]) for r in recs)
         tot_fl = sum(r[1] for r in recs)
         by = {}
@@ -558,14 +560,15 @@ def main():
         # (256 CUs x 4 SIMDs x 1024 FLOP per cycle) beside the sheet's 2.5 PFLOP/s at 2.4 GHz
         util = pmc_mfma_util(args)
         if clk is not None:
-            # LIVE: the clock probes of this very step; the peak at that clock = CUs x 4 SIMDs x 1024 FLOP per cycle (v_mfma_f32_16x16x32_bf16:
+            # LIVE: the in-kernel clock samples of this very step; the peak at that clock = CUs x 4 SIMDs x 1024 FLOP per cycle (v_mfma_f32_16x16x32_bf16:
             # 16 384 FLOP in 16 cycles per SIMD; 2.5 PFLOP/s is 256 CUs at the sheet's 2.4 GHz)
-            mhz = float(clk.mean())
+            mhz = float((clk * clk_w).sum() / clk_w.sum())
             peak_clk = n_cus * 4 * 1024 * mhz * 1e6 / 1e12
             line["roofline"].update({"clock_mhz_under_load": mhz, "clock_mhz_min_max": [float(clk.min()), float(clk.max())],
-                                     "clock_probes": int(len(clk)), "sheet_clock_mhz": sheet_khz / 1e3, "cu_count": n_cus,
+                                     "clock_samples": int(len(clk)), "sheet_clock_mhz": sheet_khz / 1e3, "cu_count": n_cus,
                                      "peak_at_clock": peak_clk, "frac_at_clock": ach / peak_clk,
-                                     "clock_source": "tvts_clock_probe behind every 8th GEMM launch of the instrumented step (s_memtime / s_memrealtime)"})
+                                     "clock_source": "shader cycles (s_memtime) over constant-rate ticks (s_memrealtime) sampled by block 0 INSIDE the "
+                                                     "plain bf16 256 x 256 NT launches of the instrumented step (TVTS_GEMM_CLOCK_SAMPLE), duration-weighted"})
         if util and "stale" not in util:
             line["roofline"].update({"mfma_busy": util["mfma_busy"], "mfma_busy_clock_mhz": util["clock_mhz_under_load"],
                                      "mfma_util_by_family": util["by_family"], "mfma_util_source": util["source"]})

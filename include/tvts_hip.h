@@ -37,6 +37,11 @@ enum {
                                    in flight: the small-batch kernel; same bits as TVTS_GEMM_TILE_128); -22 if an operand is too large
                                    for its 32-bit offsets.  Automatic where its cost model wins (csrc/gemm.hip, nt_use_ring) */
     TVTS_GEMM_NO_RING = 16384,  /* ... never take it */
+    TVTS_GEMM_CLOCK_SAMPLE = 2097152, /* tvts_gemm_nt_bf16, plain bf16 result on the 256 x 256 kernel (round 6, bench.py's instrumented step): block 0
+                                   writes {s_memtime, s_memrealtime} at its first instruction and behind its last tile into the LAST 32 bytes
+                                   of `workspace` (4 x u64: cycles0, ticks0, cycles1, ticks1) -- shader cycles over constant-rate ticks =
+                                   the clock the launch ran at.  A separate instantiation: the kernels of every other call are unchanged;
+                                   ignored where the call takes another kernel or the stream-K walk */
     TVTS_GEMM_SIDE_DERIV = 1048576 /* tvts_gemm_nt_bf16 / _fp8 / _fp8_gate (round 5): the activation forms store act'(x) in `preact` instead of the
                                    pre-activation x, the gate forms take `gate_h` as that derivative and multiply by it as is -- the forward
                                    epilogue evaluates the sigmoid / erf parts anyway, the input-gradient epilogue then needs no
@@ -441,11 +446,12 @@ int tvts_event_create(void** ev);
 int tvts_event_record(void* ev, hipStream_t stream);
 int tvts_event_elapsed_ms(void* start, void* stop, float* ms);
 int tvts_event_destroy(void* ev);
-/* clock under load (SURVEY.md 8d "confirm the peak on the box: clocks x CUs x MFMA rate"): a one-lane kernel that counts shader
-   cycles (s_memtime) over ref_ticks of the constant-rate counter (s_memrealtime); out2_u64[0] = cycles, [1] = ticks.  The rate of
-   the constant counter, the CU count and the sheet's maximum shader clock come from the device attributes.  No reference site: the
-   reference has no roofline accounting. */
-int tvts_clock_probe(void* out2_u64, int ref_ticks, hipStream_t stream);
+/* clock under load (SURVEY.md 8d "confirm the peak on the box: clocks x CUs x MFMA rate"): the rate of the constant counter
+   (s_memrealtime) in kHz, the CU count and the sheet's maximum shader clock of the device; the shader cycles themselves are sampled
+   INSIDE a GEMM launch (TVTS_GEMM_CLOCK_SAMPLE).  No reference site: the reference has no roofline accounting. */
+/* p[0:nbytes] = 0 on the stream (hipMemsetAsync): optimizer.zero_grad() of the flat gradient buffer (v2/trainer/trainer.py:476) and
+   the step's small accumulators */
+int tvts_zero_bytes(void* p, long nbytes, hipStream_t stream);
 int tvts_device_clock_info(int device, int* wall_clock_khz, int* cu_count, int* max_shader_khz);
 
 #ifdef __cplusplus

@@ -339,6 +339,20 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
             else kern = g.residual ? gemm_nt256p_kernel<0, 0, false, 256 | SKF> : gemm_nt256p_kernel<0, 0, false, SKF>;
         }
     }
+    g.clk = nullptr;
+    if constexpr (!FP8) {
+        // TVTS_GEMM_CLOCK_SAMPLE: the same kernel with the two counter samples of block 0 compiled in (the production instantiations
+        // carry nothing of it); the samples go to the last 32 bytes of the caller's workspace
+        if ((opts & 2097152) && workspace && workspace_bytes >= 64 && !g.sk_ws && ((size_t)workspace + (size_t)workspace_bytes) % 8 == 0) {
+            void (*ck)(GemmNT) = nullptr;
+            if (kern == (void (*)(GemmNT))gemm_nt256p_kernel<0, 0, false, 8192 | SD, 0>) ck = gemm_nt256p_kernel<0, 0, false, 8192 | SD | 4194304, 0>;
+            else if (kern == (void (*)(GemmNT))gemm_nt256p_kernel<0, 0, false, SD>) ck = gemm_nt256p_kernel<0, 0, false, SD | 4194304>;
+            if (ck) {
+                kern = ck;
+                g.clk = (unsigned long long*)((char*)workspace + workspace_bytes - 32);
+            }
+        }
+    }
     if (!kern) return TVTS_EINVAL;
     const int lds_bytes = 163840;  // 2 x 64 KiB stages + 8 x 4 KiB epilogue patches
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

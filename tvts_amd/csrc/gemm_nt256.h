@@ -27,6 +27,8 @@ struct GemmNT {
     // output is the operand of the next layer's forward AND weight-gradient GEMMs, the gated input gradient that of the previous
     // layer's): q8[m, n] = e4m3(out[m, n] / q8_scale[0]), q8_amax = max(q8_amax, max |out|)
     unsigned char* q8; int ldq8; const float* q8_scale; float* q8_amax;
+    // ABL & 4194304 (TVTS_GEMM_CLOCK_SAMPLE): block 0 stores {s_memtime, s_memrealtime} at its start and end here (4 x u64)
+    unsigned long long* clk;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -809,6 +811,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
     const int wm = wave >> 2, wn = wave & 3;
     char* patch = smem + 131072 + wave * 4096;
 
+    if constexpr ((ABL & 4194304) != 0) {  // clock sample: shader cycles and constant-rate ticks at the block's first instruction
+        if (blockIdx.x == 0 && tid == 0 && g.clk) { g.clk[0] = __builtin_amdgcn_s_memtime(); g.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+    }
     const int total = g.tiles_m * g.tiles_n;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const int q = total >> 3, rem = total & 7;
@@ -1158,6 +1163,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                 LOAD_A(aF[0], nxt, 0, 0);
             }
         }
+    }
+    if constexpr ((ABL & 4194304) != 0) {  // ... and behind its last tile
+        if (blockIdx.x == 0 && tid == 0 && g.clk) { g.clk[2] = __builtin_amdgcn_s_memtime(); g.clk[3] = __builtin_amdgcn_s_memrealtime(); }
     }
     if constexpr (SK) {
 #pragma unroll

@@ -325,7 +325,7 @@ class Engine:
         if t is not None and tuple(t.shape) == shape and t.dtype == dtype:
             self._seen[name] = self._tick  # (live in this step: a later request for ANOTHER shape under this name must not alias it)
             if zero:
-                t.zero_()
+                K.zero_(t)
             return t
         n = 1
         for s in shape:
@@ -340,11 +340,18 @@ class Engine:
                 back = self._back[name] = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
             t = self.buf[name] = back[:n].view(shape)
         if zero:
-            t.zero_()
+            K.zero_(t)
         return t
 
     def _f(self, name, shape, zero=False):
         return self._b(name, shape, torch.float32, zero)
+
+    def _ones(self, n):
+        """a vector of n ones (the bias gradients as 1^T dy products): a constant made once per length, never written again"""
+        t = self.buf.get(("ones", n))
+        if t is None:
+            t = self.buf[("ones", n)] = torch.ones(n, dtype=torch.float32, device=self.dev)
+        return t
 
     # ------------------------------------------------------------------ e4m3 copies (BASELINE config 4 / 5)
     # Two regimes of the e4m3 operand copies:
@@ -619,11 +626,11 @@ class Engine:
     # ------------------------------------------------------------------ text tower
     @staticmethod
     def eot_index(eot_rows, L):
-        """(int64 copy of the EOT rows, int32 position of the EOT token inside its caption).  prepare_batch makes them once and
-        keeps them in the batch dict, so that their lifetime is the batch's -- and that of a hipGraph captured over it (an
-        identity-keyed cache on the engine handed a captured graph tensors that the next capture freed)."""
+        """(None, int32 position of the EOT token inside its caption).  prepare_batch hands the positions over with the batch (made on
+        the host, so that their lifetime is the batch's -- and that of a hipGraph captured over it); this form derives them from
+        the rows for callers that drive text_forward by hand."""
         pos = (eot_rows - torch.arange(eot_rows.numel(), device=eot_rows.device, dtype=torch.int32) * L).contiguous()
-        return eot_rows.long(), pos
+        return None, pos
 
     def text_forward(self, ids_dev, eot_rows, N, L, eot_index=None):
         """eot_index: Engine.eot_index(eot_rows, L) kept by the caller (prepare_batch); made here when absent (eager use only)."""
@@ -811,7 +818,6 @@ class Engine:
             self._ln(xc, "video_model.ln_post", 1e-5, lnc, "vit.lnpost")
         elif lowres:  # ln_post on the B CLS rows in fp32: an fp32 copy of those rows (plumbing on [B, W])
             xc, xcb = self._f("vit.xcls32", (B, W)), self._b("vit.xcls16", (B, W))
-            vr64 = self.ctx.get("vid_rows64") if isinstance(self.ctx, dict) else None
             K.rows_move("gather", vid_rows, full_bf16=x, packed_f32=xc, packed_bf16=xcb)
             self._ln(xc, "video_model.ln_post", 1e-5, lnc, "vit.lnpost")
         else:
@@ -856,7 +862,7 @@ class Engine:
                     K.gemm_tn(B_["vit.xlast_b"], dout_b, self.P.g("video_model.proj"), M=M, accumulate=True)
                 K.gemm_nt(dout_b, self.P.w("video_model.proj"), dx, M=M)
             else:
-                dx.zero_()
+                K.zero_(dx)
             # pooled branch, fp32: dproj += lnc^T d_pooled, d_lnc = d_pooled proj^T, ln_post backward on the CLS rows only
             lnc = B_["vit.lnpost_cls"]
             if rg["video_model.proj"]:
@@ -1065,9 +1071,7 @@ class Engine:
         Mo, R = B * So, B * NT
         nf = B_["srt.nf"]
         K.gemm_small(dpred, nf, self.P.g("pred_model.head.weight"), M=C, N=E, K=R, sa=(1, C), sb=(E, 1), accumulate=True)
-        ones = self.buf.get(("srt.ones", R))   # a constant: made once per row count, never written again
-        if ones is None:
-            ones = self.buf[("srt.ones", R)] = torch.ones(R, dtype=torch.float32, device=self.dev)
+        ones = self._ones(R)
         K.gemm_small(ones, dpred, self.P.g("pred_model.head.bias").view(1, C), M=1, N=C, K=R, sa=(0, 1), sb=(C, 1),
                      accumulate=True)
         dnf = self._f("srt.dnf", (R, E))
@@ -1116,7 +1120,7 @@ class Engine:
         """Host-side (plumbing): dtype/device normalisation of the reference batch dict."""
         a = self.arch
         video = data["video"]
-        crop = resize = None
+        crop = resize = crop_cpu = None
         if video.dtype == torch.uint8:
             # uint8 wire format (SURVEY.md 8f N3): [B, T, H0, W0, 3] frames as decoded + resized; crop / 255 / normalise
             # happen inside the patch gather.  data["crop"]: [B, 2] (top, left) of a random crop, absent = centre crop.
@@ -1125,7 +1129,7 @@ class Engine:
             assert video.dim() == 5 and video.shape[-1] == 3, "uint8 video must be [B, T, H, W, 3]"
             video = self._clip_to_device(video).contiguous()
             if data.get("crop") is not None:
-                crop = data["crop"].to(torch.int32).contiguous().to(self.dev)
+                crop_cpu = data["crop"].detach().to("cpu", torch.int32).contiguous()
             if data.get("resize") is not None:  # the frames are the decoder's pictures: Resize(size) happens inside the gather
                 from .data_loader.transforms import resize_tables
                 resize = resize_tables(video.shape[2], video.shape[3], int(data["resize"]), self.dev)
@@ -1148,10 +1152,13 @@ class Engine:
         L = int(eot.max()) + 1
         N = ids_cpu.shape[0]
         NT = N // B
-        eot_rows = (torch.arange(N) * L + eot).to(torch.int32).to(self.dev)
-        ids_dev = ids_cpu[:, :L].to(torch.int32).contiguous().to(self.dev)
+        # every small index tensor of the batch is made on the HOST and travels in one asynchronous copy (_stage_small): no copy of
+        # this function is ordered behind the compute stream's running step, so the host prepares batch t + 1 while step t computes
+        small = {"eot_rows": (torch.arange(N) * L + eot).to(torch.int32), "eot_pos": eot.to(torch.int32),
+                 "ids": ids_cpu[:, :L].to(torch.int32).contiguous()}
         # rows sorted by token id: the token-embedding gradient is then an ordered sum per id instead of a scatter of atomics
-        tok_sort = tuple(t.to(self.dev) for t in K.token_sort(ids_cpu[:, :L]))
+        small["tok_order"], small["tok_seg"] = K.token_sort(ids_cpu[:, :L])
+        keep = None
         if "keep_ind" not in data:
             # device-drawn tube mask: data["mask_seed"] + the global number of the batch's first sample
             # reproduce the draw whatever the batch split; the reference draws it in the dataset worker
@@ -1161,23 +1168,82 @@ class Engine:
             keep = K.tube_mask(int(data["mask_seed"]), int(data.get("sample_offset", 0)), B, patches_per_frame(a),
                                n_keep(a), device=self.dev)
         else:
-            keep = data["keep_ind"].to(torch.int32)
-            if keep.dim() != 2 or keep.shape[0] not in (1, B):
-                raise ValueError(f"keep_ind {tuple(keep.shape)}: expected [B, n_keep] (or [1, n_keep] for the whole batch)")
-            if keep.numel() and (int(keep.min()) < 0 or int(keep.max()) >= patches_per_frame(a)):
+            kc = data["keep_ind"]
+            if kc.dim() != 2 or kc.shape[0] not in (1, B):
+                raise ValueError(f"keep_ind {tuple(kc.shape)}: expected [B, n_keep] (or [1, n_keep] for the whole batch)")
+            if kc.numel() and (int(kc.min()) < 0 or int(kc.max()) >= patches_per_frame(a)):
                 raise IndexError(f"keep_ind must index the {patches_per_frame(a)} patches of a frame")
-        if keep.shape[0] == 1 and B > 1:  # one tube mask for the whole batch (the downstream scripts pass arange(n)[None])
-            keep = keep.expand(B, -1)
-        keep = keep.contiguous().to(self.dev)
-        n = keep.shape[1]
+            if kc.shape[0] == 1 and B > 1:  # one tube mask for the whole batch (the downstream scripts pass arange(n)[None])
+                kc = kc.expand(B, -1)
+            if kc.is_cuda:
+                keep = kc.to(torch.int32).contiguous()
+            else:
+                small["keep"] = kc.to(torch.int32).contiguous()
+        n = (keep if keep is not None else small["keep"]).shape[1]
         S = 1 + T * n
         Sv = S - 1 if self.pooled_tail else S
         So = Sv + NT
-        sort_rows = (torch.arange(B)[:, None] * So + Sv + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32).to(self.dev)
-        vid_rows = (torch.arange(B) * S).to(torch.int32).to(self.dev)
-        return dict(video=video, crop=crop, resize=resize, ids=ids_dev, tok_sort=tok_sort, eot_rows=eot_rows, eot_index=self.eot_index(eot_rows, L),
-                    keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
-                    sort_rows=sort_rows, sort_rows64=sort_rows.long(), vid_rows=vid_rows, vid_rows64=vid_rows.long())
+        small["sort_rows"] = (torch.arange(B)[:, None] * So + Sv + torch.arange(NT)[None, :]).reshape(-1).to(torch.int32)
+        small["vid_rows"] = (torch.arange(B) * S).to(torch.int32)
+        if crop_cpu is not None:
+            small["crop"] = crop_cpu
+        if "label" in data and NT != 1:
+            small["labels"] = data["label"].detach().reshape(-1).to("cpu", torch.int32)
+        d = self._stage_small(small)
+        if keep is None:
+            keep = d["keep"]
+        return dict(video=video, crop=d.get("crop", crop), resize=resize, ids=d["ids"], tok_sort=(d["tok_order"], d["tok_seg"]),
+                    eot_rows=d["eot_rows"], eot_index=(None, d["eot_pos"]), keep=keep, B=B, T=T, N=N, NT=NT, L=L, n=n, S=S,
+                    sort_rows=d["sort_rows"], vid_rows=d["vid_rows"], labels=d.get("labels"))
+
+    STAGE_SLOTS = 4
+
+    def _stage_small(self, small: dict) -> dict:
+        """{name: small host int tensor} -> {name: device tensor}: packed into ONE page-locked staging buffer (a ring of STAGE_SLOTS, each
+        guarded by the event of its last copy) and moved by ONE asynchronous copy on the engine's copy stream; the compute stream
+        waits for it by event.  (One pageable .to(device) per tensor is a synchronous copy queued behind the running step: the host
+        would wait for the previous step to finish before it could even start preparing the next one.)"""
+        offs, total = {}, 0
+        for k, t in small.items():
+            offs[k] = total
+            total += (t.numel() * t.element_size() + 15) // 16 * 16
+        total = max(total, 16)
+        if not torch.cuda.is_available() or self.dev.type != "cuda":
+            return {k: t.to(self.dev) for k, t in small.items()}
+        ring = getattr(self, "_stage_ring", None)
+        if ring is None:
+            ring = self._stage_ring = dict(i=0, slots=[None] * self.STAGE_SLOTS)
+        i = ring["i"] = (ring["i"] + 1) % self.STAGE_SLOTS
+        slot = ring["slots"][i]
+        if slot is None or slot[0].numel() < total:
+            slot = ring["slots"][i] = [torch.empty(max(total, 1 << 16), dtype=torch.uint8, pin_memory=True), None]
+        if slot[1] is not None:
+            slot[1].synchronize()  # the copy that last read this staging buffer (STAGE_SLOTS batches ago: long done)
+        host = slot[0]
+        for k, t in small.items():
+            nb = t.numel() * t.element_size()
+            if nb:
+                host[offs[k]:offs[k] + nb].view(t.dtype).copy_(t.reshape(-1))
+        cs = getattr(self, "_copy_stream", None)
+        if cs is None:
+            cs = self._copy_stream = torch.cuda.Stream(device=self.dev)
+        cur = torch.cuda.current_stream(self.dev)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            devbuf = host[:total].to(self.dev)
+        else:
+            with torch.cuda.stream(cs):
+                devbuf = torch.empty(total, dtype=torch.uint8, device=self.dev)
+                devbuf.copy_(host[:total], non_blocking=True)
+                slot[1] = torch.cuda.Event()
+                slot[1].record(cs)
+            cur.wait_stream(cs)
+            devbuf.record_stream(cur)
+        out = {}
+        for k, t in small.items():
+            nb = t.numel() * t.element_size()
+            out[k] = devbuf[offs[k]:offs[k] + nb].view(t.dtype).view(t.shape)
+        return out
 
     def forward(self, pb: dict):
         """-> (text_emb [B,E], video_emb [B,E], pred [B*NT, n_trans] | None); all fp32 workspace tensors."""
@@ -1290,7 +1356,7 @@ class LossHead:
         if t is None or tuple(t.shape) != shape:
             t = self.buf[name] = torch.zeros(shape, dtype=torch.float32, device=self.dev)
         elif zero:
-            t.zero_()
+            K.zero_(t)
         return t
 
     def sim(self, a, b, eps=1e-8):

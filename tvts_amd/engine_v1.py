@@ -171,8 +171,7 @@ class EngineV1(Engine):
         a, P, B_ = self.arch, self.P, self.buf
         Wt, M, E = a["text_width"], N * L, a["embed"]
         K.gemm_small(dt, B_["txt.relu"], P.g("txt_proj.1.weight"), M=E, N=Wt, K=N, sa=(1, E), sb=(Wt, 1), accumulate=True)
-        ones = self._f("txt.ones", (N,))
-        ones.fill_(1.0)
+        ones = self._ones(N)
         K.gemm_small(ones, dt, P.g("txt_proj.1.bias").view(1, E), M=1, N=E, K=N, sa=(0, 1), sb=(E, 1), accumulate=True)
         dact = self._f("txt.dact", (N, Wt))
         K.gemm_small(dt, P.p("txt_proj.1.weight"), dact, M=N, N=Wt, K=E, sa=(E, 1), sb=(Wt, 1))
@@ -301,8 +300,7 @@ class EngineV1(Engine):
         # vid_proj on the CLS token: dW += d_video^T cls, db += colsum, d_cls = d_video W
         cls = self.buf["vit.cls"]
         K.gemm_small(d_video, cls, P.g("vid_proj.0.weight"), M=E, N=W, K=B, sa=(1, E), sb=(W, 1), accumulate=True)
-        ones = self._f("vit.ones", (B,))
-        ones.fill_(1.0)
+        ones = self._ones(B)
         K.gemm_small(ones, d_video, P.g("vid_proj.0.bias").view(1, E), M=1, N=E, K=B, sa=(0, 1), sb=(E, 1), accumulate=True)
         dcls = self._f("vit.dcls", (B, W))
         K.gemm_small(d_video, P.p("vid_proj.0.weight"), dcls, M=B, N=W, K=E, sa=(E, 1), sb=(W, 1))

@@ -87,7 +87,7 @@ class FusedHFAdamW(torch.optim.Optimizer):
         return super().state_dict()
 
     def zero_grad(self, set_to_none: bool = False):
-        self.store.grad.zero_()
+        K.zero_(self.store.grad)
 
     def _begin(self, device_step: bool):
         """counters of a new optimizer step (once per step, in front of its first launch)"""

@@ -18,7 +18,7 @@ import torch.distributed as dist
 
 from ..base import Multi_BaseTrainer_dist
 from ..model._common import sim_matrix  # noqa: F401  (the reference re-exports it at module scope)
-from ..step import StepRunner
+from ..step import GraphReplay, StepRunner
 
 __all__ = ["AllGather", "AllGather_multi", "Trainer_TVTSv2_B_32", "Trainer_TVTSv2_B_16", "Trainer_TVTSv2_H_14", "Trainer_TVTS"]
 
@@ -115,6 +115,8 @@ class _TrainerBase(Multi_BaseTrainer_dist):
         # the configured loss module's temperature drives the fused loss head (model/loss.py:11 NormSoftmaxLoss(temperature))
         from ..engine import LossHead
         self.runner = StepRunner(model, optimizer, LossHead(model.store.device, temperature=float(getattr(loss, "temperature", 0.05))))
+        # batches of a repeating shape are replayed from a captured hipGraph (world 1, fused optimizer; TVTS_TRAINER_GRAPH=0: eager)
+        self.replay = GraphReplay(self.runner)
 
     def _adjust_learning_rate(self, optimizer, epoch, args):
         lr_rate = 1.0
@@ -148,7 +150,7 @@ class _TrainerBase(Multi_BaseTrainer_dist):
                 loader.train_sampler.set_epoch(epoch)
         for batch_idx, data_li in enumerate(_lockstep(self.data_loader, self.len_epoch)):
             for dl_idx, data in enumerate(data_li):
-                out = self.runner.step(self._tokenize(data))
+                out = self.replay.step(self._tokenize(data))
                 log_now = batch_idx % self.log_step == 0 and self.args.local_rank == 0
                 l1 = out["loss1"]
                 l2 = out["loss2"] if out["loss2"] is not None else torch.zeros_like(l1)
@@ -265,6 +267,9 @@ class Trainer_TVTS(_TrainerBase):
         super().__init__(args, model, loss, metrics, optimizer, config, data_loader, valid_data_loader, lr_scheduler, len_epoch,
                          writer, visualizer, tokenizer, max_samples_per_epoch)
         self.base_lr = optimizer.state_dict()["param_groups"][0]["lr"]  # v1/base/base_trainer.py:30
+        # the Hugging Face tokenizer pads to the longest caption of the BATCH: the caption length -- and with it the shape of the
+        # step -- changes from batch to batch, so there is no repeating signature to capture
+        self.replay.usable = False
 
     # the dropout generator's state travels with the checkpoint: a resumed run draws the masks the uninterrupted run would have,
     # on EVERY rank -- the file (written by rank 0) holds the rank-independent part of the seed, each rank adds its own offset back
