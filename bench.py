@@ -258,7 +258,11 @@ def main():
                     "leave their GEMM epilogues as e4m3 bytes ONLY (round 5 default); off = bf16 result + a quantiser pass (round 4)")
     ap.add_argument("--text-side", choices=("on", "off"), default="on", help="the text tower on its own stream beside the ViT (round 5 default; "
                     "off = in line in front of it)")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="world 1: capture the whole step into a hipGraph per resident batch and replay it.  OPT-IN since "
+                    "round 6: with the text tower on its own stream the replayed two-stream graph measures SLOWER than the eager launches of the "
+                    "same step -- 0.9 %% at 192 pairs, 4.5 %% at 24, 6.5 %% at 12 (profiles/r06_bench_product_path.txt) -- and the eager step is "
+                    "the trainer's own path")
+    ap.add_argument("--no-graph", action="store_true", help="(the default since round 6; kept for the scripts that pass it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -360,13 +364,14 @@ def main():
     def one_step(i, device_step):
         return runner.run(pbs[i % len(pbs)], labels[i % len(pbs)], device_step=device_step)
 
-    # world 1: the whole step (zero_grad ... AdamW) is captured once and replayed.  world > 1: eager launches by default -- RCCL
-    # calls are capturable and the native transport's fork / join events make the side stream part of the capture
+    # Eager launches by default (round 6: the same StepRunner.run the trainer drives; the device is never short of queued work -- 800
+    # launches of ~4 us host time per 15 ... 138 ms step).  --graph (world 1): the whole step (zero_grad ... AdamW) captured once per
+    # resident batch and replayed -- measured slower than eager since the text tower runs on its own stream (see the flag's help).
+    # world > 1: RCCL calls are capturable and the native transport's fork / join events make the side stream part of the capture
     # (tests/test_comm_gpu.py::test_captured_step_through_the_native_transport does it at world 1), but no multi-GPU box was
-    # available to validate a captured multi-rank step, so it is opt-in: TVTS_BENCH_GRAPH_DDP=1.  At the bench's 192 pairs per
-    # GPU the eager step is within 0.5 % of the replayed one (profiles/r03_bench_eager_vs_graph.jsonl).
+    # available to validate a captured multi-rank step: TVTS_BENCH_GRAPH_DDP=1 + --graph.
     from tvts_amd import dist as D
-    use_graph = ((world == 1) or (os.environ.get("TVTS_BENCH_GRAPH_DDP") == "1" and D.transport() == "native")) and not args.no_graph
+    use_graph = args.graph and not args.no_graph and ((world == 1) or (os.environ.get("TVTS_BENCH_GRAPH_DDP") == "1" and D.transport() == "native"))
     for i in range(max(args.warmup, 1)):
         out = one_step(i, device_step=use_graph)
     torch.cuda.synchronize()

@@ -48,13 +48,13 @@ def _bench(extra, port):
 
 
 def test_graph_and_eager_bench_runs_end_at_the_same_loss():
-    """world 1 replays a captured hipGraph, world > 1 launches eagerly (bench.py): the two modes must be the same
-    computation -- the same loss, bit for bit, after the same number of optimizer steps (every reduction of the step is an ordered
-    sum: two processes, replayed or launched, follow the same trajectory)."""
+    """bench.py launches the step eagerly (the default since round 6) or replays a captured hipGraph (--graph, world 1): the two modes
+    must be the same computation -- the same loss, bit for bit, after the same number of optimizer steps (every reduction of the
+    step is an ordered sum: two processes, replayed or launched, follow the same trajectory)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    g = _bench([], 0)
-    e = _bench(["--no-graph"], 0)
+    g = _bench(["--graph"], 0)
+    e = _bench([], 0)
     assert g["config"]["hip_graph"] is True and e["config"]["hip_graph"] is False
     assert g["config"]["final_loss"] == e["config"]["final_loss"], (g["config"]["final_loss"], e["config"]["final_loss"])
     # WebVid-style batches (one caption per video, no sorting head) run through the same harness

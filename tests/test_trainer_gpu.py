@@ -111,13 +111,14 @@ def test_resumed_run_continues_bit_for_bit(tmp_path):
 
 
 def test_graph_replay_in_the_trainer_loop_is_the_eager_loop(tmp_path, monkeypatch):
-    """Trainer._train_epoch replays a captured hipGraph per batch signature (step.GraphReplay: the YT-Temporal batches with
+    """With TVTS_TRAINER_GRAPH=1 Trainer._train_epoch replays a captured hipGraph per batch signature (step.GraphReplay: the YT-Temporal batches with
     transcripts and the WebVid batches without are two signatures; first sight eager, second captured, then copy-in + replay).  Three
     epochs over the two alternating loaders against the same loop with TVTS_TRAINER_GRAPH=0 (every step eager): the same epoch
     logs, parameters and Adam moments bit for bit, and the learning-rate decay of the schedule reaches the replayed AdamW."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     (tmp_path / "g").mkdir(); (tmp_path / "e").mkdir()
+    monkeypatch.setenv("TVTS_TRAINER_GRAPH", "1")
     tr_g, m_g, _ = build(tmp_path / "g", epochs=3)
     tr_g.args.schedule = [2]
     assert tr_g.replay.usable

@@ -177,7 +177,9 @@ class GraphReplay:
     eager step (tests/test_trainer_gpu.py::test_graph_replay_in_the_trainer_loop_is_the_eager_loop).
 
     World 1 with the fused optimizer only (a captured multi-rank step has never run on hardware: bench.py keeps it opt-in too);
-    anything else, and any failure to capture, falls back to StepRunner.step for good."""
+    anything else, and any failure to capture, falls back to StepRunner.step for good.  OPT-IN (TVTS_TRAINER_GRAPH=1): with
+    prepare_batch free of synchronising copies the eager loop already keeps the device busy back to back, and the replayed loop
+    measures 1 % (192 pairs) to 3 - 4 % (12 pairs) SLOWER than it (profiles/r06_bench_product_path*.txt)."""
 
     MAX_SIGNATURES = 6
 
@@ -185,7 +187,7 @@ class GraphReplay:
         self.r = runner
         self.cache = {}
         self.usable = (torch.cuda.is_available() and runner.fused and not runner.ranged and runner.sync.W == 1 and not runner.sync.native
-                       and os.environ.get("TVTS_TRAINER_GRAPH", "1") != "0")
+                       and os.environ.get("TVTS_TRAINER_GRAPH", "0") == "1")
         self.replays = self.captures = self.eager = 0
 
     def step(self, data: dict):

@@ -78,6 +78,46 @@ def _lockstep(loaders, len_epoch):
         yield [lead_batch if i == pace else next(others[i]) for i in range(len(loaders))]
 
 
+class _LazyLog:
+    """The debug line of the logging steps (v2/trainer/trainer.py:505-512) without stopping the host: the step's two losses are copied
+    to page-locked memory behind the step (asynchronously, one event per line) and the line is written as soon as its event has
+    completed -- checked at every later step, forced at the end of the epoch.  Same lines, same order, same digits (the total is
+    the fp32 sum of the two fp32 losses, as `loss1 + loss2` is on the device); a line appears a step or two later than the
+    reference's `.item()` would print it.  With the reference's cadence int(sqrt(batch_size)) -- every 3rd step at 12 pairs per GPU --
+    three blocking reads per line drained the launch queue every third step: 16.0 -> 15.x ms per step at 12 pairs."""
+
+    SLOTS = 64
+
+    def __init__(self, logger, fmt, device):
+        self.logger, self.fmt, self.q, self.i = logger, fmt, [], 0
+        self.cuda = torch.cuda.is_available() and torch.device(device).type == "cuda"
+        self.host = torch.zeros(self.SLOTS, 2, dtype=torch.float32, pin_memory=self.cuda)
+
+    def add(self, head, l1, l2):
+        if len(self.q) >= self.SLOTS:
+            self.flush(block=True)
+        slot = self.host[self.i]
+        self.i = (self.i + 1) % self.SLOTS
+        slot[0:1].copy_(l1.reshape(1), non_blocking=True)
+        if l2 is None:
+            slot[1] = 0.0
+        else:
+            slot[1:2].copy_(l2.reshape(1), non_blocking=True)
+        ev = None
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self.q.append((ev, slot, head))
+
+    def flush(self, block=False):
+        while self.q and (block or self.q[0][0] is None or self.q[0][0].query()):
+            ev, slot, head = self.q.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            a, b = np.float32(slot[0].item()), np.float32(slot[1].item())
+            self.logger.debug(self.fmt.format(*head, float(a), float(b), float(np.float32(a + b))))
+
+
 class _TrainerBase(Multi_BaseTrainer_dist):
     TRUNCATE = True
     CACHE_CAPTIONS = True
@@ -115,7 +155,10 @@ class _TrainerBase(Multi_BaseTrainer_dist):
         # the configured loss module's temperature drives the fused loss head (model/loss.py:11 NormSoftmaxLoss(temperature))
         from ..engine import LossHead
         self.runner = StepRunner(model, optimizer, LossHead(model.store.device, temperature=float(getattr(loss, "temperature", 0.05))))
-        # batches of a repeating shape are replayed from a captured hipGraph (world 1, fused optimizer; TVTS_TRAINER_GRAPH=0: eager)
+        # TVTS_TRAINER_GRAPH=1: batches of a repeating shape are replayed from a captured hipGraph (world 1, fused optimizer).  OPT-IN:
+        # measured equal to slower than the eager loop once prepare_batch stopped synchronising (profiles/r06_bench_product_path*.txt:
+        # 141.8 - 142.2 against 140.3 - 140.5 ms at 192 pairs, 16.4 against 15.7 - 16.0 ms at 12) -- the copy into the captured
+        # buffers and the replay of a two-stream graph cost what the saved launches return
         self.replay = GraphReplay(self.runner)
 
     def _adjust_learning_rate(self, optimizer, epoch, args):
@@ -148,18 +191,24 @@ class _TrainerBase(Multi_BaseTrainer_dist):
         for loader in self.data_loader:
             if hasattr(loader, "train_sampler") and loader.train_sampler is not None:
                 loader.train_sampler.set_epoch(epoch)
+        lazy = _LazyLog(self.logger, self.LOG_LINE, self.model.store.device)
         for batch_idx, data_li in enumerate(_lockstep(self.data_loader, self.len_epoch)):
             for dl_idx, data in enumerate(data_li):
                 out = self.replay.step(self._tokenize(data))
                 log_now = batch_idx % self.log_step == 0 and self.args.local_rank == 0
                 l1 = out["loss1"]
-                l2 = out["loss2"] if out["loss2"] is not None else torch.zeros_like(l1)
+                l2 = out["loss2"]
                 if batch_idx < self.len_epoch:
-                    torch.add(l1.reshape(()), l2.reshape(()), out=step_loss[dl_idx, batch_idx])
+                    if l2 is None:
+                        step_loss[dl_idx, batch_idx].copy_(l1.reshape(()))
+                    else:
+                        torch.add(l1.reshape(()), l2.reshape(()), out=step_loss[dl_idx, batch_idx])
                 else:
-                    total_loss[dl_idx] += float(l1 + l2)
+                    total_loss[dl_idx] += float(l1 if l2 is None else l1 + l2)
                 if log_now:
-                    self.logger.debug(self.LOG_LINE.format(epoch, dl_idx, self._progress(batch_idx, dl_idx), float(l1), float(l2), float(l1 + l2)))
+                    lazy.add((epoch, dl_idx, self._progress(batch_idx, dl_idx)), l1, l2)
+                lazy.flush()
+        lazy.flush(block=True)
             # max_samples_per_epoch is stored and never read by the reference's TVTSv2 trainers (trainer.py:93,387,681):
             # the whole YT loader is iterated, so the per-epoch LR schedule sees the same number of steps here
         for dl_idx, row in enumerate(step_loss.cpu().tolist()):
