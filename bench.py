@@ -25,6 +25,10 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (measured 2495)
 PEAK_HBM_BPS = 8.0e12        # HBM3E peak, MI355X_MICROARCH.md
 ACHIEVABLE_HBM_BPS = 6.3e12  # what a streaming copy reaches on this part (same guide)
+# world 1: below this many (ViT token rows per GPU) x width^2 the eager step is bound by the host's launch rate (~800 launches of ViT-B/16 take
+# 11.5 ms however little they compute) and the captured graph is replayed by default: B/16 at 2 / 4 pairs replayed 212 / 374 pairs/s against
+# 163 - 170 / 331 - 347 eager; at 6 pairs (2.8e9) and for H/14 at its 2 pairs (4.0e9) eager wins by 2 / 7.5 % (profiles/r06_bench_launch_bound_eager_vs_graph.txt)
+GRAPH_AUTO_WORK = 2.5e9
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 peak (MX-scaled K = 128 MFMA; the non-scaled 16x16x32 fp8 form issues at the bf16 rate)
 
 
@@ -258,11 +262,12 @@ def main():
                     "leave their GEMM epilogues as e4m3 bytes ONLY (round 5 default); off = bf16 result + a quantiser pass (round 4)")
     ap.add_argument("--text-side", choices=("on", "off"), default="on", help="the text tower on its own stream beside the ViT (round 5 default; "
                     "off = in line in front of it)")
-    ap.add_argument("--graph", action="store_true", help="world 1: capture the whole step into a hipGraph per resident batch and replay it.  OPT-IN since "
-                    "round 6: with the text tower on its own stream the replayed two-stream graph measures SLOWER than the eager launches of the "
-                    "same step -- 0.9 %% at 192 pairs, 4.5 %% at 24, 6.5 %% at 12 (profiles/r06_bench_product_path.txt) -- and the eager step is "
-                    "the trainer's own path")
-    ap.add_argument("--no-graph", action="store_true", help="(the default since round 6; kept for the scripts that pass it)")
+    ap.add_argument("--graph", action="store_true", help="world 1: capture the whole step into a hipGraph per resident batch and replay it.  Since round "
+                    "6 the default is EAGER launches wherever the step is not launch-bound: with the text tower on its own stream the replayed "
+                    "two-stream graph measures SLOWER than the eager launches of the same step -- 0.6 - 0.9 %% at 192 pairs, 4.5 %% at 24, 6.5 %% at 12 "
+                    "(profiles/r06_bench_product_path.txt) -- and the eager step is the trainer's own path.  Where the step is launch-bound (GRAPH_AUTO_WORK: up to 4 pairs of "
+                    "ViT-B/16, ~800 launches for 9 ms of kernels) the host cannot keep up and the replay is taken automatically")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches whatever the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -371,7 +376,9 @@ def main():
     # (tests/test_comm_gpu.py::test_captured_step_through_the_native_transport does it at world 1), but no multi-GPU box was
     # available to validate a captured multi-rank step: TVTS_BENCH_GRAPH_DDP=1 + --graph.
     from tvts_amd import dist as D
-    use_graph = args.graph and not args.no_graph and ((world == 1) or (os.environ.get("TVTS_BENCH_GRAPH_DDP") == "1" and D.transport() == "native"))
+    launch_bound = (not v1) and float(B * (1 + T * A.n_keep(a))) * a["width"] ** 2 < GRAPH_AUTO_WORK   # ~800 launches on a handful of clips
+    use_graph = (args.graph or (launch_bound and world == 1)) and not args.no_graph and (
+        (world == 1) or (os.environ.get("TVTS_BENCH_GRAPH_DDP") == "1" and D.transport() == "native"))
     for i in range(max(args.warmup, 1)):
         out = one_step(i, device_step=use_graph)
     torch.cuda.synchronize()
