@@ -26,6 +26,7 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dense-sort-head 2>/dev
 tools/profile_step.sh ${tag}_default --text-side off > $out/profile_step.log 2>&1
 cp gpurun_out/prof_${tag}_default/summary.txt $out/kernel_summary_default_b192.txt
 cp gpurun_out/prof_${tag}_default/kernel_stats.csv $out/kernel_stats_default_b192.csv
+[ -x experiments/probes/mfma_power ] || make -C experiments probes > /dev/null 2>&1
 experiments/probes/mfma_power > $out/mfma_power_probe.txt 2>&1
 TVTS_BENCH_ORDER=gpurun_out/gemm_order.json python bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline > /dev/null 2> $out/order.err
 python tools/pmc_join.py gpurun_out/gemm_order.json gpurun_out > $out/pmc_gemm_traffic_by_shape.txt 2>> $out/order.err
