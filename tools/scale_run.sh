@@ -20,8 +20,9 @@ for n in 1 2 4 8; do
     port=$((29500 + n * 10 + ${#mode}))
     if [ $n -eq 1 ]; then cmd="python bench.py --gpus 1"; else
       cmd="python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port bench.py --gpus $n"; fi
+    gflag=""; [ $mode = native_graph ] && gflag="--graph"   # (eager launches are bench.py's default since round 6)
     echo "# N=$n mode=$mode" >> $out
-    env $env timeout 900 $cmd --steps 10 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | grep '^{' >> $out || echo "# failed or timed out" >> $out
+    env $env timeout 900 $cmd --steps 10 --warmup 3 --no-cpu-baseline $gflag "$@" 2>/dev/null | grep '^{' >> $out || echo "# failed or timed out" >> $out
   done
 done
 cat $out | cut -c1-200
