@@ -249,6 +249,8 @@ extern "C" int tvts_exp_gemm_nt(int variant, int gc, int stagger_phases, int sta
             case 163850: kern = pick_abl<32768 + 131072>(act, gate_act, gated); break;                                    // generic epilogue + stagger + pinned read / MFMA order
             case 172042: kern = pick_pasm<8192 + 32768 + 131072>(act, gate_act, gated, out_f32, residual != nullptr); break;  // hand-scheduled epilogue + stagger + pinned order
             case 163851: kern = pick_abl<32768 + 131072 + 1>(act, gate_act, gated); break;                                // no epilogue + stagger + pinned order
+            case 8552458: kern = pick_abl<32768 + 131072 + 8388608>(act, gate_act, gated); break;                               // generic epilogue, bf16-first patch where it applies (round 6)
+            case 8560650: kern = pick_pasm<8192 + 32768 + 131072 + 8388608>(act, gate_act, gated, out_f32, residual != nullptr); break;  // hand-scheduled epilogue, bf16-first patch where it applies
             case 522: kern = pick_abl<512>(act, gate_act, gated); break;   // counted vmcnt behind the epilogue
             case 1034: kern = pick_reg<1024>(act, gate_act, gated, out_f32, residual != nullptr); break; // register-path epilogue
             case 1546: kern = pick_reg<1536>(act, gate_act, gated, out_f32, residual != nullptr); break; // ... + counted vmcnt
@@ -256,7 +258,7 @@ extern "C" int tvts_exp_gemm_nt(int variant, int gc, int stagger_phases, int sta
             default: return TVTS_EINVAL;
         }
         if (!kern) return TVTS_EINVAL;
-        if (variant >= 1034 && variant != 2058 && variant != 2074 && variant != 32778 && variant != 32779 && variant != 163850 && variant != 163851 && K < 2 * BK) return TVTS_EINVAL;  // the register-path epilogue requests the bias two stages before the tile ends
+        if (variant >= 1034 && variant != 2058 && variant != 2074 && variant != 32778 && variant != 32779 && variant != 163850 && variant != 163851 && variant != 8552458 && K < 2 * BK) return TVTS_EINVAL;  // the register-path epilogue requests the bias two stages before the tile ends
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 163840, stream, g);

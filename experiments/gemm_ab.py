@@ -60,7 +60,8 @@ def main():
     catalog = {"prod": 0, "no-epi": 11, "no-side-loads": 12, "no-stores": 14, "lds+math only": 16, "stag2": 18, "stag4": 26, "sc1 st": 42,
                "plain st": 74, "nt side ld": 138, "side prefetch": 266, "prefetch+nt ld": 394, "cnt vmcnt": 522, "reg": 1034,
                "reg+cnt": 1546, "reg+cnt+stag4": 1562, "m32": 1, "pasm": 8202, "pasm+cnt": 8714, "stagdma": 32778, "pasm+stagdma": 40970, "no-epi+stagdma": 32779,
-               "pin": 163850, "pasm+pin": 172042, "no-epi+pin": 163851}
+               "pin": 163850, "pasm+pin": 172042, "no-epi+pin": 163851,
+               "b16 generic": 8552458, "b16 pasm": 8560650}  # round 6: bf16-first patch (production flags + ABL 8388608)
     names = os.environ.get("AB_VARIANTS", "prod,side prefetch,no-side-loads").split(",")
     variants = [(n, catalog[n], -1, (0, 0)) for n in names]
     tot = {v[0]: 0.0 for v in variants}
@@ -102,6 +103,14 @@ def main():
             ok = err < (3e-3 if odt == torch.bfloat16 else 1e-5) and amax <= (0.13 if odt == torch.bfloat16 else 2e-4)
             if not ok:
                 print(f"  WRONG {name} / {vn}: rel {err:.3e} max-abs {amax:.3e}", flush=True)
+            elif vn.startswith("b16"):  # the bf16-first patch claims the SAME bits as the fp32 patch (one rounding either way)
+                same = torch.equal(out, ref)
+                pre_same = ""
+                if kw.get("preact") is not None:
+                    p_new = kw["preact"].clone()
+                    exp_gemm(0, -1, (0, 0), a, b, ref, **kw)
+                    pre_same = f", side output {'identical' if torch.equal(p_new, kw['preact']) else 'DIFFERS'}"
+                print(f"  {name} / {vn}: result {'bit-identical to' if same else 'DIFFERS from'} the production kernel's (max-abs {amax:.3e}){pre_same}", flush=True)
         ts = {vn: [] for vn, *_ in vs}
         def run_sets(v, gc, stag):
             for a_, kw_, out_ in sets:

@@ -24,7 +24,10 @@ def main():
     dev = "cuda:0"
     trace = torch.zeros(256 * 32 * 6, dtype=torch.int64, device=dev)
     AB.lib.tvts_exp_set_trace(ctypes.c_void_p(trace.data_ptr()))
-    for name, n, k, kind in [("qkv fwd", 2304, 768, "plain"), ("proj f32+res", 768, 768, "res32"), ("fc1 dgrad", 768, 3072, "plain")]:
+    cases = [("qkv fwd", 2304, 768, "plain"), ("proj f32+res", 768, 768, "res32"), ("fc1 dgrad", 768, 3072, "plain")]
+    if os.environ.get("TRACE_WIDE"):  # round 6: the two-output / side-input forms whose epilogue is 8 - 11 us of a 31 us tile
+        cases = [("fc1 fwd act", 3072, 768, "act"), ("fc2 dgrad gate", 3072, 768, "gate"), ("qkv fwd", 2304, 768, "plain")]
+    for name, n, k, kind in cases:
         g = torch.Generator(device=dev).manual_seed(1)
         sets = []
         for _ in range(3):
@@ -33,6 +36,10 @@ def main():
             odt = torch.bfloat16
             if kind == "res32":
                 kw["residual"] = torch.randn(M, n, generator=g, device=dev); odt = torch.float32
+            if kind == "act":
+                kw.update(act="quick_gelu", preact=torch.empty(M, n, dtype=torch.bfloat16, device=dev))
+            if kind == "gate":
+                kw = dict(gate_h=torch.randn(M, n, generator=g, device=dev).bfloat16(), gate_act="quick_gelu")
             sets.append((a, kw, torch.empty(M, n, dtype=odt, device=dev)))
         b = (torch.randn(n, k, generator=g, device=dev) * k ** -0.5).bfloat16()
         for vn, v in [("prod", 2058), ("stag4", 2074), ("reg+cnt", 3594)]:
@@ -60,6 +67,14 @@ def main():
             ts = np.linspace(first.max(), last_end.min(), 400)
             busy = [(valid & (e0 <= x) & (e1 >= x)).sum() for x in ts]
             print(f"{'':14s} {'':8s}  blocks inside an epilogue (wave 0) over the steady part: mean {np.mean(busy):.1f} max {np.max(busy)} min {np.min(busy)} of 256", flush=True)
+            # does an epilogue take longer when more blocks are inside one at the same time?  (its length against the number of blocks inside an
+            # epilogue at its midpoint, by quartile of that number: chip-wide write bandwidth shared by coinciding epilogues would show here)
+            mids, lens = ((e0 + e1) / 2)[valid], (e1 - e0)[valid]
+            conc = np.array([(valid & (e0 <= x) & (e1 >= x)).sum() for x in mids])
+            qs = np.percentile(conc, [25, 50, 75])
+            parts = [lens[conc <= qs[0]], lens[(conc > qs[0]) & (conc <= qs[1])], lens[(conc > qs[1]) & (conc <= qs[2])], lens[conc > qs[2]]]
+            print(f"{'':14s} {'':8s}  epilogue length by concurrency quartile (blocks inside an epilogue at its midpoint <= {qs[0]:.0f} / <= {qs[1]:.0f} / <= {qs[2]:.0f} / more): "
+                  + " / ".join(f"{p.mean():.2f}" if len(p) else "-" for p in parts) + f" us; correlation {np.corrcoef(conc, lens)[0, 1]:+.2f}", flush=True)
 
 
 if __name__ == "__main__":

@@ -37,6 +37,9 @@ enum {
                                    in flight: the small-batch kernel; same bits as TVTS_GEMM_TILE_128); -22 if an operand is too large
                                    for its 32-bit offsets.  Automatic where its cost model wins (csrc/gemm.hip, nt_use_ring) */
     TVTS_GEMM_NO_RING = 16384,  /* ... never take it */
+    TVTS_GEMM_F32_PATCH = 4194304,   /* tvts_gemm_nt_bf16, 256 x 256 kernel, plain bf16 results (round 6): the fp32 LDS patch of the epilogue instead of the
+                                   bf16-first patch (the tile rounded in the accumulator layout, two 16-row slabs per 4 KiB patch) -- the same
+                                   bits either way (tests/test_bench_path_gpu.py), the old kernel for A/Bs */
     TVTS_GEMM_CLOCK_SAMPLE = 2097152, /* tvts_gemm_nt_bf16, plain bf16 result on the 256 x 256 kernel (round 6, bench.py's instrumented step): block 0
                                    writes {s_memtime, s_memrealtime} at its first instruction and behind its last tile into the LAST 32 bytes
                                    of `workspace` (4 x u64: cycles0, ticks0, cycles1, ticks1) -- shader cycles over constant-rate ticks =

@@ -91,6 +91,32 @@ def test_nt256p_bf16_plain_outputs(K, lib, M, N, Kd):
     assert rel(o128, out.float()) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,Kd", [(150720, 768, 768), (150720, 2304, 768), (40000, 512, 768), (40000, 3840, 1280), (1000, 768, 128),
+                                    (24576, 1536, 512), (150720, 768, 3072)])
+def test_nt256p_bf16_first_patch_gives_the_bits_of_the_fp32_patch(K, lib, M, N, Kd):
+    """Round 6: plain bf16 results leave the 256 x 256 kernel through the bf16-FIRST patch (the tile is rounded in the accumulator layout
+    and crosses the LDS patch as bf16, two 16-row slabs per 4 KiB patch) -- generic epilogue (N = 512 / 768 / 1536) and the
+    hand-scheduled one (N >= 2304), whole and ragged row tiles (40000 = 156 x 256 + 64; 1000 rows: three whole tiles and one of 232),
+    with and without bias.  One rounding of the same fp32 value either way: the bits of the fp32 patch (TVTS_GEMM_F32_PATCH), no row
+    past M written; fp32 results take the fp32 patch inside the same kernel and are unchanged as well."""
+    a, b, bias = operands(M, N, Kd, seed=7 + N + Kd)
+    for bi in (bias, None):
+        for dt in (torch.bfloat16, torch.float32):
+            buf, out = guard_out(M, N, dt)
+            K.gemm_nt(a, b, out, bias=bi, tile=256)
+            with K.options(nt_f32_patch=True):
+                buf0, out0 = guard_out(M, N, dt)
+                K.gemm_nt(a, b, out0, bias=bi, tile=256)
+            torch.cuda.synchronize()
+            assert torch.isfinite(out.float()).all()
+            assert torch.equal(out, out0), (dt, bi is not None, float((out.float() - out0.float()).abs().max()))
+            check_guard(buf, M); check_guard(buf0, M)
+    ref = ref_product(a, b, bias)
+    buf, out = guard_out(M, N, torch.bfloat16)
+    K.gemm_nt(a, b, out, bias=bias, tile=256)
+    assert rel(out.float(), ref) < 4e-3
+
+
 @pytest.mark.parametrize("M,N,Kd,odt", [(150720, 768, 768, torch.float32), (150720, 768, 768, torch.bfloat16),
                                         (40000, 3072, 256, torch.float32), (150720, 768, 3072, torch.float32)])
 def test_nt256p_bf16_residual_epilogue(K, lib, M, N, Kd, odt):

@@ -272,6 +272,7 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
                                       // lgkmcnt counts in the K loop instead of lgkmcnt(0), and no change in the step (145.5-146.0 ms either way)
 #endif
     constexpr int SD = TVTS_NT_SD;
+    const bool b16_patch = !(opts & 4194304);  // TVTS_GEMM_F32_PATCH: the fp32 patch of rounds 1 - 5 for the plain forms
     void (*kern)(GemmNT) = nullptr;
     if (gated) {
         if (act != ACT_NONE) return TVTS_EINVAL;
@@ -284,6 +285,14 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
     } else {
         kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, FP8, SD> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, FP8, SD>
              : act == ACT_GELU_ERF ? gemm_nt256p_kernel<2, 0, FP8, SD> : nullptr;
+        // round 6: plain results (no activation, no side input) through the bf16-FIRST patch (gemm_nt256.h, ABL 8388608: the tile is
+        // rounded in the accumulator layout and crosses the LDS patch as bf16, two slabs per patch): same bits as the fp32 patch,
+        // 187 -> 177 us at N = K = 768, 513 -> 498 us at N = 2304 (M = 150 720, profiles/r06_gemm_ab_b16_patch.txt).  The kernel takes
+        // it where the call has a bf16 result and no residual and falls back to the fp32 patch inside otherwise; TVTS_GEMM_F32_PATCH
+        // asks for the old kernel (parity test of the two).
+        if constexpr (!FP8) {
+            if (act == ACT_NONE && b16_patch) kern = gemm_nt256p_kernel<0, 0, false, SD | 8388608>;
+        }
         if constexpr (FP8) {  // the K = 128 scaled-MFMA main loop (the fp8 issue rate); TVTS_GEMM_FP8_K32 selects the 16x16x32 form
             constexpr int MX = SD | 65536;
             if (fp8_mx) kern = act == ACT_NONE ? gemm_nt256p_kernel<0, 0, true, MX> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, true, MX>
@@ -318,7 +327,7 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
                 if (!g.out_f32 && !g.residual) kern = gemm_nt256p_kernel<1, 0, false, 8192 | SD, 0>;
             } else if (act == ACT_NONE) {
                 if (g.residual) kern = g.out_f32 ? gemm_nt256p_kernel<0, 0, false, 8192 | SD, 3> : gemm_nt256p_kernel<0, 0, false, 8192 | SD, 2>;
-                else if (!g.out_f32 && g.N >= 2304) kern = gemm_nt256p_kernel<0, 0, false, 8192 | SD, 0>;
+                else if (!g.out_f32 && g.N >= 2304) kern = b16_patch ? gemm_nt256p_kernel<0, 0, false, 8192 | SD | 8388608, 0> : gemm_nt256p_kernel<0, 0, false, 8192 | SD, 0>;
             }
         }
     }
@@ -345,8 +354,8 @@ static int launch_nt256(GemmNT& g, int act, int gate_act, bool gated, int opts, 
         // carry nothing of it); the samples go to the last 32 bytes of the caller's workspace
         if ((opts & 2097152) && workspace && workspace_bytes >= 64 && !g.sk_ws && ((size_t)workspace + (size_t)workspace_bytes) % 8 == 0) {
             void (*ck)(GemmNT) = nullptr;
-            if (kern == (void (*)(GemmNT))gemm_nt256p_kernel<0, 0, false, 8192 | SD, 0>) ck = gemm_nt256p_kernel<0, 0, false, 8192 | SD | 4194304, 0>;
-            else if (kern == (void (*)(GemmNT))gemm_nt256p_kernel<0, 0, false, SD>) ck = gemm_nt256p_kernel<0, 0, false, SD | 4194304>;
+            if (kern == (void (*)(GemmNT))gemm_nt256p_kernel<0, 0, false, 8192 | SD | 8388608, 0>) ck = gemm_nt256p_kernel<0, 0, false, 8192 | SD | 8388608 | 4194304, 0>;
+            else if (kern == (void (*)(GemmNT))gemm_nt256p_kernel<0, 0, false, SD | 8388608>) ck = gemm_nt256p_kernel<0, 0, false, SD | 8388608 | 4194304>;
             if (ck) {
                 kern = ck;
                 g.clk = (unsigned long long*)((char*)workspace + workspace_bytes - 32);

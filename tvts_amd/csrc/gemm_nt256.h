@@ -788,6 +788,83 @@ __device__ __forceinline__ void epilogue256_patch_asm(const GemmNT& g, f32x4 (&a
     slab(IC<4>{}); slab(IC<5>{}); slab(IC<6>{}); slab(IC<7>{});
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16-FIRST patch epilogue (ABL & 8388608; round 6 experiment): for bf16 results with no side input (plain, activation + side output)
+// the accumulators are finished -- activation, conversion -- in the accumulator layout, where a lane owns 4 consecutive columns, and go
+// through the LDS patch as bf16: a 16-row x 64-column slab is 2 KiB instead of 4, so the 4 KiB patch holds TWO (plain: slab i + 1 is
+// written while slab i is read out -- the write -> wait -> read -> wait chain of the fp32 patch runs eight times in series per wave;
+// activation forms: result and side output of one slab), the write is one ds_write_b64 per accumulator tile instead of a b128, the
+// read-out one ds_read_b128 per 16-byte store instead of two, and the activation of slab i + 1 does not depend on the patch at all.
+// Same values, same single rounding as the fp32 patch.  8-byte granule g of row r sits at granule g ^ (r & 14): a lane's 16-byte
+// read (granules 2c, 2c + 1 of its row) stays one aligned piece at chunk c ^ ((r & 14) >> 1).
+// ------------------------------------------------------------------------------------------------
+template <int ACT, int ABL, bool FULLT>
+__device__ __forceinline__ void epilogue256_patch_b16(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn, int lane,
+                                                      char* patch, const f32x4* bias4 /* nullptr: the bias is in the accumulators */) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+    asm volatile("" : "+v"(lane));
+    const int nb = n0 + wn * 64;
+    const int li = lane & 15, gq = lane >> 4;
+    const int mw = m0 + wm * 128;
+    const int r0 = lane >> 3, c0 = (lane & 7) * 8;
+    const unsigned out_step = (unsigned)g.ldc * 2u, pre_step = (unsigned)g.ldp * 2u;
+    const unsigned out_voff = (unsigned)r0 * out_step + (unsigned)(nb + c0) * 2u;
+    const unsigned pre_voff = (unsigned)r0 * pre_step + (unsigned)(nb + c0) * 2u;
+    const unsigned wr_off = (unsigned)li * 128u;                       // + granule position * 8
+    const unsigned swz = (unsigned)(li & 14);
+    constexpr bool HAS_PRE = ACT != ACT_NONE;
+    auto slab = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        char* half = patch + (HAS_PRE ? 0 : (i & 1) * 2048);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[j][i];
+            acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (bias4) v += bias4[j];
+            const unsigned pos = wr_off + ((((unsigned)(j * 4 + gq)) ^ swz) << 3);
+            if constexpr (HAS_PRE) {
+                f32x2_ s0, s1;
+                const f32x2_ y0 = act_fwd_side_pk((f32x2_){v[0], v[1]}, ACT, g.side_deriv, s0);
+                const f32x2_ y1 = act_fwd_side_pk((f32x2_){v[2], v[3]}, ACT, g.side_deriv, s1);
+                *(bf16x4_*)(half + pos) = (bf16x4_){(bf16)y0[0], (bf16)y0[1], (bf16)y1[0], (bf16)y1[1]};
+                *(bf16x4_*)(half + 2048 + pos) = (bf16x4_){(bf16)s0[0], (bf16)s0[1], (bf16)s1[0], (bf16)s1[1]};
+            } else {
+                *(bf16x4_*)(half + pos) = (bf16x4_){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            }
+        }
+        const int m_base = mw + i * 16;
+        bf16x8 o[2], pre[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r = t * 8 + r0;
+            const unsigned rd = (unsigned)r * 128u + ((((unsigned)(lane & 7)) ^ ((unsigned)(r & 14) >> 1)) << 4);
+            o[t] = *(const bf16x8*)(half + rd);
+            if constexpr (HAS_PRE) pre[t] = *(const bf16x8*)(half + 2048 + rd);
+        }
+        if constexpr (FULLT) {
+            char* ob = (char*)g.out + (size_t)m_base * out_step;
+            if (HAS_PRE && g.preact) {
+                char* pb = (char*)g.preact + (size_t)m_base * pre_step;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) asm_store16(pre[t], pb + (size_t)(8 * t) * pre_step, pre_voff);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) asm_store16(o[t], ob + (size_t)(8 * t) * out_step, out_voff);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int r = t * 8 + r0, n = nb + c0;
+                if (m_base + r < g.M && n < g.N) {
+                    if (HAS_PRE && g.preact) store16<ABL>(g.preact + (size_t)(m_base + r) * g.ldp + n, pre[t]);
+                    store16<ABL>((bf16*)g.out + (size_t)(m_base + r) * g.ldc + n, o[t]);
+                }
+            }
+        }
+    };
+    slab(IC<0>{}); slab(IC<1>{}); slab(IC<2>{}); slab(IC<3>{});
+    slab(IC<4>{}); slab(IC<5>{}); slab(IC<6>{}); slab(IC<7>{});
+}
+
 // timing ablations of the K loop for tools/gemm_cus.py (experiment builds only, -DTVTS_LOOP_ABL=n; results are wrong by construction):
 // 1 no LDS-DMA behind the prologue, 2 no fragment reads behind the first stage, 4 no MFMAs (and with them no reads), 8 no barriers
 #ifndef TVTS_LOOP_ABL
@@ -1130,7 +1207,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                 static_assert(!FP8 && CFG >= 0, "hand-scheduled patch epilogue: bf16 operands, output kind compiled in");
                 // (the 256-tile dispatch guarantees N % 256 == 0 for this instantiation: only rows can stick out)
                 const bool full = m0 + wm * 128 + 128 <= g.M;
-                if (full) epilogue256_patch_asm<ACT, GATE, ABL, CFG, true>(g, acc, m0, n0, wm, wn, lane, patch);
+                if constexpr ((ABL & 8388608) != 0 && CFG == 0 && GATE == ACT_NONE) {  // bf16 result, no side input: bf16-first patch
+                    if (full) epilogue256_patch_b16<ACT, ABL, true>(g, acc, m0, n0, wm, wn, lane, patch, nullptr);
+                    else epilogue256_patch_b16<ACT, ABL, false>(g, acc, m0, n0, wm, wn, lane, patch, nullptr);
+                } else if (full) epilogue256_patch_asm<ACT, GATE, ABL, CFG, true>(g, acc, m0, n0, wm, wn, lane, patch);
                 else epilogue256_patch_asm<ACT, GATE, ABL, CFG, false>(g, acc, m0, n0, wm, wn, lane, patch);
             } else if constexpr ((ABL & 1024) != 0) {
                 static_assert(!FP8 && CFG >= 0, "register-path epilogue: bf16 operands, output kind compiled in");
@@ -1140,6 +1220,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
             } else {
                 if constexpr (FP8) epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, g.sa_rows ? g.sb[0] : g.sa[0] * g.sb[0],
                                                                      g.sa_rows ? g.sa : nullptr);
+                else if constexpr ((ABL & 8388608) != 0 && GATE == ACT_NONE && !SK) {
+                    if (!g.out_f32 && !g.residual && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (!g.preact || (g.ldp & 7) == 0)) {
+                        const int nbw = n0 + wn * 64, gqw = lane >> 4;
+                        f32x4 b4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int n = nbw + j * 16 + gqw * 4;
+                            b4[j] = (g.bias && n < g.N) ? *(const f32x4*)(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                        const bool full = (m0 + wm * 128 + 128 <= g.M) && (nbw + 64 <= g.N);
+                        if (full) epilogue256_patch_b16<ACT, ABL, true>(g, acc, m0, n0, wm, wn, lane, patch, b4);
+                        else epilogue256_patch_b16<ACT, ABL, false>(g, acc, m0, n0, wm, wn, lane, patch, b4);
+                    } else {
+                        epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, 1.0f);
+                    }
+                }
                 else epilogue256_patch<ACT, GATE, ABL>(g, acc, m0, n0, wm, wn, lane, patch, 1.0f);
             }
             if constexpr ((ABL & 2048) != 0) {

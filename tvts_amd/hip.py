@@ -6,6 +6,7 @@ hand-written gfx950 kernel.  Tensors must live on the GPU; a CPU tensor raises (
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -74,9 +75,11 @@ def _ld(t: torch.Tensor) -> int:
 # the call (include/tvts_hip.h, TVTS_GEMM_* / TVTS_TN_* / TVTS_ATTN_*).  Tests and benches that want a whole engine step on an
 # alternative path wrap it in `with hip.options(nt_tile=256): ...`; the defaults below are what every call uses otherwise.
 # The one product use: `nt_cus` -- the CU reservation of the persistent GEMM grid when world > 1 (tvts_amd/dist.py).
-_DEFAULTS = dict(nt_tile=0, nt_cus=0, nt_streamk=None, tn_streamk=None, fp8_k32=False, tn_tile=0, tn_splits=0, tn_early_dma=None, tn_a_fast=None,
+_DEFAULTS = dict(nt_tile=0, nt_cus=0, nt_f32_patch=False, nt_streamk=None, tn_streamk=None, fp8_k32=False, tn_tile=0, tn_splits=0, tn_early_dma=None, tn_a_fast=None,
                  attn_tr=True, attn_shared=True, attn_fused=True, attn_ablate=0)
 _OPTS = dict(_DEFAULTS)
+if os.environ.get("TVTS_NT_F32_PATCH") == "1":  # A/B switch: the fp32 LDS patch of rounds 1 - 5 for the plain NT forms (same bits)
+    _OPTS["nt_f32_patch"] = True
 
 
 class options:
@@ -122,7 +125,8 @@ def nt_opts(tile=None, cus=None, fp8_k32=None, streamk=None, side_deriv=False):
     cus = _OPTS["nt_cus"] if cus is None else cus
     k32 = _OPTS["fp8_k32"] if fp8_k32 is None else fp8_k32
     streamk = _OPTS["nt_streamk"] if streamk is None else streamk
-    return _tile_bits(tile) | (4 if k32 else 0) | (((int(cus) // 8) & 63) << 8) | _sk_bits(streamk) | ((1 << 20) if side_deriv else 0)
+    return (_tile_bits(tile) | (4 if k32 else 0) | (((int(cus) // 8) & 63) << 8) | _sk_bits(streamk) | ((1 << 20) if side_deriv else 0)
+            | ((1 << 22) if _OPTS["nt_f32_patch"] else 0))   # TVTS_GEMM_F32_PATCH
 
 
 def tn_opts(tile=None, splits=None, early_dma=None, a_fast=None, streamk=None):
