@@ -24,6 +24,8 @@ RECURRING = collections.OrderedDict([
     ("mfma_power_probe.txt", ("what a pure MFMA stream sustains on this part: shape (16x16x32 vs 32x32x16) x operands (random vs zero) x LDS reads; clock per arm", "section 7, power-limited")),
     ("cu_store_probe.txt", ("what ONE CU can store (64 B/clk) against all 256 at once (10 - 17 B/clk = the chip's write bandwidth): the NT epilogue's store tail is not the CU's store path", "section 7, Where the GEMM time is")),
     ("gemm_trace_wide_forms.txt", ("per-tile trace of the wide NT forms (fc1 forward, fc2 input gradient, qkv forward): epilogue length against the number of blocks inside an epilogue at the same time -- no dependence: the tail is CU-local", "section 7, Where the GEMM time is")),
+    ("gemm_ab_b16_patch.txt", ("bf16-first LDS patch against the fp32 patch per GEMM shape (adopted for the plain forms: same bits, 3 - 5 % per launch)", "section 5")),
+    ("bench_b16_patch_ab.txt", ("the step with / without the bf16-first patch, alternating runs on one box: +0.75 %", "section 5")),
     ("bench_product_path.txt", ("product path against bench path at 192 / 24 / 12 pairs: eager vs `--graph`, host-fed step, trainer epoch (eager and `TVTS_TRAINER_GRAPH=1`)", "section 7, table")),
     ("bench_launch_bound_eager_vs_graph.txt", ("eager against replayed graph where the step is launch-bound: 2 / 4 / 6 pairs of B/16, H/14 at its 2 pairs of 16 frames (the rule behind bench.py's automatic --graph)", "section 7, Other configurations")),
     ("bench_reference_batches.jsonl", ("the reference's own per-GPU batches (2 / 12 / 24 pairs) and WebVid-style NT = 1", "section 7")),
