@@ -189,14 +189,16 @@ static void (*pick_reg(int act, int gate_act, bool gated, int out_f32, bool res)
 template <int ABL>
 static void (*pick_pasm(int act, int gate_act, bool gated, int out_f32, bool res))(GemmNT) {
     if (act != ACT_NONE) return (gated || out_f32 || res) ? nullptr : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, false, ABL, 0> : nullptr;
-    if (gated) return out_f32 || res ? nullptr : gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, ABL, 0> : nullptr;
+    if (gated) return out_f32 || res ? nullptr : gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, ABL, 0>
+                      : gate_act == ACT_ADD_BF16 ? gemm_nt256p_kernel<0, 3, false, ABL, 0> : nullptr;
     return out_f32 ? (res ? gemm_nt256p_kernel<0, 0, false, ABL, 3> : gemm_nt256p_kernel<0, 0, false, ABL, 1>)
                    : (res ? gemm_nt256p_kernel<0, 0, false, ABL, 2> : gemm_nt256p_kernel<0, 0, false, ABL, 0>);
 }
 
 template <int ABL>
 static void (*pick_abl(int act, int gate_act, bool gated))(GemmNT) {
-    if (gated) return gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, ABL> : gemm_nt256p_kernel<0, 2, false, ABL>;
+    if (gated) return gate_act == ACT_QUICK_GELU ? gemm_nt256p_kernel<0, 1, false, ABL> : gate_act == ACT_ADD_BF16 ? gemm_nt256p_kernel<0, 3, false, ABL>
+                      : gemm_nt256p_kernel<0, 2, false, ABL>;
     return act == ACT_NONE ? gemm_nt256p_kernel<0, 0, false, ABL> : act == ACT_QUICK_GELU ? gemm_nt256p_kernel<1, 0, false, ABL>
          : gemm_nt256p_kernel<2, 0, false, ABL>;
 }
@@ -216,6 +218,8 @@ extern "C" int tvts_exp_gemm_nt(int variant, int gc, int stagger_phases, int sta
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.act = act;
     g.preact = (bf16*)preact; g.ldp = ldp; g.gate_h = (const bf16*)gate_h; g.ldh = ldh; g.gate_act = gate_act;
     g.out = out; g.ldc = ldc; g.out_f32 = out_f32; g.sa = nullptr; g.sb = nullptr; g.sa_rows = 0;
+    g.side_deriv = 1;  // the production forms of round 5: the side tensor IS act'(x)
+    g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_tol = 0; g.q8 = nullptr; g.ldq8 = 0; g.q8_scale = nullptr; g.q8_amax = nullptr; g.clk = nullptr;
     g.tiles_n = ceil_div(N, 256); g.tiles_m = ceil_div(M, 256);
     if (gc < 0) { const int tn = g.tiles_n; gc = tn >= 10 ? (tn % 6 == 0 ? 6 : tn % 5 == 0 ? 5 : 0) : 0; }
     g.gc = gc;
@@ -251,6 +255,7 @@ extern "C" int tvts_exp_gemm_nt(int variant, int gc, int stagger_phases, int sta
             case 163851: kern = pick_abl<32768 + 131072 + 1>(act, gate_act, gated); break;                                // no epilogue + stagger + pinned order
             case 8552458: kern = pick_abl<32768 + 131072 + 8388608>(act, gate_act, gated); break;                               // generic epilogue, bf16-first patch where it applies (round 6)
             case 8560650: kern = pick_pasm<8192 + 32768 + 131072 + 8388608>(act, gate_act, gated, out_f32, residual != nullptr); break;  // hand-scheduled epilogue, bf16-first patch where it applies
+            case 25337866: kern = pick_pasm<8192 + 32768 + 131072 + 8388608 + 16777216>(act, gate_act, gated, out_f32, residual != nullptr); break;  // ... and for the bf16 side-input forms
             case 522: kern = pick_abl<512>(act, gate_act, gated); break;   // counted vmcnt behind the epilogue
             case 1034: kern = pick_reg<1024>(act, gate_act, gated, out_f32, residual != nullptr); break; // register-path epilogue
             case 1546: kern = pick_reg<1536>(act, gate_act, gated, out_f32, residual != nullptr); break; // ... + counted vmcnt

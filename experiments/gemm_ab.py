@@ -18,7 +18,7 @@ lib = ctypes.CDLL(os.path.join(ROOT, "experiments", "libtvts_exp.so"))
 vp, ci = ctypes.c_void_p, ctypes.c_int
 lib.tvts_exp_gemm_nt.argtypes = [ci, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, ci, vp, ci, ci, vp, ci, ci, vp]
 lib.tvts_exp_gemm_nt.restype = ci
-ACT = {"": 0, "quick_gelu": 1, "gelu": 2}
+ACT = {"": 0, "quick_gelu": 1, "gelu": 2, "add": 3}
 
 
 def P(t):
@@ -53,6 +53,7 @@ def main():
     dev = "cuda:0"
     cases = [  # (name, M, N, K, kind)
         ("qkv fwd", M, 2304, 768, "plain"), ("proj f32+res", M, 768, 768, "res32"), ("proj bf16+res", M, 768, 768, "res16"), ("proj bf16", M, 768, 768, "plain"),
+        ("proj bf16+bf16res", M, 768, 768, "add16"), ("fc2 fwd bf16+bf16res", M, 768, 3072, "add16"),
         ("fc1 fwd gelu+pre", M, 3072, 768, "act"), ("fc2 dgrad gate", M, 3072, 768, "gate"), ("fc2 fwd f32+res", M, 768, 3072, "res32"),
         ("fc1 dgrad", M, 768, 3072, "plain"), ("qkv dgrad", M, 768, 2304, "plain"), ("square", 4096, 4096, 4096, "plain")]
     # variant 10 + ABL = the production kernel with a compile-time epilogue ablation (results are wrong by construction, not checked):
@@ -61,7 +62,7 @@ def main():
                "plain st": 74, "nt side ld": 138, "side prefetch": 266, "prefetch+nt ld": 394, "cnt vmcnt": 522, "reg": 1034,
                "reg+cnt": 1546, "reg+cnt+stag4": 1562, "m32": 1, "pasm": 8202, "pasm+cnt": 8714, "stagdma": 32778, "pasm+stagdma": 40970, "no-epi+stagdma": 32779,
                "pin": 163850, "pasm+pin": 172042, "no-epi+pin": 163851,
-               "b16 generic": 8552458, "b16 pasm": 8560650}  # round 6: bf16-first patch (production flags + ABL 8388608)
+               "b16 generic": 8552458, "b16 pasm": 8560650, "b16 side": 25337866}  # round 6: bf16-first patch (production flags + ABL 8388608)
     names = os.environ.get("AB_VARIANTS", "prod,side prefetch,no-side-loads").split(",")
     variants = [(n, catalog[n], -1, (0, 0)) for n in names]
     tot = {v[0]: 0.0 for v in variants}
@@ -85,6 +86,8 @@ def main():
                 kw.update(act="quick_gelu", preact=torch.empty(m, n, dtype=torch.bfloat16, device=dev))
             elif kind == "gate":
                 kw = dict(gate_h=torch.randn(m, n, generator=g, device=dev).bfloat16(), gate_act="quick_gelu")
+            elif kind == "add16":  # the hybrid stream's forms: bf16 result + bf16 residual through the gate slot
+                kw = dict(bias=kw["bias"], gate_h=torch.randn(m, n, generator=g, device=dev).bfloat16(), gate_act="add")
             sets.append((a, kw, torch.empty(m, n, dtype=odt, device=dev)))
         b = (torch.randn(n, k, generator=g, device=dev) * k ** -0.5).bfloat16()
         a, kw, out = sets[0]
@@ -104,6 +107,13 @@ def main():
             if not ok:
                 print(f"  WRONG {name} / {vn}: rel {err:.3e} max-abs {amax:.3e}", flush=True)
             elif vn.startswith("b16"):  # the bf16-first patch claims the SAME bits as the fp32 patch (one rounding either way)
+                if vn in ("b16 pasm", "b16 side"):  # the hand-scheduled kernels add the bias inside the K loop: compare with THEIR fp32-patch form
+                    ref2 = torch.empty_like(ref)
+                    try:
+                        exp_gemm(catalog["pasm+pin"], gc, stag, a, b, ref2, **kw)
+                        print(f"  {name} / {vn}: {'bit-identical to' if torch.equal(out, ref2) else 'DIFFERS from'} the hand-scheduled fp32-patch kernel", flush=True)
+                    except AssertionError:
+                        pass
                 same = torch.equal(out, ref)
                 pre_same = ""
                 if kw.get("preact") is not None:

@@ -25,6 +25,7 @@ RECURRING = collections.OrderedDict([
     ("cu_store_probe.txt", ("what ONE CU can store (64 B/clk) against all 256 at once (10 - 17 B/clk = the chip's write bandwidth): the NT epilogue's store tail is not the CU's store path", "section 7, Where the GEMM time is")),
     ("gemm_trace_wide_forms.txt", ("per-tile trace of the wide NT forms (fc1 forward, fc2 input gradient, qkv forward): epilogue length against the number of blocks inside an epilogue at the same time -- no dependence: the tail is CU-local", "section 7, Where the GEMM time is")),
     ("gemm_ab_b16_patch.txt", ("bf16-first LDS patch against the fp32 patch per GEMM shape (adopted for the plain forms: same bits, 3 - 5 % per launch)", "section 5")),
+    ("gemm_ab_b16_side_input_forms.txt", ("the bf16-first patch for the forms with a bf16 side input (side values loaded in the accumulator layout): same bits, 2 - 7 % SLOWER -- not adopted", "section 9, item 2")),
     ("bench_b16_patch_ab.txt", ("the step with / without the bf16-first patch, alternating runs on one box: +0.75 %", "section 5")),
     ("bench_product_path.txt", ("product path against bench path at 192 / 24 / 12 pairs: eager vs `--graph`, host-fed step, trainer epoch (eager and `TVTS_TRAINER_GRAPH=1`)", "section 7, table")),
     ("bench_launch_bound_eager_vs_graph.txt", ("eager against replayed graph where the step is launch-bound: 2 / 4 / 6 pairs of B/16, H/14 at its 2 pairs of 16 frames (the rule behind bench.py's automatic --graph)", "section 7, Other configurations")),

@@ -865,6 +865,99 @@ __device__ __forceinline__ void epilogue256_patch_b16(const GemmNT& g, f32x4 (&a
     slab(IC<4>{}); slab(IC<5>{}); slab(IC<6>{}); slab(IC<7>{});
 }
 
+// The bf16-first patch for the forms with a bf16 SIDE input (ABL & 16777216 on top of 8388608; GATE = bf16 residual add / activation-
+// gradient gate): the side values are needed where the tile is rounded, i.e. in the ACCUMULATOR layout -- lane (li, gq) of accumulator
+// tile (j, i) owns row 16 i + li, columns 16 j + 4 gq .. + 3: one 8-byte load, a wave instruction covers 16 rows x 32 bytes, the four
+// column tiles of a slab the rows' whole 128-byte lines (the first one fetches them into L1).  Inline-asm loads two slabs ahead of their
+// use and ahead of the stores of the slab in between, counted waits (issue order L0 L1 | L2 S0 | L3 S1 | ...), as in the fp32-patch path.
+// The arithmetic is the fp32 patch's (gate_apply on the fp32 accumulator value, ONE rounding): the same bits.
+// MEASURED SLOWER, NOT ADOPTED (experiment library only, profiles/r06_gemm_ab_b16_side_input_forms.txt, M = 150 720): bf16 residual add at
+// N = K = 768 212 -> 227 us, at K = 3072 627 -> 640 us, the activation-gradient gate 788 -> 843 us -- four quarter-line 8-byte loads per
+// slab cost more than the halved LDS round trip returns; these forms keep the fp32 patch with 16-byte row-segment side loads.
+struct SideAcc { unsigned long long v[4]; };  // 4 x (4 bf16): the side values of column tiles j = 0..3 of one slab
+template <int IMM>
+__device__ __forceinline__ void asm_load8(unsigned long long& d, const void* base, unsigned voff) {
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(base), "i"(IMM) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void asm_wait_vm8(SideAcc& s) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.v[0]), "+v"(s.v[1]), "+v"(s.v[2]), "+v"(s.v[3]) : "i"(N) : "memory");
+}
+template <int GATE, int ABL, bool FULLT>
+__device__ __forceinline__ void epilogue256_patch_b16_side(const GemmNT& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn, int lane,
+                                                           char* patch) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+    static_assert(GATE != ACT_NONE, "side-input form");
+    asm volatile("" : "+v"(lane));
+    const int nb = n0 + wn * 64;
+    const int li = lane & 15, gq = lane >> 4;
+    const int mw = m0 + wm * 128;
+    const int r0 = lane >> 3, c0 = (lane & 7) * 8;
+    const unsigned out_step = (unsigned)g.ldc * 2u, side_step = (unsigned)g.ldh * 2u;
+    const unsigned out_voff = (unsigned)r0 * out_step + (unsigned)(nb + c0) * 2u;
+    const unsigned side_voff = (unsigned)li * side_step + (unsigned)(nb + 4 * gq) * 2u;   // this lane's row and first column inside a slab
+    const unsigned wr_off = (unsigned)li * 128u, swz = (unsigned)(li & 14);
+    constexpr int NL = 4, NS = 2;
+    SideAcc sA, sB;
+    auto side_issue = [&](int slab_i, SideAcc& sd) {
+        const char* b = (const char*)g.gate_h + (size_t)(mw + slab_i * 16) * side_step;
+        if constexpr (FULLT) {
+            asm_load8<0>(sd.v[0], b, side_voff); asm_load8<32>(sd.v[1], b, side_voff);
+            asm_load8<64>(sd.v[2], b, side_voff); asm_load8<96>(sd.v[3], b, side_voff);
+        } else {  // edge tiles: the row clamped to the matrix
+            int m = mw + slab_i * 16 + li;
+            m = m < g.M ? m : g.M - 1;
+            const unsigned vo = (unsigned)(nb + 4 * gq) * 2u;
+            const char* rb = (const char*)g.gate_h + (size_t)m * side_step;
+            // (per-lane row base: the offset register carries it, the scalar base is the matrix)
+            const unsigned long long d = (unsigned long long)(rb - (const char*)g.gate_h);
+            const unsigned voff2 = (unsigned)d + vo;
+            asm_load8<0>(sd.v[0], g.gate_h, voff2); asm_load8<32>(sd.v[1], g.gate_h, voff2);
+            asm_load8<64>(sd.v[2], g.gate_h, voff2); asm_load8<96>(sd.v[3], g.gate_h, voff2);
+        }
+    };
+    side_issue(0, sA);
+    side_issue(1, sB);
+    auto slab = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        SideAcc& sd = (i & 1) ? sB : sA;
+        constexpr int N = !FULLT ? 0 : i == 0 ? NL : i == 1 ? NL + NS : i == 7 ? 2 * NS : NL + 2 * NS;
+        asm_wait_vm8<N>(sd);
+        char* half = patch + (i & 1) * 2048;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[j][i];  // bias included (added inside the K loop)
+            acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16x4_ h = __builtin_bit_cast(bf16x4_, sd.v[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gate_apply(v[e], (float)h[e], GATE, g.side_deriv);
+            *(bf16x4_*)(half + wr_off + ((((unsigned)(j * 4 + gq)) ^ swz) << 3)) = (bf16x4_){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        }
+        if constexpr (i + 2 < 8) side_issue(i + 2, sd);   // the slab after next, ahead of this slab's stores
+        const int m_base = mw + i * 16;
+        bf16x8 o[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r = t * 8 + r0;
+            o[t] = *(const bf16x8*)(half + (unsigned)r * 128u + ((((unsigned)(lane & 7)) ^ ((unsigned)(r & 14) >> 1)) << 4));
+        }
+        if constexpr (FULLT) {
+            char* ob = (char*)g.out + (size_t)m_base * out_step;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) asm_store16(o[t], ob + (size_t)(8 * t) * out_step, out_voff);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int r = t * 8 + r0;
+                if (m_base + r < g.M) store16<ABL>((bf16*)g.out + (size_t)(m_base + r) * g.ldc + nb + c0, o[t]);
+            }
+        }
+    };
+    slab(IC<0>{}); slab(IC<1>{}); slab(IC<2>{}); slab(IC<3>{});
+    slab(IC<4>{}); slab(IC<5>{}); slab(IC<6>{}); slab(IC<7>{});
+    if constexpr (!FULLT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // timing ablations of the K loop for tools/gemm_cus.py (experiment builds only, -DTVTS_LOOP_ABL=n; results are wrong by construction):
 // 1 no LDS-DMA behind the prologue, 2 no fragment reads behind the first stage, 4 no MFMAs (and with them no reads), 8 no barriers
 #ifndef TVTS_LOOP_ABL
@@ -1210,6 +1303,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmNT g) {
                 if constexpr ((ABL & 8388608) != 0 && CFG == 0 && GATE == ACT_NONE) {  // bf16 result, no side input: bf16-first patch
                     if (full) epilogue256_patch_b16<ACT, ABL, true>(g, acc, m0, n0, wm, wn, lane, patch, nullptr);
                     else epilogue256_patch_b16<ACT, ABL, false>(g, acc, m0, n0, wm, wn, lane, patch, nullptr);
+                } else if constexpr ((ABL & 16777216) != 0 && CFG == 0 && GATE != ACT_NONE && ACT == ACT_NONE) {  // ... with a bf16 side input
+                    if (full) epilogue256_patch_b16_side<GATE, ABL, true>(g, acc, m0, n0, wm, wn, lane, patch);
+                    else epilogue256_patch_b16_side<GATE, ABL, false>(g, acc, m0, n0, wm, wn, lane, patch);
                 } else if (full) epilogue256_patch_asm<ACT, GATE, ABL, CFG, true>(g, acc, m0, n0, wm, wn, lane, patch);
                 else epilogue256_patch_asm<ACT, GATE, ABL, CFG, false>(g, acc, m0, n0, wm, wn, lane, patch);
             } else if constexpr ((ABL & 1024) != 0) {
