@@ -138,6 +138,49 @@ def test_graph_replay_in_the_trainer_loop_is_the_eager_loop(tmp_path, monkeypatc
     assert torch.equal(m_g.store.m, m_e.store.m) and torch.equal(m_g.store.v, m_e.store.v)
 
 
+def test_lazy_log_lines_are_the_blocking_lines(tmp_path):
+    """The debug line of the logging steps (v2/trainer/trainer.py:505-512, cadence int(sqrt(batch_size))) is written from page-locked
+    copies of the losses once their event has completed (trainer._LazyLog) instead of three blocking `.item()` reads: the same
+    lines, in the same order, with the same digits as formatting the step's own loss tensors."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    tr, m, _ = build(tmp_path, epochs=1)
+    tr.do_validation = False
+    assert tr.log_step == 2  # int(sqrt(4))
+    seen, inner = [], tr.replay.step
+
+    def recording_step(data, *a, **kw):
+        out = inner(data, *a, **kw)
+        l1 = out["loss1"].reshape(()).clone()
+        l2 = out["loss2"].reshape(()).clone() if out["loss2"] is not None else torch.zeros_like(l1)
+        seen.append((float(l1), float(l2), float(l1 + l2)))   # what the reference's `.item()` calls would read
+        return out
+    tr.replay.step = recording_step
+    lines = []
+
+    class Grab(logging.Handler):
+        def emit(self, record):
+            lines.append(record.getMessage())
+    h = Grab(level=logging.DEBUG)
+    tr.logger.addHandler(h)
+    old = tr.logger.level
+    tr.logger.setLevel(logging.DEBUG)
+    try:
+        tr._train_epoch(1)
+    finally:
+        tr.logger.removeHandler(h)
+        tr.logger.setLevel(old)
+    lines = [ln for ln in lines if ln.startswith("Train Epoch")]
+    # 3 loop iterations x 2 loaders, logged at batch_idx 0 and 2
+    want = []
+    for batch_idx in range(3):
+        for dl_idx in range(2):
+            if batch_idx % tr.log_step == 0:
+                l1, l2, tot = seen[batch_idx * 2 + dl_idx]
+                want.append(tr.LOG_LINE.format(1, dl_idx, tr._progress(batch_idx, dl_idx), l1, l2, tot))
+    assert lines == want, (lines, want)
+
+
 def test_load_checkpoint_constructor_argument(tmp_path):
     """`TVTSv2_*(args, load_checkpoint=path)` (model_dist_TVTSv2_ViT_B_16.py:51-56) and the downstream class
     (downstream/model_TVTSv2_ViT_B_16.py:42-46) read the file `_save_checkpoint` writes -- which carries the config OBJECT, so
