@@ -39,7 +39,7 @@ RECURRING = collections.OrderedDict([
     ("kernel_summary_v1_t4_b256.txt", ("kernel shares of the v1 step", "")),
     ("kernel_summary_b12.txt", ("kernel shares of the 12-pair step", "section 9, item 4")),
     ("kernel_summary_b24.txt", ("kernel shares of the 24-pair step", "")),
-    ("timeline_b12.txt", ("launch-to-launch gaps of the replayed 12-pair step", "DESIGN_history A")),
+    ("timeline_b12.txt", ("launch-to-launch gaps of the 12-pair step (rounds 4 - 5: replayed graph; round 6: eager launches)", "DESIGN_history A")),
     ("timeline_b24.txt", ("the same at 24 pairs", "")),
     ("attn_bench.txt", ("every attention geometry of the step, fused against split / streaming kernels", "section 7, HBM-bound families")),
     ("attn_ablate.txt", ("where the fused attention kernels' time is (loads / phases switched off)", "section 7")),
